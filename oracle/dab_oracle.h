@@ -1,0 +1,199 @@
+/*
+ * dab_oracle.h -- CPU oracle for the DAB Mode-I demodulation + FEC hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithms of
+ * tomneda/DABstar (reference tree: /root/reference, v5.7.0) for the path
+ *   IQ -> sync -> 2048-FFT -> D-QPSK soft bits -> FIC/MSC depuncture + K=7 r=1/4
+ *   Viterbi -> energy de-dispersal -> CRC / fire code / RS(120,110).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker.  The product (dabstar_amd/, libdabx.so) never links it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - integer stages (Viterbi, puncture tables, EEP/UEP depuncture, RS, Galois,
+ *     fire code, CRC, frequency interleaver, PRS table) are PINNED: they are checked
+ *     bit-for-bit against the reference's own object code built by oracle/ref/Makefile
+ *     into oracle/_ref/libdabref.so and against the fixtures in tests/golden/.
+ *   - float front end (NCO sample reader, null-dip detector, PRS correlator, coarse
+ *     CFO, D-QPSK demapper) and the Qt-entangled glue (FicDecoder, Backend,
+ *     Mp4Processor, DabProcessor FSM) are restated line by line but PARITY UNPINNED:
+ *     those reference classes need the GUI header dabradio.h / generated ui_*.h and
+ *     FFTW3f (third party, un-vendored, not in this image), so they cannot be built
+ *     here without stand-ins.  The FFT is restated as the mathematical DFT computed in
+ *     double and rounded to float (FFTW3f, any 3.x, computes the same DFT in float).
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * /root/reference/src/).
+ */
+#ifndef DAB_ORACLE_H
+#define DAB_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Mode-I constants: common/glob_defs.h:40-55 ---- */
+#define ORA_L      76
+#define ORA_K      1536
+#define ORA_TN     2656
+#define ORA_TF     196608
+#define ORA_TS     2552
+#define ORA_TU     2048
+#define ORA_TG     504
+#define ORA_2K     3072
+#define ORA_FIC_IN 2304
+#define ORA_FIC_OUT 768
+#define ORA_CIF_BITS 55296
+#define ORA_INPUT_RATE 2048000
+#define ORA_IDX_NOT_FOUND 100000
+
+typedef struct { float re, im; } ora_cf32;
+
+/* ---------------- tables (tables.c) ---------------- */
+/* protection/protTables.cpp:36-68 : 24 puncturing vectors x 32 (1 = transmitted) */
+const int8_t *ora_pi_codes(int pi /*1..24*/);
+/* ofdm/freq_interleaver.cpp:40-76 : k in [0,1536) -> fft bin offset in [-768,768]\{0} */
+void ora_freq_interleaver(int16_t perm[ORA_K]);
+/* ofdm/phasetable.cpp:35-135 : PRS reference in the frequency domain (2048 cf32) */
+void ora_phase_table(ora_cf32 ref[ORA_TU]);
+/* decoder/fic_decoder.cpp:59-73, backend/backend.cpp:72-84 : PRBS x^9+x^5+1, all-ones */
+void ora_prbs(uint8_t *out, int n);
+
+/* ---------------- Viterbi (viterbi.c) ---------------- */
+/* support/viterbi_spiral/viterbi_spiral.cpp:95-126 + viterbi_scalar.h:9-94.
+ * input: 4*(nbits+6) soft bits (i16), output nbits bytes (1 bit/byte).
+ * tie_mode 0 = scalar/SSE2 tie rule (decision 0), 1 = AVX2 tie rule (viterbi_16way.h). */
+void ora_viterbi(const int16_t *soft, int nbits, uint8_t *out_bits);
+/* viterbi_spiral.cpp:128-164 */
+void ora_viterbi_ber(const int16_t *soft, const uint8_t *punct_table, const uint8_t *bits,
+                     int nbits, int *io_bits, int *io_errors);
+
+/* ---------------- protection (protection.c) ---------------- */
+/* Builds the depuncture index list: for each of the 4*(24*kbps+6) mother-code
+ * positions, map[pos] = index into the punctured input or -1 if punctured.
+ * returns number of transmitted bits (== CU size * 64 for legal profiles) or <0.
+ * eep: protection/eep_protection.cpp:43-167 ; uep: protection/uep_protection.cpp:52-212 */
+int ora_eep_map(int kbps, int prot_level /* 0..3, +4 => option B */, int32_t *map /* 96*kbps+24 */);
+int ora_uep_map(int kbps, int prot_level /* 1..5 */, int32_t *map);
+/* decoder/fic_decoder.cpp:79-124 */
+int ora_fic_map(int32_t map[3096]);
+/* protection/protection.cpp:46-59 : depuncture + viterbi */
+void ora_deconvolve(const int16_t *in, const int32_t *map, int kbps, uint8_t *out_bits);
+
+/* ---------------- CRC / fire code / RS ---------------- */
+int ora_check_crc_bits(const uint8_t *bits, int nbits);          /* backend/crc.cpp:98-132 */
+uint16_t ora_calc_crc(const uint8_t *data, int len);               /* backend/crc.cpp:75-86 */
+int ora_check_crc_bytes(const uint8_t *msg, int len);              /* backend/crc.cpp:88-96 */
+int ora_firecode_check(const uint8_t x[11]);                       /* backend/firecode_checker.cpp:162-165 */
+int ora_firecode_check_and_correct(uint8_t x[11]);                 /* backend/firecode_checker.cpp:168-184 */
+const uint16_t *ora_firecode_syndrome_table(void);                 /* 65536 entries */
+/* backend/reed_solomon.cpp:140-158 (dec) with (8,0435,0,1,10), cutlen 135: 120 -> 110 bytes.
+ * returns #corrected, 0 clean, -1 uncorrectable. */
+int ora_rs_dec(const uint8_t in[120], uint8_t out[110]);
+void ora_rs_enc(const uint8_t in[110], uint8_t out[120]);          /* reed_solomon.cpp:115-137 */
+
+/* ---------------- FIC (fic.c) ---------------- */
+typedef struct {
+  int32_t map[3096];
+  uint8_t punct[3096];
+  uint8_t prbs[768];
+  int16_t vit_in[3096];
+  int16_t soft[ORA_FIC_IN];
+  uint8_t fib_bits[4 * 768];   /* one bit per byte, after de-dispersal */
+  uint8_t fic_valid[4];
+  uint8_t fib_crc[12];
+  int index, fic_idx;
+  int fic_block, fic_errors, fic_bits;
+  int success_ratio;           /* 0..10 */
+  /* minimal FIB walk (decoder/fib_decoder.cpp:59-110, fib_decoder_fig0.cpp:89-101) */
+  int cif_count, cif_hi, cif_lo;
+} ora_fic;
+void ora_fic_init(ora_fic *f);
+/* decoder/fic_decoder.cpp:143-167 ; sym_idx in 1..3 */
+void ora_fic_process_block(ora_fic *f, const int16_t soft[ORA_2K], int sym_idx);
+
+/* ---------------- MSC back end (msc.c) ---------------- */
+typedef struct {
+  int subch_id, cu_start, cu_size, kbps, prot_level, short_form /* 1 = UEP */;
+} ora_subch_desc;
+
+typedef struct {
+  ora_subch_desc d;
+  int frag;                  /* cu_size*64 */
+  int16_t *hist;             /* 16 * frag */
+  int16_t *tmp;
+  int32_t *map;
+  uint8_t *prbs;
+  uint8_t *outv;             /* 24*kbps bits */
+  int cnt, idx;
+  /* DAB+ super frame (backend/audio/mp4processor.cpp:96-241) */
+  int rs_dims;
+  uint8_t *frame_bytes;      /* rs_dims*120 */
+  uint8_t *out_vec;          /* rs_dims*110 */
+  int block_fill, blocks_in_buf, sf_sync;
+  long n_cif_out;            /* number of CIFs decoded (after warm-up) */
+  long n_sf_ok, n_sf_fail, n_rs_corr, n_rs_fail, n_fc_corr, n_au_ok, n_au_bad;
+  /* sinks (optional, grown by the oracle) */
+  uint8_t *msc_bytes; size_t msc_len, msc_cap;     /* 3*kbps bytes per CIF */
+  uint8_t *sf_bytes;  size_t sf_len, sf_cap;       /* 110*kbps/8 bytes per good super frame */
+} ora_backend;
+int  ora_backend_init(ora_backend *b, const ora_subch_desc *d);
+void ora_backend_free(ora_backend *b);
+/* backend/backend.cpp:129-161 ; in = CIF soft bits of this sub-channel (frag i16) */
+void ora_backend_process(ora_backend *b, const int16_t *in);
+
+/* ---------------- OFDM front end (ofdm.c) ---------------- */
+void ora_fft2048(const ora_cf32 *in, ora_cf32 *out, int inverse); /* unnormalised DFT */
+
+typedef struct {
+  ora_cf32 phase_ref[ORA_TU];
+  float integ_abs_phase[ORA_K], mean_power[ORA_K], mean_sigma_sq[ORA_K], std_dev_sq[ORA_K];
+  float mean_null_power[ORA_TU];
+  float mean_power_ovr_all;
+  float mean_value;
+  int16_t perm[ORA_K];
+  int soft_bit_type;   /* 1,2,3 = SOFTDEC1..3 (glob_enums.h:49-56), default 1 */
+} ora_demap;
+void ora_demap_init(ora_demap *d);                                   /* ofdm_decoder.cpp:43-66 */
+void ora_demap_reset(ora_demap *d);                                  /* ofdm_decoder.cpp:90-101 */
+void ora_demap_store_ref(ora_demap *d, const ora_cf32 *fft);         /* ofdm_decoder.cpp:132-145 */
+void ora_demap_store_null(ora_demap *d, const ora_cf32 *fft);        /* ofdm_decoder.cpp:114-130 */
+void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_t out[ORA_2K]); /* :147-355 */
+
+/* PRS correlator / coarse CFO: ofdm/phasereference.cpp */
+typedef struct {
+  ora_cf32 ref[ORA_TU];
+  ora_cf32 ref_arg_conj[ORA_TU];
+  int strongest;
+} ora_phaseref;
+void ora_phaseref_init(ora_phaseref *p);
+int  ora_phaseref_correlate(ora_phaseref *p, const ora_cf32 *v, float threshold); /* :87-213 */
+int  ora_phaseref_coarse_cfo(ora_phaseref *p, const ora_cf32 *fft_sym0);          /* :223-280 */
+
+/* ---------------- whole receiver (receiver.c) : main/dab_processor.cpp ---------------- */
+typedef struct ora_receiver ora_receiver;
+ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch);
+void ora_rx_destroy(ora_receiver *r);
+/* Feed a finite cf32 buffer (file-player mode, no pacing); returns #frames processed. */
+int ora_rx_run(ora_receiver *r, const ora_cf32 *iq, size_t n_samples, int max_frames);
+/* capture buffers */
+typedef struct {
+  int n_frames;
+  uint8_t *fibs;       /* n_frames * 12 * 32 bytes (packed) */
+  uint8_t *fib_crc;    /* n_frames * 12 */
+  int16_t *soft;       /* optional: n_frames * 75 * 3072 (NULL unless enabled) */
+  int32_t *start_idx;  /* n_frames */
+  float   *fbb;        /* n_frames : BB freq offset used for symbols 1..75 */
+  int32_t *sym0_pos;   /* n_frames : absolute sample index of symbol-0 T_u start */
+} ora_rx_capture;
+void ora_rx_enable_soft_capture(ora_receiver *r, int on);
+const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);
+ora_backend *ora_rx_backend(ora_receiver *r, int i);
+ora_fic *ora_rx_fic(ora_receiver *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

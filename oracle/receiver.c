@@ -1,0 +1,258 @@
+/* receiver.c -- sample reader + null-dip detector + DabProcessor state machine over an
+ * in-memory IQ buffer (oracle; test infrastructure only; PARITY UNPINNED, see dab_oracle.h).
+ * Restates ofdm/sample_reader.cpp:102-297 (scalar build), ofdm/timesyncer.cpp:40-90 and
+ * main/dab_processor.cpp:110-442 for file-player input (no settle discard, :118-121 of
+ * sample_reader.cpp; no real-time pacing). */
+#include "dab_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct ora_receiver {
+  /* input */
+  const ora_cf32 *iq; size_t n_iq, pos; int eof;
+  /* SampleReader state (sample_reader.h:91-101) */
+  int32_t cur_phase; float s_level, peak_level;
+  /* DabProcessor state (dab_processor.h:129-138) */
+  float phase_offs_cp, freq_offs_sync, freq_offs_bb, clock_err;
+  float threshold; int sync_strongest;
+  ora_phaseref pr; ora_demap dm; ora_fic fic;
+  int n_back; ora_backend *back;
+  int16_t cif[ORA_CIF_BITS];
+  ora_cf32 buf[ORA_TN];
+  int16_t bits[ORA_2K];
+  /* capture */
+  ora_rx_capture cap; int cap_alloc; int want_soft;
+};
+
+static ora_cf32 *g_osc = NULL;   /* sample_reader.cpp:44-50 : 2 048 000-entry oscillator table */
+static void build_osc(void)
+{
+  g_osc = (ora_cf32 *)malloc(sizeof(ora_cf32) * ORA_INPUT_RATE);
+  for (int i = 0; i < ORA_INPUT_RATE; i++) {
+    g_osc[i].re = (float)cos(2.0 * M_PI * i / ORA_INPUT_RATE);
+    g_osc[i].im = (float)sin(2.0 * M_PI * i / ORA_INPUT_RATE);
+  }
+}
+
+/* sample_reader.cpp:102-297, scalar branch :212-283 (DC/IQ correction off: configuration.cpp:75-76) */
+static int get_samples(ora_receiver *r, ora_cf32 *dst, int n, float freq_bb)
+{
+  if (r->pos + (size_t)n > r->n_iq) { r->eof = 1; return 0; }   /* :108-113 -> throw 20 */
+  const int32_t f = (int32_t)roundf(freq_bb);                  /* :211 std::round */
+  const ora_cf32 *src = r->iq + r->pos;
+  for (int i = 0; i < n; i++) {
+    const ora_cf32 v = src[i];
+    const float a = sqrtf(v.re * v.re + v.im * v.im);          /* :245-248 */
+    if (a > r->peak_level) r->peak_level = a;
+    r->s_level += 0.00001f * (a - r->s_level);
+    r->cur_phase -= f;                                          /* :274-281 */
+    r->cur_phase = (r->cur_phase + ORA_INPUT_RATE) % ORA_INPUT_RATE;
+    const ora_cf32 o = g_osc[r->cur_phase];
+    dst[i].re = v.re * o.re - v.im * o.im;
+    dst[i].im = v.re * o.im + v.im * o.re;
+  }
+  r->pos += (size_t)n;
+  return n;
+}
+
+/* timesyncer.cpp:40-90 ; returns 1 established, 0 otherwise, -1 eof */
+static int time_sync(ora_receiver *r)
+{
+  enum { SEARCH = 50, BUFSZ = 4096, MASK = BUFSZ - 1 };
+  float env[BUFSZ], level = 0;
+  int idx = 0;
+  ora_cf32 s;
+  for (int i = 0; i < SEARCH; i++) {
+    if (!get_samples(r, &s, 1, 0)) return -1;
+    env[idx] = sqrtf(s.re * s.re + s.im * s.im);
+    level += env[idx];
+    ++idx;
+  }
+  int counter = 0;
+  while (level / SEARCH > 0.55f * r->s_level) {
+    if (!get_samples(r, &s, 1, 0)) return -1;
+    env[idx] = sqrtf(s.re * s.re + s.im * s.im);
+    level += env[idx] - env[(unsigned)(idx - SEARCH) & MASK];
+    idx = (idx + 1) & MASK;
+    if (++counter > ORA_TF) return 0;
+  }
+  counter = 0;
+  while (level / SEARCH < 0.75f * r->s_level) {
+    if (!get_samples(r, &s, 1, 0)) return -1;
+    env[idx] = sqrtf(s.re * s.re + s.im * s.im);
+    level += env[idx] - env[(unsigned)(idx - SEARCH) & MASK];
+    idx = (idx + 1) & MASK;
+    if (++counter > ORA_TN + SEARCH + 20) return 0;
+  }
+  return 1;
+}
+
+ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch)
+{
+  if (!g_osc) build_osc();
+  ora_receiver *r = (ora_receiver *)calloc(1, sizeof(*r));
+  r->s_level = 0.1f; r->peak_level = -1.0e6f;
+  r->threshold = 3.0f;                         /* main/dabradio.cpp:92 */
+  ora_phaseref_init(&r->pr);
+  ora_demap_init(&r->dm);
+  ora_fic_init(&r->fic);
+  r->n_back = n_subch;
+  r->back = (ora_backend *)calloc((size_t)(n_subch > 0 ? n_subch : 1), sizeof(ora_backend));
+  for (int i = 0; i < n_subch; i++)
+    if (ora_backend_init(&r->back[i], &subch[i]) != 0) { ora_rx_destroy(r); return NULL; }
+  return r;
+}
+
+void ora_rx_destroy(ora_receiver *r)
+{
+  if (!r) return;
+  for (int i = 0; i < r->n_back; i++) ora_backend_free(&r->back[i]);
+  free(r->back);
+  free(r->cap.fibs); free(r->cap.fib_crc); free(r->cap.soft); free(r->cap.start_idx); free(r->cap.fbb); free(r->cap.sym0_pos);
+  free(r);
+}
+
+void ora_rx_enable_soft_capture(ora_receiver *r, int on) { r->want_soft = on; }
+const ora_rx_capture *ora_rx_get_capture(ora_receiver *r) { return &r->cap; }
+ora_backend *ora_rx_backend(ora_receiver *r, int i) { return (i >= 0 && i < r->n_back) ? &r->back[i] : NULL; }
+ora_fic *ora_rx_fic(ora_receiver *r) { return &r->fic; }
+
+static void cap_reserve(ora_receiver *r, int n)
+{
+  if (n <= r->cap_alloc) return;
+  int na = r->cap_alloc ? r->cap_alloc * 2 : 16;
+  while (na < n) na *= 2;
+  r->cap.fibs = (uint8_t *)realloc(r->cap.fibs, (size_t)na * 12 * 32);
+  r->cap.fib_crc = (uint8_t *)realloc(r->cap.fib_crc, (size_t)na * 12);
+  r->cap.start_idx = (int32_t *)realloc(r->cap.start_idx, sizeof(int32_t) * (size_t)na);
+  r->cap.fbb = (float *)realloc(r->cap.fbb, sizeof(float) * (size_t)na);
+  r->cap.sym0_pos = (int32_t *)realloc(r->cap.sym0_pos, sizeof(int32_t) * (size_t)na);
+  if (r->want_soft) r->cap.soft = (int16_t *)realloc(r->cap.soft, sizeof(int16_t) * (size_t)na * 75 * ORA_2K);
+  r->cap_alloc = na;
+}
+
+static void limit_sym(float *v, float lim) { if (*v > lim) *v = lim; else if (*v < -lim) *v = -lim; }
+
+/* main/msc_handler.cpp:148-168 */
+static void msc_process_block(ora_receiver *r, const int16_t *bits, int blk)
+{
+  const int cur = (blk - 4) % 18;
+  memcpy(&r->cif[cur * ORA_2K], bits, sizeof(int16_t) * ORA_2K);
+  if (cur < 17) return;
+  for (int i = 0; i < r->n_back; i++) ora_backend_process(&r->back[i], &r->cif[r->back[i].d.cu_start * 64]);
+}
+
+/* dab_processor.cpp:191-265 + :304-367 + :267-302 ; returns 0 at end of input */
+static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_no)
+{
+  static ora_cf32 fin[ORA_TU], fout[ORA_TU];
+  memcpy(fin, r->buf, sizeof(fin));
+  ora_fft2048(fin, fout, 0);
+  ora_demap_store_ref(&r->dm, fout);                              /* :199-202 */
+
+  int correction = 0;
+  if (r->fic.success_ratio * 10 < 30) {                           /* :205-224 */
+    correction = ora_phaseref_coarse_cfo(&r->pr, fout);
+    if (correction != ORA_IDX_NOT_FOUND) {
+      r->freq_offs_sync += (float)correction;
+      if (fabsf(r->freq_offs_sync) > 35000.0f) r->freq_offs_sync = 0.0f;
+    }
+    if (correction != 0) r->clock_err = 0.0f;
+    r->freq_offs_bb = r->freq_offs_sync;
+  }
+  r->cap.fbb[frame_no] = r->freq_offs_bb;
+
+  /* _process_ofdm_symbols_1_to_L, :304-367 */
+  float fc_re = 0, fc_im = 0;
+  for (int sym = 1; sym < ORA_L; sym++) {
+    if (!get_samples(r, r->buf, ORA_TS, r->freq_offs_bb)) return 0;
+    *sample_count += ORA_TS;
+    for (int i = ORA_TU; i < ORA_TS; i++) {                       /* :330-333  x[i]*conj(x[i-Tu]) */
+      const ora_cf32 a = r->buf[i], b = r->buf[i - ORA_TU];
+      fc_re += a.re * b.re + a.im * b.im;
+      fc_im += a.im * b.re - a.re * b.im;
+    }
+    memcpy(fin, &r->buf[ORA_TG], sizeof(fin));
+    ora_fft2048(fin, fout, 0);
+    ora_demap_symbol(&r->dm, fout, r->clock_err, r->bits);        /* :342 */
+    if (r->want_soft) memcpy(&r->cap.soft[((size_t)frame_no * 75 + (sym - 1)) * ORA_2K], r->bits, sizeof(r->bits));
+    if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);   /* :347-350 */
+    if (sym > 3) msc_process_block(r, r->bits, sym);              /* :357-360 */
+  }
+  r->phase_offs_cp = atan2f(fc_im, fc_re);                        /* :366 */
+
+  limit_sym(&r->phase_offs_cp, 20.0f * (float)(M_PI / 180.0));    /* :240-242 */
+  r->freq_offs_sync += r->phase_offs_cp / (float)(2 * M_PI) * 1000.0f;
+  r->freq_offs_bb = r->freq_offs_sync;
+
+  /* _process_null_symbol, :267-302 */
+  if (!get_samples(r, r->buf, ORA_TN, r->freq_offs_bb)) return 0;
+  *sample_count += ORA_TN;
+  const int is_tii = (r->fic.cif_count & 7) >= 4;
+  memcpy(fin, &r->buf[ORA_TG], sizeof(fin));
+  ora_fft2048(fin, fout, 0);
+  if (!is_tii) ora_demap_store_null(&r->dm, fout);
+
+  if (correction == 0) {                                          /* :246-251 */
+    float ce = (float)ORA_INPUT_RATE * ((float)*sample_count / (float)ORA_TF - 1.0f);
+    limit_sym(&ce, 307.2f);
+    r->clock_err += 0.1f * (ce - r->clock_err);
+  }
+  return 1;
+}
+
+int ora_rx_run(ora_receiver *r, const ora_cf32 *iq, size_t n_samples, int max_frames)
+{
+  enum { WAIT_SYNC, EVAL_SYNC, REST } state = WAIT_SYNC;
+  r->iq = iq; r->n_iq = n_samples; r->pos = 0; r->eof = 0;
+  float sync_thr = 0; int sample_count = 0, frames = 0;
+  r->freq_offs_bb = 0; r->freq_offs_sync = 0; r->fic.success_ratio = 0;   /* :119-124 */
+  for (int i = 0; i < 20; i++)                                   /* :139-142 */
+    if (!get_samples(r, r->buf, ORA_TU, 0)) return 0;
+  while (!r->eof && frames < max_frames) {
+    switch (state) {
+    case WAIT_SYNC: {                                            /* :146-160 */
+      ora_demap_reset(&r->dm);
+      sample_count = 0; sync_thr = r->threshold;
+      const int ok = time_sync(r);
+      if (ok < 0) return frames;
+      state = ok ? EVAL_SYNC : WAIT_SYNC;
+      r->clock_err = 0.0f;
+      break;
+    }
+    case EVAL_SYNC: {                                            /* :389-414 */
+      if (!get_samples(r, r->buf, ORA_TU, r->freq_offs_bb)) return frames;
+      const int start = ora_phaseref_correlate(&r->pr, r->buf, sync_thr);
+      if (start < 0) { state = WAIT_SYNC; break; }
+      const int next = ORA_TU - start;
+      memmove(r->buf, &r->buf[start], sizeof(ora_cf32) * (size_t)next);
+      if (!get_samples(r, &r->buf[next], ORA_TU - next, r->freq_offs_bb)) return frames;
+      sample_count = start + ORA_TU;
+      cap_reserve(r, frames + 1);
+      r->cap.start_idx[frames] = start;
+      r->cap.sym0_pos[frames] = (int32_t)(r->pos - ORA_TU);
+      state = REST;
+      break;
+    }
+    case REST: {                                                 /* :173-180 */
+      if (!process_rest_of_frame(r, &sample_count, frames)) return frames;
+      for (int i = 0; i < 12; i++) {
+        uint8_t *dst = &r->cap.fibs[((size_t)frames * 12 + i) * 32];
+        for (int b = 0; b < 32; b++) {
+          uint8_t t = 0;
+          for (int k = 0; k < 8; k++) t = (uint8_t)((t << 1) | (r->fic.fib_bits[i * 256 + b * 8 + k] & 1));
+          dst[b] = t;
+        }
+        r->cap.fib_crc[frames * 12 + i] = r->fic.fib_crc[i];
+      }
+      frames++;
+      r->cap.n_frames = frames;
+      state = EVAL_SYNC;
+      sync_thr = 2 * r->threshold;
+      break;
+    }
+    }
+  }
+  return frames;
+}

@@ -1,0 +1,107 @@
+// ref_bind.cpp -- extern "C" access to the GENUINE reference leaf classes (test infrastructure).
+// Compiled together with the unmodified sources under /root/reference/src by oracle/ref/Makefile
+// into oracle/_ref/libdabref.so.  No reference source is copied; this file only calls the
+// reference's public (or protected, via a derived class) interfaces.
+#include "viterbi_spiral.h"
+#include "protTables.h"
+#include "eep_protection.h"
+#include "uep_protection.h"
+#include "reed_solomon.h"
+#include "firecode_checker.h"
+#include "crc.h"
+#include "freq_interleaver.h"
+#include "phasetable.h"
+#include <cstring>
+#include <vector>
+
+namespace {
+template <class P> struct Open : P {
+  using P::P;
+  // protection.h:50-53 (protected): depuncture address list -> index map
+  int map(int32_t * out, int n) {
+    for (int i = 0; i < n; i++) out[i] = -1;
+    int k = 0;
+    for (i16 * a : this->viterbiBlockAddresses) out[a - this->viterbiBlock.data()] = k++;
+    return k;
+  }
+};
+struct OpenPhase : PhaseTable { using PhaseTable::mRefTable; };
+}
+
+extern "C" {
+
+int ref_viterbi(const int16_t * soft, int nbits, uint8_t * out)   // viterbi_spiral.h:20
+{
+  ViterbiSpiral v((short)nbits, true);
+  v.deconvolve(soft, out);
+  return 0;
+}
+
+int ref_viterbi_ber(const int16_t * soft, uint8_t * punct, const uint8_t * bits, int nbits, int * io_bits, int * io_err)
+{
+  ViterbiSpiral v((short)nbits, true);
+  v.calculate_BER(soft, punct, bits, *io_bits, *io_err);
+  return 0;
+}
+
+void ref_pi_codes(int pi, int8_t * out32) { memcpy(out32, get_PI_codes((i16)pi), 32); }   // protTables.h
+
+int ref_eep_map(int kbps, int prot, int32_t * out)
+{
+  Open<EepProtection> p((i16)kbps, (i16)prot);
+  return p.map(out, 96 * kbps + 24);
+}
+int ref_uep_map(int kbps, int prot, int32_t * out)
+{
+  Open<UepProtection> p((i16)kbps, (i16)prot);
+  return p.map(out, 96 * kbps + 24);
+}
+int ref_eep_deconvolve(int kbps, int prot, const int16_t * in, int n_in, uint8_t * out)   // protection.h:44
+{
+  EepProtection p((i16)kbps, (i16)prot);
+  return p.deconvolve(in, n_in, out) ? 0 : -1;
+}
+int ref_uep_deconvolve(int kbps, int prot, const int16_t * in, int n_in, uint8_t * out)
+{
+  UepProtection p((i16)kbps, (i16)prot);
+  return p.deconvolve(in, n_in, out) ? 0 : -1;
+}
+
+int ref_rs_dec(const uint8_t * in120, uint8_t * out110)   // reed_solomon.h:28, params mp4processor.cpp:63,203
+{
+  static ReedSolomon rs(8, 0435, 0, 1, 10);
+  return rs.dec(in120, out110, 135);
+}
+void ref_rs_enc(const uint8_t * in110, uint8_t * out120)
+{
+  static ReedSolomon rs(8, 0435, 0, 1, 10);
+  rs.enc(in110, out120, 135);
+}
+
+int ref_firecode_check(const uint8_t * x11)
+{
+  static FirecodeChecker fc;
+  return fc.check(x11) ? 1 : 0;
+}
+int ref_firecode_check_and_correct(uint8_t * x12)
+{
+  static FirecodeChecker fc;
+  return fc.check_and_correct_6bits(x12) ? 1 : 0;
+}
+
+int ref_check_crc_bits(const uint8_t * bits, int n) { return check_CRC_bits(bits, n) ? 1 : 0; }
+int ref_calc_crc(const uint8_t * d, int n) { return calc_crc(d, n); }
+int ref_check_crc_bytes(const uint8_t * d, int n) { return check_crc_bytes(d, n) ? 1 : 0; }
+
+void ref_freq_interleaver(int16_t * out1536)
+{
+  FreqInterleaver f;
+  for (int k = 0; k < 1536; k++) out1536[k] = f.map_k_to_fft_bin((i16)k);
+}
+void ref_phase_table(float * out4096)
+{
+  OpenPhase p;
+  memcpy(out4096, p.mRefTable.data(), sizeof(float) * 4096);
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+/* viterbi.c -- K=7 rate-1/4 Viterbi decoder (oracle; test infrastructure only).
+ * Restates support/viterbi_spiral/viterbi_spiral.cpp:95-126 with the canonical scalar
+ * body viterbi_scalar.h:9-94 (i32 path metrics, no renormalisation, ACS ties -> 0). */
+#include "dab_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static const int kPolys[4] = {109, 79, 83, 109};   /* viterbi_spiral.cpp:132 */
+
+static int parity8(int x)
+{
+  x ^= x >> 4; x ^= x >> 2; x ^= x >> 1;
+  return x & 1;
+}
+
+/* Branch table: viterbi_spiral.cpp:27-37 == 255 * parity((2*i) & poly) (Karn's
+ * partab construction); rebuilt here instead of being listed. */
+static int g_branch[4][32];
+static int g_branch_ready = 0;
+static void build_branch(void)
+{
+  for (int p = 0; p < 4; p++)
+    for (int i = 0; i < 32; i++) g_branch[p][i] = parity8((2 * i) & kPolys[p]) ? 255 : 0;
+  g_branch_ready = 1;
+}
+
+void ora_viterbi(const int16_t *soft, int nbits, uint8_t *out_bits)
+{
+  if (!g_branch_ready) build_branch();
+  const int nsteps = nbits + 6;
+  uint64_t *dec = (uint64_t *)calloc((size_t)nsteps, sizeof(uint64_t));
+  int32_t m1[64], m2[64];
+  int32_t *old = m1, *nw = m2;
+  for (int i = 0; i < 64; i++) old[i] = 1000;      /* viterbi_spiral.cpp:98-101 */
+  old[0] = 0;
+
+  for (int t = 0; t < nsteps; t++) {
+    int sym[4];
+    for (int p = 0; p < 4; p++) {                   /* viterbi_scalar.h:34-40 */
+      int v = (int16_t)(soft[4 * t + p] + 127);
+      if (v < 0) v = 0; else if (v > 255) v = 255;
+      sym[p] = v;
+    }
+    uint64_t d = 0;
+    for (int i = 0; i < 32; i++) {                  /* viterbi_scalar.h:9-32 */
+      const int metric = (g_branch[0][i] ^ sym[0]) + (g_branch[1][i] ^ sym[1]) +
+                         (g_branch[2][i] ^ sym[2]) + (g_branch[3][i] ^ sym[3]);
+      const int m_metric = 1020 - metric;
+      const int32_t a0 = old[i] + metric, a1 = old[i + 32] + m_metric;
+      const int32_t a2 = old[i] + m_metric, a3 = old[i + 32] + metric;
+      const int d0 = (a0 - a1) > 0, d1 = (a2 - a3) > 0;
+      nw[2 * i] = d0 ? a1 : a0;
+      nw[2 * i + 1] = d1 ? a3 : a2;
+      d |= (uint64_t)(d0 | (d1 << 1)) << (2 * i);
+    }
+    dec[t] = d;
+    int32_t *tmp = old; old = nw; nw = tmp;
+  }
+
+  /* chain back: viterbi_spiral.cpp:114-125 (endstate kept as 8 bits there, >>2 = state) */
+  unsigned endstate = 0;
+  for (int fb = nbits - 1; fb >= 0; fb--) {
+    const int k = (int)((dec[fb + 6] >> (endstate >> 2)) & 1);
+    endstate = (endstate >> 1) | ((unsigned)k << 7);
+    out_bits[fb] = (uint8_t)k;
+  }
+  free(dec);
+}
+
+/* viterbi_spiral.cpp:128-164 : re-encode and compare against hard decisions */
+void ora_viterbi_ber(const int16_t *soft, const uint8_t *punct, const uint8_t *bits,
+                     int nbits, int *io_bits, int *io_errors)
+{
+  int sr = 0;
+  for (int i = 0; i < nbits + 6; i++) {
+    sr = ((sr << 1) | (i < nbits ? bits[i] : 0)) & 0xff;
+    for (int j = 0; j < 4; j++) {
+      const int b = parity8(sr & kPolys[j]);
+      if (punct[i * 4 + j]) {
+        (*io_bits)++;
+        if ((soft[i * 4 + j] > 0) != b) (*io_errors)++;
+      }
+    }
+  }
+}

@@ -1,0 +1,144 @@
+"""ctypes access to the CPU oracle (oracle/_build/liboracle.so) and, when built, to the genuine
+reference leaf objects (oracle/_ref/libdabref.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORA_DIR = os.path.join(ROOT, "oracle")
+ORA_SO = os.path.join(ORA_DIR, "_build", "liboracle.so")
+REF_SO = os.path.join(ORA_DIR, "_ref", "libdabref.so")
+
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_c64p = np.ctypeslib.ndpointer(np.complex64, flags="C_CONTIGUOUS")
+
+
+class SubchDesc(C.Structure):
+    _fields_ = [("subch_id", C.c_int), ("cu_start", C.c_int), ("cu_size", C.c_int),
+                ("kbps", C.c_int), ("prot_level", C.c_int), ("short_form", C.c_int)]
+
+
+class RxCapture(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("fibs", C.POINTER(C.c_uint8)), ("fib_crc", C.POINTER(C.c_uint8)),
+                ("soft", C.POINTER(C.c_int16)), ("start_idx", C.POINTER(C.c_int32)),
+                ("fbb", C.POINTER(C.c_float)), ("sym0_pos", C.POINTER(C.c_int32))]
+
+
+def build_oracle():
+    if not os.path.exists(ORA_SO) or any(
+            os.path.getmtime(os.path.join(ORA_DIR, f)) > os.path.getmtime(ORA_SO)
+            for f in os.listdir(ORA_DIR) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", ORA_DIR], stdout=subprocess.DEVNULL)
+    return ORA_SO
+
+
+_ora = None
+_ref = None
+
+
+def oracle():
+    global _ora
+    if _ora is not None:
+        return _ora
+    L = C.CDLL(build_oracle())
+    L.ora_pi_codes.restype = C.POINTER(C.c_int8)
+    L.ora_pi_codes.argtypes = [C.c_int]
+    L.ora_freq_interleaver.argtypes = [_i16p]
+    L.ora_phase_table.argtypes = [_c64p]
+    L.ora_prbs.argtypes = [_u8p, C.c_int]
+    L.ora_viterbi.argtypes = [_i16p, C.c_int, _u8p]
+    L.ora_viterbi_ber.argtypes = [_i16p, _u8p, _u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for f in (L.ora_eep_map, L.ora_uep_map):
+        f.argtypes = [C.c_int, C.c_int, _i32p]
+        f.restype = C.c_int
+    L.ora_fic_map.argtypes = [_i32p]
+    L.ora_fic_map.restype = C.c_int
+    L.ora_deconvolve.argtypes = [_i16p, _i32p, C.c_int, _u8p]
+    L.ora_check_crc_bits.argtypes = [_u8p, C.c_int]
+    L.ora_calc_crc.argtypes = [_u8p, C.c_int]
+    L.ora_calc_crc.restype = C.c_uint16
+    L.ora_check_crc_bytes.argtypes = [_u8p, C.c_int]
+    L.ora_firecode_check.argtypes = [_u8p]
+    L.ora_firecode_check_and_correct.argtypes = [_u8p]
+    L.ora_firecode_syndrome_table.restype = C.POINTER(C.c_uint16)
+    L.ora_rs_dec.argtypes = [_u8p, _u8p]
+    L.ora_rs_enc.argtypes = [_u8p, _u8p]
+    L.ora_fft2048.argtypes = [_c64p, _c64p, C.c_int]
+    L.ora_rx_create.restype = C.c_void_p
+    L.ora_rx_create.argtypes = [C.POINTER(SubchDesc), C.c_int]
+    L.ora_rx_destroy.argtypes = [C.c_void_p]
+    L.ora_rx_run.argtypes = [C.c_void_p, _c64p, C.c_size_t, C.c_int]
+    L.ora_rx_enable_soft_capture.argtypes = [C.c_void_p, C.c_int]
+    L.ora_rx_get_capture.restype = C.POINTER(RxCapture)
+    L.ora_rx_get_capture.argtypes = [C.c_void_p]
+    L.ora_rx_backend.restype = C.c_void_p
+    L.ora_rx_backend.argtypes = [C.c_void_p, C.c_int]
+    _ora = L
+    return L
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is not None:
+        return _ref
+    L = C.CDLL(REF_SO)
+    L.ref_viterbi.argtypes = [_i16p, C.c_int, _u8p]
+    L.ref_viterbi_ber.argtypes = [_i16p, _u8p, _u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ref_pi_codes.argtypes = [C.c_int, _i8p]
+    for f in (L.ref_eep_map, L.ref_uep_map):
+        f.argtypes = [C.c_int, C.c_int, _i32p]
+    for f in (L.ref_eep_deconvolve, L.ref_uep_deconvolve):
+        f.argtypes = [C.c_int, C.c_int, _i16p, C.c_int, _u8p]
+    L.ref_rs_dec.argtypes = [_u8p, _u8p]
+    L.ref_rs_enc.argtypes = [_u8p, _u8p]
+    L.ref_firecode_check.argtypes = [_u8p]
+    L.ref_firecode_check_and_correct.argtypes = [_u8p]
+    L.ref_check_crc_bits.argtypes = [_u8p, C.c_int]
+    L.ref_calc_crc.argtypes = [_u8p, C.c_int]
+    L.ref_check_crc_bytes.argtypes = [_u8p, C.c_int]
+    L.ref_freq_interleaver.argtypes = [_i16p]
+    L.ref_phase_table.argtypes = [_f32p]
+    _ref = L
+    return L
+
+
+# ---- small numpy-facing wrappers around the oracle -------------------------------------------
+
+def ora_viterbi(soft, nbits):
+    out = np.zeros(nbits, np.uint8)
+    oracle().ora_viterbi(np.ascontiguousarray(soft, np.int16), nbits, out)
+    return out
+
+
+def ora_eep_map(kbps, prot):
+    m = np.zeros(96 * kbps + 24, np.int32)
+    n = oracle().ora_eep_map(kbps, prot, m)
+    return n, m
+
+
+def ora_uep_map(kbps, prot):
+    m = np.zeros(96 * kbps + 24, np.int32)
+    n = oracle().ora_uep_map(kbps, prot, m)
+    return n, m
+
+
+def ora_fic_map():
+    m = np.zeros(3096, np.int32)
+    n = oracle().ora_fic_map(m)
+    return n, m
+
+
+def ora_fft(x, inverse=False):
+    out = np.zeros(2048, np.complex64)
+    oracle().ora_fft2048(np.ascontiguousarray(x, np.complex64), out, 1 if inverse else 0)
+    return out
