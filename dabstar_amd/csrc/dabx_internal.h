@@ -1,0 +1,56 @@
+// dabx_internal.h -- shared declarations of libdabx (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/dabx.h"
+
+namespace dabx {
+
+constexpr int L = 76, K = 1536, TN = 2656, TF = 196608, TS = 2552, TU = 2048, TG = 504;
+constexpr int K2 = 3072, FIC_IN = 2304, FIC_OUT = 768, CIF_BITS = 55296, INPUT_RATE = 2048000;
+constexpr int MAX_SUBCH = 64;
+constexpr int TDI_SLOTS = 32;          // time-deinterleaver ring depth in CIFs (16 history + 4 new, pow2)
+constexpr uint16_t PUNCT = 0xFFFF;     // depuncture map entry of a punctured mother-code bit
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define DABX_HIP(x)                                                                  \
+  do {                                                                               \
+    hipError_t e__ = (x);                                                            \
+    if (e__ != hipSuccess) return dabx::hip_fail(e__, #x, __FILE__, __LINE__);       \
+  } while (0)
+
+// ---- constant tables resident in HBM (one set per device) ---------------------------------------
+struct DevTables {
+  uint16_t *perm_bin;       // [1536] carrier k -> FFT bin (0..2047)                 freq_interleaver.cpp:40-76
+  int16_t *perm_rel;        // [1536] realCarrRelIdx                                   ofdm_decoder.cpp:171-179
+  float2 *prs_ref;          // [2048] phase reference symbol                           phasetable.cpp:87-101
+  float2 *prs_arg_conj;     // [2048] conj(IFFT(relative phase of PRS))                phasereference.cpp:58-66
+  float2 *twiddle;          // [2048] e^{-j 2 pi i / 2048}, computed in double
+  uint16_t *fic_map;        // [3096]                                                  fic_decoder.cpp:79-124
+  uint32_t *prbs_words;     // [288] PRBS packed MSB-first per byte, little-endian words
+  uint16_t *fc_syndrome;    // [65536] fire-code burst table                           firecode_checker.cpp:61-144
+  uint16_t *fc_crctab;      // [256] CRC table poly 0x782F
+  uint16_t *crc_ccitt;      // [256] CRC table poly 0x1021
+  uint8_t *gf_exp;          // [512] alpha^i (doubled), [255] = 0 handled in code
+  uint8_t *gf_log;          // [256]
+};
+int get_tables(const DevTables **out);          // for the current device; builds on first use
+
+// depuncture map of an MSC profile, cached per device. *n_in = #transmitted bits (cu_size*64).
+int get_profile_map(int kbps, int prot_level, int short_form, const uint16_t **dev_map, int *n_in);
+// host-side builders (tables.cpp)
+int host_profile_map(int kbps, int prot_level, int short_form, std::vector<uint16_t> &map, int *n_in);
+void host_fic_map(std::vector<uint16_t> &map);
+
+// ---- kernel launchers (device pointers, asynchronous on `st`) -------------------------------------
+// viterbi.hip
+int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits_1perbyte, hipStream_t st);
+int launch_deconvolve_i16(const int16_t *in, int in_stride, const uint16_t *map, int nbits, int batch,
+                          uint8_t *bits_1perbyte, hipStream_t st);
+int viterbi_scratch_bytes_per_trellis(int nbits);
+
+}  // namespace dabx

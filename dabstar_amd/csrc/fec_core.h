@@ -1,0 +1,145 @@
+// fec_core.h -- device functions: CRC-16, DAB+ fire code, RS(120,110) over GF(2^8).
+// Integer/byte work, one lane per code word / header; tables are read through L1/L2 (<= 130 KB total).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dabx {
+
+// check_crc_bytes / calc_crc (base/backend/crc.cpp:75-96): CRC-16-CCITT, init 0xFFFF, complemented
+__device__ __forceinline__ uint16_t crc16_ccitt(const uint8_t *d, int len, const uint16_t *tab)
+{
+  uint16_t crc = 0xFFFF;
+  for (int i = 0; i < len; i++) crc = (uint16_t)(tab[(d[i] ^ (crc >> 8)) & 0xFF] ^ (crc << 8));
+  return (uint16_t)~crc;
+}
+__device__ __forceinline__ bool crc16_check_bytes(const uint8_t *msg, int len, const uint16_t *tab)
+{
+  return crc16_ccitt(msg, len, tab) == (uint16_t)((msg[len] << 8) | msg[len + 1]);
+}
+
+// FirecodeChecker::crc16 (base/backend/firecode_checker.cpp:146-160): bytes 2..10 then 0..1
+template <class Get> __device__ __forceinline__ uint16_t firecode_syndrome(Get get, const uint16_t *fctab)
+{
+  uint16_t crc = 0;
+#pragma unroll
+  for (int i = 2; i < 11; i++) crc = (uint16_t)((crc << 8) ^ fctab[(crc >> 8) ^ get(i)]);
+  crc = (uint16_t)((crc << 8) ^ fctab[(crc >> 8) ^ get(0)]);
+  crc = (uint16_t)((crc << 8) ^ fctab[(crc >> 8) ^ get(1)]);
+  return crc;
+}
+
+// check_and_correct_6bits (firecode_checker.cpp:168-184); x has >= 12 writable bytes
+__device__ __forceinline__ bool firecode_check_and_correct(uint8_t *x, const uint16_t *fctab, const uint16_t *syn)
+{
+  const uint16_t s = firecode_syndrome([&](int i) { return x[i]; }, fctab);
+  if (s == 0) return true;
+  const uint16_t e = syn[s];
+  if (e & 0xFF) {
+    const int bit = e >> 8;
+    x[bit / 8] ^= (uint8_t)((e & 0xFF) >> (bit % 8));
+    x[bit / 8 + 1] ^= (uint8_t)((e & 0xFF) << (8 - (bit % 8)));
+    return true;
+  }
+  return false;
+}
+
+// ---- GF(2^8) helpers in the reference's index ("power") arithmetic, base/backend/galois.cpp:68-142
+struct Gf {
+  const uint8_t *ex;   // [512] alpha^i, doubled so that i+j needs no reduction
+  const uint8_t *lg;   // [256], lg[0] = 255
+  __device__ int mul(int a, int b) const { return (a == 0 || b == 0) ? 0 : ex[lg[a] + lg[b]]; }
+  __device__ int div(int a, int b) const { return a == 0 ? 0 : ex[255 + lg[a] - lg[b]]; }   // divide_poly: b == 0 -> lg = 255
+  __device__ int exp255(int p) const { return p == 255 ? 0 : ex[p]; }                        // power2poly incl. "alpha^-inf"
+};
+__device__ __forceinline__ int modnn(int x) { while (x >= 255) { x -= 255; x = (x >> 8) + (x & 255); } return x; }
+
+// ReedSolomon::dec(in, out, 135) with (8, 0435, 0, 1, 10): base/backend/reed_solomon.cpp:140-439.
+// cw: 120 received bytes (data 110 + parity 10), corrected in place exactly where the reference
+// corrects (including the partial corrections of its failure paths).  Returns #corrected / 0 / -1.
+__device__ inline int rs_decode_120(uint8_t *cw, const Gf &gf)
+{
+  constexpr int NR = 10, NN = 255, PAD = 135;
+  uint8_t syn[NR];
+  int syn_err = 0;
+  for (int r = 0; r < NR; r++) {             // :254-290 Horner; the 135 leading zeros contribute nothing
+    int s = 0;
+    for (int j = 0; j < 120; j++) s = (s == 0) ? cw[j] : (cw[j] ^ gf.ex[gf.lg[s] + r]);
+    syn[r] = (uint8_t)s;
+    syn_err |= s;
+  }
+  if (!syn_err) return 0;
+
+  uint8_t lambda[NR + 1], corr[NR], oldl[NR];   // :296-361 Berlekamp-Massey
+  for (int i = 0; i < NR; i++) { lambda[i] = 0; corr[i] = 0; }
+  lambda[NR] = 0;
+  int Kk = 1, Ll = 0, deg_lambda = 0, error = syn[0];
+  lambda[0] = 1; corr[1] = 1;
+  while (Kk < NR) {
+    for (int i = 0; i < NR; i++) oldl[i] = lambda[i];
+    for (int i = 0; i < NR; i++) lambda[i] ^= (uint8_t)gf.mul(error, corr[i]);
+    if (2 * Ll < Kk && error != 0) {
+      Ll = Kk - Ll;
+      for (int i = 0; i < NR; i++) corr[i] = (uint8_t)gf.div(oldl[i], error);
+    }
+    for (int i = NR - 1; i >= 1; i--) corr[i] = corr[i - 1];
+    corr[0] = 0;
+    error = syn[Kk];
+    for (int i = 1; i <= Kk; i++) error ^= gf.mul(syn[Kk - i], lambda[i]);
+    Kk++;
+  }
+  for (int i = 0; i < NR; i++) lambda[i] ^= (uint8_t)gf.mul(error, corr[i]);
+  for (int i = 0; i < NR; i++) {
+    if (lambda[i] != 0) deg_lambda = i;
+    lambda[i] = gf.lg[lambda[i]];            // to index form; 255 = zero
+  }
+
+  uint8_t work[NR], root_tab[NR], loc_tab[NR];   // :367-402 Chien search over all 255 positions
+  for (int i = 0; i < NR; i++) work[i] = lambda[i];
+  int root_count = 0;
+  for (int i = 1; i <= NN; i++) {
+    int result = 1;
+    for (int j = deg_lambda; j > 0; j--)
+      if (work[j] != NN) { work[j] = (uint8_t)modnn(work[j] + j); result ^= gf.ex[work[j]]; }
+    if (result != 0) continue;
+    if (root_count < NR) { root_tab[root_count] = (uint8_t)i; loc_tab[root_count] = (uint8_t)(i - 1); }
+    root_count++;
+  }
+  if (root_count != deg_lambda) return -1;
+
+  uint8_t omega[NR + 1];                     // :411-439
+  int deg_omega = 0;
+  for (int i = 0; i < NR; i++) {
+    int tmp = 0;
+    for (int j = (deg_lambda < i) ? deg_lambda : i; j >= 0; j--)
+      if (syn[i - j] != 0 && lambda[j] != NN) tmp ^= gf.ex[gf.lg[syn[i - j]] + lambda[j]];
+    if (tmp != 0) deg_omega = i;
+    omega[i] = gf.lg[tmp];
+  }
+  omega[NR] = NN;
+
+  for (int j = root_count - 1; j >= 0; j--) {   // :189-251 Forney
+    const int root = root_tab[j];
+    int num1 = 0;
+    for (int i = deg_omega; i >= 0; i--)
+      if (omega[i] != NN) num1 ^= gf.ex[modnn(omega[i] + (i * root) % NN)];
+    const int num2 = gf.ex[(root * 254) % NN];   // pow_power(root, 254) then * alpha^255 (= 1); root >= 1
+    int den = 0;
+    const int lim = ((deg_lambda < NR - 1) ? deg_lambda : NR - 1) & ~1;
+    for (int i = lim; i >= 0; i -= 2)
+      if (lambda[i + 1] != NN) den ^= gf.ex[modnn(lambda[i + 1] + (i * root) % NN)];
+    if (den == 0) return -1;
+    if (num1 != 0) {
+      if (loc_tab[j] >= NN - NR) root_count--;
+      else {
+        int t2 = modnn(gf.lg[num1] + gf.lg[num2]);
+        t2 = modnn(t2 + NN - gf.lg[den]);
+        const int k = (int)loc_tab[j] - PAD;
+        if (k >= 0) cw[k] ^= gf.ex[t2];      // positions < 135 lie in the virtual zero padding (discarded)
+      }
+    }
+  }
+  return root_count;
+}
+
+}  // namespace dabx

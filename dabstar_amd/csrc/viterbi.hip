@@ -1,0 +1,114 @@
+// viterbi.hip -- stage-level Viterbi / deconvolve kernels (see viterbi_core.h for the algorithm).
+#include "dabx_internal.h"
+#include "viterbi_core.h"
+
+namespace dabx {
+
+struct SrcI16 {                       // ViterbiSpiral::deconvolve input: 4*(n+6) int16, already depunctured
+  const int16_t *soft;
+  __device__ VitSyms operator()(int t) const
+  {
+    const short4 v = *reinterpret_cast<const short4 *>(soft + 4 * t);
+    return {vit_sym_from_i16(v.x), vit_sym_from_i16(v.y), vit_sym_from_i16(v.z), vit_sym_from_i16(v.w)};
+  }
+};
+
+struct SrcI16Map {                    // Protection::deconvolve input: punctured int16 + depuncture map
+  const int16_t *in;
+  const uint16_t *map;
+  __device__ int one(uint16_t idx) const { return vit_sym_from_i16(idx == PUNCT ? (int16_t)0 : in[idx]); }
+  __device__ VitSyms operator()(int t) const
+  {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
+    return {one(m.x), one(m.y), one(m.z), one(m.w)};
+  }
+};
+
+template <class Src>
+__device__ __forceinline__ void viterbi_wave_to_packed(const Src &src, int nbits, char *wtab, uint32_t *dec,
+                                                       uint32_t *out_words, int lane)
+{
+  const VitLaneConst k = vit_lane_const(lane);
+  vit_forward(src, nbits + 6, wtab, dec, lane, k);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);     // decision stores of this wave have left the CU before they are re-read
+  vit_traceback(dec, nbits, lane, [&](int wi, unsigned v) { if (lane == 0) out_words[wi] = v; });
+}
+
+__global__ __launch_bounds__(256) void k_viterbi_i16(const int16_t *soft, int nbits, int batch, uint32_t *dec,
+                                                     uint32_t *packed, int words_per)
+{
+  __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + wave;
+  if (job >= batch) return;
+  SrcI16 src{soft + (size_t)job * 4 * (nbits + 6)};
+  viterbi_wave_to_packed(src, nbits, wtab[wave], dec + (size_t)job * vit_scratch_words(nbits),
+                         packed + (size_t)job * words_per, lane);
+}
+
+__global__ __launch_bounds__(256) void k_deconvolve_i16(const int16_t *in, int in_stride, const uint16_t *map, int nbits,
+                                                        int batch, uint32_t *dec, uint32_t *packed, int words_per)
+{
+  __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + wave;
+  if (job >= batch) return;
+  SrcI16Map src{in + (size_t)job * in_stride, map};
+  viterbi_wave_to_packed(src, nbits, wtab[wave], dec + (size_t)job * vit_scratch_words(nbits),
+                         packed + (size_t)job * words_per, lane);
+}
+
+// packed (MSB-first bytes) -> one bit per byte, as the reference's output convention
+__global__ void k_unpack_bits(const uint32_t *packed, int words_per, int nbits, int batch, uint8_t *bits)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)batch * nbits) return;
+  const int job = (int)(i / nbits), q = (int)(i % nbits);
+  const uint8_t *b = reinterpret_cast<const uint8_t *>(packed + (size_t)job * words_per);
+  bits[i] = (b[q >> 3] >> (7 - (q & 7))) & 1;
+}
+
+int viterbi_scratch_bytes_per_trellis(int nbits) { return (int)(vit_scratch_words(nbits) * 4); }
+
+static int run_packed_then_unpack(int nbits, int batch, uint8_t *bits, hipStream_t st,
+                                  void (*launch)(uint32_t *, uint32_t *, int, void *), void *ctx)
+{
+  const int words_per = (nbits + 31) / 32;
+  uint32_t *dec = nullptr, *packed = nullptr;
+  DABX_HIP(hipMalloc(&dec, vit_scratch_words(nbits) * 4 * (size_t)batch));
+  DABX_HIP(hipMalloc(&packed, (size_t)words_per * 4 * batch));
+  launch(dec, packed, words_per, ctx);
+  const size_t total = (size_t)batch * nbits;
+  hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed, words_per, nbits,
+                     batch, bits);
+  DABX_HIP(hipGetLastError());
+  DABX_HIP(hipStreamSynchronize(st));
+  DABX_HIP(hipFree(dec));
+  DABX_HIP(hipFree(packed));
+  return 0;
+}
+
+int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits, hipStream_t st)
+{
+  struct Ctx { const int16_t *soft; int nbits, batch; hipStream_t st; } c{soft, nbits, batch, st};
+  return run_packed_then_unpack(nbits, batch, bits, st, [](uint32_t *dec, uint32_t *packed, int wp, void *p) {
+    auto *c = (Ctx *)p;
+    hipLaunchKernelGGL(k_viterbi_i16, dim3((c->batch + 3) / 4), dim3(256), 0, c->st, c->soft, c->nbits, c->batch, dec,
+                       packed, wp);
+  }, &c);
+}
+
+int launch_deconvolve_i16(const int16_t *in, int in_stride, const uint16_t *map, int nbits, int batch, uint8_t *bits,
+                          hipStream_t st)
+{
+  struct Ctx { const int16_t *in; int stride; const uint16_t *map; int nbits, batch; hipStream_t st; }
+      c{in, in_stride, map, nbits, batch, st};
+  return run_packed_then_unpack(nbits, batch, bits, st, [](uint32_t *dec, uint32_t *packed, int wp, void *p) {
+    auto *c = (Ctx *)p;
+    hipLaunchKernelGGL(k_deconvolve_i16, dim3((c->batch + 3) / 4), dim3(256), 0, c->st, c->in, c->stride, c->map,
+                       c->nbits, c->batch, dec, packed, wp);
+  }, &c);
+}
+
+}  // namespace dabx

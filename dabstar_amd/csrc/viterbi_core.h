@@ -1,0 +1,199 @@
+// viterbi_core.h -- K=7 rate-1/4 Viterbi decoder, one wavefront (64 lanes) per trellis.
+//
+// Replaces ViterbiSpiral::deconvolve (base/support/viterbi_spiral/viterbi_spiral.cpp:95-126, canonical
+// scalar body viterbi_scalar.h:9-94) with a CDNA4 formulation that is bit-identical to it:
+//
+//  * lane = trellis state, in-place butterflies.  At step t lane j holds state rotl6(j, t mod 6), so the
+//    butterfly partner (state ^ 32) is always lane j ^ (1 << ((5 - t) mod 6)): the exchange is a DPP
+//    quad_perm / row_ror or a ds_swizzle, never a general permutation, and no metric ever moves.
+//  * path metrics are kept doubled and centred: the reference adds metric / (1020 - metric) with
+//    metric = sum(Branch ^ sym); subtracting the common 510 and doubling gives w = sum(+-(2 sym - 255)),
+//    so both branches are own + w and partner - w.  Decisions depend only on metric differences and the
+//    tie rule (tie -> predecessor i, not i + 32) is kept, so every decision bit equals the reference's.
+//    int32 metrics, no renormalisation (growth <= 1020 * 9222 < 2^31), exactly like the scalar reference.
+//  * the branch metric has only 8 signed values per step (polynomials 109 and 109 coincide): they are
+//    computed once per step by the lane that fetched the step's 4 symbols and parked in LDS; each lane
+//    then reads its own value with one ds_read_i16.
+//  * decision bits are accumulated per lane (acc = 2 acc + d) and streamed to an HBM/L2-resident scratch
+//    as one coalesced 256-B store per 30 steps, so LDS does not limit occupancy.  Chain-back runs on the
+//    scalar unit: the lane index of the surviving path is a wave-uniform value, each step is one
+//    v_readlane plus a few SALU ops, and the per-step exchange bit is the only bit of it that changes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dabx {
+
+constexpr int VIT_BLK = 60;   // trellis steps per LDS block (multiple of 6, <= 64)
+constexpr int VIT_DW = 30;    // steps per 32-bit decision word (multiple of 6, <= 32)
+
+__host__ __device__ inline int vit_words(int nbits) { return (nbits + 6 + VIT_DW - 1) / VIT_DW; }
+__host__ __device__ inline int vit_blocks(int nbits) { return (nbits + 6 + VIT_BLK - 1) / VIT_BLK; }
+// decision scratch per trellis: u32[vit_blocks*2][64]
+__host__ __device__ inline size_t vit_scratch_words(int nbits) { return (size_t)vit_blocks(nbits) * 2 * 64; }
+
+struct VitSyms { int x0, x1, x2, x3; };   // 2*sym - 255 of the step's four soft symbols
+
+__device__ __forceinline__ int vit_sym_from_i16(int16_t s)
+{
+  // viterbi_scalar.h:34-40: i16 tmp = s; tmp += 127 (wraps); clamp to 0..255
+  int v = (int16_t)(s + 127);
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  return 2 * v - 255;
+}
+__device__ __forceinline__ int vit_sym_from_u8(uint8_t sym) { return 2 * (int)sym - 255; }
+
+__device__ __forceinline__ int rotl6(int x, int c) { return ((x << c) | (x >> (6 - c))) & 63; }
+
+// Byte offset (pattern index * 2) into a step's 8-entry branch-metric row, for lane j in step class c.
+__device__ __forceinline__ int vit_pat_off(int lane, int c)
+{
+  const int i = rotl6(lane, c) & 31;
+  // Branch[p][i] = parity(2i & poly_p): viterbi_spiral.cpp:27-37 with polys 109,79,83,109
+  const int c0 = ((i >> 1) ^ (i >> 2) ^ (i >> 4)) & 1;   // polys 0 and 3
+  const int c1 = (i ^ (i >> 1) ^ (i >> 2)) & 1;          // poly 1
+  const int c2 = (i ^ (i >> 3)) & 1;                     // poly 2
+  return (c0 * 4 + c1 * 2 + c2) * 2;
+}
+
+template <int C> __device__ __forceinline__ int vit_exchange(int m, int bperm_addr32)
+{
+  // partner lane = lane ^ (1 << ((5 - C) % 6))
+  if constexpr (C == 5) return __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, true);        // xor 1  quad_perm [1,0,3,2]
+  else if constexpr (C == 4) return __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, true);   // xor 2  quad_perm [2,3,0,1]
+  else if constexpr (C == 3) return __builtin_amdgcn_ds_swizzle(m, 0x101F);                    // xor 4
+  else if constexpr (C == 2) return __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, true);  // xor 8  row_ror:8
+  else if constexpr (C == 1) return __builtin_amdgcn_ds_swizzle(m, 0x401F);                    // xor 16
+  else return __builtin_amdgcn_ds_bpermute(bperm_addr32, m);                                   // xor 32
+}
+
+struct VitLaneConst {
+  int pat[6];        // LDS byte offset of this lane's branch metric within a step row, per class
+  int bperm32;       // (lane ^ 32) * 4
+};
+
+__device__ __forceinline__ VitLaneConst vit_lane_const(int lane)
+{
+  VitLaneConst k;
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    k.pat[c] = vit_pat_off(lane, c);
+  }
+  k.bperm32 = (lane ^ 32) * 4;
+  return k;
+}
+
+template <int C>
+__device__ __forceinline__ void vit_step(int &m, unsigned &acc, const char *wrow, const VitLaneConst &k)
+{
+  // lanes holding the upper (i+32) predecessor in class C: bit (5 - C) % 6 of the lane index is set
+  constexpr unsigned long long UM = C == 0 ? 0xFFFFFFFF00000000ull : C == 1 ? 0xFFFF0000FFFF0000ull
+                                  : C == 2 ? 0xFF00FF00FF00FF00ull : C == 3 ? 0xF0F0F0F0F0F0F0F0ull
+                                  : C == 4 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;
+  const int w = *reinterpret_cast<const int16_t *>(wrow + k.pat[C]);
+  const int partner = vit_exchange<C>(m, k.bperm32);
+  const int co = m + w, cp = partner - w;
+  // decision = (value through predecessor i) > (value through predecessor i+32), viterbi_scalar.h:25-26;
+  // a lower lane owns predecessor i (co), an upper lane owns predecessor i+32.
+  const unsigned long long gt = __builtin_amdgcn_ballot_w64(co > cp);
+  const unsigned long long lt = __builtin_amdgcn_ballot_w64(cp > co);
+  const unsigned long long dm = (gt & ~UM) | (lt & UM);
+  m = co < cp ? co : cp;
+  // acc = 2*acc + decision: one VALU op with the decision mask as carry-in
+  asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(acc) : "v"(acc), "s"(dm) : "vcc");
+}
+
+// Forward pass.  wtab: this wave's LDS area, VIT_BLK rows of 8 int16.  dec: u32[vit_blocks*2][64].
+template <class Src>
+__device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wtab, uint32_t *dec, int lane,
+                                            const VitLaneConst &k)
+{
+  int m = lane == 0 ? 0 : 2000;                 // viterbi_spiral.cpp:98-101 (0 / 1000), doubled
+  const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
+  for (int b = 0; b < nblk; b++) {
+    if (lane < VIT_BLK) {
+      const int t = b * VIT_BLK + lane;
+      VitSyms s = {0, 0, 0, 0};
+      if (t < nsteps) s = src(t);
+      const int y0 = s.x0 + s.x3;
+      short v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        v[q] = (short)(((q & 4) ? -y0 : y0) + ((q & 2) ? -s.x1 : s.x1) + ((q & 1) ? -s.x2 : s.x2));
+      int4 pk;
+      pk.x = (unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
+      pk.y = (unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16);
+      pk.z = (unsigned short)v[4] | ((unsigned)(unsigned short)v[5] << 16);
+      pk.w = (unsigned short)v[6] | ((unsigned)(unsigned short)v[7] << 16);
+      *reinterpret_cast<int4 *>(wtab + lane * 16) = pk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned acc = 0;
+#pragma unroll
+    for (int h = 0; h < VIT_BLK / VIT_DW; h++) {
+#pragma unroll
+      for (int s6 = 0; s6 < VIT_DW; s6 += 6) {
+        const char *row = wtab + (h * VIT_DW + s6) * 16;
+        vit_step<0>(m, acc, row + 0 * 16, k);
+        vit_step<1>(m, acc, row + 1 * 16, k);
+        vit_step<2>(m, acc, row + 2 * 16, k);
+        vit_step<3>(m, acc, row + 3 * 16, k);
+        vit_step<4>(m, acc, row + 4 * 16, k);
+        vit_step<5>(m, acc, row + 5 * 16, k);
+      }
+      dec[(size_t)(b * (VIT_BLK / VIT_DW) + h) * 64 + lane] = acc;
+      acc = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Chain-back (viterbi_spiral.cpp:114-125) in lane space.  Emits decoded bits MSB-first packed into
+// little-endian 32-bit words through `emit(word_index, value)` (called wave-uniformly, highest word first).
+template <class Emit>
+__device__ __forceinline__ void vit_traceback(const uint32_t *dec, int nbits, int lane, Emit emit)
+{
+  const int nsteps = nbits + 6;
+  int j = 0;                                   // lane of the terminal state 0
+  unsigned outw = 0;
+  int wi = (nsteps - 1) / VIT_DW;
+  unsigned hist = dec[(size_t)wi * 64 + lane];
+  // top (possibly partial) word
+  {
+    const unsigned nxt = wi > 0 ? dec[(size_t)(wi - 1) * 64 + lane] : 0u;
+    for (int s = (nsteps - 1) - wi * VIT_DW; s >= 0; --s) {
+      const int t = wi * VIT_DW + s;
+      const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, j);
+      const int kbit = (hv >> (VIT_DW - 1 - s)) & 1;
+      const int q = t - 6;
+      if (q >= 0) {
+        outw |= (unsigned)kbit << (((q >> 3) & 3) * 8 + 7 - (q & 7));
+        if ((q & 31) == 0) { emit(q >> 5, outw); outw = 0; }
+      }
+      const int p = (5 - (s % 6)) % 6;
+      j = (j & ~(1 << p)) | (kbit << p);
+    }
+    hist = nxt;
+    --wi;
+  }
+  for (; wi >= 0; --wi) {
+    const unsigned nxt = wi > 0 ? dec[(size_t)(wi - 1) * 64 + lane] : 0u;
+    const int tb = wi * VIT_DW;
+#pragma unroll
+    for (int s = VIT_DW - 1; s >= 0; --s) {
+      const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, j);
+      const int kbit = (hv >> (VIT_DW - 1 - s)) & 1;
+      const int q = tb + s - 6;
+      if (q >= 0) {
+        outw |= (unsigned)kbit << (((q >> 3) & 3) * 8 + 7 - (q & 7));
+        if ((q & 31) == 0) { emit(q >> 5, outw); outw = 0; }
+      }
+      const int p = (5 - (s % 6)) % 6;
+      j = (j & ~(1 << p)) | (kbit << p);
+    }
+    hist = nxt;
+  }
+}
+
+}  // namespace dabx

@@ -1,0 +1,170 @@
+/*
+ * dabx.h -- C ABI of libdabx: MI355X-native OFDM-demodulation + FEC back end for DAB/DAB+ Mode I.
+ *
+ * Drop-in boundary for the one hot path of tomneda/DABstar (reference tree /root/reference, paths
+ * below relative to its src/).  The reference has no FFI seam: the seam is the C++ class surface
+ * OfdmDecoder / FicDecoder / MscHandler selected at compile time (base/main/dab_processor.h:53-57
+ * picks ofdm_decoder_simd.h or ofdm_decoder.h).  A HIP back end enters as a third alternative; the
+ * functions below are what that alternative binds to (see INTEGRATION.md for the C++ stub).
+ *
+ * Conventions: extern "C", plain pointers and sizes, int return codes (0 = ok, <0 = dabx_err),
+ * caller-allocated buffers, no exceptions cross the boundary, one caller thread per handle.
+ * Functions ending in _dev take DEVICE pointers (HBM-resident batches); all others take HOST
+ * pointers and stage through the device themselves.  There is no CPU fallback: every entry point
+ * fails with DABX_E_NODEVICE when no HIP device is usable.
+ */
+#ifndef DABX_H
+#define DABX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DABX_ABI_VERSION 1
+
+typedef enum {
+  DABX_OK = 0,
+  DABX_E_NODEVICE = -1,   /* no usable HIP device / kernel image not loadable */
+  DABX_E_ARG = -2,        /* bad argument */
+  DABX_E_PROFILE = -3,    /* illegal (bit rate, protection level) combination */
+  DABX_E_HIP = -4,        /* HIP runtime error (see dabx_last_error) */
+  DABX_E_STATE = -5,      /* call not valid in this state */
+  DABX_E_NOMEM = -6
+} dabx_err;
+
+/* Mode-I constants, common/glob_defs.h:40-55 */
+enum { DABX_L = 76, DABX_K = 1536, DABX_TN = 2656, DABX_TF = 196608, DABX_TS = 2552, DABX_TU = 2048,
+       DABX_TG = 504, DABX_2K = 3072, DABX_FIC_IN = 2304, DABX_FIC_OUT = 768, DABX_CIF_BITS = 55296 };
+
+typedef struct { float re, im; } dabx_cf32;
+
+const char *dabx_last_error(void);
+int dabx_abi_version(void);
+/* Selects the HIP device for the calling thread's subsequent dabx calls (default 0). */
+int dabx_set_device(int device);
+int dabx_device_count(void);
+
+/* ===================================================================================== stage level
+ * Each entry mirrors one reference function; batch = number of independent problems.           */
+
+/* ViterbiSpiral::deconvolve (base/support/viterbi_spiral/viterbi_spiral.h:20, .cpp:95-126):
+ * soft  : batch x 4*(nbits+6) int16 mother-code soft bits (0 at punctured positions)
+ * bits  : batch x nbits bytes, one decoded bit per byte.  Canonical scalar tie rule. */
+int dabx_viterbi(const int16_t *soft, int nbits, int batch, uint8_t *bits);
+
+/* Protection::deconvolve for EEP/UEP (base/protection/protection.h:44; eep_protection.cpp:43-167,
+ * uep_protection.cpp:52-212): in = batch x cu_size*64 punctured soft bits; out = batch x 24*kbps bits
+ * (one per byte, NOT yet de-dispersed).  short_form != 0 selects the UEP table. */
+int dabx_deconvolve(const int16_t *in, int in_stride, int kbps, int prot_level, int short_form, int batch,
+                    uint8_t *bits);
+/* Size in soft bits (cu_size*64) of a legal profile, or DABX_E_PROFILE. */
+int dabx_profile_input_bits(int kbps, int prot_level, int short_form);
+
+/* FicDecoder::process_block x3 (base/decoder/fic_decoder.h:49, .cpp:143-262): soft = batch x 9216
+ * int16 (OFDM symbols 1..3); fibs = batch x 12 x 32 bytes (packed, de-dispersed);
+ * crc_ok = batch x 12 flags. */
+int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_ok);
+
+/* ReedSolomon::dec(in, out, 135) with (8,0435,0,1,10) (base/backend/reed_solomon.h:28, mp4processor.cpp:63,203):
+ * in = batch x 120, out = batch x 110, ret = batch x int16 (#corrected | 0 | -1). */
+int dabx_rs_decode(const uint8_t *in, int batch, uint8_t *out, int16_t *ret);
+
+/* FirecodeChecker::check / check_and_correct_6bits (base/backend/firecode_checker.h:42-43):
+ * x = batch x 12 bytes (11 used; byte 11 may be touched exactly as in the reference), ok = batch flags */
+int dabx_firecode_check(const uint8_t *x, int batch, uint8_t *ok);
+int dabx_firecode_check_and_correct(uint8_t *x, int batch, uint8_t *ok);
+
+/* check_crc_bytes (base/backend/crc.cpp:88-96): msgs = batch x stride bytes, CRC follows len bytes */
+int dabx_crc16_check(const uint8_t *msgs, int stride, int len, int batch, uint8_t *ok);
+
+/* fftwf_execute of the 2048-point forward/backward plan (base/main/dab_processor.cpp:63,201;
+ * ofdm/phasereference.cpp:51-52): unnormalised DFT, batch x 2048 cf32. */
+int dabx_fft2048(const dabx_cf32 *in, int batch, int inverse, dabx_cf32 *out);
+
+/* OfdmDecoder (base/ofdm/ofdm_decoder.h:46-73) -- opaque per-stream demapper state on the device. */
+typedef struct dabx_demap dabx_demap;
+int dabx_demap_create(int batch, dabx_demap **out);
+void dabx_demap_destroy(dabx_demap *d);
+int dabx_demap_reset(dabx_demap *d);                                              /* reset()  :90-101  */
+int dabx_demap_store_reference_symbol_0(dabx_demap *d, const dabx_cf32 *fft);     /* :132-145 batch x 2048 */
+int dabx_demap_store_null_symbol_without_tii(dabx_demap *d, const dabx_cf32 *fft);/* :114-130 */
+/* decode_symbol :147-355 for n_sym consecutive symbols: fft = batch x n_sym x 2048,
+ * clock_err = batch floats, soft = batch x n_sym x 3072 int16. */
+int dabx_demap_decode_symbols(dabx_demap *d, const dabx_cf32 *fft, int n_sym, const float *clock_err, int16_t *soft);
+int dabx_demap_set_soft_bit_gen_type(dabx_demap *d, int type /*1..3*/);
+
+/* PhaseReference::correlate_with_phase_ref_and_find_max_peak (base/ofdm/phasereference.cpp:87-213):
+ * v = batch x 2048 cf32, returns start index per problem (or -1). */
+int dabx_prs_correlate(const dabx_cf32 *v, int batch, float threshold, int strongest, int32_t *start_index);
+/* PhaseReference::estimate_carrier_offset_from_sync_symbol_0 (:223-280): fft = batch x 2048 */
+int dabx_coarse_cfo(const dabx_cf32 *fft_sym0, int batch, int32_t *hz);
+
+/* ===================================================================================== engine level
+ * Stream-batched receiver: the device-side equivalent of DabProcessor::run
+ * (base/main/dab_processor.cpp:110-442) for n_streams independent ensembles.                   */
+typedef struct dabx_engine dabx_engine;
+
+typedef struct {
+  int32_t n_streams;        /* independent ensembles resident on this GPU */
+  int32_t ring_frames;      /* IQ ring capacity per stream in units of T_F samples (>= 2) */
+  int32_t max_subch;        /* sub-channels decoded per stream (<= 64) */
+  int32_t out_frames;       /* output ring depth in frames (>= 1) */
+  float   sync_threshold;   /* ProcessParams::threshold, main/dabradio.cpp:92 (3.0) */
+  int32_t sync_strongest;   /* configuration.cpp:65 default 0 */
+  int32_t soft_bit_type;    /* glob_enums.h:49-56, default 1 (SOFTDEC1) */
+  int32_t fic_only;         /* 1: BASELINE config 2 (FIC Viterbi only) */
+  int32_t capture_soft;     /* 1: keep int16 soft bits of the last frame (debug / parity tests) */
+  int32_t reserved[7];
+} dabx_config;
+
+/* SDescriptorType subset (common/dab_constants.h:119-135) */
+typedef struct {
+  int32_t subch_id, cu_start, cu_size, kbps, prot_level /* +4 => EEP-B */, short_form /* 1 = UEP */;
+  int32_t dab_plus;          /* 1: run super-frame sync + RS(120,110) (Mp4Processor) */
+  int32_t reserved;
+} dabx_subch_desc;
+
+typedef struct {
+  int64_t frames;            /* frames demodulated since open */
+  int64_t samples_consumed;
+  int32_t state;             /* 0 wait-for-dip, 1 eval-sync, 2 in-frame */
+  int32_t fic_ratio_percent; /* FicDecoder::get_fic_decode_ratio_percent */
+  float   freq_offs_bb_hz, clock_err_hz, snr_db_est;
+  int32_t last_start_index, cif_count;
+  int64_t fib_ok, fib_total, sf_ok, sf_fail, rs_corrected, rs_failed, au_ok, au_bad, cifs_decoded;
+} dabx_stats;
+
+void dabx_default_config(dabx_config *cfg);
+int  dabx_create(const dabx_config *cfg, dabx_engine **out);
+void dabx_destroy(dabx_engine *e);
+/* MscHandler::set_channel equivalent for stream (or all streams when stream < 0). */
+int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
+/* Host IQ -> device ring (IDeviceHandler::getSamples contract, common/device_handler_if.h:47-48).
+ * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70) */
+int  dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_samples);
+/* Device-resident producers: ring base (cf32, capacity ring_frames*T_F) and commit of n new samples. */
+int  dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *capacity_samples);
+int  dabx_commit_iq(dabx_engine *e, int stream /* <0: all */, size_t n_samples);
+/* Advance every stream by up to max_frames frames (bounded by available samples); returns the number of
+ * batch steps executed.  Asynchronous on the engine's HIP stream unless sync != 0. */
+int  dabx_process(dabx_engine *e, int max_frames, int sync);
+int  dabx_synchronize(dabx_engine *e);
+void *dabx_hip_stream(dabx_engine *e);
+/* Results of the most recent frames (host copies). fibs: n x 12 x 32, crc: n x 12 */
+int  dabx_read_fibs(dabx_engine *e, int stream, int n_frames, uint8_t *fibs, uint8_t *crc_ok);
+/* Decoded logical frames of a sub-channel: n_cifs x 3*kbps bytes, newest last; returns #CIFs valid. */
+int  dabx_read_msc(dabx_engine *e, int stream, int subch_idx, int n_cifs, uint8_t *bytes);
+/* RS-corrected DAB+ super frames (110*kbps/8 bytes each), newest last; returns count copied. */
+int  dabx_read_superframes(dabx_engine *e, int stream, int subch_idx, int n, uint8_t *bytes);
+int  dabx_read_soft(dabx_engine *e, int stream, int16_t *soft /* 75*3072 */);
+int  dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out);
+/* Sum of the counters over all streams of this engine (the values one RCCL all-reduce combines). */
+int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -143,6 +143,9 @@ int  ora_backend_init(ora_backend *b, const ora_subch_desc *d);
 void ora_backend_free(ora_backend *b);
 /* backend/backend.cpp:129-161 ; in = CIF soft bits of this sub-channel (frag i16) */
 void ora_backend_process(ora_backend *b, const int16_t *in);
+const uint8_t *ora_backend_msc_bytes(const ora_backend *b, size_t *len);
+const uint8_t *ora_backend_sf_bytes(const ora_backend *b, size_t *len);
+void ora_backend_stats(const ora_backend *b, long out[8]);
 
 /* ---------------- OFDM front end (ofdm.c) ---------------- */
 void ora_fft2048(const ora_cf32 *in, ora_cf32 *out, int inverse); /* unnormalised DFT */

@@ -134,3 +134,12 @@ void ora_backend_process(ora_backend *b, const int16_t *in)
   b->n_cif_out++;
   mp4_add_to_frame(b, b->outv);
 }
+
+/* accessors for ctypes-based tests */
+const uint8_t *ora_backend_msc_bytes(const ora_backend *b, size_t *len) { *len = b->msc_len; return b->msc_bytes; }
+const uint8_t *ora_backend_sf_bytes(const ora_backend *b, size_t *len) { *len = b->sf_len; return b->sf_bytes; }
+void ora_backend_stats(const ora_backend *b, long out[8])
+{
+  out[0] = b->n_cif_out; out[1] = b->n_sf_ok; out[2] = b->n_sf_fail; out[3] = b->n_rs_corr;
+  out[4] = b->n_rs_fail; out[5] = b->n_fc_corr; out[6] = b->n_au_ok; out[7] = b->n_au_bad;
+}

@@ -79,6 +79,10 @@ def oracle():
     L.ora_rx_get_capture.argtypes = [C.c_void_p]
     L.ora_rx_backend.restype = C.c_void_p
     L.ora_rx_backend.argtypes = [C.c_void_p, C.c_int]
+    for f in (L.ora_backend_msc_bytes, L.ora_backend_sf_bytes):
+        f.restype = C.POINTER(C.c_uint8)
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     _ora = L
     return L
 
@@ -142,3 +146,22 @@ def ora_fft(x, inverse=False):
     out = np.zeros(2048, np.complex64)
     oracle().ora_fft2048(np.ascontiguousarray(x, np.complex64), out, 1 if inverse else 0)
     return out
+
+
+def backend_bytes(rx, i, which="msc"):
+    L = oracle()
+    b = L.ora_rx_backend(rx, i)
+    n = C.c_size_t(0)
+    p = (L.ora_backend_msc_bytes if which == "msc" else L.ora_backend_sf_bytes)(b, C.byref(n))
+    return np.ctypeslib.as_array(p, (n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+
+
+def backend_stats(rx, i):
+    out = (C.c_long * 8)()
+    oracle().ora_backend_stats(oracle().ora_rx_backend(rx, i), out)
+    return dict(zip(["cif_out", "sf_ok", "sf_fail", "rs_corr", "rs_fail", "fc_corr", "au_ok", "au_bad"], list(out)))
+
+
+def make_descs(subch):
+    return (SubchDesc * len(subch))(*[SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form)
+                                      for c in subch])

@@ -1,0 +1,54 @@
+"""GPU parity: HIP Viterbi / deconvolve through the C ABI vs the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from dabstar_amd import lib as dx
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(rng, n, count):
+    m = 4 * (n + 6)
+    rows = [rng.integers(-200, 201, m), rng.integers(-127, 128, m), np.zeros(m), np.full(m, 127), np.full(m, -127),
+            rng.choice([-32768, -32767, 32767, 32640, 32641, -200, 200], m), rng.choice([-127, 0, 127, 128, -128, 1, -1], m)]
+    while len(rows) < count:
+        rows.append(rng.integers(-60, 61, m))
+    return np.array(rows[:count], np.int16)
+
+
+@pytest.mark.parametrize("n", [768, 24 * 8, 24 * 64, 24 * 128, 24 * 320, 40, 7])
+def test_viterbi_matches_oracle(n):
+    rng = np.random.default_rng(n)
+    soft = _cases(rng, n, 9 if n > 4000 else 37)
+    got = dx.viterbi(soft, n)
+    for b in range(soft.shape[0]):
+        assert np.array_equal(got[b], ol.ora_viterbi(soft[b], n)), (n, b)
+
+
+def test_viterbi_encoded_noise():
+    """encode -> noise -> decode returns the message (property, large batch)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from tools import dab_synth as ds
+    rng = np.random.default_rng(1)
+    n, batch = 1536, 512
+    msgs = rng.integers(0, 2, (batch, n)).astype(np.uint8)
+    soft = np.stack([(ds.conv_encode(m).astype(np.int16) * 2 - 1) * 60 for m in msgs])
+    soft = (soft + rng.normal(0, 40, soft.shape)).astype(np.int16)
+    got = dx.viterbi(soft, n)
+    assert np.array_equal(got, msgs)
+    for b in (0, 17, 511):
+        assert np.array_equal(got[b], ol.ora_viterbi(soft[b], n))
+
+
+@pytest.mark.parametrize("kbps,prot,short", [(64, 2, 0), (8, 1, 0), (32, 4, 0), (128, 3, 0), (64, 3, 1), (32, 5, 1), (192, 1, 1)])
+def test_deconvolve_matches_oracle(kbps, prot, short):
+    rng = np.random.default_rng(kbps + prot)
+    n_in, m = (ol.ora_uep_map if short else ol.ora_eep_map)(kbps, prot)
+    soft = rng.integers(-150, 151, (5, n_in)).astype(np.int16)
+    got = dx.deconvolve(soft, kbps, prot, short)
+    for b in range(5):
+        exp = np.zeros(24 * kbps, np.uint8)
+        ol.oracle().ora_deconvolve(soft[b], m, kbps, exp)
+        assert np.array_equal(got[b], exp), (kbps, prot, short, b)

@@ -1,0 +1,338 @@
+"""Synthetic DAB Mode-I ensemble modulator (test/bench infrastructure, numpy only).
+
+Builds what SURVEY.md 8(d) calls the canonical synthetic ensemble: FIC with FIG 0/0 (CIF counter)
++ FIG 0/1 (sub-channel organisation), N sub-channels carrying DAB+ super frames (fire code, AU
+table, AU CRCs, RS(120,110) parity), energy dispersal, K=7 r=1/4 convolutional code with EEP/UEP/FIC
+puncturing, 16-CIF time interleaving, QPSK + frequency interleaving + pi/4-D-QPSK against the phase
+reference symbol, 2048-IFFT + 504 cyclic prefix, 2656-sample null symbol, then a channel (gain, CFO,
+timing offset, AWGN).  Everything follows ETSI EN 300 401 as mirrored by the receiver side of the
+reference (see oracle/ for file:line); the reference itself contains no modulator.
+
+The generated ensemble can be made *cyclic* (time interleaver, super frames and CIF counter wrap
+around) so that a ring buffer of n_frames frames can be replayed forever by the bench.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+L, K, TN, TF, TS, TU, TG = 76, 1536, 2656, 196608, 2552, 2048, 504
+FS = 2048000
+INTERLEAVE_MAP = np.array([0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15])
+POLYS = (109, 79, 83, 109)   # Karn bit order == octal 133,171,145,133
+
+
+# ----------------------------------------------------------------------------- tables
+def pi_code(pi: int) -> np.ndarray:
+    order = [0, 4, 2, 6, 1, 5, 3, 7]
+    base, extra = (pi - 1) // 8 + 1, (pi - 1) % 8 + 1
+    ones = [base] * 8
+    for e in range(extra):
+        ones[order[e]] = base + 1
+    return np.array([[1 if j < ones[g] else 0 for j in range(4)] for g in range(8)], np.uint8).reshape(32)
+
+
+def _blocks(L_, pi):
+    return np.tile(np.tile(pi_code(pi), 4), L_) if L_ > 0 else np.zeros(0, np.uint8)
+
+
+def eep_mask(kbps: int, prot: int) -> np.ndarray:
+    """1 = transmitted, over the 96*kbps+24 mother-code bits (EN 300 401 11.3.2)."""
+    lvl, opt = prot & 3, (prot >> 2) & 1
+    if opt == 0:
+        n = kbps // 8
+        L1, L2, p1, p2 = [(6 * n - 3, 3, 24, 23),
+                          (5, 1, 13, 12) if n == 1 else (2 * n - 3, 4 * n + 3, 14, 13),
+                          (6 * n - 3, 3, 8, 7),
+                          (4 * n - 3, 2 * n + 3, 3, 2)][lvl]
+    else:
+        n = kbps // 32
+        p1 = [10, 6, 4, 2][lvl]
+        L1, L2, p2 = 24 * n - 3, 3, p1 - 1
+    return np.concatenate([_blocks(L1, p1), _blocks(L2, p2), pi_code(8)[:24]])
+
+
+def fic_mask() -> np.ndarray:
+    return np.concatenate([_blocks(21, 16), _blocks(3, 15), pi_code(8)[:24]])
+
+
+def prbs(n: int) -> np.ndarray:
+    sr = [1] * 9
+    out = np.zeros(n, np.uint8)
+    for i in range(n):
+        b = sr[8] ^ sr[4]
+        sr = [b] + sr[:8]
+        out[i] = b
+    return out
+
+
+def freq_perm() -> np.ndarray:
+    t = np.zeros(TU, np.int64)
+    for i in range(1, TU):
+        t[i] = (13 * t[i - 1] + 511) % TU
+    keep = [v - TU // 2 for v in t if v != TU // 2 and 256 <= v <= 256 + K]
+    return np.array(keep, np.int64)
+
+
+_PRS_N_LO = [1, 2, 0, 1, 3, 2, 2, 3, 2, 1, 2, 3, 1, 2, 3, 3, 2, 2, 2, 1, 1, 3, 1, 2]
+_PRS_N_HI = [3, 1, 1, 1, 2, 2, 1, 0, 2, 2, 3, 3, 0, 2, 1, 3, 3, 3, 3, 0, 3, 0, 1, 1]
+_PRS_H = [[0, 2, 0, 0, 0, 0, 1, 1, 2, 0, 0, 0, 2, 2, 1, 1], [0, 3, 2, 3, 0, 1, 3, 0, 2, 1, 2, 3, 2, 3, 3, 0],
+          [0, 0, 0, 2, 0, 2, 1, 3, 2, 2, 0, 2, 2, 0, 1, 3], [0, 1, 2, 1, 0, 3, 3, 2, 2, 3, 2, 1, 2, 1, 3, 2]]
+
+
+def prs_spectrum() -> np.ndarray:
+    """Phase reference symbol in FFT bin order (EN 300 401 14.3.2)."""
+    z = np.zeros(TU, np.complex128)
+    for k in list(range(-768, 0)) + list(range(1, 769)):
+        if k < 0:
+            b = (k + 768) // 32
+            kp, i, n = -768 + 32 * b, b & 3, _PRS_N_LO[b]
+        else:
+            b = (k - 1) // 32
+            kp, i, n = 1 + 32 * b, (4 - (b & 3)) & 3, _PRS_N_HI[b]
+        z[k % TU] = np.exp(1j * np.pi / 2 * (_PRS_H[i][(k - kp) & 15] + n))
+    return z
+
+
+def crc16(data: bytes) -> int:
+    crc = 0xFFFF
+    for b in data:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc ^ 0xFFFF
+
+
+def firecode_parity(nine: bytes) -> int:
+    crc = 0
+    for b in nine:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x782F) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc
+
+
+# GF(256) / RS(255,245) shortened to (120,110): poly 0x11D, first root alpha^0 (EN 102 563)
+_GF_EXP = np.zeros(512, np.int64)
+_GF_LOG = np.zeros(256, np.int64)
+_x = 1
+for _i in range(255):
+    _GF_EXP[_i] = _x
+    _GF_LOG[_x] = _i
+    _x <<= 1
+    if _x & 0x100:
+        _x ^= 0x11D
+_GF_EXP[255:510] = _GF_EXP[:255]
+
+
+def _gf_mul(a, b):
+    return 0 if a == 0 or b == 0 else int(_GF_EXP[_GF_LOG[a] + _GF_LOG[b]])
+
+
+def _rs_gen():
+    g = [1]
+    for r in range(10):
+        g = [(_gf_mul(g[i], int(_GF_EXP[r])) if i < len(g) else 0) ^ (g[i - 1] if i > 0 else 0) for i in range(len(g) + 1)]
+    return g   # g[0] + g[1] x + ... + x^10
+
+
+_RS_G = _rs_gen()
+
+
+def rs_parity(data110: np.ndarray) -> np.ndarray:
+    """Systematic RS parity: remainder of data(x) * x^10 by g(x), highest power first."""
+    rem = [0] * 10
+    for d in data110:
+        fb = int(d) ^ rem[0]
+        rem = rem[1:] + [0]
+        if fb:
+            for j in range(10):
+                rem[j] ^= _gf_mul(fb, _RS_G[9 - j])
+    return np.array(rem, np.uint8)
+
+
+# ----------------------------------------------------------------------------- coding
+def conv_encode(bits: np.ndarray) -> np.ndarray:
+    """K=7 rate 1/4 mother code incl. 6 tail bits -> 4*(n+6) bits, order x0,x1,x2,x3 per input bit."""
+    n = len(bits)
+    pad = np.concatenate([np.zeros(6, np.uint8), bits.astype(np.uint8), np.zeros(6, np.uint8)])
+    out = np.zeros((n + 6, 4), np.uint8)
+    for p, poly in enumerate(POLYS):
+        acc = np.zeros(n + 6, np.uint8)
+        for d in range(7):
+            if (poly >> d) & 1:
+                acc ^= pad[6 - d: 6 - d + n + 6]
+        out[:, p] = acc
+    return out.reshape(-1)
+
+
+@dataclasses.dataclass
+class SubCh:
+    subch_id: int
+    cu_start: int
+    cu_size: int
+    kbps: int
+    prot_level: int = 2      # EEP 3-A
+    short_form: int = 0
+
+
+def default_subchannels(n: int = 18, kbps: int = 64) -> list[SubCh]:
+    cu = {8: 6, 16: 12, 32: 24, 48: 36, 64: 48, 96: 72, 128: 96}[kbps]   # EEP 3-A: 6 CU per 8 kbps
+    return [SubCh(i, i * cu, cu, kbps, 2, 0) for i in range(n)]
+
+
+def build_superframe(kbps: int, rng: np.random.Generator) -> np.ndarray:
+    """One DAB+ audio super frame (ETSI TS 102 563): 110*s payload bytes + RS parity, s = kbps/8,
+    returned as the 120*s byte sequence that is cut into 5 logical frames."""
+    s = kbps // 8
+    n = 110 * s
+    sf = rng.integers(0, 256, n).astype(np.uint8)
+    # header: dac_rate=1, sbr=1 -> 3 AUs, first starts at 6
+    sf[2] = (1 << 6) | (1 << 5) | (1 << 4)
+    a0, a1, a2 = 6, 6 + (n - 6) // 3, 6 + 2 * ((n - 6) // 3)
+    sf[3], sf[4], sf[5] = a1 >> 4, ((a1 & 0xF) << 4) | (a2 >> 8), a2 & 0xFF
+    for st, en in ((a0, a1), (a1, a2), (a2, n)):
+        c = crc16(bytes(sf[st:en - 2]))
+        sf[en - 2], sf[en - 1] = c >> 8, c & 0xFF
+    fc = firecode_parity(bytes(sf[2:11]))
+    sf[0], sf[1] = fc >> 8, fc & 0xFF
+    full = np.zeros(120 * s, np.uint8)
+    full[:n] = sf
+    for j in range(s):
+        full[n + j::s][:10] = rs_parity(sf[j::s])
+    return full
+
+
+def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndarray:
+    """3 FIBs (one FIC group, 96 bytes) for the CIF with the given counter."""
+    hi, lo = (cif_count // 250) % 20, cif_count % 250
+
+    def fig01(chs):
+        body = bytearray([0x01])          # C/N=0 OE=0 P/D=0 ext=1
+        for c in chs:
+            assert not c.short_form
+            opt, lvl = (c.prot_level >> 2) & 1, c.prot_level & 3
+            w = (c.subch_id << 26) | (c.cu_start << 16) | (1 << 15) | (opt << 12) | (lvl << 10) | c.cu_size
+            body += w.to_bytes(4, "big")
+        return bytes([len(body)]) + bytes(body)   # type 0 -> header = length
+
+    fig00 = bytes([0x05, 0x00, eid >> 8, eid & 0xFF, hi & 0x1F, lo])
+    groups = [subch[0:5], subch[5:12], subch[12:18]]
+    fibs = []
+    for g, chs in enumerate(groups):
+        data = (fig00 if g == 0 else b"") + (fig01(chs) if chs else b"")
+        assert len(data) <= 30
+        if len(data) < 30:
+            data += b"\xFF" + b"\x00" * (29 - len(data))
+        c = crc16(data)
+        fibs.append(data + bytes([c >> 8, c & 0xFF]))
+    return np.frombuffer(b"".join(fibs), np.uint8).copy()
+
+
+@dataclasses.dataclass
+class Ensemble:
+    n_frames: int
+    subch: list
+    iq: np.ndarray             # clean, unit-scaled complex64, n_frames*TF samples, frame = null + 76 symbols
+    fibs: np.ndarray           # [n_frames, 12, 32] uint8
+    msc_bytes: list            # per sub-channel: [n_cif, 3*kbps] uint8 (logical frames, de-dispersed payload)
+    superframes: list          # per sub-channel: [n_cif/5, 110*kbps/8] uint8
+    tx_bits: np.ndarray        # [n_frames, 75, 3072] uint8 transmitted (interleaved) bits per OFDM symbol
+
+
+def build_ensemble(n_frames: int = 10, subch: list | None = None, seed: int = 0, cyclic: bool = True,
+                   cif_start: int = 0) -> Ensemble:
+    subch = default_subchannels() if subch is None else subch
+    rng = np.random.default_rng(seed)
+    n_cif = 4 * n_frames
+    if cyclic:
+        assert n_cif % 5 == 0, "cyclic ensembles need a whole number of super frames"
+    # ---- MSC logical frames -> coded CIFs
+    coded = np.zeros((n_cif, 55296), np.uint8)
+    coded[:] = rng.integers(0, 2, coded.shape, dtype=np.uint8)   # padding in unused CUs
+    msc_bytes, superframes = [], []
+    for c in subch:
+        nb = 3 * c.kbps
+        n_sf = (n_cif + 4) // 5
+        sfs = [build_superframe(c.kbps, rng) for _ in range(n_sf)]
+        stream = np.concatenate(sfs)[: n_cif * nb].reshape(n_cif, nb)
+        msc_bytes.append(stream.copy())
+        superframes.append(np.stack([s[: 110 * (c.kbps // 8)] for s in sfs[: n_cif // 5]]) if n_cif >= 5 else np.zeros((0, 0), np.uint8))
+        mask = eep_mask(c.kbps, c.prot_level).astype(bool)
+        disp = prbs(24 * c.kbps)
+        for q in range(n_cif):
+            bits = np.unpackbits(stream[q]) ^ disp
+            cw = conv_encode(bits)[mask]
+            assert len(cw) == c.cu_size * 64, (len(cw), c.cu_size)
+            coded[q, c.cu_start * 64: c.cu_start * 64 + len(cw)] = cw
+    # ---- time interleaving: CIF t carries bit i of coded CIF t - map[i%16]
+    delay = INTERLEAVE_MAP[np.arange(55296) & 15]
+    tx_cif = np.zeros_like(coded)
+    for t in range(n_cif):
+        src = t - delay
+        if cyclic:
+            src %= n_cif
+            tx_cif[t] = coded[src, np.arange(55296)]
+        else:
+            ok = src >= 0
+            tx_cif[t, ok] = coded[src[ok], np.arange(55296)[ok]]
+    # ---- FIC
+    fmask = fic_mask().astype(bool)
+    fdisp = prbs(768)
+    fibs = np.zeros((n_frames, 12, 32), np.uint8)
+    tx_bits = np.zeros((n_frames, 75, 3072), np.uint8)
+    for f in range(n_frames):
+        fic = []
+        for g in range(4):
+            fb = build_fibs(subch, cif_start + 4 * f + g)
+            fibs[f, 3 * g: 3 * g + 3] = fb.reshape(3, 32)
+            fic.append(conv_encode(np.unpackbits(fb) ^ fdisp)[fmask])
+        tx_bits[f, :3] = np.concatenate(fic).reshape(3, 3072)
+        tx_bits[f, 3:] = tx_cif[4 * f: 4 * f + 4].reshape(72, 3072)
+    # ---- QPSK, frequency interleaving, D-QPSK, OFDM
+    perm = freq_perm() % TU
+    prs = prs_spectrum()
+    q = ((1 - 2.0 * tx_bits[:, :, :K]) + 1j * (1 - 2.0 * tx_bits[:, :, K:])) / np.sqrt(2)
+    iq = np.zeros((n_frames, TF), np.complex64)
+    scale = 1.0 / np.sqrt(K)          # unit mean power in the useful part
+    for f in range(n_frames):
+        z = prs.copy()
+        pos = TN
+        for l in range(L):
+            if l > 0:
+                y = np.zeros(TU, np.complex128)
+                y[perm] = q[f, l - 1]
+                z = np.where(np.abs(prs) > 0, z * np.where(y == 0, 1, y), 0)
+            t = np.fft.ifft(z) * TU * scale
+            iq[f, pos: pos + TG] = t[-TG:]
+            iq[f, pos + TG: pos + TS] = t
+            pos += TS
+    return Ensemble(n_frames, subch, iq.reshape(-1), fibs, msc_bytes, superframes, tx_bits)
+
+
+def channel(iq: np.ndarray, snr_db: float = 20.0, cfo_hz: float = 0.0, timing_offset: int = 0, gain: float = 0.25,
+            seed: int = 0, cyclic: bool = True, n_out: int | None = None) -> np.ndarray:
+    """Gain, CFO, timing offset (cyclic roll, or zero prefix when not cyclic) and AWGN. complex64."""
+    rng = np.random.default_rng(seed)
+    x = np.roll(iq, timing_offset) if cyclic else np.concatenate([np.zeros(timing_offset, iq.dtype), iq])
+    if n_out is not None:
+        reps = -(-n_out // len(x))
+        x = np.tile(x, reps)[:n_out]
+    n = np.arange(len(x), dtype=np.float64)
+    x = x * np.exp(2j * np.pi * cfo_hz * n / FS)
+    sigma = np.sqrt(10 ** (-snr_db / 10) / 2)
+    x = x + sigma * (rng.standard_normal(len(x)) + 1j * rng.standard_normal(len(x)))
+    return (gain * x).astype(np.complex64)
+
+
+def to_raw_u8(iq: np.ndarray) -> np.ndarray:
+    """.raw/.iq file format read by the reference as (u8 - 127.38)/128 (raw_reader.cpp:66-70)."""
+    v = np.empty(2 * len(iq), np.float64)
+    v[0::2], v[1::2] = iq.real, iq.imag
+    return np.clip(np.round(v * 128.0 + 127.38), 0, 255).astype(np.uint8)
+
+
+def from_raw_u8(raw: np.ndarray) -> np.ndarray:
+    v = (raw.astype(np.float32) - np.float32(127.38)) / np.float32(128.0)
+    return (v[0::2] + 1j * v[1::2]).astype(np.complex64)
