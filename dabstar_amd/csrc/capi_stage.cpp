@@ -75,4 +75,144 @@ int dabx_deconvolve(const int16_t *in, int in_stride, int kbps, int prot_level, 
   return dbits.to_host(bits, (size_t)batch * nbits);
 }
 
+int dabx_rs_decode(const uint8_t *in, int batch, uint8_t *out, int16_t *ret)
+{
+  if (!in || !out || !ret || batch <= 0) { set_error("dabx_rs_decode: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf din, dout, dret;
+  if ((rc = din.from_host(in, (size_t)batch * 120))) return rc;
+  if ((rc = dout.alloc((size_t)batch * 110))) return rc;
+  if ((rc = dret.alloc((size_t)batch * 2))) return rc;
+  if ((rc = launch_rs_decode(din.as<uint8_t>(), batch, dout.as<uint8_t>(), dret.as<int16_t>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  if ((rc = dout.to_host(out, (size_t)batch * 110))) return rc;
+  return dret.to_host(ret, (size_t)batch * 2);
+}
+
+static int firecode_common(uint8_t *x, int batch, uint8_t *ok, int correct)
+{
+  if (!x || !ok || batch <= 0) { set_error("dabx_firecode: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf dx, dok;
+  if ((rc = dx.from_host(x, (size_t)batch * 12))) return rc;
+  if ((rc = dok.alloc((size_t)batch))) return rc;
+  if ((rc = launch_firecode(dx.as<uint8_t>(), batch, correct, dok.as<uint8_t>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  if (correct && (rc = dx.to_host(x, (size_t)batch * 12))) return rc;
+  return dok.to_host(ok, (size_t)batch);
+}
+int dabx_firecode_check(const uint8_t *x, int batch, uint8_t *ok) { return firecode_common(const_cast<uint8_t *>(x), batch, ok, 0); }
+int dabx_firecode_check_and_correct(uint8_t *x, int batch, uint8_t *ok) { return firecode_common(x, batch, ok, 1); }
+
+int dabx_crc16_check(const uint8_t *msgs, int stride, int len, int batch, uint8_t *ok)
+{
+  if (!msgs || !ok || batch <= 0 || len < 0 || stride < len + 2) { set_error("dabx_crc16_check: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf dm, dok;
+  if ((rc = dm.from_host(msgs, (size_t)batch * stride))) return rc;
+  if ((rc = dok.alloc((size_t)batch))) return rc;
+  if ((rc = launch_crc16_check(dm.as<uint8_t>(), stride, len, batch, dok.as<uint8_t>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return dok.to_host(ok, (size_t)batch);
+}
+
+int dabx_fft2048(const dabx_cf32 *in, int batch, int inverse, dabx_cf32 *out)
+{
+  if (!in || !out || batch <= 0) { set_error("dabx_fft2048: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf din, dout;
+  const size_t n = (size_t)batch * TU * sizeof(float2);
+  if ((rc = din.from_host(in, n))) return rc;
+  if ((rc = dout.alloc(n))) return rc;
+  if ((rc = launch_fft2048(din.as<float2>(), batch, inverse, dout.as<float2>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return dout.to_host(out, n);
+}
+
+int dabx_prs_correlate(const dabx_cf32 *v, int batch, float threshold, int strongest, int32_t *start_index)
+{
+  if (!v || !start_index || batch <= 0) { set_error("dabx_prs_correlate: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf din, dout;
+  if ((rc = din.from_host(v, (size_t)batch * TU * sizeof(float2)))) return rc;
+  if ((rc = dout.alloc((size_t)batch * 4))) return rc;
+  if ((rc = launch_prs_correlate(din.as<float2>(), batch, threshold, strongest, dout.as<int32_t>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return dout.to_host(start_index, (size_t)batch * 4);
+}
+
+int dabx_coarse_cfo(const dabx_cf32 *fft_sym0, int batch, int32_t *hz)
+{
+  if (!fft_sym0 || !hz || batch <= 0) { set_error("dabx_coarse_cfo: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  DevBuf din, dout;
+  if ((rc = din.from_host(fft_sym0, (size_t)batch * TU * sizeof(float2)))) return rc;
+  if ((rc = dout.alloc((size_t)batch * 4))) return rc;
+  if ((rc = launch_coarse_cfo(din.as<float2>(), batch, dout.as<int32_t>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return dout.to_host(hz, (size_t)batch * 4);
+}
+
+struct dabx_demap { DemapDev d; };
+
+int dabx_demap_create(int batch, dabx_demap **out)
+{
+  if (!out || batch <= 0) { set_error("dabx_demap_create: bad argument"); return DABX_E_ARG; }
+  int rc = need_device();
+  if (rc) return rc;
+  auto *h = new dabx_demap();
+  if ((rc = demap_alloc(h->d, batch))) { delete h; return rc; }
+  if ((rc = launch_demap_init(h->d, 0))) { demap_free(h->d); delete h; return rc; }
+  DABX_HIP(hipStreamSynchronize(0));
+  *out = h;
+  return 0;
+}
+void dabx_demap_destroy(dabx_demap *d) { if (d) { demap_free(d->d); delete d; } }
+int dabx_demap_reset(dabx_demap *d)
+{
+  if (!d) return DABX_E_ARG;
+  int rc = launch_demap_reset(d->d, 0);
+  if (rc) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return 0;
+}
+int dabx_demap_set_soft_bit_gen_type(dabx_demap *d, int type)
+{
+  if (!d || type < 1 || type > 3) return DABX_E_ARG;
+  d->d.soft_type = type;
+  return 0;
+}
+static int demap_store(dabx_demap *d, const dabx_cf32 *fft, bool null_sym)
+{
+  if (!d || !fft) return DABX_E_ARG;
+  DevBuf din;
+  int rc = din.from_host(fft, (size_t)d->d.batch * TU * sizeof(float2));
+  if (rc) return rc;
+  rc = null_sym ? launch_demap_store_null(d->d, din.as<float2>(), 0) : launch_demap_store_ref(d->d, din.as<float2>(), 0);
+  if (rc) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return 0;
+}
+int dabx_demap_store_reference_symbol_0(dabx_demap *d, const dabx_cf32 *fft) { return demap_store(d, fft, false); }
+int dabx_demap_store_null_symbol_without_tii(dabx_demap *d, const dabx_cf32 *fft) { return demap_store(d, fft, true); }
+int dabx_demap_decode_symbols(dabx_demap *d, const dabx_cf32 *fft, int n_sym, const float *clock_err, int16_t *soft)
+{
+  if (!d || !fft || !clock_err || !soft || n_sym <= 0) return DABX_E_ARG;
+  const int B = d->d.batch;
+  DevBuf din, dce, dsoft;
+  int rc;
+  if ((rc = din.from_host(fft, (size_t)B * n_sym * TU * sizeof(float2)))) return rc;
+  if ((rc = dce.from_host(clock_err, (size_t)B * 4))) return rc;
+  if ((rc = dsoft.alloc((size_t)B * n_sym * K2 * 2))) return rc;
+  if ((rc = launch_demap_symbols(d->d, din.as<float2>(), n_sym, dce.as<float>(), dsoft.as<int16_t>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return dsoft.to_host(soft, (size_t)B * n_sym * K2 * 2);
+}
+
 }  // extern "C"

@@ -46,11 +46,38 @@ int get_profile_map(int kbps, int prot_level, int short_form, const uint16_t **d
 int host_profile_map(int kbps, int prot_level, int short_form, std::vector<uint16_t> &map, int *n_in);
 void host_fic_map(std::vector<uint16_t> &map);
 
+// ---- demapper state (SoA over the stream axis), OfdmDecoder members ofdm_decoder.h:88-104 ----------
+struct DemapDev {
+  float2 *phase_ref;    // [B][2048] mPhaseReference
+  float *integ;         // [B][1536] mIntegAbsPhaseVector
+  float *mean_power;    // [B][1536] mMeanPowerVector
+  float *mean_sigma;    // [B][1536] mMeanSigmaSqVector
+  float *null_power;    // [B][2048] mMeanNullPowerWithoutTII
+  float *mean_value;    // [B]       mMeanValue
+  int batch;
+  int soft_type;        // 1..3
+};
+int demap_alloc(DemapDev &d, int batch);
+void demap_free(DemapDev &d);
+
 // ---- kernel launchers (device pointers, asynchronous on `st`) -------------------------------------
 // viterbi.hip
 int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits_1perbyte, hipStream_t st);
 int launch_deconvolve_i16(const int16_t *in, int in_stride, const uint16_t *map, int nbits, int batch,
                           uint8_t *bits_1perbyte, hipStream_t st);
 int viterbi_scratch_bytes_per_trellis(int nbits);
+// fec.hip
+int launch_rs_decode(const uint8_t *in, int batch, uint8_t *out, int16_t *ret, hipStream_t st);
+int launch_firecode(uint8_t *x, int batch, int correct, uint8_t *ok, hipStream_t st);
+int launch_crc16_check(const uint8_t *msgs, int stride, int len, int batch, uint8_t *ok, hipStream_t st);
+// ofdm.hip
+int launch_fft2048(const float2 *in, int batch, int inverse, float2 *out, hipStream_t st);
+int launch_prs_correlate(const float2 *v, int batch, float threshold, int strongest, int32_t *start, hipStream_t st);
+int launch_coarse_cfo(const float2 *fft, int batch, int32_t *hz, hipStream_t st);
+int launch_demap_reset(DemapDev &d, hipStream_t st);
+int launch_demap_init(DemapDev &d, hipStream_t st);
+int launch_demap_store_ref(DemapDev &d, const float2 *fft, hipStream_t st);
+int launch_demap_store_null(DemapDev &d, const float2 *fft, hipStream_t st);
+int launch_demap_symbols(DemapDev &d, const float2 *fft, int n_sym, const float *clock_err, int16_t *soft, hipStream_t st);
 
 }  // namespace dabx

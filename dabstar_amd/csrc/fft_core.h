@@ -1,0 +1,95 @@
+// fft_core.h -- 2048-point complex FFT for one 256-thread workgroup, LDS-staged Stockham radix 8-8-8-4.
+//
+// Replaces fftwf_execute of the 2048-point c2c plans (base/main/dab_processor.cpp:63,201,276,338;
+// ofdm/phasereference.cpp:51-52): unnormalised DFT, forward = e^{-j..}, backward = e^{+j..}.
+// Thread `tid` enters with x[tid + 256 u] (u = 0..7: eight coalesced 2-KB loads of the T_u slice) and
+// leaves with X[tid + 256 u]: input and output use the same strided register layout, so element-wise
+// stages before/after the transform (NCO mix, x conj(PRS), |.|) never touch LDS.  Twiddles come from a
+// 2048-entry table computed in double on the host (16 KB, L1/L2 resident).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dabx {
+
+constexpr int FFT_LDS_FLOAT2 = 2048 + 2048 / 16;   // padded: one extra slot per 16
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+template <bool INV> __device__ __forceinline__ float2 mul_mj(float2 a)   // forward: * (-j); inverse: * (+j)
+{
+  return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+template <bool INV> __device__ __forceinline__ float2 tw_dir(float2 w) { return INV ? make_float2(w.x, -w.y) : w; }
+
+template <bool INV> __device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+  const float2 s0 = cadd(a, c), d0 = csub(a, c), s1 = cadd(b, d), d1 = mul_mj<INV>(csub(b, d));
+  a = cadd(s0, s1); c = csub(s0, s1); b = cadd(d0, d1); d = csub(d0, d1);
+}
+
+template <bool INV> __device__ __forceinline__ void dft8(float2 v[8])
+{
+  // even / odd DFT-4 then combine with W8^k
+  dft4<INV>(v[0], v[2], v[4], v[6]);
+  dft4<INV>(v[1], v[3], v[5], v[7]);
+  const float r = 0.70710678118654752440f;
+  const float2 o1 = INV ? make_float2((v[3].x - v[3].y) * r, (v[3].x + v[3].y) * r)
+                        : make_float2((v[3].x + v[3].y) * r, (v[3].y - v[3].x) * r);      // * e^{-+ j pi/4}
+  const float2 o2 = mul_mj<INV>(v[5]);
+  const float2 o3 = INV ? make_float2((-v[7].x - v[7].y) * r, (v[7].x - v[7].y) * r)
+                        : make_float2((v[7].y - v[7].x) * r, (-v[7].x - v[7].y) * r);     // * e^{-+ j 3pi/4}
+  const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+__device__ __forceinline__ int fft_pad(int i) { return i + (i >> 4); }
+
+// One radix-8 Stockham pass: v[t] = x[j + 256 t] in; results are scattered to LDS.
+template <bool INV, int NS> __device__ __forceinline__ void fft_pass8(float2 v[8], int j, float2 *lds, const float2 *tw)
+{
+  const int k = j & (NS - 1);
+  if (NS > 1) {
+#pragma unroll
+    for (int t = 1; t < 8; t++) v[t] = cmul(v[t], tw_dir<INV>(tw[t * k * (2048 / (NS * 8))]));
+  }
+  dft8<INV>(v);
+  const int base = (j - k) * 8 + k;
+#pragma unroll
+  for (int t = 0; t < 8; t++) lds[fft_pad(base + t * NS)] = v[t];
+}
+
+// Whole transform.  All 256 threads of the block must call it; `lds` holds FFT_LDS_FLOAT2 float2.
+template <bool INV> __device__ __forceinline__ void fft2048(float2 v[8], float2 *lds, const float2 *tw, int tid)
+{
+  fft_pass8<INV, 1>(v, tid, lds, tw);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 8; t++) v[t] = lds[fft_pad(tid + 256 * t)];
+  __syncthreads();
+  fft_pass8<INV, 8>(v, tid, lds, tw);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 8; t++) v[t] = lds[fft_pad(tid + 256 * t)];
+  __syncthreads();
+  fft_pass8<INV, 64>(v, tid, lds, tw);
+  __syncthreads();
+  // last pass: radix 4, NS = 512, two butterflies per thread (j = tid and tid + 256); output index j + 512 t
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int j = tid + 256 * h;
+    float2 a = lds[fft_pad(j)], b = lds[fft_pad(j + 512)], c = lds[fft_pad(j + 1024)], d = lds[fft_pad(j + 1536)];
+    b = cmul(b, tw_dir<INV>(tw[j]));
+    c = cmul(c, tw_dir<INV>(tw[2 * j]));
+    d = cmul(d, tw_dir<INV>(tw[3 * j]));
+    dft4<INV>(a, b, c, d);
+    v[h] = a; v[h + 2] = b; v[h + 4] = c; v[h + 6] = d;     // X[j + 512 t] -> register u = 2 t + h
+  }
+  __syncthreads();
+}
+
+}  // namespace dabx

@@ -1,0 +1,263 @@
+// ofdm_core.h -- device building blocks of the OFDM front end (256-thread workgroups, one per stream/symbol).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dabx_internal.h"
+#include "fft_core.h"
+
+namespace dabx {
+
+__device__ __forceinline__ float cabsf_(float2 z) { return sqrtf(z.x * z.x + z.y * z.y); }   // std::abs under -ffast-math
+
+// ---- block reductions (256 threads) -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float block_sum(float v, float *red /* >= 8 floats of LDS */, int tid)
+{
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float s = 0.f;
+  for (int w = 0; w < nw; w++) s += red[w];
+  return s;
+}
+__device__ __forceinline__ int block_min_int(int v, int *red, int tid)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  int s = red[0];
+  for (int w = 1; w < nw; w++) s = red[w] < s ? red[w] : s;
+  return s;
+}
+
+// ---- NCO: SampleReader::get_samples frequency shift (base/ofdm/sample_reader.cpp:274-281) -----------
+// The reference steps an integer phase p -= round(f) (mod 2 048 000) per sample and multiplies by
+// table[p] = (f32)cos/sin(2 pi p / 2 048 000) evaluated in double (sample_reader.cpp:44-50).
+// Here the same phasor is evaluated in closed form: e^{j 2 pi ((p0 - (n+1) f) mod R) / R}, in double,
+// rounded once to float -- no 16-MB table gather.  n = index of the sample within the read sequence.
+struct Nco {
+  double br, bi;   // phasor of this thread's first sample
+  double sr, si;   // rotation per +256 samples
+  __device__ void init(int phase0, int f, long long n0 /* index of this thread's first sample */)
+  {
+    const long long R = INPUT_RATE;
+    long long p = ((long long)phase0 - (n0 + 1) * (long long)f) % R;
+    if (p < 0) p += R;
+    long long q = (-256LL * f) % R;
+    if (q < 0) q += R;
+    sincospi(2.0 * (double)p / (double)R, &bi, &br);
+    sincospi(2.0 * (double)q / (double)R, &si, &sr);
+  }
+  __device__ float2 mix(float2 v) const
+  {
+    const float cr = (float)br, ci = (float)bi;
+    return make_float2(v.x * cr - v.y * ci, v.x * ci + v.y * cr);   // v * table[p]
+  }
+  __device__ void step()
+  {
+    const double nr = br * sr - bi * si, ni = br * si + bi * sr;
+    br = nr; bi = ni;
+  }
+};
+__device__ __forceinline__ int nco_advance(int phase0, int f, long long n)   // phase after n samples
+{
+  const long long R = INPUT_RATE;
+  long long p = ((long long)phase0 - n * (long long)f) % R;
+  if (p < 0) p += R;
+  return (int)p;
+}
+
+// ---- PRS correlator: PhaseReference::correlate_with_phase_ref_and_find_max_peak ----------------------
+// (base/ofdm/phasereference.cpp:87-213).  v = T_u samples in the strided register layout of fft_core.h.
+// Returns the start index (first local maximum above threshold * mean in [254, 1004)) or -1.
+__device__ inline int prs_correlate_block(float2 v[8], float threshold, int strongest, const DevTables &t, float2 *lds,
+                                          float *peak /* [2048] LDS */, float *red, int tid)
+{
+  fft2048<false>(v, lds, t.twiddle, tid);
+#pragma unroll
+  for (int u = 0; u < 8; u++) v[u] = cmul_conj(v[u], t.prs_ref[tid + 256 * u]);   // :97-100
+  fft2048<true>(v, lds, t.twiddle, tid);
+  float part = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; u++) { const float a = cabsf_(v[u]); peak[tid + 256 * u] = a; part += a; }   // :116-122
+  float sum = block_sum(part, red, tid) / (float)TU;
+  __syncthreads();
+  if (sum == 0.f) return -1;
+  constexpr int i0 = TG - 250, i1 = TG + 500, gap = 10;   // :136-139
+  int *ired = reinterpret_cast<int *>(red);
+  if (!strongest) {
+    // first index whose value clears the threshold and is not exceeded within the next gap-1 samples
+    int cand = 0x7fffffff;
+    for (int i = i0 + tid; i < i1; i += 256) {
+      const float p = peak[i];
+      if (p / sum > threshold) {
+        bool ok = true;
+        for (int j = 1; j < gap && i + j < i1; ++j) ok = ok && !(peak[i + j] > p);
+        if (ok && i < cand) cand = i;
+      }
+    }
+    cand = block_min_int(cand, ired, tid);
+    return cand == 0x7fffffff ? -1 : cand;
+  }
+  // strongest-peak mode keeps the reference's skip logic, which is inherently sequential (750 steps, one lane)
+  __shared__ int s_res;
+  if (tid == 0) {
+    int max_index = -1;
+    float max_l = -1000.f;
+    for (int i = i0; i < i1; ++i) {
+      if (peak[i] / sum > threshold) {
+        bool found = true;
+        for (int j = 1; j < gap && i + j < i1; ++j)
+          if (peak[i + j] > peak[i]) { found = false; break; }
+        if (found) {
+          if (peak[i] > max_l) { max_l = peak[i]; max_index = i; }
+          i += gap;
+        }
+      }
+    }
+    s_res = (max_l / sum < threshold) ? -1 : max_index;
+  }
+  __syncthreads();
+  return s_res;
+}
+
+// ---- coarse CFO: PhaseReference::estimate_carrier_offset_from_sync_symbol_0 (:223-280) -----------------
+// X = FFT of symbol 0 in the strided register layout.  Returns Hz (int) or IDX_NOT_FOUND (100000).
+__device__ inline int coarse_cfo_block(const float2 X[8], const DevTables &t, float2 *lds, float *mag /* >= 160 floats LDS */,
+                                       int tid)
+{
+  // relative phase conj(X[i]) * X[i+1]  (:282-300): neighbours live in other threads -> through LDS
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; u++) lds[fft_pad(tid + 256 * u)] = X[u];
+  __syncthreads();
+  float2 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = tid + 256 * u;
+    if (i < TU - 1) {
+      const float2 a = X[u], b = lds[fft_pad(i + 1)];
+      v[u] = make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+    } else v[u] = make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  fft2048<true>(v, lds, t.twiddle, tid);
+#pragma unroll
+  for (int u = 0; u < 8; u++) v[u] = cmul(v[u], t.prs_arg_conj[tid + 256 * u]);
+  fft2048<false>(v, lds, t.twiddle, tid);
+  // |.| of bins -70..70 -> mag[0..140]
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = tid + 256 * u;
+    if (i <= 71) mag[71 + i] = cabsf_(v[u]);            // bins 0..71 (71 only feeds the interpolation)
+    if (i >= TU - 71) mag[71 + i - TU] = cabsf_(v[u]);   // bins -71..-1
+  }
+  __syncthreads();
+  __shared__ int s_hz;
+  if (tid == 0) {
+    int index = 100000;
+    float mx = 0.f, avg = 0.f;
+    for (int i = -70; i <= 70; ++i) {
+      const float val = mag[71 + i];
+      if (val > mx) { mx = val; index = i; }
+      avg += val;
+    }
+    avg /= 141.0f;
+    if (mx < avg * 5) s_hz = 100000;
+    else {
+      const float p0 = mag[71 + index - 1], p1 = mag[71 + index], p2 = mag[71 + index + 1];
+      const float psum = (0.0f + p0) + p1 + p2;
+      const float offset = (float)index + (p2 - p0) / psum;
+      s_hz = (int)(offset * 1000.0f);
+    }
+  }
+  __syncthreads();
+  return s_hz;
+}
+
+// ---- D-QPSK soft-bit demapper: OfdmDecoder::decode_symbol (base/ofdm/ofdm_decoder.cpp:147-355) -------
+struct DemapCarrier {        // per-carrier state kept in registers across the 75 symbols of a frame
+  float2 prev;               // mPhaseReference[bin]
+  float integ, mean_power, mean_sigma_sq, null_power;
+};
+
+__device__ __forceinline__ int16_t cvt_i16_x86(float x)
+{
+  // (i16)(float) as x86-64 compiles it: cvttss2si ("integer indefinite" 0x80000000 when out of range / NaN),
+  // then the low 16 bits (ofdm_decoder.cpp:254-255)
+  if (!(fabsf(x) < 2147483648.0f)) return 0;
+  return (int16_t)(uint16_t)(uint32_t)(int32_t)x;
+}
+
+// One carrier of one symbol.  Returns |r1| (summand of mMeanValue); writes the two soft bits.
+__device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, float clock_err, float mean_value,
+                                           int soft_type, int16_t &soft_re, int16_t &soft_im)
+{
+  constexpr float ALPHA = 0.005f;
+  const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
+  const float F_RAD_PER_DEG = 0.01745329251994329577f, F_SQRT1_2 = 0.70710678118654752440f;
+  const float2 pr = c.prev;
+  const float pr_abs = cabsf_(pr);
+  float2 raw;                                                   // :188-189
+  raw.x = (x.x * pr.x + x.y * pr.y) / pr_abs;
+  raw.y = (x.y * pr.x - x.x * pr.y) / pr_abs;
+  const float phase_err = clock_err / 1024.0f * F_PI * (float)(K / 2 - rel) / (float)(K / 2) + c.integ;   // :192
+  const float xx = -phase_err, x2 = xx * xx;                    // cmplx_from_phase2, :70-88
+  const float sine = xx * (x2 * -0.16034401953220367431640625f + 0.99903142452239990234375f);
+  const float cosine = 0.9994032382965087890625f + x2 * (x2 * 3.679168224334716796875e-2f + -0.495580852031707763671875f);
+  float2 b;
+  b.x = raw.x * cosine - raw.y * sine;
+  b.y = raw.x * sine + raw.y * cosine;
+  float ph = atan2f(b.y, b.x);                                  // :197
+  if (ph < 0.0f) ph += F_PI;                                    // glob_defs.h:173-182
+  const float aph = fmodf(ph, F_PI_2);
+  c.integ += 0.2f * ALPHA * (aph - F_PI_4);                     // :201-202
+  const float lim = F_RAD_PER_DEG * 20.0f;
+  if (c.integ > lim) c.integ = lim; else if (c.integ < -lim) c.integ = -lim;
+  const float power = b.x * b.x + b.y * b.y;                    // :211-213
+  c.mean_power += ALPHA * (power - c.mean_power);
+  const float mean_level = sqrtf(c.mean_power);                 // :217-223
+  const float at_axis = mean_level * F_SQRT1_2;
+  const float rd = fabsf(b.x) - at_axis, id = fabsf(b.y) - at_axis;
+  const float sigma_sq = rd * rd + id * id;
+  c.mean_sigma_sq += ALPHA * (sigma_sq - c.mean_sigma_sq);
+  float signal_power = c.mean_power - c.null_power;             // :225-226
+  if (signal_power <= 0.0f) signal_power = 0.1f;
+  float2 r1;
+  float w2;
+  if (soft_type == 3) {                                         // :231-235
+    r1 = make_float2(b.x * pr_abs, b.y * pr_abs); w2 = -140 / mean_value;
+  } else if (soft_type == 2) {                                  // :236-242
+    float w1 = pr_abs / c.mean_sigma_sq;
+    w1 /= (c.null_power / signal_power) + 0.7f;
+    r1 = make_float2(b.x * w1, b.y * w1); w2 = -140 / mean_value;
+  } else {                                                      // :243-251
+    const float babs = sqrtf(power);
+    float w1 = sqrtf(babs * pr_abs) * mean_level;
+    w1 /= (c.null_power / signal_power) + 0.7f;
+    w1 /= c.mean_sigma_sq * babs;
+    r1 = make_float2(b.x * w1, b.y * w1); w2 = -100 / mean_value;
+  }
+  soft_re = cvt_i16_x86(r1.x * w2);                             // :254-255
+  soft_im = cvt_i16_x86(r1.y * w2);
+  c.prev = x;                                                   // :354
+  return cabsf_(r1);                                            // :256
+}
+
+__device__ __forceinline__ uint8_t soft_to_sym(int16_t s)       // viterbi_scalar.h:34-40
+{
+  int v = (int16_t)(s + 127);
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  return (uint8_t)v;
+}
+
+}  // namespace dabx

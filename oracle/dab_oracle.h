@@ -175,6 +175,13 @@ void ora_phaseref_init(ora_phaseref *p);
 int  ora_phaseref_correlate(ora_phaseref *p, const ora_cf32 *v, float threshold); /* :87-213 */
 int  ora_phaseref_coarse_cfo(ora_phaseref *p, const ora_cf32 *fft_sym0);          /* :223-280 */
 
+ora_demap *ora_demap_new(void);
+void ora_demap_free(ora_demap *d);
+void ora_demap_set_type(ora_demap *d, int type);
+ora_phaseref *ora_phaseref_new(void);
+void ora_phaseref_free(ora_phaseref *p);
+void ora_phaseref_set_strongest(ora_phaseref *p, int on);
+
 /* ---------------- whole receiver (receiver.c) : main/dab_processor.cpp ---------------- */
 typedef struct ora_receiver ora_receiver;
 ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch);

@@ -246,3 +246,11 @@ void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_
   d->mean_value = sum / (float)ORA_K;                  /* :294 */
   memcpy(d->phase_ref, fft, sizeof(d->phase_ref));     /* :354 */
 }
+
+/* heap helpers for ctypes-based tests */
+ora_demap *ora_demap_new(void) { ora_demap *d = (ora_demap *)malloc(sizeof(ora_demap)); ora_demap_init(d); return d; }
+void ora_demap_free(ora_demap *d) { free(d); }
+ora_phaseref *ora_phaseref_new(void) { ora_phaseref *p = (ora_phaseref *)malloc(sizeof(ora_phaseref)); ora_phaseref_init(p); return p; }
+void ora_phaseref_free(ora_phaseref *p) { free(p); }
+void ora_phaseref_set_strongest(ora_phaseref *p, int on) { p->strongest = on; }
+void ora_demap_set_type(ora_demap *d, int type) { d->soft_bit_type = type; }

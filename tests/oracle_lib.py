@@ -83,6 +83,18 @@ def oracle():
         f.restype = C.POINTER(C.c_uint8)
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    L.ora_demap_new.restype = C.c_void_p
+    L.ora_demap_free.argtypes = [C.c_void_p]
+    L.ora_demap_set_type.argtypes = [C.c_void_p, C.c_int]
+    L.ora_demap_reset.argtypes = [C.c_void_p]
+    L.ora_demap_store_ref.argtypes = [C.c_void_p, _c64p]
+    L.ora_demap_store_null.argtypes = [C.c_void_p, _c64p]
+    L.ora_demap_symbol.argtypes = [C.c_void_p, _c64p, C.c_float, _i16p]
+    L.ora_phaseref_new.restype = C.c_void_p
+    L.ora_phaseref_free.argtypes = [C.c_void_p]
+    L.ora_phaseref_set_strongest.argtypes = [C.c_void_p, C.c_int]
+    L.ora_phaseref_correlate.argtypes = [C.c_void_p, _c64p, C.c_float]
+    L.ora_phaseref_coarse_cfo.argtypes = [C.c_void_p, _c64p]
     _ora = L
     return L
 
