@@ -1,0 +1,436 @@
+// engine.cpp -- host side of the stream-batched receiver and the engine-level C ABI (include/dabx.h).
+#include "pipeline.h"
+#include "viterbi_core.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace dabx {
+int launch_frame_step(const EngineDev &e, hipStream_t st, hipEvent_t *ev);
+extern const char *const kStepKernelNames[8];
+int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st);
+int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st);
+int launch_fic_only(const EngineDev &e, hipStream_t st);
+int launch_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n, hipStream_t st);
+}  // namespace dabx
+using namespace dabx;
+
+struct dabx_engine {
+  dabx_config cfg{};
+  EngineDev dev{};
+  hipStream_t stream = nullptr;
+  int device = 0;
+  std::vector<unsigned long long> wr_host;     // host mirror of committed samples
+  std::vector<SubchDev> subch_host;            // [S][max_subch]
+  std::vector<void *> allocs;
+  int max_kbps = 0;
+  bool buffers_ready = false;
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;             // 9 per recorded step
+  size_t ev_used = 0;
+  double prof_ms[8] = {0};
+  long long prof_n[8] = {0};
+
+  template <class T> int alloc(T **p, size_t count, bool zero = true)
+  {
+    void *q = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    DABX_HIP(hipMalloc(&q, bytes));
+    if (zero) DABX_HIP(hipMemsetAsync(q, 0, bytes, stream));
+    allocs.push_back(q);
+    *p = reinterpret_cast<T *>(q);
+    return 0;
+  }
+};
+
+static int need_device_e()
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (libdabx has no CPU fallback)"); return DABX_E_NODEVICE; }
+  return 0;
+}
+
+extern "C" {
+
+void dabx_default_config(dabx_config *c)
+{
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->n_streams = 1; c->ring_frames = 4; c->max_subch = 18; c->out_frames = 4;
+  c->sync_threshold = 3.0f;            // main/dabradio.cpp:92
+  c->sync_strongest = 0;               // configuration.cpp:65
+  c->soft_bit_type = 1;                // glob_enums.h:49-56 (SOFTDEC1)
+}
+
+int dabx_create(const dabx_config *cfg, dabx_engine **out)
+{
+  if (!cfg || !out || cfg->n_streams <= 0 || cfg->ring_frames < 2 || cfg->max_subch < 0 || cfg->max_subch > MAX_SUBCH ||
+      cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3) {
+    set_error("dabx_create: bad configuration");
+    return DABX_E_ARG;
+  }
+  int rc = need_device_e();
+  if (rc) return rc;
+  auto *e = new dabx_engine();
+  e->cfg = *cfg;
+  DABX_HIP(hipGetDevice(&e->device));
+  DABX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  const int S = cfg->n_streams;
+  EngineDev &d = e->dev;
+  d.n_streams = S; d.max_subch = cfg->max_subch; d.out_frames = cfg->out_frames;
+  d.ring_len = cfg->ring_frames * TF;
+  d.threshold = cfg->sync_threshold; d.strongest = cfg->sync_strongest;
+  d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft;
+  const DevTables *t;
+  if ((rc = get_tables(&t))) { dabx_destroy(e); return rc; }
+#define A(x) if ((rc = (x))) { dabx_destroy(e); return rc; }
+  A(e->alloc(&d.iq, (size_t)S * d.ring_len, false));
+  A(e->alloc(&d.wr, S));
+  A(e->alloc(&d.ctl, S));
+  A(e->alloc(&d.spectra, (size_t)S * 76 * TU, false));
+  A(e->alloc(&d.cp_part, (size_t)S * 75));
+  A(e->alloc(&d.abs_part, (size_t)S * 76));
+  A(e->alloc(&d.fic_sym, (size_t)S * 3 * K2));
+  A(e->alloc(&d.tdi, (size_t)S * TDI_SLOTS * CIF_BITS));
+  A(e->alloc(&d.subch, (size_t)S * std::max(1, d.max_subch)));
+  A(e->alloc(&d.fib_out, (size_t)S * d.out_frames * 12 * 32));
+  A(e->alloc(&d.fib_crc, (size_t)S * d.out_frames * 12));
+  if (d.capture_soft) A(e->alloc(&d.soft_cap, (size_t)S * 75 * K2));
+  // demapper state (constructor defaults: ofdm_decoder.h:101-104)
+  A(demap_alloc(d.demap, S));
+  d.demap.soft_type = cfg->soft_bit_type;
+  A(launch_demap_init(d.demap, e->stream));
+  // per-stream scalars: SampleReader / DabProcessor defaults (sample_reader.h:95,101; dab_processor.h:129-138)
+  std::vector<StreamCtl> ctl(S);
+  for (auto &c : ctl) {
+    memset(&c, 0, sizeof(c));
+    c.state = ST_INIT; c.s_level = 0.1f; c.peak_level = -1.0e6f; c.sync_thr = cfg->sync_threshold;
+  }
+  DABX_HIP(hipMemcpyAsync(d.ctl, ctl.data(), sizeof(StreamCtl) * S, hipMemcpyHostToDevice, e->stream));
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  e->wr_host.assign(S, 0);
+  e->subch_host.assign((size_t)S * std::max(1, d.max_subch), SubchDev{});
+  // scratch sized for the FIC now; re-sized when sub-channels are configured
+  d.vit_stride = (int)vit_scratch_words(FIC_OUT);
+  A(e->alloc(&d.vit_scratch, (size_t)S * (4 + 4 * d.max_subch) * d.vit_stride, false));
+  d.msc_stride = 0; d.sf_stride = 0;
+#undef A
+  *out = e;
+  return 0;
+}
+
+void dabx_destroy(dabx_engine *e)
+{
+  if (!e) return;
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (void *p : e->allocs) (void)hipFree(p);
+  for (auto &ev : e->ev_pool) (void)hipEventDestroy(ev);
+  demap_free(e->dev.demap);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc, int n)
+{
+  if (!e || n < 0 || n > e->dev.max_subch || (n > 0 && !desc) || stream >= e->dev.n_streams) {
+    set_error("dabx_set_subchannels: bad argument");
+    return DABX_E_ARG;
+  }
+  EngineDev &d = e->dev;
+  int rc;
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  // current CIF counters (Backend construction time, backend.cpp:38-70)
+  std::vector<StreamCtl> ctl(d.n_streams);
+  DABX_HIP(hipMemcpy(ctl.data(), d.ctl, sizeof(StreamCtl) * d.n_streams, hipMemcpyDeviceToHost));
+  // refresh the host mirror: the device owns the dynamic fields (cif_out, super-frame state, counters)
+  DABX_HIP(hipMemcpy(e->subch_host.data(), d.subch, sizeof(SubchDev) * e->subch_host.size(), hipMemcpyDeviceToHost));
+  int max_kbps = e->max_kbps;
+  std::vector<SubchDev> row(std::max(1, d.max_subch));
+  for (int j = 0; j < n; j++) {
+    const dabx_subch_desc &q = desc[j];
+    SubchDev sc{};
+    const uint16_t *map = nullptr;
+    int n_in = 0;
+    if ((rc = get_profile_map(q.kbps, q.prot_level, q.short_form, &map, &n_in))) return rc;
+    if (q.cu_size * 64 < n_in || q.cu_start < 0 || q.cu_start + q.cu_size > 864) {
+      set_error("sub-channel %d: %d CU at %d do not hold %d coded bits", j, q.cu_size, q.cu_start, n_in);
+      return DABX_E_PROFILE;
+    }
+    sc.cu_start = q.cu_start; sc.cu_size = q.cu_size; sc.kbps = q.kbps; sc.prot_level = q.prot_level;
+    sc.short_form = q.short_form; sc.dab_plus = q.dab_plus; sc.nbits = 24 * q.kbps; sc.active = 1; sc.map = map;
+    row[j] = sc;
+    max_kbps = std::max(max_kbps, q.kbps);
+  }
+  // (re)allocate output rings / scratch when the largest bit rate grows
+  if (max_kbps > e->max_kbps) {
+    e->max_kbps = max_kbps;
+    d.msc_stride = 3 * max_kbps;
+    d.sf_stride = ((110 * max_kbps / 8) + 15) & ~15;
+    d.vit_stride = (int)std::max(vit_scratch_words(FIC_OUT), vit_scratch_words(24 * max_kbps));
+    if ((rc = e->alloc(&d.msc_out, (size_t)d.n_streams * d.max_subch * MSC_SLOTS * d.msc_stride))) return rc;
+    if ((rc = e->alloc(&d.sf_out, (size_t)d.n_streams * d.max_subch * SF_SLOTS * d.sf_stride))) return rc;
+    if ((rc = e->alloc(&d.vit_scratch, (size_t)d.n_streams * (4 + 4 * d.max_subch) * d.vit_stride, false))) return rc;
+    // sub-channels configured earlier restart their output rings
+    for (auto &sc : e->subch_host) { sc.cif_out = 0; sc.blocks_in_buf = 0; sc.sf_sync = 0; sc.sf_count = 0; }
+  }
+  for (int s = 0; s < d.n_streams; s++) {
+    if (stream >= 0 && s != stream) continue;
+    for (int j = 0; j < d.max_subch; j++) {
+      SubchDev sc = j < n ? row[j] : SubchDev{};
+      sc.start_cif = ctl[s].cif_no;
+      e->subch_host[(size_t)s * d.max_subch + j] = sc;
+    }
+  }
+  DABX_HIP(hipMemcpy(d.subch, e->subch_host.data(), sizeof(SubchDev) * e->subch_host.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *cap)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !ring) return DABX_E_ARG;
+  *ring = e->dev.iq + (size_t)stream * e->dev.ring_len;
+  if (cap) *cap = (size_t)e->dev.ring_len;
+  return 0;
+}
+
+int dabx_commit_iq(dabx_engine *e, int stream, size_t n)
+{
+  if (!e || stream >= e->dev.n_streams) return DABX_E_ARG;
+  for (int s = 0; s < e->dev.n_streams; s++)
+    if (stream < 0 || s == stream) e->wr_host[s] += n;
+  return launch_commit(e->dev, stream, n, e->stream);
+}
+
+int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !iq || fmt < 0 || fmt > 2 || n > (size_t)e->dev.ring_len) {
+    set_error("dabx_push_iq: bad argument");
+    return DABX_E_ARG;
+  }
+  if (n == 0) return 0;
+  static const int bps[3] = {8, 4, 2};
+  void *stage = nullptr;
+  DABX_HIP(hipMalloc(&stage, n * bps[fmt]));
+  DABX_HIP(hipMemcpyAsync(stage, iq, n * bps[fmt], hipMemcpyHostToDevice, e->stream));
+  int rc = launch_convert_iq(stage, fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, e->stream);
+  if (!rc) rc = dabx_commit_iq(e, stream, n);
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  DABX_HIP(hipFree(stage));
+  return rc;
+}
+
+int dabx_process(dabx_engine *e, int max_frames, int sync)
+{
+  if (!e || max_frames < 0) return DABX_E_ARG;
+  for (int i = 0; i < max_frames; i++) {
+    hipEvent_t *ev = nullptr;
+    if (e->profiling) {
+      if (e->ev_used + 9 > e->ev_pool.size()) {
+        const size_t old = e->ev_pool.size();
+        e->ev_pool.resize(old + 9 * 64);
+        for (size_t k = old; k < e->ev_pool.size(); k++) DABX_HIP(hipEventCreate(&e->ev_pool[k]));
+      }
+      ev = &e->ev_pool[e->ev_used];
+      e->ev_used += 9;
+    }
+    const int rc = launch_frame_step(e->dev, e->stream, ev);
+    if (rc) return rc;
+  }
+  if (sync) DABX_HIP(hipStreamSynchronize(e->stream));
+  return max_frames;
+}
+
+int dabx_synchronize(dabx_engine *e)
+{
+  if (!e) return DABX_E_ARG;
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  return 0;
+}
+void *dabx_hip_stream(dabx_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+static int fetch_ctl(dabx_engine *e, int stream, StreamCtl *c)
+{
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  DABX_HIP(hipMemcpy(c, e->dev.ctl + stream, sizeof(StreamCtl), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int dabx_read_fibs(dabx_engine *e, int stream, int n_frames, uint8_t *fibs, uint8_t *crc)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || n_frames <= 0 || n_frames > e->dev.out_frames || !fibs || !crc) return DABX_E_ARG;
+  StreamCtl c;
+  int rc = fetch_ctl(e, stream, &c);
+  if (rc) return rc;
+  const int have = (int)std::min<long long>(c.frames, n_frames);
+  for (int i = 0; i < have; i++) {            // oldest first
+    const long long fr = c.frames - have + i;
+    const int slot = (int)(fr % e->dev.out_frames);
+    DABX_HIP(hipMemcpy(fibs + (size_t)i * 384, e->dev.fib_out + ((size_t)stream * e->dev.out_frames + slot) * 384, 384, hipMemcpyDeviceToHost));
+    DABX_HIP(hipMemcpy(crc + (size_t)i * 12, e->dev.fib_crc + ((size_t)stream * e->dev.out_frames + slot) * 12, 12, hipMemcpyDeviceToHost));
+  }
+  return have;
+}
+
+static int fetch_subch(dabx_engine *e, int stream, int j, SubchDev *sc)
+{
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  DABX_HIP(hipMemcpy(sc, e->dev.subch + (size_t)stream * e->dev.max_subch + j, sizeof(SubchDev), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int dabx_read_msc(dabx_engine *e, int stream, int j, int n_cifs, uint8_t *bytes)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || j < 0 || j >= e->dev.max_subch || n_cifs <= 0 || n_cifs > MSC_SLOTS || !bytes) return DABX_E_ARG;
+  SubchDev sc;
+  int rc = fetch_subch(e, stream, j, &sc);
+  if (rc) return rc;
+  if (!sc.active) return 0;
+  const int have = (int)std::min<long long>(sc.cif_out, n_cifs), nb = 3 * sc.kbps;
+  for (int i = 0; i < have; i++) {
+    const long long q = sc.cif_out - have + i;
+    DABX_HIP(hipMemcpy(bytes + (size_t)i * nb,
+                       e->dev.msc_out + (((size_t)stream * e->dev.max_subch + j) * MSC_SLOTS + (size_t)(q % MSC_SLOTS)) * e->dev.msc_stride,
+                       nb, hipMemcpyDeviceToHost));
+  }
+  return have;
+}
+
+int dabx_read_superframes(dabx_engine *e, int stream, int j, int n, uint8_t *bytes)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || j < 0 || j >= e->dev.max_subch || n <= 0 || n > SF_SLOTS || !bytes) return DABX_E_ARG;
+  SubchDev sc;
+  int rc = fetch_subch(e, stream, j, &sc);
+  if (rc) return rc;
+  if (!sc.active) return 0;
+  const int have = (int)std::min<long long>(sc.sf_count, n), nb = 110 * sc.kbps / 8;
+  for (int i = 0; i < have; i++) {
+    const long long q = sc.sf_count - have + i;
+    DABX_HIP(hipMemcpy(bytes + (size_t)i * nb,
+                       e->dev.sf_out + (((size_t)stream * e->dev.max_subch + j) * SF_SLOTS + (size_t)(q % SF_SLOTS)) * e->dev.sf_stride,
+                       nb, hipMemcpyDeviceToHost));
+  }
+  return have;
+}
+
+int dabx_read_soft(dabx_engine *e, int stream, int16_t *soft)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !soft) return DABX_E_ARG;
+  if (!e->dev.soft_cap) { set_error("engine was created without capture_soft"); return DABX_E_STATE; }
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  DABX_HIP(hipMemcpy(soft, e->dev.soft_cap + (size_t)stream * 75 * K2, sizeof(int16_t) * 75 * K2, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !out) return DABX_E_ARG;
+  StreamCtl c;
+  int rc = fetch_ctl(e, stream, &c);
+  if (rc) return rc;
+  memset(out, 0, sizeof(*out));
+  out->frames = c.frames; out->samples_consumed = (int64_t)c.rd; out->state = c.state;
+  out->fic_ratio_percent = c.fic_ratio * 10; out->freq_offs_bb_hz = c.f_bb; out->clock_err_hz = c.clock_err;
+  out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;
+  out->fib_ok = c.fib_ok; out->fib_total = c.fib_total;
+  std::vector<SubchDev> sc(std::max(1, e->dev.max_subch));
+  DABX_HIP(hipMemcpy(sc.data(), e->dev.subch + (size_t)stream * e->dev.max_subch, sizeof(SubchDev) * e->dev.max_subch, hipMemcpyDeviceToHost));
+  for (int j = 0; j < e->dev.max_subch; j++) {
+    out->sf_ok += sc[j].sf_ok; out->sf_fail += sc[j].sf_fail; out->rs_corrected += sc[j].rs_corr; out->rs_failed += sc[j].rs_fail;
+    out->au_ok += sc[j].au_ok; out->au_bad += sc[j].au_bad; out->cifs_decoded += sc[j].cif_out;
+  }
+  return 0;
+}
+
+int dabx_get_counters(dabx_engine *e, int64_t out[16])
+{
+  if (!e || !out) return DABX_E_ARG;
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  const int S = e->dev.n_streams;
+  std::vector<StreamCtl> ctl(S);
+  std::vector<SubchDev> sc((size_t)S * std::max(1, e->dev.max_subch));
+  DABX_HIP(hipMemcpy(ctl.data(), e->dev.ctl, sizeof(StreamCtl) * S, hipMemcpyDeviceToHost));
+  DABX_HIP(hipMemcpy(sc.data(), e->dev.subch, sizeof(SubchDev) * sc.size(), hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof(int64_t) * 16);
+  for (auto &c : ctl) {
+    out[0] += c.frames; out[1] += (int64_t)c.rd; out[2] += c.fib_ok; out[3] += c.fib_total; out[4] += c.sync_lost;
+    out[5] += (c.state == ST_EVAL_SYNC);
+  }
+  for (auto &q : sc) {
+    out[6] += q.cif_out; out[7] += q.sf_ok; out[8] += q.sf_fail; out[9] += q.rs_corr; out[10] += q.rs_fail;
+    out[11] += q.fc_corr; out[12] += q.au_ok; out[13] += q.au_bad;
+    out[14] += (int64_t)q.cif_out * 3 * q.kbps;                 // MSC bytes out
+  }
+  return 0;
+}
+
+int dabx_set_profiling(dabx_engine *e, int on)
+{
+  if (!e) return DABX_E_ARG;
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  e->profiling = on != 0;
+  e->ev_used = 0;
+  for (int k = 0; k < 8; k++) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
+  return 0;
+}
+
+int dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t launches[DABX_MAX_KERNELS],
+                     const char *names[DABX_MAX_KERNELS])
+{
+  if (!e || !total_ms || !launches || !names) return DABX_E_ARG;
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  for (size_t base = 0; base + 9 <= e->ev_used; base += 9)
+    for (int k = 0; k < 8; k++) {
+      float ms = 0.f;
+      DABX_HIP(hipEventElapsedTime(&ms, e->ev_pool[base + k], e->ev_pool[base + k + 1]));
+      e->prof_ms[k] += ms; e->prof_n[k]++;
+    }
+  e->ev_used = 0;
+  for (int k = 0; k < 8; k++) { total_ms[k] = e->prof_ms[k]; launches[k] = e->prof_n[k]; names[k] = kStepKernelNames[k]; }
+  return 8;
+}
+
+// ---- stage-level FIC decode through the pipeline kernel (FicDecoder::process_block x 3) ------------
+int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_ok)
+{
+  if (!soft || !fibs || !crc_ok || batch <= 0) { set_error("dabx_fic_decode: bad argument"); return DABX_E_ARG; }
+  int rc = need_device_e();
+  if (rc) return rc;
+  dabx_config cfg;
+  dabx_default_config(&cfg);
+  cfg.n_streams = batch; cfg.ring_frames = 2; cfg.max_subch = 0; cfg.out_frames = 1; cfg.fic_only = 1;
+  // a minimal engine gives us the buffers; the IQ ring is not touched
+  dabx_engine *e = nullptr;
+  cfg.ring_frames = 2;
+  {
+    // avoid the (large) IQ ring for big batches: temporarily shrink via a dedicated light-weight allocation
+    e = new dabx_engine();
+    e->cfg = cfg;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DABX_E_HIP; }
+    EngineDev &d = e->dev;
+    d.n_streams = batch; d.max_subch = 0; d.out_frames = 1; d.fic_only = 1;
+    d.vit_stride = (int)vit_scratch_words(FIC_OUT);
+#define A(x) if ((rc = (x))) { dabx_destroy(e); return rc; }
+    A(e->alloc(&d.ctl, batch));
+    A(e->alloc(&d.fic_sym, (size_t)batch * 3 * K2));
+    A(e->alloc(&d.fib_out, (size_t)batch * 384));
+    A(e->alloc(&d.fib_crc, (size_t)batch * 12));
+    A(e->alloc(&d.vit_scratch, (size_t)batch * 4 * d.vit_stride, false));
+    std::vector<StreamCtl> ctl(batch);
+    for (auto &c : ctl) { memset(&c, 0, sizeof(c)); c.frame_ok = 1; }
+    DABX_HIP(hipMemcpyAsync(d.ctl, ctl.data(), sizeof(StreamCtl) * batch, hipMemcpyHostToDevice, e->stream));
+    int16_t *dsoft = nullptr;
+    A(e->alloc(&dsoft, (size_t)batch * 3 * K2, false));
+    DABX_HIP(hipMemcpyAsync(dsoft, soft, sizeof(int16_t) * (size_t)batch * 3 * K2, hipMemcpyHostToDevice, e->stream));
+    A(launch_i16_to_sym(dsoft, d.fic_sym, (size_t)batch * 3 * K2, e->stream));
+    A(launch_fic_only(d, e->stream));
+#undef A
+    DABX_HIP(hipStreamSynchronize(e->stream));
+    DABX_HIP(hipMemcpy(fibs, d.fib_out, (size_t)batch * 384, hipMemcpyDeviceToHost));
+    DABX_HIP(hipMemcpy(crc_ok, d.fib_crc, (size_t)batch * 12, hipMemcpyDeviceToHost));
+  }
+  dabx_destroy(e);
+  return 0;
+}
+
+}  // extern "C"

@@ -59,7 +59,7 @@ struct EngineDev {
   int32_t strongest, fic_only, capture_soft;
   int32_t msc_stride;             // bytes per logical-frame slot (3 * max kbps)
   int32_t sf_stride;              // bytes per super-frame slot (110 * max kbps / 8)
-  int32_t vit_words_fic, vit_words_msc;   // decision-scratch words per trellis
+  int32_t vit_stride;             // decision-scratch words per trellis (max over FIC and all sub-channels)
   float2 *iq;                     // [S][ring_len]
   unsigned long long *wr;         // [S] absolute index one past the last committed sample
   StreamCtl *ctl;                 // [S]

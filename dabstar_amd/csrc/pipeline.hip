@@ -1,0 +1,664 @@
+// pipeline.hip -- per-frame kernels of the stream-batched receiver.  One batch step advances every
+// stream that is in lock (and has a frame of samples) by one DAB frame; this file is the device-side
+// equivalent of DabProcessor::run (base/main/dab_processor.cpp:110-442).
+//
+//   k_acquire      ST_INIT / ST_WAIT_SYNC: level seeding + null-dip detector (timesyncer.cpp:40-90)
+//   k_frame_head   PRS correlation -> start index, symbol-0 FFT, optional coarse CFO (dab_processor.cpp:389-414, 191-224)
+//   k_symbols      symbols 1..75: NCO mix, cyclic-prefix correlation, FFT (dab_processor.cpp:304-341)
+//   k_demap_frame  75 x decode_symbol, soft bits -> Viterbi symbols -> FIC buffer / time-deinterleaver ring
+//   k_fic_frame    4 x depuncture + Viterbi + PRBS + 12 x CRC + FIG 0/0 walk (fic_decoder.cpp:143-262)
+//   k_frame_tail   fine CFO, null symbol, clock error, cursor bookkeeping (dab_processor.cpp:226-302)
+//   k_msc_frame    time de-interleave + depuncture + Viterbi + PRBS per (CIF, sub-channel) (backend.cpp:129-161)
+//   k_dabplus      super-frame sync, RS(120,110), fire code, AU CRCs (mp4processor.cpp:96-333)
+#include "pipeline.h"
+#include "ofdm_core.h"
+#include "viterbi_core.h"
+#include "fec_core.h"
+
+namespace dabx {
+
+__device__ __forceinline__ float2 ring_load(const float2 *ring, int ring_len, unsigned long long abs_idx)
+{
+  return ring[(size_t)(abs_idx % (unsigned long long)ring_len)];
+}
+
+// ------------------------------------------------------------------------------------------------ acquire
+// Sample-serial by nature (IIR level + 50-tap moving sum with data-dependent stop): lane 0 walks the
+// stream while the wave prefetches 256 samples at a time.  Only runs out of lock.
+__global__ __launch_bounds__(64) void k_acquire(EngineDev e)
+{
+  const int s = blockIdx.x, lane = threadIdx.x;
+  StreamCtl &c = e.ctl[s];
+  const int st = c.state;
+  if (lane == 0) c.frame_ok = 0;
+  if (st == ST_EVAL_SYNC) return;
+  const unsigned long long avail = e.wr[s] - c.rd;
+  if (avail < (unsigned long long)ACQ_NEED) return;
+  // WAIT_FOR_TIME_SYNC_MARKER entry (dab_processor.cpp:146-153): decoder reset
+  for (int i = lane; i < K; i += 64) {
+    e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
+  }
+  for (int i = lane; i < TU; i += 64) e.demap.null_power[(size_t)s * TU + i] = 0.f;
+
+  __shared__ float chunk[256];
+  __shared__ float env[64];
+  __shared__ int s_done, s_consumed, s_ok;
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  if (lane == 0) { s_done = 0; s_consumed = 0; s_ok = 0; }
+  // lane-0 state machine
+  int phase = (st == ST_INIT) ? 0 : 1;     // 0 seed level, 1 first 50, 2 wait for dip, 3 wait for end of dip
+  int remain = (st == ST_INIT) ? 20 * TU : 50, counter = 0, idx = 0;
+  float s_level = c.s_level, peak_level = c.peak_level, level = 0.f;
+  unsigned long long pos = c.rd;
+  int consumed = 0;
+  __syncthreads();
+  while (true) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float2 v = ring_load(ring, e.ring_len, pos + lane + 64 * q);
+      chunk[lane + 64 * q] = sqrtf(v.x * v.x + v.y * v.y);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int i = 0; i < 256 && !s_done; i++) {
+        // loop conditions are evaluated BEFORE the next sample is read (timesyncer.cpp:58,74)
+        if (phase == 2 && !(level / 50.f > 0.55f * s_level)) { phase = 3; counter = 0; }
+        if (phase == 3 && !(level / 50.f < 0.75f * s_level)) { s_done = 1; s_ok = 1; break; }
+        const float a = chunk[i];
+        if (a > peak_level) peak_level = a;                  // sample_reader.cpp:246-248
+        s_level += 0.00001f * (a - s_level);
+        consumed++;
+        if (phase == 0) { if (--remain == 0) { phase = 1; remain = 50; level = 0.f; idx = 0; } }
+        else if (phase == 1) {
+          env[idx & 63] = a; level += a; ++idx;
+          if (--remain == 0) phase = 2;
+        } else {
+          env[idx & 63] = a;
+          level += a - env[(idx - 50) & 63];
+          ++idx;
+          ++counter;
+          if (phase == 2 && counter > TF) { s_done = 1; s_ok = 0; }                       // NO_DIP_FOUND
+          else if (phase == 3 && counter > TN + 50 + 20) { s_done = 1; s_ok = 0; }       // NO_END_OF_DIP_FOUND
+        }
+      }
+      s_consumed = consumed;
+    }
+    __syncthreads();
+    if (s_done) break;
+    pos += 256;
+  }
+  if (lane == 0) {
+    c.rd += (unsigned long long)s_consumed;     // frequency offset is 0 while searching: NCO phase unchanged
+    c.s_level = s_level; c.peak_level = peak_level;
+    c.sample_count = 0;
+    c.sync_thr = e.threshold;
+    c.clock_err = 0.0f;
+    c.state = s_ok ? ST_EVAL_SYNC : ST_WAIT_SYNC;
+  }
+}
+
+// --------------------------------------------------------------------------------------------- frame head
+__global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
+{
+  __shared__ float2 lds[FFT_LDS_FLOAT2];
+  __shared__ float peak[TU];
+  __shared__ float red[8];
+  __shared__ float mag[160];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  StreamCtl &c = e.ctl[s];
+  if (c.state != ST_EVAL_SYNC) return;
+  const unsigned long long avail = e.wr[s] - c.rd;
+  if (avail < (unsigned long long)FRAME_NEED) return;
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned long long rd = c.rd;
+  const int phase0 = c.nco_phase;
+  const int f = (int)roundf(c.f_bb);                       // sample_reader.cpp:211
+
+  float2 v[8];
+  Nco nco;
+  nco.init(phase0, f, tid);
+#pragma unroll
+  for (int u = 0; u < 8; u++) { v[u] = nco.mix(ring_load(ring, e.ring_len, rd + tid + 256 * u)); nco.step(); }
+  const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
+  __syncthreads();
+  if (start < 0) {                                         // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER
+    if (tid == 0) {
+      c.rd = rd + TU;
+      c.nco_phase = nco_advance(phase0, f, TU);
+      c.state = ST_WAIT_SYNC;
+      c.sync_lost++;
+    }
+    return;
+  }
+  // symbol 0 = samples [start, start + Tu) of the same (mixed) stream, :402-411
+  nco.init(phase0, f, (long long)start + tid);
+#pragma unroll
+  for (int u = 0; u < 8; u++) { v[u] = nco.mix(ring_load(ring, e.ring_len, rd + start + tid + 256 * u)); nco.step(); }
+  fft2048<false>(v, lds, t.twiddle, tid);                 // dab_processor.cpp:199-201
+#pragma unroll
+  for (int u = 0; u < 8; u++) e.demap.phase_ref[(size_t)s * TU + tid + 256 * u] = v[u];   // store_reference_symbol_0
+
+  int correction = 0;
+  float f_sync = c.f_sync, f_bb = c.f_bb, clock_err = c.clock_err;
+  if (c.fic_ratio * 10 < 30) {                            // :205-224
+    correction = coarse_cfo_block(v, t, lds, mag, tid);
+    if (correction != 100000) {
+      f_sync += (float)correction;
+      if (fabsf(f_sync) > 35000.0f) f_sync = 0.0f;
+    }
+    if (correction != 0) clock_err = 0.0f;
+    f_bb = f_sync;
+  }
+  if (tid == 0) {
+    c.start_index = start;
+    c.sample_count = start + TU;
+    c.sym0_pos = rd + start;
+    c.phase_sym1 = nco_advance(phase0, f, (long long)start + TU);
+    c.correction = correction;
+    c.f_sync = f_sync; c.f_bb = f_bb; c.clock_err = clock_err;
+    c.f_frame = (int)roundf(f_bb);
+    c.frame_ok = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ symbols
+// grid (76, S): x = 0..74 -> OFDM symbols 1..75.  (The null symbol is handled by k_frame_tail: it needs the
+// fine-CFO update that depends on all 75 cyclic-prefix correlations.)
+__global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
+{
+  __shared__ float2 lds[FFT_LDS_FLOAT2];
+  __shared__ float red[8];
+  const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;   // l = symbol index - 1
+  const StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned long long base = c.sym0_pos + TU + (unsigned long long)l * TS;   // first sample (CP) of this symbol
+  const int f = c.f_frame;
+  const long long n0 = (long long)l * TS;                                        // samples read since symbol 1 began
+
+  // cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504 (dab_processor.cpp:330-333) on the RAW samples;
+  // the NCO contributes the constant factor e^{-j 2 pi f Tu / fs} which k_frame_tail applies once.
+  float cre = 0.f, cim = 0.f, asum = 0.f;
+  for (int i = tid; i < TG; i += 256) {
+    const float2 a = ring_load(ring, e.ring_len, base + TU + i), b = ring_load(ring, e.ring_len, base + i);
+    cre += a.x * b.x + a.y * b.y;
+    cim += a.y * b.x - a.x * b.y;
+    asum += cabsf_(b);
+  }
+  float2 v[8];
+  Nco nco;
+  nco.init(c.phase_sym1, f, n0 + TG + tid);
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const float2 x = ring_load(ring, e.ring_len, base + TG + tid + 256 * u);
+    asum += cabsf_(x);
+    v[u] = nco.mix(x);
+    nco.step();
+  }
+  cre = block_sum(cre, red, tid);
+  cim = block_sum(cim, red, tid);
+  asum = block_sum(asum, red, tid);
+  if (tid == 0) { e.cp_part[(size_t)s * 75 + l] = make_float2(cre, cim); e.abs_part[(size_t)s * 76 + l] = asum; }
+  fft2048<false>(v, lds, t.twiddle, tid);                 // :337-338
+  float2 *dst = e.spectra + ((size_t)s * 76 + l) * TU;
+#pragma unroll
+  for (int u = 0; u < 8; u++) dst[tid + 256 * u] = v[u];
+}
+
+// -------------------------------------------------------------------------------------------------- demap
+__global__ __launch_bounds__(256) void k_demap_frame(EngineDev e, DevTables t)
+{
+  __shared__ float red[8];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  DemapDev &d = e.demap;
+  DemapCarrier cr[6];
+  int bin[6], rel[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int k = tid + 256 * q;
+    bin[q] = t.perm_bin[k]; rel[q] = t.perm_rel[k];
+    cr[q].prev = d.phase_ref[(size_t)s * TU + bin[q]];
+    cr[q].integ = d.integ[(size_t)s * K + k];
+    cr[q].mean_power = d.mean_power[(size_t)s * K + k];
+    cr[q].mean_sigma_sq = d.mean_sigma[(size_t)s * K + k];
+    cr[q].null_power = d.null_power[(size_t)s * TU + bin[q]];
+  }
+  float mean_value = d.mean_value[s];
+  const float ce = c.clock_err;                           // mClockErrHz of the previous frame, dab_processor.cpp:342
+  const long long cif0 = c.cif_no;
+  uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
+  uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
+  int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
+  const int n_sym = e.fic_only ? 75 : 75;                 // the demapper state advances on all 75 symbols in every mode
+  for (int l = 0; l < n_sym; l++) {
+    const float2 *X = e.spectra + ((size_t)s * 76 + l) * TU;
+    uint8_t *o;
+    if (l < 3) o = fic + l * K2;                          // symbols 1..3 -> FIC
+    else {                                                // msc_handler.cpp:148-168 : 18 symbols per CIF
+      const int m = l - 3, cif = m / 18, blk = m % 18;
+      o = tdi + (size_t)((cif0 + cif) & (TDI_SLOTS - 1)) * CIF_BITS + blk * K2;
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      int16_t sr, si;
+      part += demap_one(cr[q], X[bin[q]], rel[q], ce, mean_value, d.soft_type, sr, si);
+      const int k = tid + 256 * q;
+      o[k] = soft_to_sym(sr);
+      o[K + k] = soft_to_sym(si);
+      if (cap) { cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
+    }
+    mean_value = block_sum(part, red, tid) / (float)K;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int k = tid + 256 * q;
+    d.integ[(size_t)s * K + k] = cr[q].integ;
+    d.mean_power[(size_t)s * K + k] = cr[q].mean_power;
+    d.mean_sigma[(size_t)s * K + k] = cr[q].mean_sigma_sq;
+  }
+  if (tid == 0) d.mean_value[s] = mean_value;
+}
+
+// ---------------------------------------------------------------------------------------------------- FIC
+struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map
+  const uint8_t *sym;
+  const uint16_t *map;
+  __device__ int one(uint16_t idx) const { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : sym[idx]); }
+  __device__ VitSyms operator()(int t) const
+  {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
+    return {one(m.x), one(m.y), one(m.z), one(m.w)};
+  }
+};
+
+__global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
+{
+  __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
+  __shared__ uint8_t crc_ok[12];
+  const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  {
+    SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + wave * FIC_IN, t.fic_map};
+    uint32_t *dec = e.vit_scratch + ((size_t)s * (4 + 4 * e.max_subch) + wave) * (size_t)e.vit_stride;
+    const VitLaneConst k = vit_lane_const(lane);
+    vit_forward(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint32_t *prbs = t.prbs_words;
+    uint32_t *fw = fibw[wave];
+    vit_traceback(dec, FIC_OUT, lane, [&](int wi, unsigned v) { if (lane == 0) fw[wi] = v ^ prbs[wi]; });   // fic_decoder.cpp:219-222
+  }
+  __syncthreads();
+  const int slot = (int)(c.frames % e.out_frames);
+  uint8_t *fo = e.fib_out + ((size_t)s * e.out_frames + slot) * 12 * 32;
+  if (threadIdx.x < 12) {                    // one lane per FIB: CRC (crc.cpp:98-132 == CCITT over 30 bytes vs the last 2)
+    const int fibi = threadIdx.x;
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(&fibw[fibi / 3][0]) + (fibi % 3) * 32;
+    crc_ok[fibi] = crc16_check_bytes(b, 30, t.crc_ccitt);
+  }
+  for (int i = threadIdx.x; i < 96; i += 256) reinterpret_cast<uint32_t *>(fo)[i] = fibw[i / 24][i % 24];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // per-FIB bookkeeping in FIB order (fic_decoder.cpp:234-261) + FIG walk for the CIF counter
+    int ratio = c.fic_ratio, cif_count = c.cif_count;
+    long long ok = 0;
+    for (int fibi = 0; fibi < 12; fibi++) {
+      e.fib_crc[((size_t)s * e.out_frames + slot) * 12 + fibi] = crc_ok[fibi];
+      if (crc_ok[fibi]) {
+        ok++;
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(&fibw[fibi / 3][0]) + (fibi % 3) * 32;
+        int p = 0;                          // fib_decoder.cpp:59-110
+        while (p < 30) {
+          const int type = b[p] >> 5, len = b[p] & 0x1F;
+          if (type == 7 && len == 0x1F) break;
+          if (type == 0 && p + 5 < 32 && (b[p + 1] & 0x1F) == 0)                       // FIG 0/0, fib_decoder_fig0.cpp:89-101
+            cif_count = (b[p + 4] & 0x1F) * 250 + b[p + 5];
+          p += len + 1;
+        }
+        if (ratio < 10) ratio++;
+      } else if (ratio > 0) ratio--;
+    }
+    c.fic_ratio = ratio; c.cif_count = cif_count;
+    c.fib_ok += ok; c.fib_total += 12;
+  }
+}
+
+// --------------------------------------------------------------------------------------------- frame tail
+__global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
+{
+  __shared__ float2 lds[FFT_LDS_FLOAT2];
+  __shared__ float red[8];
+  __shared__ float s_fbb;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  // fine CFO from the 75 cyclic-prefix correlations (dab_processor.cpp:366, 236-242)
+  float cre = 0.f, cim = 0.f, asum = 0.f;
+  if (tid < 75) { const float2 p = e.cp_part[(size_t)s * 75 + tid]; cre = p.x; cim = p.y; asum = e.abs_part[(size_t)s * 76 + tid]; }
+  cre = block_sum(cre, red, tid);
+  cim = block_sum(cim, red, tid);
+  asum = block_sum(asum, red, tid);
+  const int f = c.f_frame;
+  if (tid == 0) {
+    // the reference correlates NCO-mixed samples: x'[i] conj(x'[i-Tu]) = x[i] conj(x[i-Tu]) e^{-j 2 pi f Tu / fs}
+    double sr, cr;
+    sincospi(-2.0 * (double)(((long long)f * TU) % INPUT_RATE) / (double)INPUT_RATE, &sr, &cr);
+    const float rr = cre * (float)cr - cim * (float)sr, ri = cre * (float)sr + cim * (float)cr;
+    float ph = atan2f(ri, rr);
+    const float lim = 20.0f * 0.01745329251994329577f;
+    if (ph > lim) ph = lim; else if (ph < -lim) ph = -lim;
+    c.phase_offs = ph;
+    c.f_sync += ph / 6.28318530717958647692f * 1000.0f;
+    c.f_bb = c.f_sync;
+    s_fbb = c.f_bb;
+  }
+  __syncthreads();
+  // null symbol (dab_processor.cpp:267-302): T_n samples with the updated frequency, FFT of [Tg, Tg+Tu)
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned long long base = c.sym0_pos + TU + 75ull * TS;
+  const int phase_null = nco_advance(c.phase_sym1, f, 75LL * TS);
+  const int f2 = (int)roundf(s_fbb);
+  float2 v[8];
+  Nco nco;
+  nco.init(phase_null, f2, TG + tid);
+  float an = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const float2 x = ring_load(ring, e.ring_len, base + TG + tid + 256 * u);
+    an += cabsf_(x);
+    v[u] = nco.mix(x);
+    nco.step();
+  }
+  an = block_sum(an, red, tid);
+  fft2048<false>(v, lds, t.twiddle, tid);
+  const bool is_tii = (c.cif_count & 7) >= 4;              // :274
+  if (!is_tii) {                                           // store_null_symbol_without_tii
+    const float kMinNoisePower = (1.0f / 32767.0f) * (1.0f / 32767.0f);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int bin = tid + 256 * u;
+      if ((bin >= 1 && bin <= K / 2) || bin >= TU - K / 2) {
+        float *np = &e.demap.null_power[(size_t)s * TU + bin];
+        const float power = v[u].x * v[u].x + v[u].y * v[u].y + kMinNoisePower;
+        *np += 0.05f * (power - *np);
+      }
+    }
+  }
+  if (tid == 0) {
+    const int sample_count = c.sample_count + 75 * TS + TN;
+    if (c.correction == 0) {                               // :246-251
+      float ce = (float)INPUT_RATE * ((float)sample_count / (float)TF - 1.0f);
+      if (ce > 307.2f) ce = 307.2f; else if (ce < -307.2f) ce = -307.2f;
+      c.clock_err += 0.1f * (ce - c.clock_err);
+    }
+    // level IIR of SampleReader over the samples of this frame, applied per chunk with the chunk mean
+    // (approximation of sample_reader.cpp:246-248; only used by the out-of-lock dip detector)
+    const int nread = sample_count;
+    const float mean_abs = (asum + an * ((float)TN / (float)TU)) / (float)(75 * TS + TN);
+    c.s_level += (1.0f - __expf((float)nread * -0.00001f)) * (mean_abs - c.s_level);
+    c.sample_count = sample_count;
+    c.rd = base + TN;
+    c.nco_phase = nco_advance(phase_null, f2, TN);
+    c.cif_no += 4;
+    c.frames += 1;
+    c.sync_thr = 2.0f * e.threshold;                       // :178
+    c.state = ST_EVAL_SYNC;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- MSC
+struct SrcMsc {                        // time de-interleaver read + depuncture (backend.cpp:131-139, protection.cpp:46-59)
+  const uint8_t *tdi;                  // this stream's ring
+  const uint16_t *map;
+  long long r;                         // CIF being output
+  int base;                            // cu_start * 64
+  __device__ int one(uint16_t idx) const
+  {
+    if (idx == PUNCT) return vit_sym_from_u8(127);
+    // out_r[i] = in_{r-16+map[i&15]}[i], map = {0,8,4,12,2,10,6,14,1,9,5,13,3,11,7,15} (bit reversal of 4 bits)
+    const int i4 = idx & 15;
+    const int m = ((i4 & 1) << 3) | ((i4 & 2) << 1) | ((i4 & 4) >> 1) | ((i4 & 8) >> 3);
+    const long long q = r - 16 + m;
+    return vit_sym_from_u8(tdi[(size_t)(q & (TDI_SLOTS - 1)) * CIF_BITS + base + idx]);
+  }
+  __device__ VitSyms operator()(int t) const
+  {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
+    return {one(m.x), one(m.y), one(m.z), one(m.w)};
+  }
+};
+
+__global__ __launch_bounds__(256) void k_msc_frame(EngineDev e, DevTables t)
+{
+  __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + wave;
+  const int per_stream = 4 * e.max_subch;
+  const int s = job / per_stream;
+  if (s >= e.n_streams) return;
+  const int rem = job % per_stream, j = rem >> 2, cif = rem & 3;
+  const StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  const SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
+  if (!sc.active) return;
+  const long long first_r = c.cif_no - 4;       // k_frame_tail already advanced cif_no by 4
+  const long long r = first_r + cif;
+  const long long valid_from = sc.start_cif + 16;   // de-interleaver filled (backend.cpp:146-150)
+  if (r < valid_from) return;
+  const long long out_idx = sc.cif_out + (r - (first_r > valid_from ? first_r : valid_from));
+  SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64};
+  uint32_t *dec = e.vit_scratch + ((size_t)s * (4 + 4 * e.max_subch) + 4 + rem) * (size_t)e.vit_stride;
+  const VitLaneConst k = vit_lane_const(lane);
+  vit_forward(src, sc.nbits + 6, wtab[wave], dec, lane, k);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  uint32_t *out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)s * e.max_subch + j) * MSC_SLOTS + (size_t)(out_idx % MSC_SLOTS)) * e.msc_stride);
+  const uint32_t *prbs = t.prbs_words;
+  vit_traceback(dec, sc.nbits, lane, [&](int wi, unsigned v) { if (lane == 0) out[wi] = v ^ prbs[wi]; });   // backend.cpp:155-158
+}
+
+// ------------------------------------------------------------------------------------------------- DAB+
+// One wave per (stream, sub-channel); walks the logical frames produced in this batch step.
+__global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
+{
+  const int job = blockIdx.x, lane = threadIdx.x;
+  const int s = job / e.max_subch, j = job % e.max_subch;
+  const StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
+  if (!sc.active) return;
+  const long long first_r = c.cif_no - 4;
+  long long n_new = 0;
+  for (int cif = 0; cif < 4; cif++) if (first_r + cif >= sc.start_cif + 16) n_new++;
+  if (n_new == 0) return;
+  const int R = sc.kbps / 8, nbytes = 3 * sc.kbps;
+  const uint8_t *ring = e.msc_out + ((size_t)s * e.max_subch + j) * MSC_SLOTS * e.msc_stride;
+  const Gf gf{t.gf_exp, t.gf_log};
+  long long cif_out = sc.cif_out;
+  int blocks_in_buf = sc.blocks_in_buf, sf_sync = sc.sf_sync;
+  long long sf_count = sc.sf_count, sf_ok = 0, sf_fail = 0, rs_corr = 0, rs_fail = 0, fc_corr = 0, au_ok = 0, au_bad = 0;
+  __shared__ int s_flag;
+  __shared__ int s_au[8];
+  __shared__ __attribute__((aligned(16))) uint8_t sf[110 * 48 + 16];   // RS-corrected super frame (<= 384 kbit/s)
+  for (long long n = 0; n < n_new; n++) {
+    const long long newest = cif_out;        // index of the logical frame just added
+    cif_out++;
+    if (!sc.dab_plus) continue;
+    blocks_in_buf++;                         // mp4processor.cpp:113
+    if (blocks_in_buf < 5) continue;
+    const long long oldest = newest - 4;
+    auto wbyte = [&](int x) -> uint8_t {     // byte x of the 5-frame window, oldest first
+      return ring[(size_t)((oldest + x / nbytes) % MSC_SLOTS) * e.msc_stride + (x % nbytes)];
+    };
+    if (sf_sync == 0) {                      // :132-142
+      const bool ok = firecode_syndrome([&](int i) { return wbyte(i); }, t.fc_crctab) == 0;
+      if (ok) sf_sync = 4; else { blocks_in_buf = 4; continue; }
+    }
+    blocks_in_buf = 0;                       // :147
+    // _process_reed_solomon_frame, :184-241: code word j2 = bytes (j2 + k R), k < 120
+    uint8_t *sfo = e.sf_out + (((size_t)s * e.max_subch + j) * SF_SLOTS + (size_t)(sf_count % SF_SLOTS)) * e.sf_stride;
+    int my_ret = 0;
+    if (lane < R) {
+      uint8_t cw[120];
+      for (int k = 0; k < 120; k++) cw[k] = wbyte(lane + k * R);
+      my_ret = rs_decode_120(cw, gf);
+      for (int k = 0; k < 110; k++) sf[lane + k * R] = cw[k];
+    }
+    // lane-wise results -> wave totals
+    int corr = (lane < R && my_ret > 0) ? my_ret : 0, fail = (lane < R && my_ret < 0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { corr += __shfl_xor(corr, o); fail += __shfl_xor(fail, o); }
+    rs_corr += corr; rs_fail += fail;
+    __syncthreads();
+    if (lane == 0) {
+      uint8_t hdr[12];
+      for (int i = 0; i < 12; i++) hdr[i] = sf[i];
+      const bool ok = firecode_check_and_correct(hdr, t.fc_crctab, t.fc_syndrome);
+      int flag = ok ? 1 : 0;
+      if (ok) {
+        bool changed = false;
+        for (int i = 0; i < 11; i++) changed = changed || (hdr[i] != wbyte(i));
+        if (changed) flag |= 2;
+        for (int i = 0; i < 12; i++) sf[i] = hdr[i];
+        // AU table, mp4processor.cpp:256-306
+        const int dac = (hdr[2] >> 6) & 1, sbr = (hdr[2] >> 5) & 1, end = 110 * R;
+        int n_au;
+        switch (2 * dac + sbr) {
+        case 0: n_au = 4; s_au[0] = 8; s_au[1] = hdr[3] * 16 + (hdr[4] >> 4); s_au[2] = (hdr[4] & 0xf) * 256 + hdr[5];
+                s_au[3] = hdr[6] * 16 + (hdr[7] >> 4); s_au[4] = end; break;
+        case 1: n_au = 2; s_au[0] = 5; s_au[1] = hdr[3] * 16 + (hdr[4] >> 4); s_au[2] = end; break;
+        case 2: n_au = 6; s_au[0] = 11; s_au[1] = hdr[3] * 16 + (hdr[4] >> 4); s_au[2] = (hdr[4] & 0xf) * 256 + hdr[5];
+                s_au[3] = hdr[6] * 16 + (hdr[7] >> 4); s_au[4] = (hdr[7] & 0xf) * 256 + hdr[8];
+                s_au[5] = hdr[9] * 16 + (hdr[10] >> 4); s_au[6] = end; break;
+        default: n_au = 3; s_au[0] = 6; s_au[1] = hdr[3] * 16 + (hdr[4] >> 4); s_au[2] = (hdr[4] & 0xf) * 256 + hdr[5];
+                s_au[3] = end; break;
+        }
+        s_au[7] = n_au;
+      }
+      s_flag = flag;
+    }
+    __syncthreads();
+    const int flag = s_flag;
+    if (flag & 1) {                          // :149-158
+      if (flag & 2) fc_corr++;
+      sf_sync = 4; sf_ok++; sf_count++;
+      const int n_au = s_au[7];
+      int good = 0, bad = 0;
+      if (lane < n_au) {                     // :318-333 AU CRCs, one lane per AU
+        const int st = s_au[lane], len = s_au[lane + 1] - st - 2;
+        if (len > 960 || len < 0 || st + len + 2 > 110 * R) bad = 1;
+        else if (crc16_check_bytes(sf + st, len, t.crc_ccitt)) good = 1; else bad = 1;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { good += __shfl_xor(good, o); bad += __shfl_xor(bad, o); }
+      au_ok += good; au_bad += bad;
+      for (int i = lane; i < (110 * R + 3) / 4; i += 64)
+        reinterpret_cast<uint32_t *>(sfo)[i] = reinterpret_cast<const uint32_t *>(sf)[i];
+    } else {                                 // :159-169
+      sf_sync--;
+      if (sf_sync == 0) { blocks_in_buf = 4; sf_fail++; }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    sc.cif_out = cif_out; sc.blocks_in_buf = blocks_in_buf; sc.sf_sync = sf_sync; sc.sf_count = sf_count;
+    sc.sf_ok += sf_ok; sc.sf_fail += sf_fail; sc.rs_corr += rs_corr; sc.rs_fail += rs_fail;
+    sc.fc_corr += fc_corr; sc.au_ok += au_ok; sc.au_bad += au_bad;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+extern const char *const kStepKernelNames[8];
+const char *const kStepKernelNames[8] = {"k_acquire", "k_frame_head", "k_symbols", "k_demap_frame", "k_fic_frame",
+                                         "k_frame_tail", "k_msc_frame", "k_dabplus"};
+
+// ev: optional 9 events (boundaries before/after each of the 8 kernels); null = no profiling
+int launch_frame_step(const EngineDev &e, hipStream_t st, hipEvent_t *ev)
+{
+  const DevTables *t;
+  int rc = get_tables(&t);
+  if (rc) return rc;
+#define MARK(i) do { if (ev) DABX_HIP(hipEventRecord(ev[i], st)); } while (0)
+  MARK(0);
+  hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e);
+  MARK(1);
+  hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t);
+  MARK(2);
+  hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t);
+  MARK(3);
+  hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t);
+  MARK(4);
+  hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t);
+  MARK(5);
+  hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t);
+  MARK(6);
+  if (!e.fic_only && e.max_subch > 0 && e.msc_out) {
+    const int jobs = e.n_streams * 4 * e.max_subch;
+    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, st, e, *t);
+    MARK(7);
+    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, *t);
+    MARK(8);
+  } else { MARK(7); MARK(8); }
+#undef MARK
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_fic_only(const EngineDev &e, hipStream_t st)
+{
+  const DevTables *t;
+  int rc = get_tables(&t);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void k_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sym[i] = soft_to_sym(soft[i]);
+}
+int launch_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_i16_to_sym, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, soft, sym, n);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void k_commit(unsigned long long *wr, int n_streams, int stream, unsigned long long n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_streams && (stream < 0 || i == stream)) wr[i] += n;
+}
+int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_commit, dim3((e.n_streams + 255) / 256), dim3(256), 0, st, e.wr, e.n_streams, stream, n);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+// host IQ formats -> cf32 ring (raw_reader.cpp:66-70, wav_reader.cpp:164)
+__global__ void k_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float2 v;
+  if (fmt == 0) v = reinterpret_cast<const float2 *>(src)[i];
+  else if (fmt == 1) { const short2 q = reinterpret_cast<const short2 *>(src)[i]; v = make_float2(q.x / 32768.0f, q.y / 32768.0f); }
+  else { const uchar2 q = reinterpret_cast<const uchar2 *>(src)[i]; v = make_float2((q.x - 127.38f) / 128.0f, (q.y - 127.38f) / 128.0f); }
+  ring[(size_t)((wr0 + i) % (unsigned long long)ring_len)] = v;
+}
+int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_convert_iq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, fmt, ring, ring_len, wr0, n);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dabx

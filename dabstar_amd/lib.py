@@ -156,3 +156,126 @@ class Demap:
         out = np.zeros((self.batch, fft.shape[1], 3072), np.int16)
         check(load().dabx_demap_decode_symbols(self._h, _p(fft), fft.shape[1], _p(ce), _p(out)))
         return out
+
+
+# ---------------------------------------------------------------------------------- engine level
+class Config(C.Structure):
+    _fields_ = [("n_streams", C.c_int32), ("ring_frames", C.c_int32), ("max_subch", C.c_int32), ("out_frames", C.c_int32),
+                ("sync_threshold", C.c_float), ("sync_strongest", C.c_int32), ("soft_bit_type", C.c_int32),
+                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class SubchDesc(C.Structure):
+    _fields_ = [("subch_id", C.c_int32), ("cu_start", C.c_int32), ("cu_size", C.c_int32), ("kbps", C.c_int32),
+                ("prot_level", C.c_int32), ("short_form", C.c_int32), ("dab_plus", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("frames", C.c_int64), ("samples_consumed", C.c_int64), ("state", C.c_int32), ("fic_ratio_percent", C.c_int32),
+                ("freq_offs_bb_hz", C.c_float), ("clock_err_hz", C.c_float), ("snr_db_est", C.c_float),
+                ("last_start_index", C.c_int32), ("cif_count", C.c_int32),
+                ("fib_ok", C.c_int64), ("fib_total", C.c_int64), ("sf_ok", C.c_int64), ("sf_fail", C.c_int64),
+                ("rs_corrected", C.c_int64), ("rs_failed", C.c_int64), ("au_ok", C.c_int64), ("au_bad", C.c_int64),
+                ("cifs_decoded", C.c_int64)]
+
+
+COUNTER_NAMES = ["frames", "samples", "fib_ok", "fib_total", "sync_lost", "streams_locked", "cifs_decoded", "sf_ok", "sf_fail",
+                 "rs_corrected", "rs_failed", "fc_corrected", "au_ok", "au_bad", "msc_bytes", "reserved"]
+TF = 196608
+
+
+class Engine:
+    """Stream-batched receiver (device-side DabProcessor::run for n_streams ensembles)."""
+
+    def __init__(self, n_streams=1, ring_frames=4, max_subch=18, out_frames=4, fic_only=False, capture_soft=False,
+                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False):
+        L = load()
+        cfg = Config()
+        L.dabx_default_config(C.byref(cfg))
+        cfg.n_streams, cfg.ring_frames, cfg.max_subch, cfg.out_frames = n_streams, ring_frames, max_subch, out_frames
+        cfg.fic_only, cfg.capture_soft, cfg.sync_threshold = int(fic_only), int(capture_soft), sync_threshold
+        cfg.soft_bit_type, cfg.sync_strongest = soft_bit_type, int(sync_strongest)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(L.dabx_create(C.byref(cfg), C.byref(self._h)))
+        self.subch = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().dabx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_subchannels(self, subch, stream=-1, dab_plus=True):
+        arr = (SubchDesc * max(1, len(subch)))()
+        for i, c in enumerate(subch):
+            arr[i] = SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, int(dab_plus), 0)
+        check(load().dabx_set_subchannels(self._h, stream, arr, len(subch)))
+        self.subch = list(subch)
+
+    def push_iq(self, stream, iq):
+        iq = np.ascontiguousarray(iq)
+        fmt = {np.dtype(np.complex64): 0, np.dtype(np.int16): 1, np.dtype(np.uint8): 2}[iq.dtype]
+        n = iq.size if fmt == 0 else iq.size // 2
+        check(load().dabx_push_iq(self._h, stream, _p(iq), fmt, n))
+
+    def ring_ptr(self, stream):
+        p, cap = C.c_void_p(), C.c_size_t()
+        check(load().dabx_iq_ring_dev(self._h, stream, C.byref(p), C.byref(cap)))
+        return p.value, cap.value
+
+    def commit(self, n_samples, stream=-1):
+        check(load().dabx_commit_iq(self._h, stream, n_samples))
+
+    def process(self, max_frames, sync=True):
+        return check(load().dabx_process(self._h, max_frames, int(sync)))
+
+    def synchronize(self):
+        check(load().dabx_synchronize(self._h))
+
+    def hip_stream(self):
+        load().dabx_hip_stream.restype = C.c_void_p
+        return load().dabx_hip_stream(self._h)
+
+    def read_fibs(self, stream, n_frames=1):
+        fibs = np.zeros((n_frames, 12, 32), np.uint8)
+        crc = np.zeros((n_frames, 12), np.uint8)
+        n = check(load().dabx_read_fibs(self._h, stream, n_frames, _p(fibs), _p(crc)))
+        return fibs[:n], crc[:n]
+
+    def read_msc(self, stream, j, n_cifs=4):
+        nb = 3 * self.subch[j].kbps
+        out = np.zeros((n_cifs, nb), np.uint8)
+        n = check(load().dabx_read_msc(self._h, stream, j, n_cifs, _p(out)))
+        return out[:n]
+
+    def read_superframes(self, stream, j, n=1):
+        nb = 110 * self.subch[j].kbps // 8
+        out = np.zeros((n, nb), np.uint8)
+        k = check(load().dabx_read_superframes(self._h, stream, j, n, _p(out)))
+        return out[:k]
+
+    def read_soft(self, stream):
+        out = np.zeros((75, 3072), np.int16)
+        check(load().dabx_read_soft(self._h, stream, _p(out)))
+        return out
+
+    def stats(self, stream):
+        st = Stats()
+        check(load().dabx_get_stats(self._h, stream, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def counters(self):
+        out = (C.c_int64 * 16)()
+        check(load().dabx_get_counters(self._h, out))
+        return dict(zip(COUNTER_NAMES, list(out)))
+
+
+def fic_decode(soft):
+    """soft: [batch, 3*3072] int16 (OFDM symbols 1..3) -> (fibs [batch,12,32], crc_ok [batch,12])."""
+    soft = np.ascontiguousarray(soft, np.int16).reshape(-1, 9216)
+    fibs = np.zeros((soft.shape[0], 12, 32), np.uint8)
+    crc = np.zeros((soft.shape[0], 12), np.uint8)
+    check(load().dabx_fic_decode(_p(soft), soft.shape[0], _p(fibs), _p(crc)))
+    return fibs, crc

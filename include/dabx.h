@@ -163,6 +163,14 @@ int  dabx_read_soft(dabx_engine *e, int stream, int16_t *soft /* 75*3072 */);
 int  dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out);
 /* Sum of the counters over all streams of this engine (the values one RCCL all-reduce combines). */
 int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
+/* Per-kernel timing with HIP events recorded on the engine's stream around every launch of a batch step
+ * (bench.py's roofline leg).  dabx_get_profile drains the events recorded since the last call: for each of
+ * the n kernels of a step it returns the accumulated milliseconds and the number of launches; names[i]
+ * points to a static string.  Returns n. */
+#define DABX_MAX_KERNELS 16
+int  dabx_set_profiling(dabx_engine *e, int on);
+int  dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t launches[DABX_MAX_KERNELS],
+                      const char *names[DABX_MAX_KERNELS]);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,8 @@ def oracle():
         f.restype = C.POINTER(C.c_uint8)
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    L.ora_fic_init.argtypes = [C.c_void_p]
+    L.ora_fic_process_block.argtypes = [C.c_void_p, _i16p, C.c_int]
     L.ora_demap_new.restype = C.c_void_p
     L.ora_demap_free.argtypes = [C.c_void_p]
     L.ora_demap_set_type.argtypes = [C.c_void_p, C.c_int]

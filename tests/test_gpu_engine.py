@@ -1,0 +1,158 @@
+"""GPU end-to-end parity: the stream-batched engine vs the CPU oracle receiver on the same IQ.
+
+Bar (BASELINE.json / SURVEY.md 8d): FIB bytes + CRC flags, MSC logical-frame bytes and RS-corrected
+super frames are BIT-EXACT; the float soft bits are compared by tolerance."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from dabstar_amd import lib as dx
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tools import dab_synth as ds  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_run(x, subch, want_soft=False):
+    L = ol.oracle()
+    rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    L.ora_rx_enable_soft_capture(rx, int(want_soft))
+    n = L.ora_rx_run(rx, x, len(x), 10000)
+    cap = L.ora_rx_get_capture(rx).contents
+    res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy(),
+               crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy(),
+               start=np.ctypeslib.as_array(cap.start_idx, (n,)).copy(),
+               fbb=np.ctypeslib.as_array(cap.fbb, (n,)).copy(),
+               msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
+               sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
+               stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
+    if want_soft:
+        res["soft"] = np.ctypeslib.as_array(cap.soft, (n, 75, 3072)).copy()
+    L.ora_rx_destroy(rx)
+    return res
+
+
+def _engine_run(x, subch, n_frames, **kw):
+    eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=max(1, len(subch)), out_frames=4, **kw)
+    if subch:
+        eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    fibs, crc, msc, sfs, starts, fbbs = [], [], [[] for _ in subch], [[] for _ in subch], [], []
+    last_sf = [0] * len(subch)
+    for step in range(n_frames + 3):
+        before = eng.stats(0)["frames"]
+        eng.process(1)
+        st = eng.stats(0)
+        if st["frames"] == before:
+            continue
+        f, c = eng.read_fibs(0, 1)
+        fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
+        for j in range(len(subch)):
+            m = eng.read_msc(0, j, 4)
+            msc[j].append((st["frames"], m))
+    return eng, np.array(fibs), np.array(crc), msc, np.array(starts), np.array(fbbs)
+
+
+@pytest.mark.parametrize("seed,snr,cfo,toff", [(1, 20.0, 1234.5, 50000), (2, 12.0, -1987.0, 170001), (3, 30.0, 0.0, 3)])
+def test_fic_and_msc_bit_exact_vs_oracle(seed, snr, cfo, toff):
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=seed)
+    n_total = 28 * ds.TF
+    x = ds.channel(ens.iq, snr_db=snr, cfo_hz=cfo, timing_offset=toff, seed=seed, n_out=n_total)
+    ora = _oracle_run(x, subch)
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"])
+    n = min(len(fibs), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 20
+    assert np.array_equal(starts[:n], ora["start"][:n])
+    assert np.array_equal(crc[:n], ora["crc"][:n])
+    assert np.array_equal(fibs[:n], ora["fibs"][:n])
+    assert crc[6:n].all()                                      # locked and error free after the CFO has converged
+    # MSC logical frames: the engine ring keeps the newest 16 per sub-channel; the oracle kept the whole stream
+    cnt = eng.counters()
+    st = eng.stats(0)
+    frames_done = st["frames"]
+    k = frames_done * 4 - 16                                   # logical frames decoded per sub-channel (16-CIF warm-up)
+    assert cnt["cifs_decoded"] == 18 * k
+    total_sf = st["sf_ok"] // 18
+    assert st["sf_ok"] == 18 * total_sf and st["sf_fail"] == 0 and total_sf >= 3
+    for j in range(18):
+        o = ora["msc"][j].reshape(-1, 192)
+        got = eng.read_msc(0, j, 16)
+        assert len(got) == 16 and np.array_equal(got, o[k - 16:k]), j
+        sf_o = ora["sf"][j].reshape(-1, 880)
+        got_sf = eng.read_superframes(0, j, 4)
+        assert len(got_sf) == min(4, total_sf) and np.array_equal(got_sf, sf_o[total_sf - len(got_sf):total_sf]), j
+        # ... and they are the transmitted super frames (cyclic ensemble of 8)
+        assert any(np.array_equal(got_sf[-1], ens.superframes[j][q]) for q in range(8)), j
+    # the oracle also pushes the CIFs of a final, partially read frame through its back ends: totals are
+    # comparable only when both decoded the same number of logical frames
+    if cnt["cifs_decoded"] == sum(x_["cif_out"] for x_ in ora["stats"]):
+        assert cnt["sf_ok"] == sum(x_["sf_ok"] for x_ in ora["stats"])
+        assert cnt["au_ok"] == sum(x_["au_ok"] for x_ in ora["stats"])
+        assert cnt["rs_corrected"] == sum(x_["rs_corr"] for x_ in ora["stats"])
+        assert cnt["au_bad"] == sum(x_["au_bad"] for x_ in ora["stats"])
+    eng.close()
+
+
+def test_soft_bits_within_tolerance_and_transmitted_data_recovered():
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=7)
+    x = ds.channel(ens.iq, snr_db=20.0, cfo_hz=-433.0, timing_offset=1000, seed=7, n_out=14 * ds.TF)
+    ora = _oracle_run(x, subch, want_soft=True)
+    eng = dx.Engine(n_streams=1, ring_frames=15, max_subch=18, capture_soft=True)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    done = 0
+    for _ in range(ora["n"] + 3):
+        eng.process(1)
+        fr = eng.stats(0)["frames"]
+        if fr > done:
+            done = fr
+            if done in (1, 6, 12):
+                got = eng.read_soft(0).astype(np.int32)
+                exp = ora["soft"][done - 1].astype(np.int32)
+                d = np.abs(got - exp)
+                # 1 Hz steps of round(f_bb) can differ between the two float pipelines while the loop converges,
+                # so the tight bound is asserted once it has settled; signs must agree wherever |soft| > 8.
+                if done >= 6:
+                    assert (d > 2).mean() < 2e-3, (done, (d > 2).mean(), d.max())
+                strong = np.abs(exp) > 8
+                assert np.array_equal(got[strong] > 0, exp[strong] > 0)
+    # transmitted FIBs recovered
+    fibs, crc = eng.read_fibs(0, 1)
+    assert crc.all()
+    assert any(np.array_equal(fibs[0], ens.fibs[f]) for f in range(10))
+    eng.close()
+
+
+def test_fic_decode_stage_matches_oracle():
+    rng = np.random.default_rng(3)
+    ens = ds.build_ensemble(5, seed=9)
+    soft = ((ens.tx_bits[:4, :3].reshape(4, 9216).astype(np.int16) * 2 - 1) * 70)
+    soft = (soft + rng.normal(0, 45, soft.shape)).astype(np.int16)
+    soft[3] = rng.integers(-100, 100, 9216)                 # garbage -> CRC failures, still identical
+    fibs, crc = dx.fic_decode(soft)
+    L = ol.oracle()
+    for b in range(4):
+        fic = (C.c_uint8 * 40000)()                          # ora_fic is < 40 kB
+        L.ora_fic_init(fic)
+        for sidx in range(3):
+            L.ora_fic_process_block(fic, np.ascontiguousarray(soft[b, sidx * 3072:(sidx + 1) * 3072]), sidx + 1)
+        # fib_bits live at a fixed offset: recompute through the public capture instead
+        exp_bits = np.zeros((4, 768), np.uint8)
+        n_in, m = ol.ora_fic_map()
+        prbs = np.zeros(768, np.uint8); L.ora_prbs(prbs, 768)
+        for g in range(4):
+            blk = np.zeros(3096, np.int16)
+            blk[m >= 0] = soft[b, g * 2304:(g + 1) * 2304][m[m >= 0]]
+            exp_bits[g] = ol.ora_viterbi(blk, 768) ^ prbs
+        exp_fibs = np.packbits(exp_bits.reshape(12, 256), axis=1)
+        exp_crc = np.array([L.ora_check_crc_bits(np.ascontiguousarray(exp_bits.reshape(12, 256)[i]), 256) for i in range(12)], np.uint8)
+        assert np.array_equal(fibs[b], exp_fibs) and np.array_equal(crc[b], exp_crc), b
+    assert crc[:3].all() and not crc[3].any()
+    assert np.array_equal(fibs[0], ens.fibs[0])
