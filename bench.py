@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- DAB Mode-I ensembles (frames) per second on MI355X: IQ -> MSC bytes, whole chain.
+
+Workload (BASELINE.json configs[3]): 512 synthetic Mode-I IQ streams resident in HBM per GPU, each a full
+ensemble of 18 x 64 kbit/s EEP 3-A DAB+ sub-channels (CIF exactly full), AWGN 20 dB, per-stream CFO and
+timing offset.  A step = every stream advances by one 96-ms frame: PRS sync, 76 FFTs, D-QPSK demap,
+FIC (4 Viterbi + 12 CRC), MSC (72 time-deinterleave + depuncture + Viterbi), RS(120,110) + fire code.
+value = frames/s summed over all GPUs (weak scaling: 512 streams per GPU).
+
+Launch: python bench.py --gpus 1            (single process)
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   (one rank per GPU)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TF = 196608
+A_FRAME = 2115456          # algorithmic HBM bytes per frame, SURVEY.md 8(d)
+# per-kernel share of those bytes (DESIGN.md "Kernels"): what each kernel must move at least
+A_KERNEL = {
+    "k_acquire": 0,
+    "k_frame_head": 2 * 2048 * 8 + 2048 * 8,          # sync window + symbol 0 in, reference spectrum out
+    "k_symbols": 75 * 2552 * 8 + 75 * 2048 * 8,       # IQ of symbols 1..75 in, spectra out
+    "k_demap_frame": 75 * 2048 * 8 + 75 * 3072 + 86016,   # spectra in, Viterbi symbols out, carry state r+w
+    "k_fic_frame": 9216 + 384,
+    "k_frame_tail": 2048 * 8 + 2 * 2048 * 4,
+    "k_msc_frame": 4 * 55296 + 4 * 3456,              # time-deinterleaver read, packed logical frames out
+    "k_dabplus": 4 * 3456 * 5 // 5 + 18 * 880 * 4 // 5,
+}
+HBM_PEAK = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=512, help="streams (ensembles) resident per GPU")
+    ap.add_argument("--ensembles", type=int, default=4, help="distinct synthetic ensembles shared by the streams")
+    ap.add_argument("--snr", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=300)
+    ap.add_argument("--fic-only", action="store_true", help="BASELINE config 2 instead of config 4")
+    return ap.parse_args()
+
+
+def hip():
+    L = C.CDLL("libamdhip64.so")
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return L
+
+
+def fill_rings(eng, torch, dev, args, rank, subch):
+    """Synthetic IQ for every stream, generated on the GPU from a few clean cyclic ensembles (10 frames each)."""
+    from tools import dab_synth as ds
+    from dabstar_amd import shard
+    n_frames = 10
+    base = []
+    for e in range(args.ensembles):
+        ens = ds.build_ensemble(n_frames, subch, seed=1000 * rank + e, cyclic=True)
+        base.append(torch.from_numpy(ens.iq).to(dev))
+    n = n_frames * TF
+    t = torch.arange(n, device=dev, dtype=torch.float64)
+    H = hip()
+    sigma = float(np.sqrt(10 ** (-args.snr / 10) / 2))
+    gen = torch.Generator(device=dev)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    for s, sid in enumerate(shard.streams_for_rank(rank, world, args.streams)):
+        gen.manual_seed(sid)
+        toff, cfo = shard.stream_params(sid, TF)                       # CFO is phase-continuous over the 0.96-s ring
+        x = torch.roll(base[s % args.ensembles], toff)
+        ph = (2.0 * np.pi * cfo / 2048000.0) * t
+        rot = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64)
+        noise = torch.complex(torch.randn(n, device=dev, generator=gen), torch.randn(n, device=dev, generator=gen)) * sigma
+        y = ((x * rot + noise) * 0.25).to(torch.complex64).contiguous()
+        ptr, cap = eng.ring_ptr(s)
+        assert cap == n
+        torch.cuda.synchronize()
+        rc = H.hipMemcpy(ptr, y.data_ptr(), n * 8, 3)                  # device to device
+        assert rc == 0, rc
+    torch.cuda.synchronize()
+    return n_frames
+
+
+def cpu_baseline(args, subch):
+    """The oracle (CPU port of the reference algorithm) on one stream of the same workload, one core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from tools import dab_synth as ds
+    ens = ds.build_ensemble(10, subch, seed=0, cyclic=True)
+    n = args.cpu_frames
+    x10 = ds.channel(ens.iq, snr_db=args.snr, cfo_hz=417.0 / 0.96, timing_offset=12345, seed=0)   # cyclic, 10 frames
+    x = np.ascontiguousarray(np.tile(x10, (n + 2 + 9) // 10))
+    L = ol.oracle()
+    rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    t0 = time.perf_counter()
+    got = L.ora_rx_run(rx, x, len(x), n)
+    dt = time.perf_counter() - t0
+    L.ora_rx_destroy(rx)
+    return {"value": round(got / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of 1 stream (18x64k EEP3-A, %g dB) through oracle/ (scalar C, -O2)" % (got, args.snr)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)     # RCCL
+    from dabstar_amd import lib as dx
+    from tools import dab_synth as ds
+    dx.check(dx.load().dabx_set_device(local_rank))
+
+    subch = ds.default_subchannels(18, 64)
+    eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=2, fic_only=args.fic_only)
+    if not args.fic_only:
+        eng.set_subchannels(subch)
+    ring_frames = fill_rings(eng, torch, dev, args, rank, subch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(n=1):
+        for _ in range(n):
+            eng.commit(TF)             # one more frame of (periodic) IQ becomes readable for every stream
+            eng.process(1, sync=False)
+
+    # priming (untimed, not part of warmup): acquisition, CFO pull-in, 16-CIF de-interleaver fill, super-frame sync
+    eng.commit(ring_frames * TF - TF)
+    step(40)
+    eng.synchronize()
+    c0 = eng.counters()
+    step(args.warmup)
+    eng.synchronize()
+    c1 = eng.counters()
+
+    dx.check(dx.load().dabx_set_profiling(eng._h, 1))
+    barrier()
+    t0 = time.perf_counter()
+    step(args.steps)
+    eng.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    c2 = eng.counters()
+    ms = (C.c_double * 16)(); cnt = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
+    nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
+    dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+
+    frames = c2["frames"] - c1["frames"]
+    fib_ok, fib_tot = c2["fib_ok"] - c1["fib_ok"], c2["fib_total"] - c1["fib_total"]
+    # max over ranks of the elapsed time, sum over ranks of the counters (the only collectives of the path)
+    from dabstar_amd import shard
+    dt, (frames, fib_ok, fib_tot, sf_ok, sf_fail, msc_bytes, locked) = shard.reduce_results(
+        dist, torch, dev, dt, [frames, fib_ok, fib_tot, c2["sf_ok"] - c1["sf_ok"], c2["sf_fail"] - c1["sf_fail"],
+                               c2["msc_bytes"] - c1["msc_bytes"], c2["streams_locked"]])
+
+    if rank == 0:
+        value = frames / dt
+        kern = {names[i].decode(): (ms[i] / max(1, cnt[i])) for i in range(nk)}
+        dom = max(kern, key=kern.get)
+        units = args.streams                                   # frames per launch on this GPU
+        achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32+i32", "data": "synthetic",
+            "config": {"workload": ("FIC only, " if args.fic_only else "") +
+                       "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
+                       "AWGN %g dB, per-stream CFO/timing" % (args.streams, args.snr),
+                       "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
+                       "x_realtime_per_gpu": round(value / world / (2048000.0 / TF), 1),
+                       "msamples_per_s": round(value * TF / 1e6, 1)},
+            "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
+            "streams_locked": locked, "superframes_ok": sf_ok, "superframes_failed": sf_fail, "msc_bytes": msc_bytes,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": A_KERNEL[dom] * units,
+                         "avg_launch_ms": round(kern[dom], 4)},
+            "chain": {"algorithmic_bytes_per_frame": A_FRAME, "achieved_GBps": round(value / world * A_FRAME / 1e9, 2),
+                      "frac_of_hbm_peak": round(value / world * A_FRAME / HBM_PEAK, 6),
+                      "kernel_ms_per_step": {k: round(v, 4) for k, v in kern.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, subch)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

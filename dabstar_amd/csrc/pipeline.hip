@@ -464,6 +464,11 @@ __global__ __launch_bounds__(256) void k_msc_frame(EngineDev e, DevTables t)
 
 // ------------------------------------------------------------------------------------------------- DAB+
 // One wave per (stream, sub-channel); walks the logical frames produced in this batch step.
+// The 5-frame window is staged in LDS once per super frame.  RS code word j is the byte sequence
+// window[j + k R], k < 120 (mp4processor.cpp:193-201) and its corrected data bytes go back to the same
+// positions of mOutVec (:225-228), so the super frame is simply window[0 .. 110 R) corrected in place.
+// Syndromes of all R code words x 10 roots are evaluated lane-parallel (Horner over LDS); the full
+// Berlekamp-Massey / Chien / Forney decoder runs only for code words whose syndromes are not all zero.
 __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
 {
   const int job = blockIdx.x, lane = threadIdx.x;
@@ -476,15 +481,18 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
   long long n_new = 0;
   for (int cif = 0; cif < 4; cif++) if (first_r + cif >= sc.start_cif + 16) n_new++;
   if (n_new == 0) return;
-  const int R = sc.kbps / 8, nbytes = 3 * sc.kbps;
+  const int R = sc.kbps / 8, nbytes = 3 * sc.kbps;         // nbytes = 24 R
   const uint8_t *ring = e.msc_out + ((size_t)s * e.max_subch + j) * MSC_SLOTS * e.msc_stride;
-  const Gf gf{t.gf_exp, t.gf_log};
   long long cif_out = sc.cif_out;
   int blocks_in_buf = sc.blocks_in_buf, sf_sync = sc.sf_sync;
   long long sf_count = sc.sf_count, sf_ok = 0, sf_fail = 0, rs_corr = 0, rs_fail = 0, fc_corr = 0, au_ok = 0, au_bad = 0;
+  __shared__ __attribute__((aligned(16))) uint8_t win[120 * 48 + 16];   // 5 logical frames (<= 384 kbit/s)
+  __shared__ uint8_t gexp[512], glog[256];
+  __shared__ unsigned syn_or[48];                           // != 0: some syndrome of the code word is non-zero
+  __shared__ uint8_t hdr0[12];
   __shared__ int s_flag;
   __shared__ int s_au[8];
-  __shared__ __attribute__((aligned(16))) uint8_t sf[110 * 48 + 16];   // RS-corrected super frame (<= 384 kbit/s)
+  bool tables_ready = false;
   for (long long n = 0; n < n_new; n++) {
     const long long newest = cif_out;        // index of the logical frame just added
     cif_out++;
@@ -492,39 +500,63 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
     blocks_in_buf++;                         // mp4processor.cpp:113
     if (blocks_in_buf < 5) continue;
     const long long oldest = newest - 4;
-    auto wbyte = [&](int x) -> uint8_t {     // byte x of the 5-frame window, oldest first
-      return ring[(size_t)((oldest + x / nbytes) % MSC_SLOTS) * e.msc_stride + (x % nbytes)];
-    };
-    if (sf_sync == 0) {                      // :132-142
-      const bool ok = firecode_syndrome([&](int i) { return wbyte(i); }, t.fc_crctab) == 0;
+    if (sf_sync == 0) {                      // :132-142: fire code over the first 11 bytes of the oldest frame
+      const uint8_t *f0 = ring + (size_t)(oldest % MSC_SLOTS) * e.msc_stride;
+      const bool ok = firecode_syndrome([&](int i) { return f0[i]; }, t.fc_crctab) == 0;
       if (ok) sf_sync = 4; else { blocks_in_buf = 4; continue; }
     }
     blocks_in_buf = 0;                       // :147
-    // _process_reed_solomon_frame, :184-241: code word j2 = bytes (j2 + k R), k < 120
-    uint8_t *sfo = e.sf_out + (((size_t)s * e.max_subch + j) * SF_SLOTS + (size_t)(sf_count % SF_SLOTS)) * e.sf_stride;
-    int my_ret = 0;
-    if (lane < R) {
-      uint8_t cw[120];
-      for (int k = 0; k < 120; k++) cw[k] = wbyte(lane + k * R);
-      my_ret = rs_decode_120(cw, gf);
-      for (int k = 0; k < 110; k++) sf[lane + k * R] = cw[k];
+    // ---- stage the window (coalesced 4-byte loads) and the GF tables
+    __syncthreads();
+    if (!tables_ready) {
+      for (int i = lane; i < 512; i += 64) gexp[i] = t.gf_exp[i];
+      for (int i = lane; i < 256; i += 64) glog[i] = t.gf_log[i];
+      tables_ready = true;
     }
-    // lane-wise results -> wave totals
-    int corr = (lane < R && my_ret > 0) ? my_ret : 0, fail = (lane < R && my_ret < 0) ? 1 : 0;
+    for (int f = 0; f < 5; f++) {
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + (size_t)((oldest + f) % MSC_SLOTS) * e.msc_stride);
+      uint32_t *dst = reinterpret_cast<uint32_t *>(win + f * nbytes);
+      for (int i = lane; i < nbytes / 4; i += 64) dst[i] = src[i];
+    }
+    for (int i = lane; i < R; i += 64) syn_or[i] = 0;
+    if (lane < 12) hdr0[lane] = 0;
+    __syncthreads();
+    if (lane < 11) hdr0[lane] = win[lane];
+    // ---- syndromes: pair p = (root, code word), reed_solomon.cpp:254-290 (Horner, leading zeros skipped)
+    for (int p = lane; p < 10 * R; p += 64) {
+      const int cw = p % R, root = p / R;
+      int sy = 0;
+      for (int k = 0; k < 120; k++) {
+        const int b = win[cw + k * R];
+        sy = (sy == 0) ? b : (b ^ gexp[glog[sy] + root]);
+      }
+      if (sy) atomicOr(&syn_or[cw], 1u);
+    }
+    __syncthreads();
+    // ---- full decoder only where needed (one lane per dirty code word)
+    int my_ret = 0;
+    if (lane < R && syn_or[lane]) {
+      uint8_t cw[120];
+      for (int k = 0; k < 120; k++) cw[k] = win[lane + k * R];
+      const Gf gf{gexp, glog};
+      my_ret = rs_decode_120(cw, gf);
+      for (int k = 0; k < 110; k++) win[lane + k * R] = cw[k];
+    }
+    int corr = my_ret > 0 ? my_ret : 0, fail = my_ret < 0 ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { corr += __shfl_xor(corr, o); fail += __shfl_xor(fail, o); }
     rs_corr += corr; rs_fail += fail;
     __syncthreads();
     if (lane == 0) {
       uint8_t hdr[12];
-      for (int i = 0; i < 12; i++) hdr[i] = sf[i];
-      const bool ok = firecode_check_and_correct(hdr, t.fc_crctab, t.fc_syndrome);
+      for (int i = 0; i < 12; i++) hdr[i] = win[i];
+      const bool ok = firecode_check_and_correct(hdr, t.fc_crctab, t.fc_syndrome);   // :230-240
       int flag = ok ? 1 : 0;
       if (ok) {
         bool changed = false;
-        for (int i = 0; i < 11; i++) changed = changed || (hdr[i] != wbyte(i));
+        for (int i = 0; i < 11; i++) changed = changed || (hdr[i] != hdr0[i]);
         if (changed) flag |= 2;
-        for (int i = 0; i < 12; i++) sf[i] = hdr[i];
+        for (int i = 0; i < 12; i++) win[i] = hdr[i];
         // AU table, mp4processor.cpp:256-306
         const int dac = (hdr[2] >> 6) & 1, sbr = (hdr[2] >> 5) & 1, end = 110 * R;
         int n_au;
@@ -546,24 +578,25 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
     const int flag = s_flag;
     if (flag & 1) {                          // :149-158
       if (flag & 2) fc_corr++;
-      sf_sync = 4; sf_ok++; sf_count++;
+      sf_sync = 4; sf_ok++;
       const int n_au = s_au[7];
       int good = 0, bad = 0;
       if (lane < n_au) {                     // :318-333 AU CRCs, one lane per AU
         const int st = s_au[lane], len = s_au[lane + 1] - st - 2;
         if (len > 960 || len < 0 || st + len + 2 > 110 * R) bad = 1;
-        else if (crc16_check_bytes(sf + st, len, t.crc_ccitt)) good = 1; else bad = 1;
+        else if (crc16_check_bytes(win + st, len, t.crc_ccitt)) good = 1; else bad = 1;
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { good += __shfl_xor(good, o); bad += __shfl_xor(bad, o); }
       au_ok += good; au_bad += bad;
+      uint8_t *sfo = e.sf_out + (((size_t)s * e.max_subch + j) * SF_SLOTS + (size_t)(sf_count % SF_SLOTS)) * e.sf_stride;
       for (int i = lane; i < (110 * R + 3) / 4; i += 64)
-        reinterpret_cast<uint32_t *>(sfo)[i] = reinterpret_cast<const uint32_t *>(sf)[i];
+        reinterpret_cast<uint32_t *>(sfo)[i] = reinterpret_cast<const uint32_t *>(win)[i];
+      sf_count++;
     } else {                                 // :159-169
       sf_sync--;
       if (sf_sync == 0) { blocks_in_buf = 4; sf_fail++; }
     }
-    __syncthreads();
   }
   if (lane == 0) {
     sc.cif_out = cif_out; sc.blocks_in_buf = blocks_in_buf; sc.sf_sync = sf_sync; sc.sf_count = sf_count;

@@ -130,11 +130,15 @@ class Demap:
         check(load().dabx_demap_create(batch, C.byref(self._h)))
 
     def close(self):
-        if self._h:
-            load().dabx_demap_destroy(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.dabx_demap_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reset(self):
         check(load().dabx_demap_reset(self._h))
@@ -201,11 +205,15 @@ class Engine:
         self.subch = []
 
     def close(self):
-        if getattr(self, "_h", None):
-            load().dabx_destroy(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.dabx_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_subchannels(self, subch, stream=-1, dab_plus=True):
         arr = (SubchDesc * max(1, len(subch)))()

@@ -1,0 +1,70 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py (stream sharding + counter/time reduction)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from dabstar_amd import shard  # noqa: E402
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(__file__))
+    import oracle_lib as ol
+    from tools import dab_synth as ds
+    ids = shard.streams_for_rank(rank, world, 3)
+    # per-rank "work" on its own shard: FIC-decode each stream's first frame with the CPU checker
+    ens = ds.build_ensemble(5, seed=11)
+    fib_ok = fib_total = 0
+    L = ol.oracle()
+    for gid in ids:
+        toff, cfo = shard.stream_params(gid)
+        rng = np.random.default_rng(gid)
+        soft = ((ens.tx_bits[gid % 5, :3].reshape(9216).astype(np.int16) * 2 - 1) * 60 + rng.normal(0, 30, 9216)).astype(np.int16)
+        n_in, m = ol.ora_fic_map()
+        prbs = np.zeros(768, np.uint8)
+        L.ora_prbs(prbs, 768)
+        for g in range(4):
+            blk = np.zeros(3096, np.int16)
+            blk[m >= 0] = soft[g * 2304:(g + 1) * 2304][m[m >= 0]]
+            bits = ol.ora_viterbi(blk, 768) ^ prbs
+            for k in range(3):
+                fib_ok += int(L.ora_check_crc_bits(np.ascontiguousarray(bits[256 * k:256 * k + 256]), 256))
+                fib_total += 1
+    elapsed, (frames, ok, tot) = shard.reduce_results(dist, torch, torch.device("cpu"), 0.5 + rank, [len(ids), fib_ok, fib_total])
+    q.put((rank, ids, elapsed, frames, ok, tot))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reduction():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort()
+    ids0, ids1 = res[0][1], res[1][1]
+    assert sorted(ids0 + ids1) == list(range(6)) and not set(ids0) & set(ids1)      # disjoint cover
+    for r in res:
+        assert r[2] == pytest.approx(1.5)          # MAX over ranks
+        assert r[3] == 6 and r[4] == 72 and r[5] == 72      # SUM over ranks; every FIB CRC passes
+
+
+def test_stream_params_are_deterministic_and_rank_independent():
+    a = [shard.stream_params(g) for g in range(16)]
+    b = [shard.stream_params(g) for g in range(16)]
+    assert a == b and len(set(a)) == 16
+    assert shard.streams_for_rank(3, 8, 512)[0] == 1536
