@@ -219,7 +219,8 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   b.y = raw.x * sine + raw.y * cosine;
   float ph = atan2f(b.y, b.x);                                  // :197
   if (ph < 0.0f) ph += F_PI;                                    // glob_defs.h:173-182
-  const float aph = fmodf(ph, F_PI_2);
+  // fmod(ph, pi/2) for ph in [0, pi]: pi_f == 2 * (pi/2)_f exactly and ph - n*c is exact (Sterbenz), so this is fmodf bit for bit
+  const float aph = ph < F_PI_2 ? ph : (ph < F_PI ? ph - F_PI_2 : ph - F_PI);
   c.integ += 0.2f * ALPHA * (aph - F_PI_4);                     // :201-202
   const float lim = F_RAD_PER_DEG * 20.0f;
   if (c.integ > lim) c.integ = lim; else if (c.integ < -lim) c.integ = -lim;

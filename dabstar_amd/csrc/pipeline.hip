@@ -17,10 +17,20 @@
 
 namespace dabx {
 
-__device__ __forceinline__ float2 ring_load(const float2 *ring, int ring_len, unsigned long long abs_idx)
-{
-  return ring[(size_t)(abs_idx % (unsigned long long)ring_len)];
-}
+// IQ ring addressing: one 64-bit modulo per thread and kernel (for the window base), then 32-bit
+// add + conditional subtract per sample.
+struct RingView {
+  const float2 *p;
+  unsigned len, base;
+  __device__ RingView(const float2 *ring, int ring_len, unsigned long long abs_base)
+      : p(ring), len((unsigned)ring_len), base((unsigned)(abs_base % (unsigned long long)ring_len)) {}
+  __device__ float2 at(unsigned i) const     // i < len
+  {
+    unsigned o = base + i;
+    if (o >= len) o -= len;
+    return p[o];
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ acquire
 // Sample-serial by nature (IIR level + 50-tap moving sum with data-dependent stop): lane 0 walks the
@@ -49,13 +59,14 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
   int phase = (st == ST_INIT) ? 0 : 1;     // 0 seed level, 1 first 50, 2 wait for dip, 3 wait for end of dip
   int remain = (st == ST_INIT) ? 20 * TU : 50, counter = 0, idx = 0;
   float s_level = c.s_level, peak_level = c.peak_level, level = 0.f;
-  unsigned long long pos = c.rd;
+  const RingView rv(ring, e.ring_len, c.rd);
+  unsigned pos = 0;
   int consumed = 0;
   __syncthreads();
   while (true) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const float2 v = ring_load(ring, e.ring_len, pos + lane + 64 * q);
+      const float2 v = rv.at(pos + lane + 64 * q);
       chunk[lane + 64 * q] = sqrtf(v.x * v.x + v.y * v.y);
     }
     __syncthreads();
@@ -117,8 +128,9 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
   float2 v[8];
   Nco nco;
   nco.init(phase0, f, tid);
+  const RingView rv(ring, e.ring_len, rd);
 #pragma unroll
-  for (int u = 0; u < 8; u++) { v[u] = nco.mix(ring_load(ring, e.ring_len, rd + tid + 256 * u)); nco.step(); }
+  for (int u = 0; u < 8; u++) { v[u] = nco.mix(rv.at(tid + 256 * u)); nco.step(); }
   const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
   __syncthreads();
   if (start < 0) {                                         // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
   // symbol 0 = samples [start, start + Tu) of the same (mixed) stream, :402-411
   nco.init(phase0, f, (long long)start + tid);
 #pragma unroll
-  for (int u = 0; u < 8; u++) { v[u] = nco.mix(ring_load(ring, e.ring_len, rd + start + tid + 256 * u)); nco.step(); }
+  for (int u = 0; u < 8; u++) { v[u] = nco.mix(rv.at(start + tid + 256 * u)); nco.step(); }
   fft2048<false>(v, lds, t.twiddle, tid);                 // dab_processor.cpp:199-201
 #pragma unroll
   for (int u = 0; u < 8; u++) e.demap.phase_ref[(size_t)s * TU + tid + 256 * u] = v[u];   // store_reference_symbol_0
@@ -179,8 +191,9 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
   // cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504 (dab_processor.cpp:330-333) on the RAW samples;
   // the NCO contributes the constant factor e^{-j 2 pi f Tu / fs} which k_frame_tail applies once.
   float cre = 0.f, cim = 0.f, asum = 0.f;
+  const RingView rv(ring, e.ring_len, base);
   for (int i = tid; i < TG; i += 256) {
-    const float2 a = ring_load(ring, e.ring_len, base + TU + i), b = ring_load(ring, e.ring_len, base + i);
+    const float2 a = rv.at(TU + i), b = rv.at(i);
     cre += a.x * b.x + a.y * b.y;
     cim += a.y * b.x - a.x * b.y;
     asum += cabsf_(b);
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
   nco.init(c.phase_sym1, f, n0 + TG + tid);
 #pragma unroll
   for (int u = 0; u < 8; u++) {
-    const float2 x = ring_load(ring, e.ring_len, base + TG + tid + 256 * u);
+    const float2 x = rv.at(TG + tid + 256 * u);
     asum += cabsf_(x);
     v[u] = nco.mix(x);
     nco.step();
@@ -278,6 +291,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
+  __shared__ uint32_t raw[4][32];           // chain-back output, 30 bits per word (26 words + padding)
   __shared__ uint8_t crc_ok[12];
   const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   StreamCtl &c = e.ctl[s];
@@ -289,9 +303,10 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
     vit_forward(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
-    const uint32_t *prbs = t.prbs_words;
-    uint32_t *fw = fibw[wave];
-    vit_traceback(dec, FIC_OUT, lane, [&](int wi, unsigned v) { if (lane == 0) fw[wi] = v ^ prbs[wi]; });   // fic_decoder.cpp:219-222
+    vit_traceback(dec, FIC_OUT, lane, raw[wave]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 24) fibw[wave][lane] = vit_output_word(raw[wave], lane) ^ t.prbs_words[lane];   // fic_decoder.cpp:219-222
   }
   __syncthreads();
   const int slot = (int)(c.frames % e.out_frames);
@@ -367,9 +382,10 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   Nco nco;
   nco.init(phase_null, f2, TG + tid);
   float an = 0.f;
+  const RingView rv(ring, e.ring_len, base);
 #pragma unroll
   for (int u = 0; u < 8; u++) {
-    const float2 x = ring_load(ring, e.ring_len, base + TG + tid + 256 * u);
+    const float2 x = rv.at(TG + tid + 256 * u);
     an += cabsf_(x);
     v[u] = nco.mix(x);
     nco.step();
@@ -433,9 +449,10 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
   }
 };
 
-__global__ __launch_bounds__(256) void k_msc_frame(EngineDev e, DevTables t)
+__global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  __shared__ uint32_t raw[4][VIT_RAW_WORDS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + wave;
   const int per_stream = 4 * e.max_subch;
@@ -458,8 +475,10 @@ __global__ __launch_bounds__(256) void k_msc_frame(EngineDev e, DevTables t)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t *out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)s * e.max_subch + j) * MSC_SLOTS + (size_t)(out_idx % MSC_SLOTS)) * e.msc_stride);
-  const uint32_t *prbs = t.prbs_words;
-  vit_traceback(dec, sc.nbits, lane, [&](int wi, unsigned v) { if (lane == 0) out[wi] = v ^ prbs[wi]; });   // backend.cpp:155-158
+  vit_traceback(dec, sc.nbits, lane, raw[wave]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int w = lane; w < sc.nbits / 32; w += 64) out[w] = vit_output_word(raw[wave], w) ^ t.prbs_words[w];   // backend.cpp:155-158
 }
 
 // ------------------------------------------------------------------------------------------------- DAB+

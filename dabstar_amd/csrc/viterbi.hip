@@ -25,25 +25,29 @@ struct SrcI16Map {                    // Protection::deconvolve input: punctured
 };
 
 template <class Src>
-__device__ __forceinline__ void viterbi_wave_to_packed(const Src &src, int nbits, char *wtab, uint32_t *dec,
+__device__ __forceinline__ void viterbi_wave_to_packed(const Src &src, int nbits, char *wtab, uint32_t *raw, uint32_t *dec,
                                                        uint32_t *out_words, int lane)
 {
   const VitLaneConst k = vit_lane_const(lane);
   vit_forward(src, nbits + 6, wtab, dec, lane, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);     // decision stores of this wave have left the CU before they are re-read
-  vit_traceback(dec, nbits, lane, [&](int wi, unsigned v) { if (lane == 0) out_words[wi] = v; });
+  vit_traceback(dec, nbits, lane, raw);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int w = lane; w < (nbits + 31) / 32; w += 64) out_words[w] = vit_output_word(raw, w);
 }
 
 __global__ __launch_bounds__(256) void k_viterbi_i16(const int16_t *soft, int nbits, int batch, uint32_t *dec,
                                                      uint32_t *packed, int words_per)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  __shared__ uint32_t raw[4][VIT_RAW_WORDS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + wave;
   if (job >= batch) return;
   SrcI16 src{soft + (size_t)job * 4 * (nbits + 6)};
-  viterbi_wave_to_packed(src, nbits, wtab[wave], dec + (size_t)job * vit_scratch_words(nbits),
+  viterbi_wave_to_packed(src, nbits, wtab[wave], raw[wave], dec + (size_t)job * vit_scratch_words(nbits),
                          packed + (size_t)job * words_per, lane);
 }
 
@@ -51,11 +55,12 @@ __global__ __launch_bounds__(256) void k_deconvolve_i16(const int16_t *in, int i
                                                         int batch, uint32_t *dec, uint32_t *packed, int words_per)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
+  __shared__ uint32_t raw[4][VIT_RAW_WORDS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + wave;
   if (job >= batch) return;
   SrcI16Map src{in + (size_t)job * in_stride, map};
-  viterbi_wave_to_packed(src, nbits, wtab[wave], dec + (size_t)job * vit_scratch_words(nbits),
+  viterbi_wave_to_packed(src, nbits, wtab[wave], raw[wave], dec + (size_t)job * vit_scratch_words(nbits),
                          packed + (size_t)job * words_per, lane);
 }
 

@@ -149,51 +149,84 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
   }
 }
 
-// Chain-back (viterbi_spiral.cpp:114-125) in lane space.  Emits decoded bits MSB-first packed into
-// little-endian 32-bit words through `emit(word_index, value)` (called wave-uniformly, highest word first).
-template <class Emit>
-__device__ __forceinline__ void vit_traceback(const uint32_t *dec, int nbits, int lane, Emit emit)
+// Chain-back (viterbi_spiral.cpp:114-125) in lane space, on the scalar unit.
+// The lane index j of the surviving path is wave-uniform; one trellis step is
+//   k = bit (29 - s) of hist[lane j]   (v_readlane_b32 + s_bfe_u32)
+//   j = (j & ~(1 << p)) | (k << p)     (the exchange bit of that step is the only bit that changes)
+// The decoded bits of a 30-step word are collected LSB = earliest step into raw[wi] (LDS, one dword per
+// word, written by lane 0); vit_pack_output() turns them into MSB-first packed bytes afterwards.
+constexpr int VIT_RAW_WORDS = 312;          // >= vit_words(9216) + 3
+
+template <int S> __device__ __forceinline__ void vit_tb_step(unsigned hist, int &j, unsigned &acc)
+{
+  // Written in SALU form by hand: hipcc otherwise keeps j in a VGPR and pays ~6 VALU per step.
+  // s_nop 3: SALU write of the lane-select SGPR -> v_readlane needs 4 wait states (hipcc pads nothing in asm).
+  constexpr int P = (5 - (S % 6)) % 6;
+  constexpr int BFE = (1 << 16) | (VIT_DW - 1 - S);      // s_bfe_u32: width 1, offset = bit of step S
+  unsigned hv, k;
+  asm volatile("s_nop 3\n\t"
+               "v_readlane_b32 %[hv], %[hist], %[j]\n\t"
+               "s_bfe_u32 %[k], %[hv], %[bfe]\n\t"
+               "s_lshl1_add_u32 %[acc], %[acc], %[k]\n\t"
+               "s_lshl_b32 %[k], %[k], %[p]\n\t"
+               "s_andn2_b32 %[j], %[j], %[bit]\n\t"
+               "s_or_b32 %[j], %[j], %[k]"
+               : [hv] "=&s"(hv), [k] "=&s"(k), [acc] "+s"(acc), [j] "+s"(j)
+               : [hist] "v"(hist), [bfe] "n"(BFE), [p] "n"(P), [bit] "n"(1 << P)
+               : "scc");
+}
+
+__device__ __forceinline__ void vit_traceback(const uint32_t *dec, int nbits, int lane, uint32_t *raw)
 {
   const int nsteps = nbits + 6;
   int j = 0;                                   // lane of the terminal state 0
-  unsigned outw = 0;
   int wi = (nsteps - 1) / VIT_DW;
   unsigned hist = dec[(size_t)wi * 64 + lane];
-  // top (possibly partial) word
-  {
+  {                                            // top (possibly partial) word: run-time step range
     const unsigned nxt = wi > 0 ? dec[(size_t)(wi - 1) * 64 + lane] : 0u;
-    for (int s = (nsteps - 1) - wi * VIT_DW; s >= 0; --s) {
-      const int t = wi * VIT_DW + s;
-      const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, j);
-      const int kbit = (hv >> (VIT_DW - 1 - s)) & 1;
-      const int q = t - 6;
-      if (q >= 0) {
-        outw |= (unsigned)kbit << (((q >> 3) & 3) * 8 + 7 - (q & 7));
-        if ((q & 31) == 0) { emit(q >> 5, outw); outw = 0; }
-      }
+    unsigned acc = 0;
+    const int s_top = (nsteps - 1) - wi * VIT_DW;
+    for (int s = s_top; s >= 0; --s) {
+      const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, __builtin_amdgcn_readfirstlane(j));
+      const unsigned k = (hv >> (VIT_DW - 1 - s)) & 1u;
+      acc = (acc << 1) | k;
       const int p = (5 - (s % 6)) % 6;
-      j = (j & ~(1 << p)) | (kbit << p);
+      j = (j & ~(1 << p)) | ((int)k << p);
     }
+    j = __builtin_amdgcn_readfirstlane(j);
+    acc = __builtin_amdgcn_readfirstlane(acc);
+    if (lane == 0) { raw[wi] = acc; raw[wi + 1] = 0; raw[wi + 2] = 0; }
     hist = nxt;
     --wi;
   }
   for (; wi >= 0; --wi) {
     const unsigned nxt = wi > 0 ? dec[(size_t)(wi - 1) * 64 + lane] : 0u;
-    const int tb = wi * VIT_DW;
-#pragma unroll
-    for (int s = VIT_DW - 1; s >= 0; --s) {
-      const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, j);
-      const int kbit = (hv >> (VIT_DW - 1 - s)) & 1;
-      const int q = tb + s - 6;
-      if (q >= 0) {
-        outw |= (unsigned)kbit << (((q >> 3) & 3) * 8 + 7 - (q & 7));
-        if ((q & 31) == 0) { emit(q >> 5, outw); outw = 0; }
-      }
-      const int p = (5 - (s % 6)) % 6;
-      j = (j & ~(1 << p)) | (kbit << p);
-    }
+    unsigned acc = 0;
+    vit_tb_step<29>(hist, j, acc); vit_tb_step<28>(hist, j, acc); vit_tb_step<27>(hist, j, acc);
+    vit_tb_step<26>(hist, j, acc); vit_tb_step<25>(hist, j, acc); vit_tb_step<24>(hist, j, acc);
+    vit_tb_step<23>(hist, j, acc); vit_tb_step<22>(hist, j, acc); vit_tb_step<21>(hist, j, acc);
+    vit_tb_step<20>(hist, j, acc); vit_tb_step<19>(hist, j, acc); vit_tb_step<18>(hist, j, acc);
+    vit_tb_step<17>(hist, j, acc); vit_tb_step<16>(hist, j, acc); vit_tb_step<15>(hist, j, acc);
+    vit_tb_step<14>(hist, j, acc); vit_tb_step<13>(hist, j, acc); vit_tb_step<12>(hist, j, acc);
+    vit_tb_step<11>(hist, j, acc); vit_tb_step<10>(hist, j, acc); vit_tb_step<9>(hist, j, acc);
+    vit_tb_step<8>(hist, j, acc);  vit_tb_step<7>(hist, j, acc);  vit_tb_step<6>(hist, j, acc);
+    vit_tb_step<5>(hist, j, acc);  vit_tb_step<4>(hist, j, acc);  vit_tb_step<3>(hist, j, acc);
+    vit_tb_step<2>(hist, j, acc);  vit_tb_step<1>(hist, j, acc);  vit_tb_step<0>(hist, j, acc);
+    if (lane == 0) raw[wi] = acc;
     hist = nxt;
   }
+}
+
+// raw[] (bit b of word g = decision of trellis step 30 g + b = decoded bit q = 30 g + b - 6) -> output word w:
+// bits q = 32 w .. 32 w + 31, first bit in the MSB of the first byte (FicDecoder / Mp4Processor byte packing).
+__device__ __forceinline__ uint32_t vit_output_word(const uint32_t *raw, int w)
+{
+  const int t0 = 32 * w + 6, g0 = t0 / VIT_DW, b0 = t0 - g0 * VIT_DW;
+  unsigned long long v = (unsigned long long)raw[g0] | ((unsigned long long)raw[g0 + 1] << 30);
+  v >>= b0;
+  v |= (unsigned long long)raw[g0 + 2] << (60 - b0);
+  const uint32_t bits = (uint32_t)v;                 // bit i = decoded bit 32 w + i
+  return __builtin_bswap32(__builtin_bitreverse32(bits));
 }
 
 }  // namespace dabx
