@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_rs_decode(const uint8_t *in, int batch,
     cw[4 * k] = v & 0xFF; cw[4 * k + 1] = (v >> 8) & 0xFF; cw[4 * k + 2] = (v >> 16) & 0xFF; cw[4 * k + 3] = v >> 24;
   }
   const Gf gf{t.gf_exp, t.gf_log};
-  const int r = rs_decode_120(cw, gf);
+  const int r = rs_decode_120(CwArray{cw}, gf);
   ret[i] = (int16_t)r;
   for (int k = 0; k < 110; k++) out[(size_t)i * 110 + k] = cw[k];
 }

@@ -54,17 +54,30 @@ struct Gf {
 };
 __device__ __forceinline__ int modnn(int x) { while (x >= 255) { x -= 255; x = (x >> 8) + (x & 255); } return x; }
 
+struct CwArray {      // code word in a private array
+  uint8_t *p;
+  __device__ int get(int k) const { return p[k]; }
+  __device__ void xor_at(int k, uint8_t v) const { p[k] ^= v; }
+};
+struct CwStrided {    // code word j of an RS-interleaved super frame: bytes j + k R
+  uint8_t *p;
+  int stride;
+  __device__ int get(int k) const { return p[k * stride]; }
+  __device__ void xor_at(int k, uint8_t v) const { p[k * stride] ^= v; }
+};
+
 // ReedSolomon::dec(in, out, 135) with (8, 0435, 0, 1, 10): base/backend/reed_solomon.cpp:140-439.
 // cw: 120 received bytes (data 110 + parity 10), corrected in place exactly where the reference
 // corrects (including the partial corrections of its failure paths).  Returns #corrected / 0 / -1.
-__device__ inline int rs_decode_120(uint8_t *cw, const Gf &gf)
+template <class CW>   // CW: byte accessor with uint8_t get(int k) / void xor_at(int k, uint8_t v), k < 120
+__device__ inline int rs_decode_120(CW cw, const Gf &gf)
 {
   constexpr int NR = 10, NN = 255, PAD = 135;
   uint8_t syn[NR];
   int syn_err = 0;
   for (int r = 0; r < NR; r++) {             // :254-290 Horner; the 135 leading zeros contribute nothing
     int s = 0;
-    for (int j = 0; j < 120; j++) s = (s == 0) ? cw[j] : (cw[j] ^ gf.ex[gf.lg[s] + r]);
+    for (int j = 0; j < 120; j++) { const int b = cw.get(j); s = (s == 0) ? b : (b ^ gf.ex[gf.lg[s] + r]); }
     syn[r] = (uint8_t)s;
     syn_err |= s;
   }
@@ -135,7 +148,7 @@ __device__ inline int rs_decode_120(uint8_t *cw, const Gf &gf)
         int t2 = modnn(gf.lg[num1] + gf.lg[num2]);
         t2 = modnn(t2 + NN - gf.lg[den]);
         const int k = (int)loc_tab[j] - PAD;
-        if (k >= 0) cw[k] ^= gf.ex[t2];      // positions < 135 lie in the virtual zero padding (discarded)
+        if (k >= 0) cw.xor_at(k, gf.ex[t2]);   // positions < 135 lie in the virtual zero padding (discarded)
       }
     }
   }

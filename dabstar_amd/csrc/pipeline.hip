@@ -555,11 +555,8 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
     // ---- full decoder only where needed (one lane per dirty code word)
     int my_ret = 0;
     if (lane < R && syn_or[lane]) {
-      uint8_t cw[120];
-      for (int k = 0; k < 120; k++) cw[k] = win[lane + k * R];
       const Gf gf{gexp, glog};
-      my_ret = rs_decode_120(cw, gf);
-      for (int k = 0; k < 110; k++) win[lane + k * R] = cw[k];
+      my_ret = rs_decode_120(CwStrided{win + lane, R}, gf);   // corrects in place
     }
     int corr = my_ret > 0 ? my_ret : 0, fail = my_ret < 0 ? 1 : 0;
 #pragma unroll
