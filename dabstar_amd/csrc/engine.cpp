@@ -3,12 +3,14 @@
 #include "viterbi_core.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace dabx {
-int launch_frame_step(const EngineDev &e, hipStream_t st, hipEvent_t *ev);
-extern const char *const kStepKernelNames[8];
+int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk);
+int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, hipStream_t st, Marker &mk);
+extern const char *const kStepKernelNames[10];
 int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st);
 int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st);
 int launch_fic_only(const EngineDev &e, hipStream_t st);
@@ -26,11 +28,12 @@ struct dabx_engine {
   std::vector<void *> allocs;
   int max_kbps = 0;
   bool buffers_ready = false;
-  bool profiling = false;
-  std::vector<hipEvent_t> ev_pool;             // 9 per recorded step
-  size_t ev_used = 0;
-  double prof_ms[8] = {0};
-  long long prof_n[8] = {0};
+  Marker mk;
+  double prof_ms[N_STEP_KERNELS] = {0};
+  long long prof_n[N_STEP_KERNELS] = {0};
+  int pending_frames = 0;                      // front-end steps whose CIFs still await the MSC decoder
+  bool have_fast = false;
+  MscFast fast{};
 
   template <class T> int alloc(T **p, size_t count, bool zero = true)
   {
@@ -113,7 +116,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   e->subch_host.assign((size_t)S * std::max(1, d.max_subch), SubchDev{});
   // scratch sized for the FIC now; re-sized when sub-channels are configured
   d.vit_stride = (int)vit_scratch_words(FIC_OUT);
-  A(e->alloc(&d.vit_scratch, (size_t)S * (4 + 4 * d.max_subch) * d.vit_stride, false));
+  A(e->alloc(&d.vit_scratch, (size_t)S * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * d.vit_stride, false));
   d.msc_stride = 0; d.sf_stride = 0;
 #undef A
   *out = e;
@@ -125,7 +128,7 @@ void dabx_destroy(dabx_engine *e)
   if (!e) return;
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (void *p : e->allocs) (void)hipFree(p);
-  for (auto &ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -170,7 +173,7 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
     d.vit_stride = (int)std::max(vit_scratch_words(FIC_OUT), vit_scratch_words(24 * max_kbps));
     if ((rc = e->alloc(&d.msc_out, (size_t)d.n_streams * d.max_subch * MSC_SLOTS * d.msc_stride))) return rc;
     if ((rc = e->alloc(&d.sf_out, (size_t)d.n_streams * d.max_subch * SF_SLOTS * d.sf_stride))) return rc;
-    if ((rc = e->alloc(&d.vit_scratch, (size_t)d.n_streams * (4 + 4 * d.max_subch) * d.vit_stride, false))) return rc;
+    if ((rc = e->alloc(&d.vit_scratch, (size_t)d.n_streams * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * d.vit_stride, false))) return rc;
     // sub-channels configured earlier restart their output rings
     for (auto &sc : e->subch_host) { sc.cif_out = 0; sc.blocks_in_buf = 0; sc.sf_sync = 0; sc.sf_count = 0; }
   }
@@ -183,6 +186,37 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
     }
   }
   DABX_HIP(hipMemcpy(d.subch, e->subch_host.data(), sizeof(SubchDev) * e->subch_host.size(), hipMemcpyHostToDevice));
+  // Uniform configuration (every slot of every stream active with one and the same profile): lane-per-trellis decoder
+  e->have_fast = false;
+  if (d.max_subch > 0) {
+    const SubchDev &f0 = e->subch_host[0];
+    bool uniform = f0.active != 0;
+    for (const auto &sc : e->subch_host)
+      uniform = uniform && sc.active && sc.kbps == f0.kbps && sc.prot_level == f0.prot_level && sc.short_form == f0.short_form &&
+                sc.cu_size == f0.cu_size;
+    const size_t jobs = (size_t)d.n_streams * 4 * MSC_BATCH_FRAMES * d.max_subch;
+    // 64 trellises per wave: pays once there are >= ~512 waves per launch; DABX_MSC_FAST_MIN_JOBS overrides (tests)
+    size_t min_jobs = 64 * 512;
+    if (const char *ev = getenv("DABX_MSC_FAST_MIN_JOBS")) min_jobs = (size_t)atoll(ev);
+    if (uniform && jobs >= min_jobs) {
+      std::vector<uint16_t> m;
+      int n_in = 0;
+      if ((rc = host_profile_map(f0.kbps, f0.prot_level, f0.short_form, m, &n_in))) return rc;
+      if (n_in % 64 == 0 && n_in == f0.cu_size * 64) {
+        for (auto &v : m) if (v == PUNCT) v = (uint16_t)n_in;
+        uint16_t *map2 = nullptr;
+        if ((rc = e->alloc(&map2, m.size(), false))) return rc;
+        DABX_HIP(hipMemcpy(map2, m.data(), m.size() * 2, hipMemcpyHostToDevice));
+        const size_t groups = (jobs + 63) / 64;
+        MscFast f{};
+        f.n_in = n_in; f.nbits = 24 * f0.kbps; f.min_jobs = (int)min_jobs; f.map2 = map2;
+        if ((rc = e->alloc(&f.inT, groups * (size_t)(n_in / 4 + 1) * 64, false))) return rc;
+        if ((rc = e->alloc(&f.decT, groups * (size_t)(f.nbits + 6) * 64, false))) return rc;
+        e->fast = f;
+        e->have_fast = true;
+      }
+    }
+  }
   return 0;
 }
 
@@ -223,19 +257,17 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
 int dabx_process(dabx_engine *e, int max_frames, int sync)
 {
   if (!e || max_frames < 0) return DABX_E_ARG;
+  // The front end (sync, FFT, demap, FIC) has frame-to-frame feedback and runs once per frame; the MSC decoder
+  // has none, so its CIFs are decoded MSC_BATCH_FRAMES frames at a time (more trellises per launch) and always
+  // before this call returns.
   for (int i = 0; i < max_frames; i++) {
-    hipEvent_t *ev = nullptr;
-    if (e->profiling) {
-      if (e->ev_used + 9 > e->ev_pool.size()) {
-        const size_t old = e->ev_pool.size();
-        e->ev_pool.resize(old + 9 * 64);
-        for (size_t k = old; k < e->ev_pool.size(); k++) DABX_HIP(hipEventCreate(&e->ev_pool[k]));
-      }
-      ev = &e->ev_pool[e->ev_used];
-      e->ev_used += 9;
-    }
-    const int rc = launch_frame_step(e->dev, e->stream, ev);
+    int rc = launch_front_step(e->dev, e->stream, e->mk);
     if (rc) return rc;
+    if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
+      rc = launch_msc_batch(e->dev, e->pending_frames, e->have_fast ? &e->fast : nullptr, e->stream, e->mk);
+      if (rc) return rc;
+      e->pending_frames = 0;
+    }
   }
   if (sync) DABX_HIP(hipStreamSynchronize(e->stream));
   return max_frames;
@@ -368,9 +400,10 @@ int dabx_set_profiling(dabx_engine *e, int on)
 {
   if (!e) return DABX_E_ARG;
   DABX_HIP(hipStreamSynchronize(e->stream));
-  e->profiling = on != 0;
-  e->ev_used = 0;
-  for (int k = 0; k < 8; k++) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
+  e->mk.on = on != 0;
+  e->mk.used = 0;
+  e->mk.recs.clear();
+  for (int k = 0; k < N_STEP_KERNELS; k++) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
   return 0;
 }
 
@@ -379,15 +412,15 @@ int dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t 
 {
   if (!e || !total_ms || !launches || !names) return DABX_E_ARG;
   DABX_HIP(hipStreamSynchronize(e->stream));
-  for (size_t base = 0; base + 9 <= e->ev_used; base += 9)
-    for (int k = 0; k < 8; k++) {
-      float ms = 0.f;
-      DABX_HIP(hipEventElapsedTime(&ms, e->ev_pool[base + k], e->ev_pool[base + k + 1]));
-      e->prof_ms[k] += ms; e->prof_n[k]++;
-    }
-  e->ev_used = 0;
-  for (int k = 0; k < 8; k++) { total_ms[k] = e->prof_ms[k]; launches[k] = e->prof_n[k]; names[k] = kStepKernelNames[k]; }
-  return 8;
+  for (const auto &r : e->mk.recs) {
+    float ms = 0.f;
+    DABX_HIP(hipEventElapsedTime(&ms, e->mk.pool[r.a], e->mk.pool[r.b]));
+    e->prof_ms[r.k] += ms; e->prof_n[r.k]++;
+  }
+  e->mk.recs.clear();
+  e->mk.used = 0;
+  for (int k = 0; k < N_STEP_KERNELS; k++) { total_ms[k] = e->prof_ms[k]; launches[k] = e->prof_n[k]; names[k] = kStepKernelNames[k]; }
+  return N_STEP_KERNELS;
 }
 
 // ---- stage-level FIC decode through the pipeline kernel (FicDecoder::process_block x 3) ------------

@@ -4,7 +4,8 @@
 
 namespace dabx {
 
-constexpr int MSC_SLOTS = 16;     // ring of decoded logical frames per sub-channel (>= 5 + 4)
+constexpr int MSC_SLOTS = 32;     // ring of decoded logical frames per sub-channel (>= 16 new + 4 of the previous super frame)
+constexpr int MSC_BATCH_FRAMES = 4; // frames whose MSC CIFs are decoded together (the MSC has no feedback into the front end)
 constexpr int SF_SLOTS = 4;       // ring of RS-corrected super frames per sub-channel
 constexpr int ACQ_NEED = 20 * TU + 50 + (TF + 1) + (TN + 50 + 21) + 64;   // worst-case samples one acquisition pass may read
 constexpr int FRAME_NEED = TF + 2 * TU;                                    // worst-case samples one in-lock frame may read
@@ -17,6 +18,7 @@ struct StreamCtl {
   unsigned long long rd;          // absolute index of the next unread sample
   unsigned long long sym0_pos;    // absolute index of the T_u part of symbol 0 of the current frame
   long long cif_no;               // CIFs written to the time-deinterleaver ring so far
+  long long msc_done_cif;         // CIFs already passed through the MSC decoder (<= cif_no, lag <= 16)
   long long frames;               // frames demodulated
   int32_t state;
   int32_t nco_phase;              // currentPhase
@@ -77,5 +79,67 @@ struct EngineDev {
   uint8_t *sf_out;                // [S][max_subch][SF_SLOTS][sf_stride]
   int16_t *soft_cap;              // [S][75][3072] or null
 };
+
+// ---- uniform-profile fast path of the MSC decoder (vit_t.hip) -----------------------------------------------
+struct MscFast {
+  int n_in, nbits;          // soft bits per job (cu_size*64), decoded bits (24*kbps)
+  int min_jobs;             // below this the wave-per-trellis kernel is used
+  const uint16_t *map2;     // depuncture map with punctured entries remapped to n_in
+  uint32_t *inT;            // [groups][n_in/4 + 1][64] transposed de-interleaved symbols
+  uint2 *decT;              // [groups][nbits + 6][64] decision words
+};
+
+// ---- profiling hook: HIP events around every kernel launch of a batch step ------------------------------------
+constexpr int N_STEP_KERNELS = 10;
+struct Marker {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Rec { int k; size_t a, b; };
+  std::vector<Rec> recs;
+  size_t open_ev[N_STEP_KERNELS] = {0};
+  size_t take(hipStream_t st)
+  {
+    if (used == pool.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); pool.push_back(ev); }
+    (void)hipEventRecord(pool[used], st);
+    return used++;
+  }
+  void begin(int k, hipStream_t st) { if (on) open_ev[k] = take(st); }
+  void end(int k, hipStream_t st) { if (on) recs.push_back(Rec{k, open_ev[k], take(st)}); }
+};
+
+// ---- MSC job decoding shared by the decoder kernels: job J = (stream, pending CIF k, sub-channel j) -------------
+struct MscJob {
+  int s, k, j;
+  long long r;          // CIF to output
+  bool valid;
+  long long out_idx;    // index of the logical frame in the sub-channel's output ring
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ MscJob msc_job(const EngineDev &e, int J, int cifs)
+{
+  MscJob q;
+  const int per_stream = cifs * e.max_subch;
+  q.s = J / per_stream;
+  const int rem = J - q.s * per_stream;
+  q.k = rem / e.max_subch;
+  q.j = rem - q.k * e.max_subch;
+  q.valid = false; q.r = 0; q.out_idx = 0;
+  if (q.s >= e.n_streams) return q;
+  const StreamCtl &c = e.ctl[q.s];
+  const SubchDev &sc = e.subch[(size_t)q.s * e.max_subch + q.j];
+  q.r = c.msc_done_cif + q.k;
+  const long long valid_from = sc.start_cif + 16;                 // de-interleaver filled, backend.cpp:146-150
+  q.valid = sc.active && q.r < c.cif_no && q.r >= valid_from;
+  q.out_idx = sc.cif_out + (q.r - (c.msc_done_cif > valid_from ? c.msc_done_cif : valid_from));
+  return q;
+}
+// TDI ring, planar: within a CIF slot soft bit i lives at plane (i & 15), position (i >> 4)
+__device__ __forceinline__ size_t tdi_off(long long cif, int i)
+{
+  return (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)(i & 15) * (CIF_BITS / 16) + (size_t)(i >> 4);
+}
+#endif
 
 }  // namespace dabx

@@ -247,20 +247,20 @@ __global__ __launch_bounds__(256) void k_demap_frame(EngineDev e, DevTables t)
   const int n_sym = e.fic_only ? 75 : 75;                 // the demapper state advances on all 75 symbols in every mode
   for (int l = 0; l < n_sym; l++) {
     const float2 *X = e.spectra + ((size_t)s * 76 + l) * TU;
-    uint8_t *o;
-    if (l < 3) o = fic + l * K2;                          // symbols 1..3 -> FIC
-    else {                                                // msc_handler.cpp:148-168 : 18 symbols per CIF
-      const int m = l - 3, cif = m / 18, blk = m % 18;
-      o = tdi + (size_t)((cif0 + cif) & (TDI_SLOTS - 1)) * CIF_BITS + blk * K2;
-    }
+    const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     float part = 0.f;
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       int16_t sr, si;
       part += demap_one(cr[q], X[bin[q]], rel[q], ce, mean_value, d.soft_type, sr, si);
       const int k = tid + 256 * q;
-      o[k] = soft_to_sym(sr);
-      o[K + k] = soft_to_sym(si);
+      if (l < 3) {                                        // symbols 1..3 -> FIC
+        fic[l * K2 + k] = soft_to_sym(sr);
+        fic[l * K2 + K + k] = soft_to_sym(si);
+      } else {                                            // MSC -> planar time-de-interleaver ring
+        tdi[tdi_off(cif0 + cif, blk * K2 + k)] = soft_to_sym(sr);
+        tdi[tdi_off(cif0 + cif, blk * K2 + K + k)] = soft_to_sym(si);
+      }
       if (cap) { cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
     }
     mean_value = block_sum(part, red, tid) / (float)K;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
   if (!c.frame_ok) return;
   {
     SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + wave * FIC_IN, t.fic_map};
-    uint32_t *dec = e.vit_scratch + ((size_t)s * (4 + 4 * e.max_subch) + wave) * (size_t)e.vit_stride;
+    uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + wave) * (size_t)e.vit_stride;
     const VitLaneConst k = vit_lane_const(lane);
     vit_forward(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -440,7 +440,7 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
     const int i4 = idx & 15;
     const int m = ((i4 & 1) << 3) | ((i4 & 2) << 1) | ((i4 & 4) >> 1) | ((i4 & 8) >> 3);
     const long long q = r - 16 + m;
-    return vit_sym_from_u8(tdi[(size_t)(q & (TDI_SLOTS - 1)) * CIF_BITS + base + idx]);
+    return vit_sym_from_u8(tdi[tdi_off(q, base + idx)]);
   }
   __device__ VitSyms operator()(int t) const
   {
@@ -449,27 +449,19 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
   }
 };
 
-__global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t)
+__global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, int cifs)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t raw[4][VIT_RAW_WORDS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + wave;
-  const int per_stream = 4 * e.max_subch;
-  const int s = job / per_stream;
-  if (s >= e.n_streams) return;
-  const int rem = job % per_stream, j = rem >> 2, cif = rem & 3;
-  const StreamCtl &c = e.ctl[s];
-  if (!c.frame_ok) return;
+  const MscJob q = msc_job(e, job, cifs);
+  if (!q.valid) return;
+  const int s = q.s, j = q.j;
   const SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
-  if (!sc.active) return;
-  const long long first_r = c.cif_no - 4;       // k_frame_tail already advanced cif_no by 4
-  const long long r = first_r + cif;
-  const long long valid_from = sc.start_cif + 16;   // de-interleaver filled (backend.cpp:146-150)
-  if (r < valid_from) return;
-  const long long out_idx = sc.cif_out + (r - (first_r > valid_from ? first_r : valid_from));
+  const long long r = q.r, out_idx = q.out_idx;
   SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64};
-  uint32_t *dec = e.vit_scratch + ((size_t)s * (4 + 4 * e.max_subch) + 4 + rem) * (size_t)e.vit_stride;
+  uint32_t *dec = e.vit_scratch + ((size_t)e.n_streams * 4 + (size_t)job) * (size_t)e.vit_stride;
   const VitLaneConst k = vit_lane_const(lane);
   vit_forward(src, sc.nbits + 6, wtab[wave], dec, lane, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -493,12 +485,10 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
   const int job = blockIdx.x, lane = threadIdx.x;
   const int s = job / e.max_subch, j = job % e.max_subch;
   const StreamCtl &c = e.ctl[s];
-  if (!c.frame_ok) return;
   SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
   if (!sc.active) return;
-  const long long first_r = c.cif_no - 4;
-  long long n_new = 0;
-  for (int cif = 0; cif < 4; cif++) if (first_r + cif >= sc.start_cif + 16) n_new++;
+  long long n_new = 0;                        // logical frames the decoder just produced for this sub-channel
+  for (long long r = c.msc_done_cif; r < c.cif_no; r++) if (r >= sc.start_cif + 16) n_new++;
   if (n_new == 0) return;
   const int R = sc.kbps / 8, nbytes = 3 * sc.kbps;         // nbytes = 24 R
   const uint8_t *ring = e.msc_out + ((size_t)s * e.max_subch + j) * MSC_SLOTS * e.msc_stride;
@@ -622,38 +612,56 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-extern const char *const kStepKernelNames[8];
-const char *const kStepKernelNames[8] = {"k_acquire", "k_frame_head", "k_symbols", "k_demap_frame", "k_fic_frame",
-                                         "k_frame_tail", "k_msc_frame", "k_dabplus"};
+__global__ void k_msc_done(EngineDev e)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < e.n_streams) e.ctl[s].msc_done_cif = e.ctl[s].cif_no;
+}
 
-// ev: optional 9 events (boundaries before/after each of the 8 kernels); null = no profiling
-int launch_frame_step(const EngineDev &e, hipStream_t st, hipEvent_t *ev)
+extern const char *const kStepKernelNames[10];
+const char *const kStepKernelNames[10] = {"k_acquire", "k_frame_head", "k_symbols", "k_demap_frame", "k_fic_frame",
+                                          "k_frame_tail", "k_msc_prep", "k_msc_vitT", "k_msc_frame", "k_dabplus"};
+
+// Front end of one batch step (everything with frame-to-frame feedback).  mark(i) is called before kernel i
+// and once more after the last one (profiling hook, may be empty).
+int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
-#define MARK(i) do { if (ev) DABX_HIP(hipEventRecord(ev[i], st)); } while (0)
-  MARK(0);
-  hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e);
-  MARK(1);
-  hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t);
-  MARK(2);
-  hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t);
-  MARK(3);
-  hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t);
-  MARK(4);
-  hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t);
-  MARK(5);
-  hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t);
-  MARK(6);
-  if (!e.fic_only && e.max_subch > 0 && e.msc_out) {
-    const int jobs = e.n_streams * 4 * e.max_subch;
-    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, st, e, *t);
-    MARK(7);
-    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, *t);
-    MARK(8);
-  } else { MARK(7); MARK(8); }
-#undef MARK
+  mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
+  mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
+  mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+  mk.begin(3, st); hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(3, st);
+  mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(4, st);
+  mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, uint32_t *inT, uint2 *decT,
+                    hipStream_t st, Marker &mk);
+
+// MSC decode of the CIFs produced by the last `frames` front-end steps (<= MSC_BATCH_FRAMES) + DAB+ stage.
+int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, hipStream_t st, Marker &mk)
+{
+  const DevTables *t;
+  int rc = get_tables(&t);
+  if (rc) return rc;
+  if (e.fic_only || e.max_subch <= 0 || !e.msc_out) return 0;
+  const int cifs = 4 * frames;
+  const int jobs = e.n_streams * cifs * e.max_subch;
+  if (fast && jobs >= fast->min_jobs) {
+    if ((rc = launch_msc_vitT(e, cifs, fast->n_in, fast->nbits, fast->map2, fast->inT, fast->decT, st, mk))) return rc;
+  } else {
+    mk.begin(8, st);
+    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, st, e, *t, cifs);
+    mk.end(8, st);
+  }
+  mk.begin(9, st);
+  hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, *t);
+  hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, st, e);
+  mk.end(9, st);
   DABX_HIP(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generator for dabstar_amd/csrc/vit_t_gen.h: the lane-per-trellis K=7 r=1/4 Viterbi forward steps.
+
+Scheme (see DESIGN.md "Viterbi, lane = trellis"): one lane decodes one trellis; the 64 path metrics live in 32
+VGPRs as packed int16 pairs.  Label L (6 bits) = register index (bits 0..4) + half (bit 5); at step t of class
+c = t mod 6 label L holds state rotl6(L, c), so the butterfly partner is always L ^ (1 << p), p = (5 - c) mod 6:
+for c != 0 a different REGISTER (same half) -> pure packed add/sub/min on register pairs, nothing moves; for
+c == 0 the other HALF of the same register (op_sel swap).  Metrics are the reference's doubled and centred
+(w = sum +-(2 sym - 255)), int16 with a re-centring every 12 steps (spread <= 14240 + 12*1020 < 32767), decisions
+are the sign bits of (upper-path - lower-path), i.e. exactly viterbi_scalar.h's `m0 > m1` with ties -> 0.
+
+This file also contains the pure-Python model of the scheme used to validate it against the oracle
+(`python tools/gen_vit_t.py --selftest`)."""
+import sys
+
+H = 5
+
+
+def rotl6(x, c):
+    c %= 6
+    return ((x << c) | (x >> (6 - c))) & 63
+
+
+def pat_q(i):
+    c0 = ((i >> 1) ^ (i >> 2) ^ (i >> 4)) & 1
+    c1 = (i ^ (i >> 1) ^ (i >> 2)) & 1
+    c2 = (i ^ (i >> 3)) & 1
+    return c0 * 4 + c1 * 2 + c2
+
+
+def class_plan(c):
+    """Returns the static plan of step class c: list of (ra, rb, q_lo, q_hi) register pairs (c != 0) or
+    per-register q (c == 0), and the decision bit position of every label."""
+    p = (5 - c) % 6
+    plan = {"c": c, "p": p}
+    if c == 0:
+        plan["regs"] = [(r, pat_q(r)) for r in range(32)]          # state = label; butterfly i = r
+        dlist = [("m", r) for r in range(32)]                       # merged (dd.lo, ee.hi): labels r (lo), r|32 (hi)
+        labels = {("m", r): (r, r | 32) for r in range(32)}
+    else:
+        pairs = []
+        for ra in range(32):
+            if (ra >> p) & 1:
+                continue
+            rb = ra | (1 << p)
+            pairs.append((ra, rb, pat_q(rotl6(ra, c) & 31), pat_q(rotl6(ra | 32, c) & 31)))
+        plan["pairs"] = pairs
+        dlist, labels = [], {}
+        for k, (ra, rb, _, _) in enumerate(pairs):
+            dlist += [("a", k), ("b", k)]
+            labels[("a", k)] = (ra, ra | 32)
+            labels[("b", k)] = (rb, rb | 32)
+    # perm j takes S0 = dlist[2j], S1 = dlist[2j+1]; result bytes: [S1.lo, S1.hi, S0.lo, S0.hi] sign bytes
+    pos = [None] * 64
+    for j in range(16):
+        a, k = j // 8, j % 8
+        s0, s1 = dlist[2 * j], dlist[2 * j + 1]
+        for b, lab in enumerate((labels[s1][0], labels[s1][1], labels[s0][0], labels[s0][1])):
+            pos[lab] = 32 * a + 8 * b + 7 - k
+    plan["dlist"] = dlist
+    plan["pos"] = pos
+    return plan
+
+
+PLANS = [class_plan(c) for c in range(6)]
+
+
+# ------------------------------------------------------------------------------------------- python model
+def model_decode(soft, nbits):
+    """Bit-level model of the generated kernel for ONE trellis (numpy int16 semantics emulated with ints)."""
+    import numpy as np
+    nst = nbits + 6
+    sym = np.clip((soft.astype(np.int64) + 127).astype(np.int16).astype(np.int64), 0, 255).reshape(nst, 4)
+    xs = 2 * sym - 255
+
+    def wrap(v):
+        return ((v + 32768) & 0xFFFF) - 32768
+
+    R = [[2000, 2000] for _ in range(32)]
+    R[0][0] = 0
+    dec = []
+    for t in range(nst):
+        c = t % 6
+        if c == 0 and (t // 6) % 2 == 0:
+            ref = R[0][0]
+            R = [[wrap(a - ref), wrap(b - ref)] for a, b in R]
+        y0, x1, x2 = xs[t, 0] + xs[t, 3], xs[t, 1], xs[t, 2]
+        W = [(1 - 2 * ((q >> 2) & 1)) * y0 + (1 - 2 * ((q >> 1) & 1)) * x1 + (1 - 2 * (q & 1)) * x2 for q in range(8)]
+        pl = PLANS[c]
+        word = 0
+        if c == 0:
+            for r, q in pl["regs"]:
+                lo, hi = R[r]
+                w = W[q]
+                t1 = (wrap(lo + w), wrap(hi + w)); t2 = (wrap(lo - w), wrap(hi - w))
+                new = (min(t1[0], t2[1]), min(t1[1], t2[0]))
+                d_lo, d_hi = wrap(t2[1] - t1[0]), wrap(t1[1] - t2[0])
+                assert abs(lo + w) < 32768 and abs(hi + w) < 32768
+                if d_lo < 0: word |= 1 << pl["pos"][r]
+                if d_hi < 0: word |= 1 << pl["pos"][r | 32]
+                R[r] = list(new)
+        else:
+            for ra, rb, ql, qh in pl["pairs"]:
+                A, B = R[ra], R[rb]
+                M = (W[ql], W[qh])
+                a0 = [wrap(A[h] + M[h]) for h in (0, 1)]; b0 = [wrap(B[h] - M[h]) for h in (0, 1)]
+                a1 = [wrap(A[h] - M[h]) for h in (0, 1)]; b1 = [wrap(B[h] + M[h]) for h in (0, 1)]
+                for h in (0, 1):
+                    if wrap(b0[h] - a0[h]) < 0: word |= 1 << pl["pos"][ra | (32 * h)]
+                    if wrap(b1[h] - a1[h]) < 0: word |= 1 << pl["pos"][rb | (32 * h)]
+                R[ra] = [min(a0[h], b0[h]) for h in (0, 1)]
+                R[rb] = [min(a1[h], b1[h]) for h in (0, 1)]
+        dec.append(word)
+    L = 0
+    out = np.zeros(nbits, np.uint8)
+    for t in range(nst - 1, 5, -1):
+        c = t % 6
+        k = (dec[t] >> PLANS[c]["pos"][L]) & 1
+        out[t - 6] = k
+        p = PLANS[c]["p"]
+        L = (L & ~(1 << p)) | (k << p)
+    return out
+
+
+def selftest():
+    import os
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import oracle_lib as ol
+    rng = np.random.default_rng(0)
+    for n in (768, 1536, 192):
+        for case in range(5):
+            m = 4 * (n + 6)
+            soft = [rng.integers(-200, 201, m), rng.integers(-40, 41, m), rng.choice([-127, 0, 127, 128, -128, 1, -1], m),
+                    rng.choice([-32768, 32767, 32640, -200, 200, 0], m), np.zeros(m)][case].astype(np.int16)
+            assert np.array_equal(model_decode(soft, n), ol.ora_viterbi(soft, n)), (n, case)
+    print("lane-per-trellis model == oracle")
+
+
+if __name__ == "__main__":
+    if "--selftest" in sys.argv:
+        selftest()
+
+
+# ------------------------------------------------------------------------------------------- code emitter
+def emit():
+    o = []
+    A = o.append
+    A("// vit_t_gen.h -- GENERATED by tools/gen_vit_t.py; do not edit.  Lane-per-trellis Viterbi forward steps.")
+    A("// One lane = one trellis; R[32] = 64 path metrics as packed int16 pairs (label = register | half << 5).")
+    A("#pragma once")
+    A("#include <hip/hip_runtime.h>")
+    A("namespace dabx { namespace vt {")
+    A("typedef short s2 __attribute__((ext_vector_type(2)));")
+    A("__device__ __forceinline__ unsigned u(s2 v) { return __builtin_bit_cast(unsigned, v); }")
+    A("__device__ __forceinline__ s2 s(unsigned v) { return __builtin_bit_cast(s2, v); }")
+    A("__device__ __forceinline__ s2 pk(int lo, int hi) { return s(__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u)); }")
+    A("__device__ __forceinline__ s2 swp(s2 v) { return s(__builtin_amdgcn_alignbit(u(v), u(v), 16)); }")
+    A("__device__ __forceinline__ s2 mn(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }")
+    A("// sign bytes of two packed difference registers -> bits 7,15,23,31 = [s1.lo, s1.hi, s0.lo, s0.hi]")
+    A("__device__ __forceinline__ unsigned sg(s2 s0, s2 s1) { return __builtin_amdgcn_perm(u(s0), u(s1), 0x07050301u); }")
+    A("template <int K> __device__ __forceinline__ void fold(unsigned &acc, unsigned p)")
+    A("{ if (K == 0) acc = p & 0x80808080u; else acc = ((p >> K) & (0x80808080u >> K)) | acc; }")
+    A("")
+    A("// exchange bit of each step class and decision bit position of every label (chain-back tables)")
+    A("__device__ constexpr unsigned char VT_P[6] = {%s};" % ", ".join(str(pl["p"]) for pl in PLANS))
+    A("__device__ constexpr unsigned char VT_POS[6][64] = {")
+    for pl in PLANS:
+        A("  {%s}," % ", ".join(str(x) for x in pl["pos"]))
+    A("};")
+    A("")
+    A("// W[q], q = c0*4 + c1*2 + c2: branch metric (1-2c0) y0 + (1-2c1) x1 + (1-2c2) x2 of pattern q")
+    for pl in PLANS:
+        c = pl["c"]
+        A("__device__ __forceinline__ void step%d(s2 (&R)[32], const int (&W)[8], unsigned &acc0, unsigned &acc1)" % c)
+        A("{")
+        if c == 0:
+            qs = sorted(set(min(q, 7 - q) for _, q in pl["regs"]))
+            for q in qs:
+                A("  const s2 M%d = pk(W[%d], W[%d]);" % (q, q, q))
+            for r, q in pl["regs"]:
+                cq, flip = (q, False) if q < 4 else (7 - q, True)
+                A("  { const s2 t1 = R[%d] %s M%d, t2 = swp(R[%d] %s M%d);" % (r, "-" if flip else "+", cq, r, "+" if flip else "-", cq))
+                A("    R[%d] = mn(t1, t2); const s2 dd = t2 - t1, ee = t1 - t2;" % r)
+                A("    const s2 m%d = s(__builtin_amdgcn_perm(u(ee), u(dd), 0x07060100u));" % r)   # (dd.lo, ee.hi)
+                if r % 2 == 1:
+                    j = r // 2
+                    A("    fold<%d>(acc%d, sg(m%d, m%d)); }" % (j % 8, j // 8, r - 1, r))
+                else:
+                    A("  }" if False else "    (void)0; }")
+            # the m registers of even r must outlive their block: re-emit with explicit declarations
+        else:
+            combos = {}
+            for ra, rb, ql, qh in pl["pairs"]:
+                key = (ql, qh) if ql < 4 else (7 - ql, 7 - qh)
+                combos.setdefault(key, len(combos))
+            for (ql, qh), idx in combos.items():
+                A("  const s2 M%d = pk(W[%d], W[%d]);" % (idx, ql, qh))
+            for k, (ra, rb, ql, qh) in enumerate(pl["pairs"]):
+                flip = ql >= 4
+                key = (ql, qh) if not flip else (7 - ql, 7 - qh)
+                m = "M%d" % combos[key]
+                pa, pb = ("-", "+") if flip else ("+", "-")
+                A("  { const s2 a0 = R[%d] %s %s, b0 = R[%d] %s %s, a1 = R[%d] %s %s, b1 = R[%d] %s %s;" %
+                  (ra, pa, m, rb, pb, m, ra, pb, m, rb, pa, m))
+                A("    R[%d] = mn(a0, b0); R[%d] = mn(a1, b1); fold<%d>(acc%d, sg(b0 - a0, b1 - a1)); }" % (ra, rb, k % 8, k // 8))
+        A("}")
+        A("")
+    A("}}  // namespace dabx::vt")
+    return "\n".join(o) + "\n"
+
+
+def emit_fixed():
+    """Class 0 needs the merged difference registers of two consecutive registers in one perm: emit it flat."""
+    txt = emit()
+    # rebuild step0 body cleanly
+    pl = PLANS[0]
+    body = ["__device__ __forceinline__ void step0(s2 (&R)[32], const int (&W)[8], unsigned &acc0, unsigned &acc1)", "{"]
+    qs = sorted(set(min(q, 7 - q) for _, q in pl["regs"]))
+    for q in qs:
+        body.append("  const s2 M%d = pk(W[%d], W[%d]);" % (q, q, q))
+    for j in range(16):
+        names = []
+        for r in (2 * j, 2 * j + 1):
+            q = pl["regs"][r][1]
+            cq, flip = (q, False) if q < 4 else (7 - q, True)
+            body.append("  const s2 t1_%d = R[%d] %s M%d, t2_%d = swp(R[%d] %s M%d);" % (r, r, "-" if flip else "+", cq, r, r, "+" if flip else "-", cq))
+            body.append("  R[%d] = mn(t1_%d, t2_%d);" % (r, r, r))
+            body.append("  const s2 m_%d = s(__builtin_amdgcn_perm(u(t1_%d - t2_%d), u(t2_%d - t1_%d), 0x07060100u));" % (r, r, r, r, r))
+            names.append("m_%d" % r)
+        body.append("  fold<%d>(acc%d, sg(%s, %s));" % (j % 8, j // 8, names[0], names[1]))
+    body.append("}")
+    a = txt.index("__device__ __forceinline__ void step0(")
+    b = txt.index("__device__ __forceinline__ void step1(")
+    return txt[:a] + "\n".join(body) + "\n\n" + txt[b:]
+
+
+if __name__ == "__main__" and "--emit" in sys.argv:
+    import os
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dabstar_amd", "csrc", "vit_t_gen.h")
+    open(out, "w").write(emit_fixed())
+    print("wrote", os.path.normpath(out))
+    for pl in PLANS[1:]:
+        combos = set((ql, qh) if ql < 4 else (7 - ql, 7 - qh) for _, _, ql, qh in pl["pairs"])
+        print("class", pl["c"], "p", pl["p"], "distinct packed M:", len(combos))
