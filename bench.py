@@ -131,7 +131,7 @@ def main():
     dx.check(dx.load().dabx_set_device(local_rank))
 
     subch = ds.default_subchannels(18, 64)
-    eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=2, fic_only=args.fic_only)
+    eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, fic_only=args.fic_only)
     if not args.fic_only:
         eng.set_subchannels(subch)
     ring_frames = fill_rings(eng, torch, dev, args, rank, subch)
@@ -143,11 +143,11 @@ def main():
         torch.cuda.synchronize()
 
     def step(n=1):
-        # one step = one frame for every stream; the engine decodes the MSC of up to 4 frames per launch, so the
-        # steps are issued in chunks of 4 (all work of the n steps is complete when the stream is drained)
+        # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch, so the
+        # steps are issued in chunks of 7 (all work of the n steps is complete when the stream is drained)
         done = 0
         while done < n:
-            m = min(4, n - done)
+            m = min(7, n - done)       # MSC_BATCH_FRAMES
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=False)
             done += m

@@ -12,7 +12,7 @@ namespace dabx {
 constexpr int L = 76, K = 1536, TN = 2656, TF = 196608, TS = 2552, TU = 2048, TG = 504;
 constexpr int K2 = 3072, FIC_IN = 2304, FIC_OUT = 768, CIF_BITS = 55296, INPUT_RATE = 2048000;
 constexpr int MAX_SUBCH = 64;
-constexpr int TDI_SLOTS = 32;          // time-deinterleaver ring depth in CIFs (16 history + 4 new, pow2)
+constexpr int TDI_SLOTS = 64;          // time-deinterleaver ring depth in CIFs (16 history + 4*MSC_BATCH_FRAMES new, pow2)
 constexpr uint16_t PUNCT = 0xFFFF;     // depuncture map entry of a punctured mother-code bit
 
 void set_error(const char *fmt, ...);

@@ -17,53 +17,92 @@ namespace dabx {
 __device__ __forceinline__ int bitrev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
 
 // ---------------------------------------------------------------------------------------------------- prepare
-// grid = groups, 256 threads: lane = job within the group, pg = plane group (planes 4pg .. 4pg+3).
+// grid = groups, 256 threads.  Per chunk of PCH ring positions: (1) every (job, plane) run of PCH bytes is read
+// with lanes ALONG the run (coalesced; a lane-per-job read would touch 64 different lines per instruction) into
+// LDS; (2) lane = job, pg = plane group: 4 planes x 1 dword -> 4x4 byte transpose in registers (8 v_perm) ->
+// 4 idx-ordered dwords, stored as inT[q][job] (256-B coalesced rows).
+constexpr int PCH = 64;                       // positions per chunk (bytes per plane run)
+constexpr int PJS = 16 * PCH + 4;             // LDS job stride in bytes (+4: conflict-free ds_read across jobs)
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_in, uint32_t *inT)
 {
-  const int g = blockIdx.x, lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const MscJob q = msc_job(e, g * 64 + lane, cifs);
+  __shared__ __attribute__((aligned(16))) uint8_t tile[64 * PJS];
+  __shared__ const uint8_t *s_base[64];      // per job: stream ring + cu_start*4 (nullptr = invalid job)
+  __shared__ long long s_r[64];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, pg = tid >> 6;
+  if (tid < 64) {
+    const MscJob q = msc_job(e, g * 64 + tid, cifs);
+    s_base[tid] = q.valid ? e.tdi + (size_t)q.s * TDI_SLOTS * CIF_BITS + e.subch[(size_t)q.s * e.max_subch + q.j].cu_start * 4 : nullptr;
+    s_r[tid] = q.r;
+  }
   const int rows = n_in / 4 + 1;
   uint32_t *dst = inT + (size_t)g * rows * 64 + lane;
   if (pg == 0) dst[(size_t)(rows - 1) * 64] = 0x7F7F7F7Fu;        // punctured soft bit = 0 -> symbol 127
-  if (!q.valid) return;
-  const SubchDev &sc = e.subch[(size_t)q.s * e.max_subch + q.j];
-  const uint8_t *tdi = e.tdi + (size_t)q.s * TDI_SLOTS * CIF_BITS;
-  const uint32_t *src[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int p = 4 * pg + i;
-    // out_r[idx] = in_{r-16+map[idx&15]}[idx], map = 4-bit reversal (backend.cpp:129); planar ring: plane = idx & 15
-    const long long cif = q.r - 16 + bitrev4(p);
-    src[i] = reinterpret_cast<const uint32_t *>(tdi + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)p * (CIF_BITS / 16) + sc.cu_start * 4);
-  }
-  const int nd = n_in / 64;                                        // dwords per plane
-  for (int d = 0; d < nd; d++) {
-    const uint32_t m0 = src[0][d], m1 = src[1][d], m2 = src[2][d], m3 = src[3][d];
-    const uint32_t a = __builtin_amdgcn_perm(m1, m0, 0x05010400u), b = __builtin_amdgcn_perm(m1, m0, 0x07030602u);
-    const uint32_t c = __builtin_amdgcn_perm(m3, m2, 0x05010400u), f = __builtin_amdgcn_perm(m3, m2, 0x07030602u);
-    // position P = 4 d + k holds idx = 16 P + plane: dword q = idx / 4 = 4 P + pg
-    dst[(size_t)(4 * (4 * d + 0) + pg) * 64] = __builtin_amdgcn_perm(c, a, 0x05040100u);
-    dst[(size_t)(4 * (4 * d + 1) + pg) * 64] = __builtin_amdgcn_perm(c, a, 0x07060302u);
-    dst[(size_t)(4 * (4 * d + 2) + pg) * 64] = __builtin_amdgcn_perm(f, b, 0x05040100u);
-    dst[(size_t)(4 * (4 * d + 3) + pg) * 64] = __builtin_amdgcn_perm(f, b, 0x07060302u);
+  __syncthreads();
+  const int npos = n_in / 16;                                      // ring positions per plane of one job
+  for (int p0 = 0; p0 < npos; p0 += PCH) {
+    const int cw = (npos - p0 < PCH ? npos - p0 : PCH) / 4;       // dwords per run in this chunk (npos % 4 == 0)
+    // (1) coalesced load: item = (job, plane, dword)
+    for (int it = tid; it < 64 * 16 * cw; it += 256) {
+      const int d = it % cw, jp = it / cw, pl = jp & 15, job = jp >> 4;
+      const uint8_t *base = s_base[job];
+      uint32_t v = 0x7F7F7F7Fu;
+      if (base) {
+        // out_r[idx] = in_{r-16+map[idx&15]}[idx], map = 4-bit reversal (backend.cpp:129); planar ring: plane = idx & 15
+        const long long cif = s_r[job] - 16 + bitrev4(pl);
+        v = *reinterpret_cast<const uint32_t *>(base + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d);
+      }
+      *reinterpret_cast<uint32_t *>(tile + job * PJS + pl * PCH + 4 * d) = v;
+    }
+    __syncthreads();
+    // (2) lane = job: transpose 4 planes x 4 positions, write idx-ordered dwords
+    const uint8_t *mine = tile + lane * PJS + (4 * pg) * PCH;
+    for (int d = 0; d < cw; d++) {
+      const uint32_t m0 = *reinterpret_cast<const uint32_t *>(mine + 0 * PCH + 4 * d), m1 = *reinterpret_cast<const uint32_t *>(mine + 1 * PCH + 4 * d);
+      const uint32_t m2 = *reinterpret_cast<const uint32_t *>(mine + 2 * PCH + 4 * d), m3 = *reinterpret_cast<const uint32_t *>(mine + 3 * PCH + 4 * d);
+      const uint32_t a = __builtin_amdgcn_perm(m1, m0, 0x05010400u), b = __builtin_amdgcn_perm(m1, m0, 0x07030602u);
+      const uint32_t c = __builtin_amdgcn_perm(m3, m2, 0x05010400u), f = __builtin_amdgcn_perm(m3, m2, 0x07030602u);
+      const int P = p0 + 4 * d;                                    // position P + k holds idx = 16 (P + k) + plane: dword 4 (P + k) + pg
+      dst[(size_t)(4 * (P + 0) + pg) * 64] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+      dst[(size_t)(4 * (P + 1) + pg) * 64] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+      dst[(size_t)(4 * (P + 2) + pg) * 64] = __builtin_amdgcn_perm(f, b, 0x05040100u);
+      dst[(size_t)(4 * (P + 3) + pg) * 64] = __builtin_amdgcn_perm(f, b, 0x07060302u);
+    }
+    __syncthreads();
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- decode
-__device__ __forceinline__ int vt_sym(const uint32_t *in_lane, unsigned idx)
+// Symbols of one 6-step cycle: 24 transposed dwords (one coalesced load each; the index is wave-uniform) plus the
+// byte lane of every symbol (2 bits each).  Fetched one cycle ahead so no memory latency sits on the ACS chain.
+struct VtCycle { uint32_t w[24]; unsigned long long sh; };
+
+__device__ __forceinline__ void vt_fetch(VtCycle &c, const uint32_t *in_lane, const uint16_t *map, int t0)
 {
-  const uint32_t w = in_lane[(size_t)(idx >> 2) * 64];
-  return 2 * (int)((w >> ((idx & 3) * 8)) & 0xFFu) - 255;
+  c.sh = 0;
+#pragma unroll
+  for (int s6 = 0; s6 < 6; s6++) {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * (t0 + s6));   // wave-uniform
+    const unsigned idx[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      c.w[4 * s6 + p] = in_lane[(size_t)(idx[p] >> 2) * 64];
+      c.sh |= (unsigned long long)(idx[p] & 3) << (2 * (4 * s6 + p));
+    }
+  }
 }
 
 template <int C>
-__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const uint32_t *in_lane, const uint16_t *map, int t, uint2 *dec_lane)
+__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, uint2 *dec_lane)
 {
-  const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);   // wave-uniform
-  const int x0 = vt_sym(in_lane, m.x), x1 = vt_sym(in_lane, m.y), x2 = vt_sym(in_lane, m.z), x3 = vt_sym(in_lane, m.w);
-  const int y0 = x0 + x3, a1 = y0 + x1, a2 = y0 - x1;
+  int x[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const unsigned sh = (unsigned)((cy.sh >> (2 * (4 * C + p))) & 3) * 8;
+    x[p] = 2 * (int)((cy.w[4 * C + p] >> sh) & 0xFFu) - 255;
+  }
+  const int y0 = x[0] + x[3], a1 = y0 + x[1], a2 = y0 - x[1];
   int W[8];
-  W[0] = a1 + x2; W[1] = a1 - x2; W[2] = a2 + x2; W[3] = a2 - x2;
+  W[0] = a1 + x[2]; W[1] = a1 - x[2]; W[2] = a2 + x[2]; W[3] = a2 - x[2];
   W[4] = -W[3]; W[5] = -W[2]; W[6] = -W[1]; W[7] = -W[0];
   unsigned acc0, acc1;
   if constexpr (C == 0) vt::step0(R, W, acc0, acc1);
@@ -73,6 +112,16 @@ __device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const uint32_t *in_lane,
   else if constexpr (C == 4) vt::step4(R, W, acc0, acc1);
   else vt::step5(R, W, acc0, acc1);
   dec_lane[(size_t)t * 64] = make_uint2(acc0, acc1);
+}
+
+__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane)
+{
+  vt_one<0>(R, cy, t0 + 0, dec_lane);
+  vt_one<1>(R, cy, t0 + 1, dec_lane);
+  vt_one<2>(R, cy, t0 + 2, dec_lane);
+  vt_one<3>(R, cy, t0 + 3, dec_lane);
+  vt_one<4>(R, cy, t0 + 4, dec_lane);
+  vt_one<5>(R, cy, t0 + 5, dec_lane);
 }
 
 // grid = groups, 64 threads.  map: depuncture map with PUNCT remapped to n_in (the 0x7F row).
@@ -91,18 +140,21 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, int n_in
 #pragma unroll
   for (int r = 0; r < 32; r++) R[r] = vt::pk(2000, 2000);          // viterbi_spiral.cpp:98-101 (0 / 1000), doubled
   R[0] = vt::pk(0, 2000);
-  for (int t = 0; t < nsteps; t += 6) {
-    if (((t / 6) & 1) == 0) {                                      // re-centre every 12 steps on the metric of label 0
+  VtCycle ca, cb;
+  vt_fetch(ca, in_lane, map, 0);
+  for (int t = 0; t < nsteps; t += 12) {                           // nsteps is a multiple of 6
+    const bool second = t + 6 < nsteps;
+    if (second) vt_fetch(cb, in_lane, map, t + 6);
+    {                                                              // re-centre every 12 steps on the metric of label 0
       const vt::s2 ref = vt::pk(R[0].x, R[0].x);
 #pragma unroll
       for (int r = 0; r < 32; r++) R[r] = R[r] - ref;
     }
-    vt_one<0>(R, in_lane, map, t + 0, dec_lane);
-    vt_one<1>(R, in_lane, map, t + 1, dec_lane);
-    vt_one<2>(R, in_lane, map, t + 2, dec_lane);
-    vt_one<3>(R, in_lane, map, t + 3, dec_lane);
-    vt_one<4>(R, in_lane, map, t + 4, dec_lane);
-    vt_one<5>(R, in_lane, map, t + 5, dec_lane);
+    vt_cycle(R, ca, t, dec_lane);
+    if (second) {
+      if (t + 12 < nsteps) vt_fetch(ca, in_lane, map, t + 12);
+      vt_cycle(R, cb, t + 6, dec_lane);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -114,18 +166,42 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, int n_in
     out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)q.s * e.max_subch + q.j) * MSC_SLOTS + (size_t)(q.out_idx % MSC_SLOTS)) * e.msc_stride);
   int L = 0;
   unsigned outw = 0;
-  for (int t = nsteps - 1; t >= 6; --t) {
-    const int c = t % 6, p = 5 - c;                                // VT_P[c] = (5 - c) % 6
-    const uint2 w = dec_lane[(size_t)t * 64];
-    const int pos = pos_tab[c][L];
-    const unsigned bit = (((pos & 32) ? w.y : w.x) >> (pos & 31)) & 1u;
-    const int qb = t - 6;
-    outw |= bit << (((qb >> 3) & 3) * 8 + 7 - (qb & 7));
-    L = (L & ~(1 << p)) | ((int)bit << p);
-    if ((qb & 31) == 0) {
-      if (out) out[qb >> 5] = outw ^ prbs[qb >> 5];
-      outw = 0;
+  // decision words are fetched two 6-step cycles ahead of their use: the load address does not depend on the path,
+  // only the bit that is picked does, so the HBM/L2 latency of the (long since written) words is off the chain
+  uint2 wa[6], wb[6];
+  int tc = nsteps - 6;                                            // first step of the cycle being consumed
+#pragma unroll
+  for (int i = 0; i < 6; i++) wa[i] = dec_lane[(size_t)(tc + i) * 64];
+  auto consume = [&](const uint2 (&w)[6], int t0) {
+#pragma unroll
+    for (int c = 5; c >= 0; --c) {
+      const int t = t0 + c, p = 5 - c;                            // VT_P[c] = (5 - c) % 6
+      if (t < 6) continue;
+      const int pos = pos_tab[c][L];
+      const unsigned bit = (((pos & 32) ? w[c].y : w[c].x) >> (pos & 31)) & 1u;
+      const int qb = t - 6;
+      outw |= bit << (((qb >> 3) & 3) * 8 + 7 - (qb & 7));
+      L = (L & ~(1 << p)) | ((int)bit << p);
+      if ((qb & 31) == 0) {
+        if (out) out[qb >> 5] = outw ^ prbs[qb >> 5];
+        outw = 0;
+      }
     }
+  };
+  while (tc >= 0) {
+    if (tc >= 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) wb[i] = dec_lane[(size_t)(tc - 6 + i) * 64];
+    }
+    consume(wa, tc);
+    tc -= 6;
+    if (tc < 0) break;
+    if (tc >= 6) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) wa[i] = dec_lane[(size_t)(tc - 6 + i) * 64];
+    }
+    consume(wb, tc);
+    tc -= 6;
   }
 }
 

@@ -160,7 +160,9 @@ def emit():
     A("// sign bytes of two packed difference registers -> bits 7,15,23,31 = [s1.lo, s1.hi, s0.lo, s0.hi]")
     A("__device__ __forceinline__ unsigned sg(s2 s0, s2 s1) { return __builtin_amdgcn_perm(u(s0), u(s1), 0x07050301u); }")
     A("template <int K> __device__ __forceinline__ void fold(unsigned &acc, unsigned p)")
-    A("{ if (K == 0) acc = p & 0x80808080u; else acc = ((p >> K) & (0x80808080u >> K)) | acc; }")
+    A("{ constexpr unsigned M = 0x80808080u >> K;   // shift + v_and_or_b32 per perm (hipcc splits the and/or otherwise)")
+    A("  if (K == 0) acc = p & M;")
+    A("  else { const unsigned t = p >> K; asm(\"v_and_or_b32 %0, %1, %2, %0\" : \"+v\"(acc) : \"v\"(t), \"s\"(M)); } }")
     A("")
     A("// exchange bit of each step class and decision bit position of every label (chain-back tables)")
     A("__device__ constexpr unsigned char VT_P[6] = {%s};" % ", ".join(str(pl["p"]) for pl in PLANS))
