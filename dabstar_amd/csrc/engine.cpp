@@ -92,6 +92,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.wr, S));
   A(e->alloc(&d.ctl, S));
   A(e->alloc(&d.spectra, (size_t)S * 76 * TU, false));
+  A(e->alloc(&d.nco_tid, (size_t)S * 256));
   A(e->alloc(&d.cp_part, (size_t)S * 75));
   A(e->alloc(&d.abs_part, (size_t)S * 76));
   A(e->alloc(&d.fic_sym, (size_t)S * 3 * K2));

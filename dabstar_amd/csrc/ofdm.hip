@@ -101,17 +101,17 @@ __global__ void k_demap_store_null(DemapDev d, const float2 *fft)
   }
 }
 
-// decode_symbol for n_sym consecutive symbols of one stream per block (256 threads x 6 carriers)
-__global__ __launch_bounds__(256) void k_demap_symbols(DemapDev d, const float2 *fft, int n_sym, const float *clock_err,
+// decode_symbol for n_sym consecutive symbols of one stream per block (512 threads x 3 carriers)
+__global__ __launch_bounds__(512) void k_demap_symbols(DemapDev d, const float2 *fft, int n_sym, const float *clock_err,
                                                        int16_t *soft, DevTables t)
 {
   __shared__ float red[8];
   const int s = blockIdx.x, tid = threadIdx.x;
-  DemapCarrier c[6];
-  int bin[6], rel[6];
+  DemapCarrier c[3];
+  int bin[3], rel[3];
 #pragma unroll
-  for (int q = 0; q < 6; q++) {
-    const int k = tid + 256 * q;
+  for (int q = 0; q < 3; q++) {
+    const int k = tid + 512 * q;
     bin[q] = t.perm_bin[k]; rel[q] = t.perm_rel[k];
     c[q].prev = d.phase_ref[(size_t)s * TU + bin[q]];
     c[q].integ = d.integ[(size_t)s * K + k];
@@ -124,19 +124,20 @@ __global__ __launch_bounds__(256) void k_demap_symbols(DemapDev d, const float2 
   for (int l = 0; l < n_sym; l++) {
     const float2 *X = fft + ((size_t)s * n_sym + l) * TU;
     int16_t *o = soft + ((size_t)s * n_sym + l) * K2;
+    const float w2 = demap_w2(mean_value, d.soft_type);
     float part = 0.f;
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
+    for (int q = 0; q < 3; q++) {
       int16_t sr, si;
-      part += demap_one(c[q], X[bin[q]], rel[q], ce, mean_value, d.soft_type, sr, si);
-      o[tid + 256 * q] = sr;
-      o[K + tid + 256 * q] = si;
+      part += demap_one(c[q], X[bin[q]], rel[q], ce, w2, d.soft_type, sr, si);
+      o[tid + 512 * q] = sr;
+      o[K + tid + 512 * q] = si;
     }
-    mean_value = block_sum(part, red, tid) / (float)K;   // :294
+    mean_value = block_sum(part, red, tid) * (1.0f / (float)K);   // :294
   }
 #pragma unroll
-  for (int q = 0; q < 6; q++) {
-    const int k = tid + 256 * q;
+  for (int q = 0; q < 3; q++) {
+    const int k = tid + 512 * q;
     d.integ[(size_t)s * K + k] = c[q].integ;
     d.mean_power[(size_t)s * K + k] = c[q].mean_power;
     d.mean_sigma[(size_t)s * K + k] = c[q].mean_sigma_sq;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_demap_symbols(DemapDev d, const float2 
   // :354 mPhaseReference <- last symbol (all 2048 bins)
   if (n_sym > 0) {
     const float2 *X = fft + ((size_t)s * n_sym + (n_sym - 1)) * TU;
-    for (int i = tid; i < TU; i += 256) d.phase_ref[(size_t)s * TU + i] = X[i];
+    for (int i = tid; i < TU; i += 512) d.phase_ref[(size_t)s * TU + i] = X[i];
   }
   if (tid == 0) d.mean_value[s] = mean_value;
 }
@@ -201,7 +202,7 @@ int launch_demap_store_null(DemapDev &d, const float2 *fft, hipStream_t st)
 int launch_demap_symbols(DemapDev &d, const float2 *fft, int n_sym, const float *clock_err, int16_t *soft, hipStream_t st)
 {
   GET_TABLES(t);
-  hipLaunchKernelGGL(k_demap_symbols, dim3(d.batch), dim3(256), 0, st, d, fft, n_sym, clock_err, soft, *t);
+  hipLaunchKernelGGL(k_demap_symbols, dim3(d.batch), dim3(512), 0, st, d, fft, n_sym, clock_err, soft, *t);
   DABX_HIP(hipGetLastError());
   return 0;
 }

@@ -57,6 +57,33 @@ struct Nco {
     sincospi(2.0 * (double)p / (double)R, &bi, &br);
     sincospi(2.0 * (double)q / (double)R, &si, &sr);
   }
+  // Same phasor from a block-uniform base e^{j 2 pi ((p0 - (nb+1) f) mod R)/R} (one lane evaluates it) times the
+  // per-thread factor e^{-j 2 pi f tid / R} tabulated once per frame: removes two double sincospi per thread and symbol.
+  __device__ void init_from(double2 base, double2 step, double2 tid_factor)
+  {
+    br = base.x * tid_factor.x - base.y * tid_factor.y;
+    bi = base.x * tid_factor.y + base.y * tid_factor.x;
+    sr = step.x; si = step.y;
+  }
+  __device__ static void block_consts(int phase0, int f, long long nb, double2 &base, double2 &step)
+  {
+    const long long R = INPUT_RATE;
+    long long p = ((long long)phase0 - (nb + 1) * (long long)f) % R;
+    if (p < 0) p += R;
+    long long q = (-256LL * f) % R;
+    if (q < 0) q += R;
+    sincospi(2.0 * (double)p / (double)R, &base.y, &base.x);
+    sincospi(2.0 * (double)q / (double)R, &step.y, &step.x);
+  }
+  __device__ static double2 tid_factor(int f, int tid)
+  {
+    const long long R = INPUT_RATE;
+    long long p = (-(long long)tid * (long long)f) % R;
+    if (p < 0) p += R;
+    double2 r;
+    sincospi(2.0 * (double)p / (double)R, &r.y, &r.x);
+    return r;
+  }
   __device__ float2 mix(float2 v) const
   {
     const float cr = (float)br, ci = (float)bi;
@@ -198,35 +225,62 @@ __device__ __forceinline__ int16_t cvt_i16_x86(float x)
   return (int16_t)(uint16_t)(uint32_t)(int32_t)x;
 }
 
+// atan2 for the demapper: octant reduction + Abramowitz-Stegun 4.4.49 (|err| <= 2e-8 rad on [0,1]); the phase only
+// feeds the +-20 degree integrator with gain 1e-3, so this is far inside the soft-bit tolerance.
+__device__ __forceinline__ float atan2_as(float y, float x)
+{
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mnv = fminf(ax, ay);
+  const float t = mnv * __builtin_amdgcn_rcpf(mx);
+  const float z = t * t;
+  float p = 0.0028662257f;
+  p = __builtin_fmaf(p, z, -0.0161657367f);
+  p = __builtin_fmaf(p, z, 0.0429096138f);
+  p = __builtin_fmaf(p, z, -0.0752896400f);
+  p = __builtin_fmaf(p, z, 0.1065626393f);
+  p = __builtin_fmaf(p, z, -0.1420889944f);
+  p = __builtin_fmaf(p, z, 0.1999355085f);
+  p = __builtin_fmaf(p, z, -0.3333314528f);
+  float r = __builtin_fmaf(p * z, t, t);
+  if (mx == 0.0f) r = 0.0f;
+  if (ay > ax) r = 1.57079632679489661923f - r;
+  if (x < 0.0f) r = 3.14159265358979323846f - r;
+  return y < 0.0f ? -r : r;
+}
+
 // One carrier of one symbol.  Returns |r1| (summand of mMeanValue); writes the two soft bits.
-__device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, float clock_err, float mean_value,
+// Arithmetic follows ofdm_decoder.cpp:147-355 operation by operation; divisions and square roots use the
+// hardware v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE expansions (the reference itself is built with
+// -ffast-math): 2x fewer VALU instructions, soft bits differ from the IEEE evaluation by at most 1 LSB.
+__device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, float clock_err, float w2,
                                            int soft_type, int16_t &soft_re, int16_t &soft_im)
 {
   constexpr float ALPHA = 0.005f;
   const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
   const float F_RAD_PER_DEG = 0.01745329251994329577f, F_SQRT1_2 = 0.70710678118654752440f;
   const float2 pr = c.prev;
-  const float pr_abs = cabsf_(pr);
+  const float pr_abs = __builtin_amdgcn_sqrtf(pr.x * pr.x + pr.y * pr.y);
+  const float pr_inv = __builtin_amdgcn_rcpf(pr_abs);
   float2 raw;                                                   // :188-189
-  raw.x = (x.x * pr.x + x.y * pr.y) / pr_abs;
-  raw.y = (x.y * pr.x - x.x * pr.y) / pr_abs;
-  const float phase_err = clock_err / 1024.0f * F_PI * (float)(K / 2 - rel) / (float)(K / 2) + c.integ;   // :192
+  raw.x = (x.x * pr.x + x.y * pr.y) * pr_inv;
+  raw.y = (x.y * pr.x - x.x * pr.y) * pr_inv;
+  const float phase_err = clock_err * (F_PI / 1024.0f / (float)(K / 2)) * (float)(K / 2 - rel) + c.integ;   // :192
   const float xx = -phase_err, x2 = xx * xx;                    // cmplx_from_phase2, :70-88
   const float sine = xx * (x2 * -0.16034401953220367431640625f + 0.99903142452239990234375f);
   const float cosine = 0.9994032382965087890625f + x2 * (x2 * 3.679168224334716796875e-2f + -0.495580852031707763671875f);
   float2 b;
   b.x = raw.x * cosine - raw.y * sine;
   b.y = raw.x * sine + raw.y * cosine;
-  float ph = atan2f(b.y, b.x);                                  // :197
+  float ph = atan2_as(b.y, b.x);                                // :197
   if (ph < 0.0f) ph += F_PI;                                    // glob_defs.h:173-182
-  // fmod(ph, pi/2) for ph in [0, pi]: pi_f == 2 * (pi/2)_f exactly and ph - n*c is exact (Sterbenz), so this is fmodf bit for bit
+  // fmod(ph, pi/2) for ph in [0, pi]: pi_f == 2 * (pi/2)_f exactly and ph - n*c is exact (Sterbenz)
   const float aph = ph < F_PI_2 ? ph : (ph < F_PI ? ph - F_PI_2 : ph - F_PI);
   c.integ += 0.2f * ALPHA * (aph - F_PI_4);                     // :201-202
   const float lim = F_RAD_PER_DEG * 20.0f;
   if (c.integ > lim) c.integ = lim; else if (c.integ < -lim) c.integ = -lim;
   const float power = b.x * b.x + b.y * b.y;                    // :211-213
   c.mean_power += ALPHA * (power - c.mean_power);
-  const float mean_level = sqrtf(c.mean_power);                 // :217-223
+  const float mean_level = __builtin_amdgcn_sqrtf(c.mean_power);   // :217-223
   const float at_axis = mean_level * F_SQRT1_2;
   const float rd = fabsf(b.x) - at_axis, id = fabsf(b.y) - at_axis;
   const float sigma_sq = rd * rd + id * id;
@@ -234,24 +288,27 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   float signal_power = c.mean_power - c.null_power;             // :225-226
   if (signal_power <= 0.0f) signal_power = 0.1f;
   float2 r1;
-  float w2;
   if (soft_type == 3) {                                         // :231-235
-    r1 = make_float2(b.x * pr_abs, b.y * pr_abs); w2 = -140 / mean_value;
+    r1 = make_float2(b.x * pr_abs, b.y * pr_abs);
   } else if (soft_type == 2) {                                  // :236-242
-    float w1 = pr_abs / c.mean_sigma_sq;
-    w1 /= (c.null_power / signal_power) + 0.7f;
-    r1 = make_float2(b.x * w1, b.y * w1); w2 = -140 / mean_value;
+    float w1 = pr_abs * __builtin_amdgcn_rcpf(c.mean_sigma_sq);
+    w1 *= __builtin_amdgcn_rcpf(c.null_power * __builtin_amdgcn_rcpf(signal_power) + 0.7f);
+    r1 = make_float2(b.x * w1, b.y * w1);
   } else {                                                      // :243-251
-    const float babs = sqrtf(power);
-    float w1 = sqrtf(babs * pr_abs) * mean_level;
-    w1 /= (c.null_power / signal_power) + 0.7f;
-    w1 /= c.mean_sigma_sq * babs;
-    r1 = make_float2(b.x * w1, b.y * w1); w2 = -100 / mean_value;
+    const float babs = __builtin_amdgcn_sqrtf(power);
+    float w1 = __builtin_amdgcn_sqrtf(babs * pr_abs) * mean_level;
+    w1 *= __builtin_amdgcn_rcpf(c.null_power * __builtin_amdgcn_rcpf(signal_power) + 0.7f);
+    w1 *= __builtin_amdgcn_rcpf(c.mean_sigma_sq * babs);
+    r1 = make_float2(b.x * w1, b.y * w1);
   }
-  soft_re = cvt_i16_x86(r1.x * w2);                             // :254-255
+  soft_re = cvt_i16_x86(r1.x * w2);                             // :254-255, w2 = -100 (-140) / mMeanValue
   soft_im = cvt_i16_x86(r1.y * w2);
   c.prev = x;                                                   // :354
-  return cabsf_(r1);                                            // :256
+  return __builtin_amdgcn_sqrtf(r1.x * r1.x + r1.y * r1.y);     // :256
+}
+__device__ __forceinline__ float demap_w2(float mean_value, int soft_type)
+{
+  return (soft_type == 1 ? -100.0f : -140.0f) * __builtin_amdgcn_rcpf(mean_value);
 }
 
 __device__ __forceinline__ uint8_t soft_to_sym(int16_t s)       // viterbi_scalar.h:34-40

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
     if (correction != 0) clock_err = 0.0f;
     f_bb = f_sync;
   }
+  e.nco_tid[(size_t)s * 256 + tid] = Nco::tid_factor((int)roundf(f_bb), tid);
   if (tid == 0) {
     c.start_index = start;
     c.sample_count = start + TU;
@@ -200,7 +201,10 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
   }
   float2 v[8];
   Nco nco;
-  nco.init(c.phase_sym1, f, n0 + TG + tid);
+  __shared__ double2 s_nco[2];
+  if (tid == 0) Nco::block_consts(c.phase_sym1, f, n0 + TG, s_nco[0], s_nco[1]);
+  __syncthreads();
+  nco.init_from(s_nco[0], s_nco[1], e.nco_tid[(size_t)s * 256 + tid]);
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const float2 x = rv.at(TG + tid + 256 * u);
@@ -219,18 +223,18 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
 }
 
 // -------------------------------------------------------------------------------------------------- demap
-__global__ __launch_bounds__(256) void k_demap_frame(EngineDev e, DevTables t)
+__global__ __launch_bounds__(512) void k_demap_frame(EngineDev e, DevTables t)
 {
   __shared__ float red[8];
   const int s = blockIdx.x, tid = threadIdx.x;
   const StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   DemapDev &d = e.demap;
-  DemapCarrier cr[6];
-  int bin[6], rel[6];
+  DemapCarrier cr[3];
+  int bin[3], rel[3];
 #pragma unroll
-  for (int q = 0; q < 6; q++) {
-    const int k = tid + 256 * q;
+  for (int q = 0; q < 3; q++) {
+    const int k = tid + 512 * q;
     bin[q] = t.perm_bin[k]; rel[q] = t.perm_rel[k];
     cr[q].prev = d.phase_ref[(size_t)s * TU + bin[q]];
     cr[q].integ = d.integ[(size_t)s * K + k];
@@ -244,16 +248,16 @@ __global__ __launch_bounds__(256) void k_demap_frame(EngineDev e, DevTables t)
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
   uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
-  const int n_sym = e.fic_only ? 75 : 75;                 // the demapper state advances on all 75 symbols in every mode
-  for (int l = 0; l < n_sym; l++) {
+  for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
     const float2 *X = e.spectra + ((size_t)s * 76 + l) * TU;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
+    const float w2 = demap_w2(mean_value, d.soft_type);
     float part = 0.f;
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
+    for (int q = 0; q < 3; q++) {
       int16_t sr, si;
-      part += demap_one(cr[q], X[bin[q]], rel[q], ce, mean_value, d.soft_type, sr, si);
-      const int k = tid + 256 * q;
+      part += demap_one(cr[q], X[bin[q]], rel[q], ce, w2, d.soft_type, sr, si);
+      const int k = tid + 512 * q;
       if (l < 3) {                                        // symbols 1..3 -> FIC
         fic[l * K2 + k] = soft_to_sym(sr);
         fic[l * K2 + K + k] = soft_to_sym(si);
@@ -263,11 +267,11 @@ __global__ __launch_bounds__(256) void k_demap_frame(EngineDev e, DevTables t)
       }
       if (cap) { cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
     }
-    mean_value = block_sum(part, red, tid) / (float)K;
+    mean_value = block_sum(part, red, tid) * (1.0f / (float)K);
   }
 #pragma unroll
-  for (int q = 0; q < 6; q++) {
-    const int k = tid + 256 * q;
+  for (int q = 0; q < 3; q++) {
+    const int k = tid + 512 * q;
     d.integ[(size_t)s * K + k] = cr[q].integ;
     d.mean_power[(size_t)s * K + k] = cr[q].mean_power;
     d.mean_sigma[(size_t)s * K + k] = cr[q].mean_sigma_sq;
@@ -632,7 +636,7 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
   mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
-  mk.begin(3, st); hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(3, st);
+  mk.begin(3, st); hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(512), 0, st, e, *t); mk.end(3, st);
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
   DABX_HIP(hipGetLastError());
