@@ -9,7 +9,7 @@
 
 namespace dabx {
 int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk);
-int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, hipStream_t st, Marker &mk);
+int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, EngineStreams &ss, Marker &mk);
 extern const char *const kStepKernelNames[10];
 int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st);
 int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st);
@@ -21,7 +21,9 @@ using namespace dabx;
 struct dabx_engine {
   dabx_config cfg{};
   EngineDev dev{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;                // == ss.a (front end)
+  EngineStreams ss;
+  BatchSnap *snap_buf[2] = {nullptr, nullptr};
   int device = 0;
   std::vector<unsigned long long> wr_host;     // host mirror of committed samples
   std::vector<SubchDev> subch_host;            // [S][max_subch]
@@ -46,6 +48,13 @@ struct dabx_engine {
     return 0;
   }
 };
+
+static int sync_all(dabx_engine *e)
+{
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
+  return 0;
+}
 
 static int need_device_e()
 {
@@ -79,6 +88,10 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   e->cfg = *cfg;
   DABX_HIP(hipGetDevice(&e->device));
   DABX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->ss.a = e->stream;
+  DABX_HIP(hipStreamCreateWithFlags(&e->ss.b, hipStreamNonBlocking));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming));
   const int S = cfg->n_streams;
   EngineDev &d = e->dev;
   d.n_streams = S; d.max_subch = cfg->max_subch; d.out_frames = cfg->out_frames;
@@ -93,6 +106,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.ctl, S));
   A(e->alloc(&d.spectra, (size_t)S * 76 * TU, false));
   A(e->alloc(&d.nco_tid, (size_t)S * 256));
+  A(e->alloc(&e->snap_buf[0], S));
+  A(e->alloc(&e->snap_buf[1], S));
+  d.snap = e->snap_buf[0];
   A(e->alloc(&d.cp_part, (size_t)S * 75));
   A(e->alloc(&d.abs_part, (size_t)S * 76));
   A(e->alloc(&d.fic_sym, (size_t)S * 3 * K2));
@@ -128,6 +144,9 @@ void dabx_destroy(dabx_engine *e)
 {
   if (!e) return;
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->ss.b) { (void)hipStreamSynchronize(e->ss.b); (void)hipStreamDestroy(e->ss.b); }
+  if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
+  if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (void *p : e->allocs) (void)hipFree(p);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
@@ -143,7 +162,7 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
   }
   EngineDev &d = e->dev;
   int rc;
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if ((rc = sync_all(e))) return rc;
   // current CIF counters (Backend construction time, backend.cpp:38-70)
   std::vector<StreamCtl> ctl(d.n_streams);
   DABX_HIP(hipMemcpy(ctl.data(), d.ctl, sizeof(StreamCtl) * d.n_streams, hipMemcpyDeviceToHost));
@@ -211,7 +230,8 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
         const size_t groups = (jobs + 63) / 64;
         MscFast f{};
         f.n_in = n_in; f.nbits = 24 * f0.kbps; f.min_jobs = (int)min_jobs; f.map2 = map2;
-        if ((rc = e->alloc(&f.inT, groups * (size_t)(n_in / 4 + 1) * 64, false))) return rc;
+        if ((rc = e->alloc(&f.inT[0], groups * (size_t)(n_in / 4 + 1) * 64, false))) return rc;
+        if ((rc = e->alloc(&f.inT[1], groups * (size_t)(n_in / 4 + 1) * 64, false))) return rc;
         if ((rc = e->alloc(&f.decT, groups * (size_t)(f.nbits + 6) * 64, false))) return rc;
         e->fast = f;
         e->have_fast = true;
@@ -265,26 +285,26 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     int rc = launch_front_step(e->dev, e->stream, e->mk);
     if (rc) return rc;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
-      rc = launch_msc_batch(e->dev, e->pending_frames, e->have_fast ? &e->fast : nullptr, e->stream, e->mk);
+      e->dev.snap = e->snap_buf[e->ss.batch_parity];
+      rc = launch_msc_batch(e->dev, e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk);
       if (rc) return rc;
       e->pending_frames = 0;
     }
   }
-  if (sync) DABX_HIP(hipStreamSynchronize(e->stream));
+  if (sync && (max_frames = sync_all(e) ? -1 : max_frames) < 0) return DABX_E_HIP;
   return max_frames;
 }
 
 int dabx_synchronize(dabx_engine *e)
 {
   if (!e) return DABX_E_ARG;
-  DABX_HIP(hipStreamSynchronize(e->stream));
-  return 0;
+  return sync_all(e);
 }
 void *dabx_hip_stream(dabx_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 static int fetch_ctl(dabx_engine *e, int stream, StreamCtl *c)
 {
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (int rc = sync_all(e)) return rc;
   DABX_HIP(hipMemcpy(c, e->dev.ctl + stream, sizeof(StreamCtl), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -307,7 +327,7 @@ int dabx_read_fibs(dabx_engine *e, int stream, int n_frames, uint8_t *fibs, uint
 
 static int fetch_subch(dabx_engine *e, int stream, int j, SubchDev *sc)
 {
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (int rc = sync_all(e)) return rc;
   DABX_HIP(hipMemcpy(sc, e->dev.subch + (size_t)stream * e->dev.max_subch + j, sizeof(SubchDev), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -350,7 +370,7 @@ int dabx_read_soft(dabx_engine *e, int stream, int16_t *soft)
 {
   if (!e || stream < 0 || stream >= e->dev.n_streams || !soft) return DABX_E_ARG;
   if (!e->dev.soft_cap) { set_error("engine was created without capture_soft"); return DABX_E_STATE; }
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (int rc = sync_all(e)) return rc;
   DABX_HIP(hipMemcpy(soft, e->dev.soft_cap + (size_t)stream * 75 * K2, sizeof(int16_t) * 75 * K2, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -378,7 +398,7 @@ int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)
 int dabx_get_counters(dabx_engine *e, int64_t out[16])
 {
   if (!e || !out) return DABX_E_ARG;
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (int rc0 = sync_all(e)) return rc0;
   const int S = e->dev.n_streams;
   std::vector<StreamCtl> ctl(S);
   std::vector<SubchDev> sc((size_t)S * std::max(1, e->dev.max_subch));
@@ -400,7 +420,7 @@ int dabx_get_counters(dabx_engine *e, int64_t out[16])
 int dabx_set_profiling(dabx_engine *e, int on)
 {
   if (!e) return DABX_E_ARG;
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (int rc = sync_all(e)) return rc;
   e->mk.on = on != 0;
   e->mk.used = 0;
   e->mk.recs.clear();
@@ -412,7 +432,7 @@ int dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t 
                      const char *names[DABX_MAX_KERNELS])
 {
   if (!e || !total_ms || !launches || !names) return DABX_E_ARG;
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  if (int rc = sync_all(e)) return rc;
   for (const auto &r : e->mk.recs) {
     float ms = 0.f;
     DABX_HIP(hipEventElapsedTime(&ms, e->mk.pool[r.a], e->mk.pool[r.b]));
@@ -441,6 +461,7 @@ int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_
     e = new dabx_engine();
     e->cfg = cfg;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DABX_E_HIP; }
+    e->ss.a = e->stream;
     EngineDev &d = e->dev;
     d.n_streams = batch; d.max_subch = 0; d.out_frames = 1; d.fic_only = 1;
     d.vit_stride = (int)vit_scratch_words(FIC_OUT);

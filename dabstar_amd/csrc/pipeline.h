@@ -55,6 +55,10 @@ struct SubchDev {
   long long sf_ok, sf_fail, rs_corr, rs_fail, fc_corr, au_ok, au_bad;
 };
 
+// Per-batch snapshot of the CIF counters: the MSC kernels of a batch run on their own HIP stream while the front
+// end already advances cif_no for the next frames.
+struct BatchSnap { long long msc_done, cif_no; };
+
 struct EngineDev {
   int32_t n_streams, max_subch, out_frames;
   int32_t ring_len;               // IQ ring capacity per stream in samples
@@ -80,6 +84,7 @@ struct EngineDev {
   uint8_t *msc_out;               // [S][max_subch][MSC_SLOTS][msc_stride]
   uint8_t *sf_out;                // [S][max_subch][SF_SLOTS][sf_stride]
   int16_t *soft_cap;              // [S][75][3072] or null
+  BatchSnap *snap;                // [S] counters of the MSC batch being decoded
 };
 
 // ---- uniform-profile fast path of the MSC decoder (vit_t.hip) -----------------------------------------------
@@ -87,8 +92,17 @@ struct MscFast {
   int n_in, nbits;          // soft bits per job (cu_size*64), decoded bits (24*kbps)
   int min_jobs;             // below this the wave-per-trellis kernel is used
   const uint16_t *map2;     // depuncture map with punctured entries remapped to n_in
-  uint32_t *inT;            // [groups][n_in/4 + 1][64] transposed de-interleaved symbols
+  uint32_t *inT[2];         // [groups][n_in/4 + 1][64] transposed de-interleaved symbols, double-buffered per batch
   uint2 *decT;              // [groups][nbits + 6][64] decision words
+};
+
+// HIP streams/events of the engine: front end on `a`; the long lane-per-trellis decode of batch n runs on `b`
+// while `a` already demodulates the frames of batch n+1.
+struct EngineStreams {
+  hipStream_t a = nullptr, b = nullptr;
+  hipEvent_t prep_done = nullptr, msc_done = nullptr;
+  bool msc_in_flight = false;
+  int batch_parity = 0;
 };
 
 // ---- profiling hook: HIP events around every kernel launch of a batch step ------------------------------------
@@ -129,12 +143,12 @@ __device__ __forceinline__ MscJob msc_job(const EngineDev &e, int J, int cifs)
   q.j = rem - q.k * e.max_subch;
   q.valid = false; q.r = 0; q.out_idx = 0;
   if (q.s >= e.n_streams) return q;
-  const StreamCtl &c = e.ctl[q.s];
+  const BatchSnap c = e.snap[q.s];
   const SubchDev &sc = e.subch[(size_t)q.s * e.max_subch + q.j];
-  q.r = c.msc_done_cif + q.k;
+  q.r = c.msc_done + q.k;
   const long long valid_from = sc.start_cif + 16;                 // de-interleaver filled, backend.cpp:146-150
   q.valid = sc.active && q.r < c.cif_no && q.r >= valid_from;
-  q.out_idx = sc.cif_out + (q.r - (c.msc_done_cif > valid_from ? c.msc_done_cif : valid_from));
+  q.out_idx = sc.cif_out + (q.r - (c.msc_done > valid_from ? c.msc_done : valid_from));
   return q;
 }
 // TDI ring, planar: within a CIF slot soft bit i lives at plane (i & 15), position (i >> 4)

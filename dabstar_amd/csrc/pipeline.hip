@@ -248,15 +248,24 @@ __global__ __launch_bounds__(512) void k_demap_frame(EngineDev e, DevTables t)
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
   uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
+  float2 xn[3];                                           // spectrum values of the next symbol (gather latency off the chain)
+  {
+    const float2 *X0 = e.spectra + (size_t)s * 76 * TU;
+#pragma unroll
+    for (int q = 0; q < 3; q++) xn[q] = X0[bin[q]];
+  }
   for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
-    const float2 *X = e.spectra + ((size_t)s * 76 + l) * TU;
+    const float2 *X = e.spectra + ((size_t)s * 76 + (l < 74 ? l + 1 : l)) * TU;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, d.soft_type);
+    float2 xc[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { xc[q] = xn[q]; xn[q] = X[bin[q]]; }
     float part = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       int16_t sr, si;
-      part += demap_one(cr[q], X[bin[q]], rel[q], ce, w2, d.soft_type, sr, si);
+      part += demap_one(cr[q], xc[q], rel[q], ce, w2, d.soft_type, sr, si);
       const int k = tid + 512 * q;
       if (l < 3) {                                        // symbols 1..3 -> FIC
         fic[l * K2 + k] = soft_to_sym(sr);
@@ -488,11 +497,11 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
 {
   const int job = blockIdx.x, lane = threadIdx.x;
   const int s = job / e.max_subch, j = job % e.max_subch;
-  const StreamCtl &c = e.ctl[s];
   SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
   if (!sc.active) return;
+  const BatchSnap bs = e.snap[s];
   long long n_new = 0;                        // logical frames the decoder just produced for this sub-channel
-  for (long long r = c.msc_done_cif; r < c.cif_no; r++) if (r >= sc.start_cif + 16) n_new++;
+  for (long long r = bs.msc_done; r < bs.cif_no; r++) if (r >= sc.start_cif + 16) n_new++;
   if (n_new == 0) return;
   const int R = sc.kbps / 8, nbytes = 3 * sc.kbps;         // nbytes = 24 R
   const uint8_t *ring = e.msc_out + ((size_t)s * e.max_subch + j) * MSC_SLOTS * e.msc_stride;
@@ -616,10 +625,15 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
+__global__ void k_msc_snap(EngineDev e)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < e.n_streams) e.snap[s] = BatchSnap{e.ctl[s].msc_done_cif, e.ctl[s].cif_no};
+}
 __global__ void k_msc_done(EngineDev e)
 {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < e.n_streams) e.ctl[s].msc_done_cif = e.ctl[s].cif_no;
+  if (s < e.n_streams) e.ctl[s].msc_done_cif = e.snap[s].cif_no;
 }
 
 extern const char *const kStepKernelNames[10];
@@ -643,11 +657,13 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
   return 0;
 }
 
-int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, uint32_t *inT, uint2 *decT,
+int launch_msc_prep(const EngineDev &e, int cifs, int n_in, uint32_t *inT, hipStream_t st, Marker &mk);
+int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, const uint32_t *inT, uint2 *decT,
                     hipStream_t st, Marker &mk);
 
 // MSC decode of the CIFs produced by the last `frames` front-end steps (<= MSC_BATCH_FRAMES) + DAB+ stage.
-int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, hipStream_t st, Marker &mk)
+// `e.snap` must point at the snapshot buffer of this batch.
+int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, EngineStreams &ss, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
@@ -655,17 +671,31 @@ int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, hipStr
   if (e.fic_only || e.max_subch <= 0 || !e.msc_out) return 0;
   const int cifs = 4 * frames;
   const int jobs = e.n_streams * cifs * e.max_subch;
-  if (fast && jobs >= fast->min_jobs) {
-    if ((rc = launch_msc_vitT(e, cifs, fast->n_in, fast->nbits, fast->map2, fast->inT, fast->decT, st, mk))) return rc;
+  // the previous batch (stream b) owns SubchDev / msc_done_cif until it has finished
+  if (ss.msc_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0)); ss.msc_in_flight = false; }
+  hipLaunchKernelGGL(k_msc_snap, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e);
+  if (fast && jobs >= fast->min_jobs && ss.b) {
+    uint32_t *inT = fast->inT[ss.batch_parity];
+    if ((rc = launch_msc_prep(e, cifs, fast->n_in, inT, ss.a, mk))) return rc;
+    DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
+    DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+    if ((rc = launch_msc_vitT(e, cifs, fast->n_in, fast->nbits, fast->map2, inT, fast->decT, ss.b, mk))) return rc;
+    mk.begin(9, ss.b);
+    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.b, e, *t);
+    hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.b, e);
+    mk.end(9, ss.b);
+    DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
+    ss.msc_in_flight = true;
   } else {
-    mk.begin(8, st);
-    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, st, e, *t, cifs);
-    mk.end(8, st);
+    mk.begin(8, ss.a);
+    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs);
+    mk.end(8, ss.a);
+    mk.begin(9, ss.a);
+    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.a, e, *t);
+    hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e);
+    mk.end(9, ss.a);
   }
-  mk.begin(9, st);
-  hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, *t);
-  hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, st, e);
-  mk.end(9, st);
+  ss.batch_parity ^= 1;
   DABX_HIP(hipGetLastError());
   return 0;
 }

@@ -21,7 +21,7 @@ __device__ __forceinline__ int bitrev4(int v) { return ((v & 1) << 3) | ((v & 2)
 // with lanes ALONG the run (coalesced; a lane-per-job read would touch 64 different lines per instruction) into
 // LDS; (2) lane = job, pg = plane group: 4 planes x 1 dword -> 4x4 byte transpose in registers (8 v_perm) ->
 // 4 idx-ordered dwords, stored as inT[q][job] (256-B coalesced rows).
-constexpr int PCH = 64;                       // positions per chunk (bytes per plane run)
+constexpr int PCH = 32;                       // positions per chunk (bytes per plane run); 33 KB of LDS -> 4 blocks per CU
 constexpr int PJS = 16 * PCH + 4;             // LDS job stride in bytes (+4: conflict-free ds_read across jobs)
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_in, uint32_t *inT)
 {
@@ -42,8 +42,12 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_i
   for (int p0 = 0; p0 < npos; p0 += PCH) {
     const int cw = (npos - p0 < PCH ? npos - p0 : PCH) / 4;       // dwords per run in this chunk (npos % 4 == 0)
     // (1) coalesced load: item = (job, plane, dword)
+    const bool full = cw == PCH / 4;
     for (int it = tid; it < 64 * 16 * cw; it += 256) {
-      const int d = it % cw, jp = it / cw, pl = jp & 15, job = jp >> 4;
+      int d, jp;
+      if (full) { d = it & (PCH / 4 - 1); jp = it / (PCH / 4); }   // shifts/masks for whole chunks
+      else { d = it % cw; jp = it / cw; }
+      const int pl = jp & 15, job = jp >> 4;
       const uint8_t *base = s_base[job];
       uint32_t v = 0x7F7F7F7Fu;
       if (base) {
@@ -206,16 +210,23 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, int n_in
 }
 
 // ---------------------------------------------------------------------------------------------------- launch
-int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, uint32_t *inT, uint2 *decT,
+// prep on stream a (reads the TDI ring before the front end moves on), decode on stream b.
+int launch_msc_prep(const EngineDev &e, int cifs, int n_in, uint32_t *inT, hipStream_t st, Marker &mk)
+{
+  const int jobs = e.n_streams * cifs * e.max_subch, groups = (jobs + 63) / 64;
+  mk.begin(6, st);
+  hipLaunchKernelGGL(k_msc_prep, dim3(groups), dim3(256), 0, st, e, cifs, n_in, inT);
+  mk.end(6, st);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, const uint32_t *inT, uint2 *decT,
                     hipStream_t st, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
   const int jobs = e.n_streams * cifs * e.max_subch, groups = (jobs + 63) / 64;
-  mk.begin(6, st);
-  hipLaunchKernelGGL(k_msc_prep, dim3(groups), dim3(256), 0, st, e, cifs, n_in, inT);
-  mk.end(6, st);
   mk.begin(7, st);
   hipLaunchKernelGGL(k_msc_vitT, dim3(groups), dim3(64), 0, st, e, cifs, n_in, nbits, map2, inT, decT, t->prbs_words);
   mk.end(7, st);
