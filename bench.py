@@ -43,8 +43,8 @@ HBM_PEAK = 8.0e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=49)
+    ap.add_argument("--warmup", type=int, default=14)
     ap.add_argument("--streams", type=int, default=512, help="streams (ensembles) resident per GPU")
     ap.add_argument("--ensembles", type=int, default=4, help="distinct synthetic ensembles shared by the streams")
     ap.add_argument("--snr", type=float, default=20.0)
@@ -189,6 +189,13 @@ def main():
         dom = max(share, key=share.get)
         units = args.streams * args.steps / launches[dom]      # frames one launch of that kernel processes
         achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
+        traffic = None
+        try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/prof_round.sh)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("streams") == args.streams and dom in tj["kernels"] and units == args.streams * (7 if dom.startswith("k_msc") else 1):
+                traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,7 +210,7 @@ def main():
             "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
             "streams_locked": locked, "superframes_ok": sf_ok, "superframes_failed": sf_fail, "msc_bytes": msc_bytes,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": units,
                          "avg_launch_ms": round(kern[dom], 4)},
             "chain": {"algorithmic_bytes_per_frame": A_FRAME, "achieved_GBps": round(value / world * A_FRAME / 1e9, 2),

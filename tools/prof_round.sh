@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round profile (run on the GPU box through gpurun): rocprofv3 kernel stats of the default bench command, PMC passes for
+# the hot kernels, and the HBM traffic per launch (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM").
+# Usage: tools/prof_round.sh <tag>      -> gpurun_out/<tag>/...
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/stats_bench.log 2>&1
+FILT="k_msc_vitT|k_msc_prep|k_demap_frame|k_symbols|k_dabplus|k_fic_frame|k_frame_head|k_frame_tail"
+ARGS="--steps 14 --warmup 7 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  --kernel-include-regex "$FILT" -d $OUT/p1 --output-format csv -- python3 bench.py $ARGS > $OUT/p1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+  --kernel-include-regex "$FILT" -d $OUT/p2 --output-format csv -- python3 bench.py $ARGS > $OUT/p2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$FILT" -d $OUT/p3 --output-format csv -- python3 bench.py $ARGS > $OUT/p3.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$FILT" -d $OUT/p4 --output-format csv -- python3 bench.py $ARGS > $OUT/p4.log 2>&1
+python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, json, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/p[34]/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0].replace("dabx::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, v in acc.items():
+    # full-size launches only (the 7-frame batches): take the maximum-valued half
+    fs = sorted(v.get("FETCH_SIZE", [0])); ws = sorted(v.get("WRITE_SIZE", [0]))
+    f = sum(fs[len(fs) // 2:]) / max(1, len(fs[len(fs) // 2:])); w = sum(ws[len(ws) // 2:]) / max(1, len(ws[len(ws) // 2:]))
+    res[k] = {"fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE doubled (gfx950), mean over full-size launches",
+           "streams": 512, "kernels": res}, open(out + "/traffic.json", "w"), indent=1)
+PY
+cat $OUT/bench.json
