@@ -375,6 +375,16 @@ int dabx_read_soft(dabx_engine *e, int stream, int16_t *soft)
   return 0;
 }
 
+int dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !out || max_out <= 0) return DABX_E_ARG;
+  const int nf = e->dev.out_frames;
+  std::vector<uint8_t> fibs((size_t)nf * 384), crc((size_t)nf * 12);
+  const int have = dabx_read_fibs(e, stream, nf, fibs.data(), crc.data());
+  if (have < 0) return have;
+  return dabx_parse_fibs(fibs.data(), crc.data(), have * 12, out, max_out, nullptr);
+}
+
 int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)
 {
   if (!e || stream < 0 || stream >= e->dev.n_streams || !out) return DABX_E_ARG;

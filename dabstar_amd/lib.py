@@ -218,7 +218,8 @@ class Engine:
     def set_subchannels(self, subch, stream=-1, dab_plus=True):
         arr = (SubchDesc * max(1, len(subch)))()
         for i, c in enumerate(subch):
-            arr[i] = SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, int(dab_plus), 0)
+            dp = getattr(c, "dab_plus", -1)      # discovered descriptors carry FIG 0/2's answer; -1 = not yet known
+            arr[i] = SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, int(dab_plus) if dp < 0 else dp, 0)
         check(load().dabx_set_subchannels(self._h, stream, arr, len(subch)))
         self.subch = list(subch)
 
@@ -252,6 +253,11 @@ class Engine:
         n = check(load().dabx_read_fibs(self._h, stream, n_frames, _p(fibs), _p(crc)))
         return fibs[:n], crc[:n]
 
+    def discover_subchannels(self, stream, max_out=64):
+        out = (SubchDesc * max_out)()
+        n = check(load().dabx_discover_subchannels(self._h, stream, out, max_out))
+        return [out[i] for i in range(n)]
+
     def read_msc(self, stream, j, n_cifs=4):
         nb = 3 * self.subch[j].kbps
         out = np.zeros((n_cifs, nb), np.uint8)
@@ -278,6 +284,16 @@ class Engine:
         out = (C.c_int64 * 16)()
         check(load().dabx_get_counters(self._h, out))
         return dict(zip(COUNTER_NAMES, list(out)))
+
+
+def parse_fibs(fibs, crc_ok, max_out=64):
+    """FIB/FIG subset (host only): -> (list of SubchDesc, cif_count)."""
+    fibs = np.ascontiguousarray(fibs, np.uint8).reshape(-1, 32)
+    crc_ok = np.ascontiguousarray(crc_ok, np.uint8).reshape(-1)
+    out = (SubchDesc * max_out)()
+    cif = C.c_int32(-1)
+    n = check(load().dabx_parse_fibs(_p(fibs), _p(crc_ok), fibs.shape[0], out, max_out, C.byref(cif)))
+    return [out[i] for i in range(n)], cif.value
 
 
 def fic_decode(soft):

@@ -102,6 +102,14 @@ int dabx_prs_correlate(const dabx_cf32 *v, int batch, float threshold, int stron
 /* PhaseReference::estimate_carrier_offset_from_sync_symbol_0 (:223-280): fft = batch x 2048 */
 int dabx_coarse_cfo(const dabx_cf32 *fft_sym0, int batch, int32_t *hz);
 
+/* FIB/FIG subset (host side, no device needed): sub-channel organisation FIG 0/1, service components FIG 0/2,
+ * CIF counter FIG 0/0 -- base/decoder/fib_decoder.cpp:59-110, fib_decoder_fig0.cpp:89-101, 142-224, 230-293,
+ * getters fib_decoder.cpp:547-557, 673-691.  fibs = n x 32 bytes as delivered by dabx_read_fibs / dabx_fic_decode.
+ * Returns the number of sub-channels found (sorted by SubChId); dab_plus = 1 / 0 / -1 (ASCTy 63 / other / unknown). */
+struct dabx_subch_desc_s;
+int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, struct dabx_subch_desc_s *out, int max_out,
+                    int32_t *cif_count);
+
 /* ===================================================================================== engine level
  * Stream-batched receiver: the device-side equivalent of DabProcessor::run
  * (base/main/dab_processor.cpp:110-442) for n_streams independent ensembles.                   */
@@ -121,7 +129,7 @@ typedef struct {
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */
-typedef struct {
+typedef struct dabx_subch_desc_s {
   int32_t subch_id, cu_start, cu_size, kbps, prot_level /* +4 => EEP-B */, short_form /* 1 = UEP */;
   int32_t dab_plus;          /* 1: run super-frame sync + RS(120,110) (Mp4Processor) */
   int32_t reserved;
@@ -155,6 +163,9 @@ int  dabx_synchronize(dabx_engine *e);
 void *dabx_hip_stream(dabx_engine *e);
 /* Results of the most recent frames (host copies). fibs: n x 12 x 32, crc: n x 12 */
 int  dabx_read_fibs(dabx_engine *e, int stream, int n_frames, uint8_t *fibs, uint8_t *crc_ok);
+/* Sub-channel table announced in the FIBs of the newest frames of `stream` (dabx_parse_fibs over the FIB ring);
+ * feed the result to dabx_set_subchannels to decode "everything found in the FIC" like EtiGenerator does. */
+int  dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
 /* Decoded logical frames of a sub-channel: n_cifs x 3*kbps bytes, newest last; returns #CIFs valid. */
 int  dabx_read_msc(dabx_engine *e, int stream, int subch_idx, int n_cifs, uint8_t *bytes);
 /* RS-corrected DAB+ super frames (110*kbps/8 bytes each), newest last; returns count copied. */

@@ -147,6 +147,10 @@ const uint8_t *ora_backend_msc_bytes(const ora_backend *b, size_t *len);
 const uint8_t *ora_backend_sf_bytes(const ora_backend *b, size_t *len);
 void ora_backend_stats(const ora_backend *b, long out[8]);
 
+/* FIB/FIG subset (fib.c): FIG 0/0, 0/1, 0/2 -- decoder/fib_decoder.cpp:59-110, fib_decoder_fig0.cpp */
+int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, ora_subch_desc *out, int *dab_plus, int max_out,
+                   int *cif_count);
+
 /* ---------------- OFDM front end (ofdm.c) ---------------- */
 void ora_fft2048(const ora_cf32 *in, ora_cf32 *out, int inverse); /* unnormalised DFT */
 

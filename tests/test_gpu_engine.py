@@ -187,3 +187,26 @@ def test_many_streams_fast_msc_path_matches_single_stream_path(monkeypatch):
             assert np.array_equal(eng.read_superframes(s, j, 4), ref.read_superframes(0, j, 4)), (s, j)
         ref.close()
     eng.close()
+
+
+def test_subchannels_discovered_from_the_decoded_fic_then_decoded():
+    """no configuration from outside -- FIG 0/1 + 0/2 from the engine's own FIBs select the
+    sub-channels (what FibDecoder hands DabRadio::set_audio_channel), which then decode cleanly."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=33)
+    x = ds.channel(ens.iq, snr_db=20.0, cfo_hz=-321.0, timing_offset=4242, seed=9, n_out=20 * ds.TF)
+    eng = dx.Engine(n_streams=1, ring_frames=21, max_subch=18, out_frames=4)
+    eng.push_iq(0, x)
+    eng.process(6)
+    found = eng.discover_subchannels(0)
+    assert [(f.subch_id, f.cu_start, f.cu_size, f.kbps, f.prot_level, f.short_form, f.dab_plus) for f in found] == \
+           [(c.subch_id, c.cu_start, c.cu_size, 64, 2, 0, 1) for c in subch]
+    eng.set_subchannels(found)
+    eng.process(12)
+    st = eng.stats(0)
+    assert st["sf_fail"] == 0 and st["sf_ok"] >= 18 and st["fib_ok"] == st["fib_total"]
+    ref = _oracle_run(x, subch)
+    sf = eng.read_superframes(0, 5, 1)
+    osf = ref["sf"][5].reshape(-1, sf.shape[-1])
+    assert any(np.array_equal(sf[0], o) for o in osf)
+    eng.close()

@@ -217,11 +217,25 @@ def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndar
             body += w.to_bytes(4, "big")
         return bytes([len(body)]) + bytes(body)   # type 0 -> header = length
 
+    def fig02(chs):
+        body = bytearray([0x02])          # C/N=0 OE=0 P/D=0 ext=2
+        for c in chs:                     # one programme service per sub-channel, one DAB+ audio component (ASCTy 63)
+            sid = 0x1000 + c.subch_id
+            comp = (0 << 14) | (63 << 8) | (c.subch_id << 2) | (1 << 1)
+            body += bytes([sid >> 8, sid & 0xFF, 0x01, comp >> 8, comp & 0xFF])
+        return bytes([len(body)]) + bytes(body)
+
     fig00 = bytes([0x05, 0x00, eid >> 8, eid & 0xFF, hi & 0x1F, lo])
-    groups = [subch[0:5], subch[5:12], subch[12:18]]
+    phase = cif_count % 4                 # FIG 0/1 on even CIFs, FIG 0/2 on odd ones (15 + 3 services)
+    if phase in (0, 2):
+        payloads = [fig01(subch[0:5]), fig01(subch[5:12]), fig01(subch[12:18])]
+    elif phase == 1:
+        payloads = [fig02(subch[0:4]), fig02(subch[4:9]), fig02(subch[9:14])]
+    else:
+        payloads = [fig02(subch[14:18]), b"", b""]
     fibs = []
-    for g, chs in enumerate(groups):
-        data = (fig00 if g == 0 else b"") + (fig01(chs) if chs else b"")
+    for g, pl in enumerate(payloads):
+        data = (fig00 if g == 0 else b"") + (pl if len(pl) > 2 else b"")
         assert len(data) <= 30
         if len(data) < 30:
             data += b"\xFF" + b"\x00" * (29 - len(data))
