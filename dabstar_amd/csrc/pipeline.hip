@@ -625,10 +625,13 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-__global__ void k_msc_snap(EngineDev e)
+__global__ void k_msc_snap(EngineDev e, int cifs)
 {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < e.n_streams) e.snap[s] = BatchSnap{e.ctl[s].msc_done_cif, e.ctl[s].cif_no};
+  if (s >= e.n_streams) return;
+  // CIFs older than this batch were produced while no sub-channel was configured (no MSC batches ran): skip them
+  const long long cif_no = e.ctl[s].cif_no, done = e.ctl[s].msc_done_cif;
+  e.snap[s] = BatchSnap{done > cif_no - cifs ? done : cif_no - cifs, cif_no};
 }
 __global__ void k_msc_done(EngineDev e)
 {
@@ -673,7 +676,7 @@ int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, Engine
   const int jobs = e.n_streams * cifs * e.max_subch;
   // the previous batch (stream b) owns SubchDev / msc_done_cif until it has finished
   if (ss.msc_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0)); ss.msc_in_flight = false; }
-  hipLaunchKernelGGL(k_msc_snap, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e);
+  hipLaunchKernelGGL(k_msc_snap, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e, cifs);
   if (fast && jobs >= fast->min_jobs && ss.b) {
     uint32_t *inT = fast->inT[ss.batch_parity];
     if ((rc = launch_msc_prep(e, cifs, fast->n_in, inT, ss.a, mk))) return rc;

@@ -202,11 +202,15 @@ def test_subchannels_discovered_from_the_decoded_fic_then_decoded():
     assert [(f.subch_id, f.cu_start, f.cu_size, f.kbps, f.prot_level, f.short_form, f.dab_plus) for f in found] == \
            [(c.subch_id, c.cu_start, c.cu_size, 64, 2, 0, 1) for c in subch]
     eng.set_subchannels(found)
-    eng.process(12)
+    eng.process(12)                 # 7 + 5 frames: the de-interleaver warm-up ends inside the first MSC batch
     st = eng.stats(0)
-    assert st["sf_fail"] == 0 and st["sf_ok"] >= 18 and st["fib_ok"] == st["fib_total"]
+    assert st["sf_fail"] == 0 and st["sf_ok"] >= 18 and st["fib_ok"] >= st["fib_total"] - 24   # two settling frames, as in the oracle
     ref = _oracle_run(x, subch)
-    sf = eng.read_superframes(0, 5, 1)
-    osf = ref["sf"][5].reshape(-1, sf.shape[-1])
-    assert any(np.array_equal(sf[0], o) for o in osf)
+    for j in (0, 5, 17):
+        sf = eng.read_superframes(0, j, 4)
+        assert len(sf) == 4                                   # (48 - 16) logical frames -> 4..6 windows, ring read of 4
+        osf = ref["sf"][j].reshape(-1, 880)
+        for k in range(4):
+            assert any(np.array_equal(sf[k], ens.superframes[j][q]) for q in range(8)), (j, k)
+            assert any(np.array_equal(sf[k], o) for o in osf), (j, k)
     eng.close()
