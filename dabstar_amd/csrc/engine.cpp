@@ -275,6 +275,35 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
   return rc;
 }
 
+int dabx_read_iq(dabx_engine *e, int stream, uint64_t first, size_t n, float *iq_out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !iq_out) return DABX_E_ARG;
+  const unsigned long long wr = e->wr_host[stream];
+  if (first + n > wr || wr - first > (unsigned long long)e->dev.ring_len) { set_error("dabx_read_iq: samples not in the ring"); return DABX_E_STATE; }
+  if (int rc = sync_all(e)) return rc;
+  const float2 *ring = e->dev.iq + (size_t)stream * e->dev.ring_len;
+  size_t done = 0;
+  while (done < n) {
+    const size_t o = (size_t)((first + done) % (unsigned long long)e->dev.ring_len);
+    const size_t take = std::min(n - done, (size_t)e->dev.ring_len - o);
+    DABX_HIP(hipMemcpy(iq_out + 2 * done, ring + o, take * sizeof(float2), hipMemcpyDeviceToHost));
+    done += take;
+  }
+  return 0;
+}
+
+// internal hook of iqfile.cpp (not part of include/dabx.h)
+int dabx_internal_ring_info(dabx_engine *e, int stream, float2 **ring, int *ring_len, unsigned long long *wr, unsigned long long *rd, hipStream_t *st)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams) { set_error("bad engine / stream"); return DABX_E_ARG; }
+  if (int rc = sync_all(e)) return rc;
+  StreamCtl c;
+  DABX_HIP(hipMemcpy(&c, e->dev.ctl + stream, sizeof(StreamCtl), hipMemcpyDeviceToHost));
+  *ring = e->dev.iq + (size_t)stream * e->dev.ring_len; *ring_len = e->dev.ring_len;
+  *wr = e->wr_host[stream]; *rd = c.rd; *st = e->stream;
+  return 0;
+}
+
 int dabx_process(dabx_engine *e, int max_frames, int sync)
 {
   if (!e || max_frames < 0) return DABX_E_ARG;

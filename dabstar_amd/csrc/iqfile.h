@@ -1,0 +1,20 @@
+// iqfile.h -- internal: recorded-IQ decode/resample launchers (iqfile.hip) and the engine hooks they need.
+#pragma once
+#include "dabx_internal.h"
+
+namespace dabx {
+
+struct IqDecode {      // by-value kernel argument
+  int family, container, big_endian, swap_iq;
+  int bytes;           // per channel
+  float int_scale;     // 1 / 2^(bits-1) for the integer containers
+};
+int launch_decode_iq(const uint8_t *src, const IqDecode &d, float2 *dst, unsigned long long dst0, int dst_len, size_t n, hipStream_t st);
+int launch_resample_1ms(const float2 *V, int M, const int16_t *tab_int, const float *tab_frac, float2 *dst, unsigned long long dst0,
+                        int dst_len, size_t n_out, hipStream_t st);
+
+// engine.cpp: ring of a stream, its write position (host mirror), the read position (device, synchronises) and stream
+}  // namespace dabx
+
+extern "C" int dabx_internal_ring_info(dabx_engine *e, int stream, float2 **ring, int *ring_len, unsigned long long *wr,
+                                        unsigned long long *rd, hipStream_t *st);

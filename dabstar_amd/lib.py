@@ -30,6 +30,12 @@ def load(build_if_missing=True):
         raise DabxError("libdabx.so is missing: run `python -m dabstar_amd.build` (needs hipcc)")
     L = C.CDLL(lib_path())
     L.dabx_last_error.restype = C.c_char_p
+    for name in ("dabx_convert_iq_bytes", "dabx_feed_bytes", "dabx_feed_bound"):
+        getattr(L, name).restype = C.c_longlong
+    L.dabx_feed_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.dabx_feed_bound.argtypes = [C.c_void_p, C.c_size_t]
+    L.dabx_feed_close.argtypes = [C.c_void_p]
+    L.dabx_convert_iq_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     _LIB = L
     return L
 
@@ -174,6 +180,18 @@ class SubchDesc(C.Structure):
                 ("prot_level", C.c_int32), ("short_form", C.c_int32), ("dab_plus", C.c_int32), ("reserved", C.c_int32)]
 
 
+class IqFormat(C.Structure):
+    """dabx_iq_format: family 0 raw / 1 wav / 2 uff; container 0 u8, 1 s8, 2 i16, 3 i24, 4 i32, 5 f32."""
+    _fields_ = [("family", C.c_int32), ("container", C.c_int32), ("big_endian", C.c_int32), ("swap_iq", C.c_int32),
+                ("bits", C.c_int32), ("sample_rate", C.c_int32), ("data_offset", C.c_int64), ("data_bytes", C.c_int64)]
+
+    def sample_bytes(self):
+        return 2 * (1, 1, 2, 3, 4, 4)[self.container]
+
+    def as_tuple(self):
+        return tuple(getattr(self, k) for k, _ in self._fields_)
+
+
 class Stats(C.Structure):
     _fields_ = [("frames", C.c_int64), ("samples_consumed", C.c_int64), ("state", C.c_int32), ("fic_ratio_percent", C.c_int32),
                 ("freq_offs_bb_hz", C.c_float), ("clock_err_hz", C.c_float), ("snr_db_est", C.c_float),
@@ -228,6 +246,11 @@ class Engine:
         fmt = {np.dtype(np.complex64): 0, np.dtype(np.int16): 1, np.dtype(np.uint8): 2}[iq.dtype]
         n = iq.size if fmt == 0 else iq.size // 2
         check(load().dabx_push_iq(self._h, stream, _p(iq), fmt, n))
+
+    def read_iq(self, stream, first, n):
+        out = np.zeros(n, np.complex64)
+        check(load().dabx_read_iq(self._h, stream, C.c_uint64(first), C.c_size_t(n), _p(out)))
+        return out
 
     def ring_ptr(self, stream):
         p, cap = C.c_void_p(), C.c_size_t()
@@ -284,6 +307,78 @@ class Engine:
         out = (C.c_int64 * 16)()
         check(load().dabx_get_counters(self._h, out))
         return dict(zip(COUNTER_NAMES, list(out)))
+
+
+def probe_iq_file(path):
+    """Host only: container / sample format of a recorded-IQ file (.raw/.iq, .sdr/.wav, .uff)."""
+    fmt = IqFormat()
+    check(load().dabx_probe_iq_file(os.fsencode(path), C.byref(fmt)))
+    return fmt
+
+
+def convert_iq_bytes(fmt, payload):
+    """One-shot GPU decode (+ resample) of payload bytes -> complex64 at 2.048 MS/s."""
+    payload = np.frombuffer(payload, np.uint8) if not isinstance(payload, np.ndarray) else np.ascontiguousarray(payload, np.uint8)
+    n_in = payload.size // fmt.sample_bytes()
+    cap = n_in if fmt.sample_rate == 2048000 else (n_in // (fmt.sample_rate // 1000) + 1) * 2048
+    out = np.zeros(max(cap, 1), np.complex64)
+    n = check(load().dabx_convert_iq_bytes(C.byref(fmt), _p(payload), payload.size, _p(out), out.size))
+    return out[:n]
+
+
+class Feed:
+    """Streaming file feed into one stream's IQ ring (dabx_feed_*)."""
+
+    def __init__(self, engine, stream, fmt):
+        self._h = C.c_void_p()
+        self.fmt = fmt
+        check(load().dabx_feed_open(engine._h, stream, C.byref(fmt), C.byref(self._h)))
+
+    def push(self, payload):
+        payload = np.frombuffer(payload, np.uint8) if not isinstance(payload, np.ndarray) else np.ascontiguousarray(payload, np.uint8)
+        return check(load().dabx_feed_bytes(self._h, _p(payload), payload.size))
+
+    def bound(self, n_bytes):
+        return check(load().dabx_feed_bound(self._h, n_bytes))
+
+    def close(self):
+        if self._h and _LIB is not None:
+            _LIB.dabx_feed_close(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def play_file(engine, stream, path, block_frames=4, on_block=None):
+    """Un-paced replay of a recorded file through one stream: probe, feed in blocks, process as frames become
+    available.  Like the reference's readers (raw_reader.cpp:140-150, wav_reader.cpp:164-177) the final partial
+    32768-unit read block is dropped.  Returns the number of frames processed."""
+    fmt = probe_iq_file(path)
+    unit = 32768 if fmt.family == 0 else 32768 * fmt.sample_bytes()      # raw: bytes, wav: frames
+    if fmt.family == 2:
+        unit = (fmt.sample_rate // 1000) * fmt.sample_bytes()            # uff: 1-ms reads, xml_reader.cpp:224-226
+    n_units = fmt.data_bytes // unit
+    feed = Feed(engine, stream, fmt)
+    frames = 0
+    per_block = max(1, (block_frames * 196608 * fmt.sample_bytes() * (fmt.sample_rate // 1000) // 2048) // unit)
+    with open(path, "rb") as fh:
+        fh.seek(fmt.data_offset)
+        done = 0
+        while done < n_units:
+            take = min(per_block, n_units - done)
+            feed.push(fh.read(take * unit))
+            done += take
+            before = engine.stats(stream)["frames"]
+            engine.process(block_frames + 1)
+            frames += engine.stats(stream)["frames"] - before
+            if on_block:
+                on_block(engine)
+    feed.close()
+    return frames
 
 
 def parse_fibs(fibs, crc_ok, max_out=64):

@@ -156,6 +156,9 @@ int  dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_
 /* Device-resident producers: ring base (cf32, capacity ring_frames*T_F) and commit of n new samples. */
 int  dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *capacity_samples);
 int  dabx_commit_iq(dabx_engine *e, int stream /* <0: all */, size_t n_samples);
+/* Host copy of ring samples [first, first + n) counted from the first sample ever committed (scopes, tests);
+ * they must still be in the ring. */
+int  dabx_read_iq(dabx_engine *e, int stream, uint64_t first, size_t n, float *iq_out);
 /* Advance every stream by up to max_frames frames (bounded by available samples); returns the number of
  * batch steps executed.  Asynchronous on the engine's HIP stream unless sync != 0. */
 int  dabx_process(dabx_engine *e, int max_frames, int sync);
@@ -182,6 +185,53 @@ int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
 int  dabx_set_profiling(dabx_engine *e, int on);
 int  dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t launches[DABX_MAX_KERNELS],
                       const char *names[DABX_MAX_KERNELS]);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Recorded-IQ files: the byte formats the reference's file readers accept, decoded and -- for
+ * recordings that are not at 2.048 MS/s -- resampled ON THE GPU into a stream's IQ ring.  Only the raw bytes cross
+ * PCIe (2..8 B per sample instead of 8).
+ *   family RAW  .raw/.iq   uint8 IQ, (x - 127.38)/128                      devices/filereaders/raw_files/raw_reader.cpp:66-70,155-158
+ *   family WAV  .sdr/.wav  RIFF/WAVE, 2 channels, 1.536..3.0 MS/s, normalised like libsndfile's sf_readf_float
+ *                          (wav_files/wavfiles.cpp:55-92, wav_reader.cpp:164): u8 (x-128)/128, s8 x/128, i16 x/2^15,
+ *                          i24 x/2^23, i32 (float)x/2^31, f32 as stored
+ *   family UFF  .uff       XML header + payload (xml_filereader/xml_descriptor.cpp:98-240, xml_reader.cpp:254-398):
+ *                          int8 x/127, uint8 (x-127.38)/128, int16/24/32 x/2^(Bits-1), float32; MSB|LSB; IQ|QI
+ * Resampling follows the reference's non-liquid build: 1-ms blocks of rate/1000 input samples are linearly
+ * interpolated to 2048 output samples (wav_reader.cpp:67-82,190-206; xml_reader.cpp:76-81,226-248; the two readers
+ * differ in their table arithmetic and in how the first block is primed, selected by `family`).
+ * Deliberate deviations, each a defect of the reference rather than a format rule: UFF QI/uint8 and
+ * QI/float32 are decoded as the swapped IQ forms, UFF int24/MSB takes the Q middle byte from its own sample, and
+ * single-channel (I-only / Q-only) UFF files are refused. */
+enum { DABX_FAMILY_RAW = 0, DABX_FAMILY_WAV = 1, DABX_FAMILY_UFF = 2 };
+enum { DABX_C_U8 = 0, DABX_C_S8 = 1, DABX_C_I16 = 2, DABX_C_I24 = 3, DABX_C_I32 = 4, DABX_C_F32 = 5 };
+typedef struct dabx_iq_format_s {
+  int32_t family;        /* DABX_FAMILY_* : normalisation rule + resampler flavour */
+  int32_t container;     /* DABX_C_* */
+  int32_t big_endian;    /* UFF Ordering="MSB", RIFX */
+  int32_t swap_iq;       /* UFF channel order Q,I */
+  int32_t bits;          /* UFF Bits attribute: integer scale is 2^(bits-1) */
+  int32_t sample_rate;   /* Hz; 2048000 = no resampling */
+  int64_t data_offset;   /* first payload byte in the file */
+  int64_t data_bytes;    /* payload length (clipped to the file) */
+} dabx_iq_format;
+typedef struct dabx_feed dabx_feed;
+
+/* Host only: recognise the container by content (RIFF/RIFX magic, "<?xml"/"<SDR" header) else by extension
+ * (.raw/.iq) and fill *fmt.  DABX_E_ARG for unreadable / unsupported files (dabx_last_error says why). */
+int  dabx_probe_iq_file(const char *path, dabx_iq_format *fmt);
+/* Bytes per complex sample of a format (2, 4, 6 or 8), or DABX_E_ARG. */
+int  dabx_iq_sample_bytes(const dabx_iq_format *fmt);
+/* One-shot conversion (stage level, fresh resampler state): payload bytes -> cf32 at 2.048 MS/s on the host.
+ * Returns the number of complex samples written (<= max_out), or < 0. */
+long long dabx_convert_iq_bytes(const dabx_iq_format *fmt, const void *bytes, size_t n_bytes, float *iq_out, size_t max_out);
+/* Streaming feed into the IQ ring of `stream`: keeps the resampler state between calls; any split of the payload
+ * into calls gives the same samples.  dabx_feed_bytes returns the number of 2.048 MS/s samples committed to the
+ * ring, DABX_E_STATE when the ring cannot take them (process first), or another error. */
+int  dabx_feed_open(dabx_engine *e, int stream, const dabx_iq_format *fmt, dabx_feed **out);
+long long dabx_feed_bytes(dabx_feed *f, const void *bytes, size_t n_bytes);
+/* Upper bound of the samples dabx_feed_bytes(n_bytes) can commit (ring-space planning). */
+long long dabx_feed_bound(const dabx_feed *f, size_t n_bytes);
+void dabx_feed_close(dabx_feed *f);
 
 #ifdef __cplusplus
 }
