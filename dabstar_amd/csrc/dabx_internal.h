@@ -45,6 +45,7 @@ int get_profile_map(int kbps, int prot_level, int short_form, const uint16_t **d
 // host-side builders (tables.cpp)
 int host_profile_map(int kbps, int prot_level, int short_form, std::vector<uint16_t> &map, int *n_in);
 void host_fic_map(std::vector<uint16_t> &map);
+bool fib_cif_count(const uint8_t *fib, int *hi, int *lo);   // fib.cpp
 
 // ---- demapper state (SoA over the stream axis), OfdmDecoder members ofdm_decoder.h:88-104 ----------
 struct DemapDev {

@@ -27,6 +27,9 @@ struct dabx_engine {
   int device = 0;
   std::vector<unsigned long long> wr_host;     // host mirror of committed samples
   std::vector<SubchDev> subch_host;            // [S][max_subch]
+  std::vector<int> subch_id_host;              // [S][max_subch] SubChId (host only: ETI STC field)
+  struct EtiCursor { long long next_cif = -1; int hi = -1, lo = -1; long long fib_frames_seen = 0; };
+  std::vector<EtiCursor> eti;                  // [S]
   std::vector<void *> allocs;
   int max_kbps = 0;
   bool buffers_ready = false;
@@ -131,6 +134,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   DABX_HIP(hipStreamSynchronize(e->stream));
   e->wr_host.assign(S, 0);
   e->subch_host.assign((size_t)S * std::max(1, d.max_subch), SubchDev{});
+  e->subch_id_host.assign((size_t)S * std::max(1, d.max_subch), -1);
+  e->eti.assign((size_t)S, dabx_engine::EtiCursor{});
   // scratch sized for the FIC now; re-sized when sub-channels are configured
   d.vit_stride = (int)vit_scratch_words(FIC_OUT);
   A(e->alloc(&d.vit_scratch, (size_t)S * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * d.vit_stride, false));
@@ -203,6 +208,8 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
       SubchDev sc = j < n ? row[j] : SubchDev{};
       sc.start_cif = ctl[s].cif_no;
       e->subch_host[(size_t)s * d.max_subch + j] = sc;
+      e->subch_id_host[(size_t)s * d.max_subch + j] = j < n ? desc[j].subch_id : -1;
+      e->eti[s] = dabx_engine::EtiCursor{};
     }
   }
   DABX_HIP(hipMemcpy(d.subch, e->subch_host.data(), sizeof(SubchDev) * e->subch_host.size(), hipMemcpyHostToDevice));
@@ -393,6 +400,73 @@ int dabx_read_superframes(dabx_engine *e, int stream, int j, int n, uint8_t *byt
                        nb, hipMemcpyDeviceToHost));
   }
   return have;
+}
+
+int dabx_read_eti(dabx_engine *e, int stream, int max_frames, uint8_t *out, int32_t *lost_cifs)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || max_frames < 0 || (!out && max_frames)) return DABX_E_ARG;
+  if (lost_cifs) *lost_cifs = 0;
+  if (e->dev.fic_only) { set_error("dabx_read_eti: engine was created FIC-only"); return DABX_E_STATE; }
+  StreamCtl c;
+  int rc = fetch_ctl(e, stream, &c);
+  if (rc) return rc;
+  const EngineDev &d = e->dev;
+  std::vector<SubchDev> row(std::max(1, d.max_subch));
+  DABX_HIP(hipMemcpy(row.data(), d.subch + (size_t)stream * d.max_subch, sizeof(SubchDev) * d.max_subch, hipMemcpyDeviceToHost));
+  std::vector<int> act;
+  for (int j = 0; j < d.max_subch; j++) if (row[j].active) act.push_back(j);
+  // CIFs [lo_cif, hi_cif) are complete in both rings
+  long long hi_cif = act.empty() ? c.cif_no : c.msc_done_cif, lo_cif = std::max(0ll, (c.frames - d.out_frames) * 4);
+  for (int j : act) lo_cif = std::max(lo_cif, row[j].start_cif + 16 + std::max(0ll, row[j].cif_out - MSC_SLOTS));
+  dabx_engine::EtiCursor &cur = e->eti[stream];
+  if (cur.next_cif < 0) { cur.next_cif = lo_cif; cur.fib_frames_seen = lo_cif / 4; }
+  if (cur.next_cif < lo_cif) {
+    if (lost_cifs) *lost_cifs = (int32_t)(lo_cif - cur.next_cif);
+    cur.next_cif = lo_cif;
+  }
+  cur.fib_frames_seen = std::max(cur.fib_frames_seen, std::max(0ll, c.frames - d.out_frames));
+  int n = 0;
+  std::vector<uint8_t> fibs(384), msc((size_t)act.size() * std::max(1, d.msc_stride));
+  std::vector<dabx_subch_desc> desc(act.size());
+  std::vector<const uint8_t *> ptr(act.size());
+  for (size_t a = 0; a < act.size(); a++) {
+    const SubchDev &sc = row[act[a]];
+    desc[a] = dabx_subch_desc{e->subch_id_host[(size_t)stream * d.max_subch + act[a]], sc.cu_start, sc.cu_size, sc.kbps, sc.prot_level, sc.short_form, sc.dab_plus, 0};
+    ptr[a] = msc.data() + a * (size_t)d.msc_stride;
+  }
+  long long fib_frame = -1;
+  while (n < max_frames && cur.next_cif < hi_cif) {
+    const long long r = cur.next_cif, F = r / 4;
+    // FibDecoder state at symbol 4 of frame F: every FIB up to and including this frame's 12 has been parsed
+    while (cur.fib_frames_seen <= F) {
+      const long long G = cur.fib_frames_seen;
+      std::vector<uint8_t> fb(384), fc(12);
+      const size_t slot = (size_t)stream * d.out_frames + (size_t)(G % d.out_frames);
+      DABX_HIP(hipMemcpy(fb.data(), d.fib_out + slot * 384, 384, hipMemcpyDeviceToHost));
+      DABX_HIP(hipMemcpy(fc.data(), d.fib_crc + slot * 12, 12, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 12; i++) if (fc[i]) fib_cif_count(fb.data() + 32 * i, &cur.hi, &cur.lo);
+      if (G == F) { fibs = fb; fib_frame = F; }
+      cur.fib_frames_seen++;
+    }
+    if (fib_frame != F) {
+      const size_t slot = (size_t)stream * d.out_frames + (size_t)(F % d.out_frames);
+      DABX_HIP(hipMemcpy(fibs.data(), d.fib_out + slot * 384, 384, hipMemcpyDeviceToHost));
+      fib_frame = F;
+    }
+    cur.next_cif++;
+    if (cur.hi < 0 || cur.lo < 0) continue;              // eti_generator.cpp:156-160: no FIG 0/0 yet
+    for (size_t a = 0; a < act.size(); a++) {
+      const SubchDev &sc = row[act[a]];
+      const long long lf = r - sc.start_cif - 16;
+      DABX_HIP(hipMemcpy(msc.data() + a * (size_t)d.msc_stride,
+                         d.msc_out + (((size_t)stream * d.max_subch + act[a]) * MSC_SLOTS + (size_t)(lf % MSC_SLOTS)) * d.msc_stride,
+                         (size_t)3 * sc.kbps, hipMemcpyDeviceToHost));
+    }
+    rc = dabx_eti_frame(cur.hi, cur.lo, (int)(r & 3), desc.data(), (int)desc.size(), fibs.data() + 96 * (r & 3), ptr.data(), out + (size_t)n * 6144);
+    if (rc < 0) return rc;
+    n++;
+  }
+  return n;
 }
 
 int dabx_read_soft(dabx_engine *e, int stream, int16_t *soft)

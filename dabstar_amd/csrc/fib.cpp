@@ -31,6 +31,7 @@ static unsigned bits(const uint8_t *b, int off, int n)   // MSB-first bit field 
 
 struct FibTable {
   std::map<int, dabx_subch_desc> subch;     // by SubChId, first description wins (fib_decoder_fig0.cpp:151-153)
+  std::vector<int> order;                   // SubChIds in order of first appearance (the reference's vector order)
   std::map<int, int> ascty;                 // SubChId -> ASCTy of its audio component (FIG 0/2, TMId 0)
   int cif_count = -1;
   bool restart = false;
@@ -77,6 +78,7 @@ static void walk_fib(const uint8_t *fib, FibTable &t)
             for (auto &kv : t.subch)                                                  // :204-209 overlap -> restart
               if (q.cu_start < kv.second.cu_start + kv.second.cu_size && kv.second.cu_start < q.cu_start + q.cu_size) { t.restart = true; return; }
             t.subch[q.subch_id] = q;
+            t.order.push_back(q.subch_id);
           }
         }
       } else if (ext == 2 && cn == 0) {                                              // :230-293
@@ -98,13 +100,29 @@ static void walk_fib(const uint8_t *fib, FibTable &t)
   }
 }
 
+// FIG 0/0 of one FIB -> CIF counter halves (mCifCount_hi / _lo, fib_decoder_fig0.cpp:89-101); false if the FIB has none
+bool fib_cif_count(const uint8_t *fib, int *hi, int *lo)
+{
+  bool found = false;
+  int p = 0;
+  while (p < 30) {
+    const int type = fib[p] >> 5, len = fib[p] & 0x1F;
+    if (type == 7 && len == 0x1F) break;
+    if (p + 1 + len > 30) break;
+    if (type == 0 && len >= 5 && (fib[p + 1] & 0x1F) == 0) { *hi = fib[p + 4] & 0x1F; *lo = fib[p + 5]; found = true; }
+    p += len + 1;
+  }
+  return found;
+}
+
 }  // namespace dabx
 
 using namespace dabx;
 
 extern "C" {
 
-// fibs: n x 32 bytes, crc_ok: n flags.  Returns the number of sub-channels written to out (sorted by SubChId),
+// fibs: n x 32 bytes, crc_ok: n flags.  Returns the number of sub-channels written to out (in order of first appearance, like
+// FibDecoder::get_sub_channel_id_list, fib_decoder.cpp:547-557),
 // dab_plus = 1 when FIG 0/2 announces ASCTy 63 for it (backend_driver.cpp:41-50), -1 when unknown yet.
 int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, dabx_subch_desc *out, int max_out, int32_t *cif_count)
 {
@@ -117,9 +135,9 @@ int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, dabx
   }
   if (cif_count) *cif_count = t.cif_count;
   int n = 0;
-  for (auto &kv : t.subch) {
+  for (int id : t.order) {
     if (n >= max_out) break;
-    dabx_subch_desc q = kv.second;
+    dabx_subch_desc q = t.subch[id];
     const auto it = t.ascty.find(q.subch_id);
     q.dab_plus = it == t.ascty.end() ? -1 : (it->second == 63 ? 1 : 0);
     out[n++] = q;

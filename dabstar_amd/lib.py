@@ -281,6 +281,12 @@ class Engine:
         n = check(load().dabx_discover_subchannels(self._h, stream, out, max_out))
         return [out[i] for i in range(n)]
 
+    def read_eti(self, stream, max_frames=32):
+        out = np.zeros((max_frames, 6144), np.uint8)
+        lost = C.c_int32(0)
+        n = check(load().dabx_read_eti(self._h, stream, max_frames, _p(out), C.byref(lost)))
+        return out[:n], lost.value
+
     def read_msc(self, stream, j, n_cifs=4):
         nb = 3 * self.subch[j].kbps
         out = np.zeros((n_cifs, nb), np.uint8)
@@ -307,6 +313,17 @@ class Engine:
         out = (C.c_int64 * 16)()
         check(load().dabx_get_counters(self._h, out))
         return dict(zip(COUNTER_NAMES, list(out)))
+
+
+def eti_frame(cif_hi, cif_lo, minor, subch, fic96, msc):
+    """Host only: one 6144-byte ETI(NI) frame; subch = SubchDesc list (FIC order), msc = list of byte arrays."""
+    arr = (SubchDesc * max(1, len(subch)))(*subch)
+    bufs = [np.ascontiguousarray(m, np.uint8) for m in msc]
+    ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+    fic96 = np.ascontiguousarray(fic96, np.uint8)
+    out = np.zeros(6144, np.uint8)
+    used = check(load().dabx_eti_frame(cif_hi, cif_lo, minor, arr, len(subch), _p(fic96), ptrs, _p(out)))
+    return out, used
 
 
 def probe_iq_file(path):

@@ -105,7 +105,8 @@ int dabx_coarse_cfo(const dabx_cf32 *fft_sym0, int batch, int32_t *hz);
 /* FIB/FIG subset (host side, no device needed): sub-channel organisation FIG 0/1, service components FIG 0/2,
  * CIF counter FIG 0/0 -- base/decoder/fib_decoder.cpp:59-110, fib_decoder_fig0.cpp:89-101, 142-224, 230-293,
  * getters fib_decoder.cpp:547-557, 673-691.  fibs = n x 32 bytes as delivered by dabx_read_fibs / dabx_fic_decode.
- * Returns the number of sub-channels found (sorted by SubChId); dab_plus = 1 / 0 / -1 (ASCTy 63 / other / unknown). */
+ * Returns the number of sub-channels found (in order of first appearance, as FibDecoder::get_sub_channel_id_list
+ * lists them); dab_plus = 1 / 0 / -1 (ASCTy 63 / other / unknown). */
 struct dabx_subch_desc_s;
 int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, struct dabx_subch_desc_s *out, int max_out,
                     int32_t *cif_count);
@@ -232,6 +233,22 @@ long long dabx_feed_bytes(dabx_feed *f, const void *bytes, size_t n_bytes);
 /* Upper bound of the samples dabx_feed_bytes(n_bytes) can commit (ring-space planning). */
 long long dabx_feed_bound(const dabx_feed *f, size_t n_bytes);
 void dabx_feed_close(dabx_feed *f);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ETI(NI) output: the 6144-byte / 24-ms container EtiGenerator writes
+ * (base/eti_handler/eti_generator.cpp:169-199 frame assembly, :207-308 header).
+ * dabx_eti_frame is host only: cif_hi/cif_lo are FibDecoder::get_cif_count's values when the frame's FIC had been
+ * parsed, minor the CIF's position 0..3 in the transmission frame, sc/msc the sub-channels in FIC order with their
+ * 3*kbps logical-frame bytes, fic96 the three FIBs of this CIF.  Returns the bytes used before the 0x55 padding. */
+#define DABX_ETI_FRAME_BYTES 6144
+int  dabx_eti_frame(int cif_hi, int cif_lo, int minor, const dabx_subch_desc *sc, int n_subch, const uint8_t *fic96,
+                    const uint8_t *const *msc, uint8_t *out /* 6144 */);
+/* ETI frames of `stream` for the CIFs decoded since the previous call (at most max_frames, oldest first), assembled
+ * from the engine's FIB and logical-frame rings for the configured sub-channels.  Like the reference the FIC of a
+ * CIF is paired with the (time-de-interleaved) MSC data that completes with that CIF; frames start once every
+ * sub-channel's de-interleaver is filled and FIG 0/0 has been seen.  *lost_cifs (optional) counts CIFs that had
+ * already left the rings: call at least every min(out_frames, 8) processed frames.  Returns the frame count. */
+int  dabx_read_eti(dabx_engine *e, int stream, int max_frames, uint8_t *out, int32_t *lost_cifs);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,9 @@ void ora_backend_stats(const ora_backend *b, long out[8]);
 int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, ora_subch_desc *out, int *dab_plus, int max_out,
                    int *cif_count);
 
+/* ETI(NI) frame of one CIF (eti.c): eti_generator.cpp:169-199, :207-308; returns the bytes used before the 0x55 padding */
+int ora_eti_frame(int hi, int lo, int minor, const ora_subch_desc *sc, int nst, const uint8_t *fic96, const uint8_t *const *msc, uint8_t *eti);
+
 /* recorded-IQ payload -> cf32 at 2.048 MS/s (iqfile.c); family 0 raw / 1 wav / 2 uff, container 0 u8 1 s8 2 i16 3 i24 4 i32 5 f32 */
 long long ora_iq_convert(int family, int container, int big_endian, int swap_iq, int bits, int rate, const uint8_t *bytes,
                          long long n_bytes, float *out, long long max_out);

@@ -22,11 +22,12 @@ static const short prot_tab[64][3] = {
 
 typedef struct { int used; ora_subch_desc d; int ascty; } slot_t;
 
-/* returns the number of sub-channels (ordered by SubChId); dab_plus[i] = 1/0/-1 */
+/* returns the number of sub-channels (in order of first appearance); dab_plus[i] = 1/0/-1 */
 int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, ora_subch_desc *out, int *dab_plus, int max_out,
                    int *cif_count)
 {
   slot_t tab[64];
+  int order[64], n_order = 0;                              /* first-appearance order, fib_decoder.cpp:547-557 */
   memset(tab, 0, sizeof(tab));
   for (int i = 0; i < 64; i++) tab[i].ascty = -1;
   int cif = -1;
@@ -70,7 +71,7 @@ int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, 
               for (int k = 0; k < 64 && !restart; k++)
                 if (tab[k].used && q.cu_start < tab[k].d.cu_start + tab[k].d.cu_size && tab[k].d.cu_start < q.cu_start + q.cu_size) restart = 1;
               if (restart) break;
-              tab[q.subch_id].used = 1; tab[q.subch_id].d = q;
+              tab[q.subch_id].used = 1; tab[q.subch_id].d = q; order[n_order++] = q.subch_id;
             }
           }
         } else if (ext == 2 && cn == 0) {
@@ -89,11 +90,13 @@ int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, 
       }
       processed += (int)len + 1;
     }
-    if (restart) { memset(tab, 0, sizeof(tab)); for (int i = 0; i < 64; i++) tab[i].ascty = -1; cif = -1; }
+    if (restart) { memset(tab, 0, sizeof(tab)); for (int i = 0; i < 64; i++) tab[i].ascty = -1; cif = -1; n_order = 0; }
   }
   if (cif_count) *cif_count = cif;
   int n = 0;
-  for (int k = 0; k < 64 && n < max_out; k++)
-    if (tab[k].used) { out[n] = tab[k].d; dab_plus[n] = tab[k].ascty < 0 ? -1 : (tab[k].ascty == 63); n++; }
+  for (int i = 0; i < n_order && n < max_out; i++) {
+    const int k = order[i];
+    out[n] = tab[k].d; dab_plus[n] = tab[k].ascty < 0 ? -1 : (tab[k].ascty == 63); n++;
+  }
   return n;
 }

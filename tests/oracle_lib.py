@@ -84,6 +84,7 @@ def oracle():
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.ora_parse_fibs.argtypes = [_u8p, _u8p, C.c_int, C.POINTER(SubchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    L.ora_eti_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(SubchDesc), C.c_int, _u8p, C.POINTER(C.c_void_p), _u8p]
     L.ora_iq_convert.restype = C.c_longlong
     L.ora_iq_convert.argtypes = [C.c_int] * 6 + [_u8p, C.c_longlong, C.c_void_p, C.c_longlong]
     L.ora_fic_init.argtypes = [C.c_void_p]

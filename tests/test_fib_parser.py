@@ -72,6 +72,14 @@ def test_short_form_eepb_and_conflicts_match_oracle():
     assert _dx_parse(fib2[None], np.ones(1, np.uint8))[0] == []
 
 
+def test_subchannels_come_in_order_of_first_appearance():
+    body = bytes([0x01]) + _fig01_long(40, 500, 0, 2, 48) + _fig01_long(7, 100, 0, 2, 48) + _fig01_long(21, 0, 0, 2, 48)
+    fib = _fib([bytes([len(body)]) + body])
+    got, _ = _dx_parse(fib[None], np.ones(1, np.uint8))
+    assert [g[0] for g in got] == [40, 7, 21]                 # FibDecoder::get_sub_channel_id_list, fib_decoder.cpp:547-557
+    assert got == _oracle_parse(fib[None], np.ones(1, np.uint8))[0]
+
+
 def test_all_64_short_form_indices_match_oracle_table():
     for base in range(0, 64, 8):
         body = bytes([0x01]) + b"".join(_fig01_short(base + k, 0, base + k) for k in range(8))

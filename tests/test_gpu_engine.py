@@ -214,3 +214,41 @@ def test_subchannels_discovered_from_the_decoded_fic_then_decoded():
             assert any(np.array_equal(sf[k], ens.superframes[j][q]) for q in range(8)), (j, k)
             assert any(np.array_equal(sf[k], o) for o in osf), (j, k)
     eng.close()
+
+
+def test_eti_frames_carry_the_fic_and_the_logical_frames_of_each_cif():
+    """dabx_read_eti (eti_generator.cpp:169-199): every emitted frame == the oracle's ETI assembly of that CIF's FIBs,
+    FIG 0/0 counter and the oracle receiver's MSC bytes; frames are consecutive across calls."""
+    import test_eti as te
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=12, cif_start=240)          # CIF counter wraps 249 -> 0 inside the run
+    x = ds.channel(ens.iq, snr_db=22.0, cfo_hz=77.0, timing_offset=2222, seed=4, n_out=22 * ds.TF)
+    ora = _oracle_run(x, subch)
+    eng = dx.Engine(n_streams=1, ring_frames=23, max_subch=18, out_frames=8)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    frames = []
+    for chunk in (5, 7, 3, 6):
+        eng.process(chunk)
+        f, lost = eng.read_eti(0, 64)
+        assert lost == 0
+        frames.append(f)
+    frames = np.concatenate(frames)
+    n_frames = eng.stats(0)["frames"]
+    assert len(frames) == 4 * n_frames - 16                               # one per CIF once the de-interleavers are filled
+    descs = [dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0) for c in subch]
+    fct = []
+    for i, f in enumerate(frames):
+        r = 16 + i                                                        # CIF index since lock
+        F, k = divmod(r, 4)
+        fib = ora["fibs"][F].reshape(-1)
+        hi, lo = int(fib[4] & 0x1F), int(fib[5])                          # FIG 0/0 leads FIB 0 of every CIF in the synthetic
+        for g in range(4):                                                # ensemble: the state after the frame is FIB 9's
+            if ora["crc"][F][3 * g]:
+                hi, lo = int(ora["fibs"][F][3 * g][4] & 0x1F), int(ora["fibs"][F][3 * g][5])
+        msc = [ora["msc"][j].reshape(-1, 192)[r - 16] for j in range(18)]
+        want, _ = te._ora_frame(hi, lo, k, descs, fib[96 * k:96 * k + 96], msc)
+        assert np.array_equal(f, want), i
+        fct.append(int(f[4]))
+    assert len(set(fct)) > 40 and min(fct) < 10 and max(fct) > 240     # FCT ran through the 249 -> 0 wrap
+    eng.close()
