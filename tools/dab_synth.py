@@ -175,6 +175,8 @@ class SubCh:
     kbps: int
     prot_level: int = 2      # EEP 3-A
     short_form: int = 0
+    mask: object = None      # optional puncturing mask over the 96*kbps+24 mother-code bits (UEP: from the caller)
+    dab_plus: int = 1        # 0: payload is an opaque byte stream (MP2 / data), no super-frame structure
 
 
 def default_subchannels(n: int = 18, kbps: int = 64) -> list[SubCh]:
@@ -204,6 +206,12 @@ def build_superframe(kbps: int, rng: np.random.Generator) -> np.ndarray:
     return full
 
 
+UEP_ROWS = [(k, l) for k, ls in [(32, (5, 4, 3, 2, 1)), (48, (5, 4, 3, 2, 1)), (56, (5, 4, 3, 2)), (64, (5, 4, 3, 2, 1)),
+                                 (80, (5, 4, 3, 2, 1)), (96, (5, 4, 3, 2, 1)), (112, (5, 4, 3, 2)), (128, (5, 4, 3, 2, 1)),
+                                 (160, (5, 4, 3, 2, 1)), (192, (5, 4, 3, 2, 1)), (224, (5, 4, 3, 2, 1)), (256, (5, 4, 3, 2, 1)),
+                                 (320, (5, 4, 2)), (384, (5, 3, 1))] for l in ls]
+
+
 def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndarray:
     """3 FIBs (one FIC group, 96 bytes) for the CIF with the given counter."""
     hi, lo = (cif_count // 250) % 20, cif_count % 250
@@ -211,7 +219,10 @@ def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndar
     def fig01(chs):
         body = bytearray([0x01])          # C/N=0 OE=0 P/D=0 ext=1
         for c in chs:
-            assert not c.short_form
+            if c.short_form:              # UEP: table index of (bit rate, protection level), EN 300 401 table 8
+                idx = UEP_ROWS.index((c.kbps, c.prot_level))
+                body += bytes([(c.subch_id << 2) | (c.cu_start >> 8), c.cu_start & 0xFF, idx])
+                continue
             opt, lvl = (c.prot_level >> 2) & 1, c.prot_level & 3
             w = (c.subch_id << 26) | (c.cu_start << 16) | (1 << 15) | (opt << 12) | (lvl << 10) | c.cu_size
             body += w.to_bytes(4, "big")
@@ -221,7 +232,7 @@ def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndar
         body = bytearray([0x02])          # C/N=0 OE=0 P/D=0 ext=2
         for c in chs:                     # one programme service per sub-channel, one DAB+ audio component (ASCTy 63)
             sid = 0x1000 + c.subch_id
-            comp = (0 << 14) | (63 << 8) | (c.subch_id << 2) | (1 << 1)
+            comp = (0 << 14) | ((63 if c.dab_plus else 0) << 8) | (c.subch_id << 2) | (1 << 1)
             body += bytes([sid >> 8, sid & 0xFF, 0x01, comp >> 8, comp & 0xFF])
         return bytes([len(body)]) + bytes(body)
 
@@ -269,16 +280,16 @@ def build_ensemble(n_frames: int = 10, subch: list | None = None, seed: int = 0,
     for c in subch:
         nb = 3 * c.kbps
         n_sf = (n_cif + 4) // 5
-        sfs = [build_superframe(c.kbps, rng) for _ in range(n_sf)]
+        sfs = [build_superframe(c.kbps, rng) if c.dab_plus else rng.integers(0, 256, 15 * c.kbps).astype(np.uint8) for _ in range(n_sf)]
         stream = np.concatenate(sfs)[: n_cif * nb].reshape(n_cif, nb)
         msc_bytes.append(stream.copy())
         superframes.append(np.stack([s[: 110 * (c.kbps // 8)] for s in sfs[: n_cif // 5]]) if n_cif >= 5 else np.zeros((0, 0), np.uint8))
-        mask = eep_mask(c.kbps, c.prot_level).astype(bool)
+        mask = (eep_mask(c.kbps, c.prot_level) if c.mask is None else np.asarray(c.mask)).astype(bool)
         disp = prbs(24 * c.kbps)
         for q in range(n_cif):
             bits = np.unpackbits(stream[q]) ^ disp
             cw = conv_encode(bits)[mask]
-            assert len(cw) == c.cu_size * 64, (len(cw), c.cu_size)
+            assert len(cw) <= c.cu_size * 64, (len(cw), c.cu_size)      # some UEP profiles leave padding bits
             coded[q, c.cu_start * 64: c.cu_start * 64 + len(cw)] = cw
     # ---- time interleaving: CIF t carries bit i of coded CIF t - map[i%16]
     delay = INTERLEAVE_MAP[np.arange(55296) & 15]
