@@ -535,6 +535,7 @@ int dabx_set_profiling(dabx_engine *e, int on)
   if (!e) return DABX_E_ARG;
   if (int rc = sync_all(e)) return rc;
   e->mk.on = on != 0;
+  e->mk.only = on >= 2 ? on - 2 : -1;
   e->mk.used = 0;
   e->mk.recs.clear();
   for (int k = 0; k < N_STEP_KERNELS; k++) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }

@@ -109,6 +109,7 @@ struct EngineStreams {
 constexpr int N_STEP_KERNELS = 10;
 struct Marker {
   bool on = false;
+  int only = -1;                  // >= 0: instrument just this kernel (2 events per launch instead of 2 per kernel)
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   struct Rec { int k; size_t a, b; };
@@ -120,8 +121,8 @@ struct Marker {
     (void)hipEventRecord(pool[used], st);
     return used++;
   }
-  void begin(int k, hipStream_t st) { if (on) open_ev[k] = take(st); }
-  void end(int k, hipStream_t st) { if (on) recs.push_back(Rec{k, open_ev[k], take(st)}); }
+  void begin(int k, hipStream_t st) { if (on && (only < 0 || only == k)) open_ev[k] = take(st); }
+  void end(int k, hipStream_t st) { if (on && (only < 0 || only == k)) recs.push_back(Rec{k, open_ev[k], take(st)}); }
 };
 
 // ---- MSC job decoding shared by the decoder kernels: job J = (stream, pending CIF k, sub-channel j) -------------
