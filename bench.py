@@ -37,6 +37,7 @@ A_KERNEL = {
     "k_msc_frame": 4 * 55296 + 4 * 3456,              # time-deinterleaver read, packed logical frames out
     "k_dabplus": 4 * 3456 * 5 // 5 + 18 * 880 * 4 // 5,
 }
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4      # wave64 VALU instructions per second, whole chip (MI355X_MICROARCH.md)
 HBM_PEAK = 8.0e12
 
 
@@ -194,13 +195,17 @@ def main():
         launches = {names[i].decode(): int(cnt[i]) for i in range(nk) if cnt[i]}
         units = args.streams * args.steps / launches[dom]      # frames one launch of that kernel processes
         achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
-        traffic = None
+        traffic = valu = None
         try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/prof_round.sh)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if tj.get("streams") == args.streams and dom in tj["kernels"] and units == args.streams * (7 if dom.startswith("k_msc") else 1):
                 traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"])
+                vi = tj["kernels"][dom].get("valu_wave_insts_per_launch")
+                if vi:      # issue-rate view of the same launch: wave64 VALU instructions / (1024 SIMDs x 2.4 GHz / 4 cycles)
+                    valu = {"wave_insts_per_launch": int(vi), "issue_peak_per_s": VALU_ISSUE_PEAK,
+                            "util": round(vi / (kern[dom] * 1e-3) / VALU_ISSUE_PEAK, 4)}
         except Exception:
-            traffic = None
+            traffic = valu = None
         out = {
             "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,7 +222,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": units,
-                         "avg_launch_ms": round(kern[dom], 4)},
+                         "avg_launch_ms": round(kern[dom], 4), "valu": valu},
             "chain": {"algorithmic_bytes_per_frame": A_FRAME, "achieved_GBps": round(value / world * A_FRAME / 1e9, 2),
                       "frac_of_hbm_peak": round(value / world * A_FRAME / HBM_PEAK, 6),
                       "kernel_ms_per_step_warmup": {k: round(v, 4) for k, v in share.items()}},

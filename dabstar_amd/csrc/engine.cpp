@@ -3,6 +3,7 @@
 #include "viterbi_core.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -90,9 +91,14 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   auto *e = new dabx_engine();
   e->cfg = *cfg;
   DABX_HIP(hipGetDevice(&e->device));
-  DABX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  // front end (frame-to-frame feedback = critical path) above the batched MSC decode; DABX_STREAM_PRIO=a,b overrides
+  int prio_lo = 0, prio_hi = 0, pa, pb;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // lo = least urgent (numerically greatest)
+  pa = prio_hi; pb = prio_lo;
+  if (const char *ev = getenv("DABX_STREAM_PRIO")) { if (sscanf(ev, "%d,%d", &pa, &pb) != 2) { pa = prio_hi; pb = prio_lo; } }
+  DABX_HIP(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, pa));
   e->ss.a = e->stream;
-  DABX_HIP(hipStreamCreateWithFlags(&e->ss.b, hipStreamNonBlocking));
+  DABX_HIP(hipStreamCreateWithPriority(&e->ss.b, hipStreamNonBlocking, pb));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming));
   const int S = cfg->n_streams;

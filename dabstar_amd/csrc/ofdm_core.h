@@ -7,6 +7,9 @@
 namespace dabx {
 
 __device__ __forceinline__ float cabsf_(float2 z) { return sqrtf(z.x * z.x + z.y * z.y); }   // std::abs under -ffast-math
+// |z| with the 1-ulp hardware square root: only for the signal-level tracker, which is itself applied per chunk
+// (k_frame_tail) and feeds nothing but the out-of-lock dip detector
+__device__ __forceinline__ float cabsf_level(float2 z) { return __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y); }
 
 // ---- block reductions (256 threads) -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
@@ -91,7 +94,7 @@ struct Nco {
   }
   __device__ void step()
   {
-    const double nr = br * sr - bi * si, ni = br * si + bi * sr;
+    const double nr = __builtin_fma(br, sr, -(bi * si)), ni = __builtin_fma(br, si, bi * sr);   // 4 DP ops instead of 6
     br = nr; bi = ni;
   }
 };

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
     const float2 a = rv.at(TU + i), b = rv.at(i);
     cre += a.x * b.x + a.y * b.y;
     cim += a.y * b.x - a.x * b.y;
-    asum += cabsf_(b);
+    asum += cabsf_level(b);
   }
   float2 v[8];
   Nco nco;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const float2 x = rv.at(TG + tid + 256 * u);
-    asum += cabsf_(x);
+    asum += cabsf_level(x);
     v[u] = nco.mix(x);
     nco.step();
   }
@@ -223,18 +223,19 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
 }
 
 // -------------------------------------------------------------------------------------------------- demap
-__global__ __launch_bounds__(512) void k_demap_frame(EngineDev e, DevTables t)
+constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t)
 {
-  __shared__ float red[8];
+  __shared__ float red[16];
   const int s = blockIdx.x, tid = threadIdx.x;
   const StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   DemapDev &d = e.demap;
-  DemapCarrier cr[3];
-  int bin[3], rel[3];
+  DemapCarrier cr[DEMAP_Q];
+  int bin[DEMAP_Q], rel[DEMAP_Q];
 #pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const int k = tid + 512 * q;
+  for (int q = 0; q < DEMAP_Q; q++) {
+    const int k = tid + DEMAP_THREADS * q;
     bin[q] = t.perm_bin[k]; rel[q] = t.perm_rel[k];
     cr[q].prev = d.phase_ref[(size_t)s * TU + bin[q]];
     cr[q].integ = d.integ[(size_t)s * K + k];
@@ -248,25 +249,25 @@ __global__ __launch_bounds__(512) void k_demap_frame(EngineDev e, DevTables t)
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
   uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
-  float2 xn[3];                                           // spectrum values of the next symbol (gather latency off the chain)
+  float2 xn[DEMAP_Q];                                           // spectrum values of the next symbol (gather latency off the chain)
   {
     const float2 *X0 = e.spectra + (size_t)s * 76 * TU;
 #pragma unroll
-    for (int q = 0; q < 3; q++) xn[q] = X0[bin[q]];
+    for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[bin[q]];
   }
   for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
     const float2 *X = e.spectra + ((size_t)s * 76 + (l < 74 ? l + 1 : l)) * TU;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, d.soft_type);
-    float2 xc[3];
+    float2 xc[DEMAP_Q];
 #pragma unroll
-    for (int q = 0; q < 3; q++) { xc[q] = xn[q]; xn[q] = X[bin[q]]; }
+    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[bin[q]]; }
     float part = 0.f;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
+    for (int q = 0; q < DEMAP_Q; q++) {
       int16_t sr, si;
       part += demap_one(cr[q], xc[q], rel[q], ce, w2, d.soft_type, sr, si);
-      const int k = tid + 512 * q;
+      const int k = tid + DEMAP_THREADS * q;
       if (l < 3) {                                        // symbols 1..3 -> FIC
         fic[l * K2 + k] = soft_to_sym(sr);
         fic[l * K2 + K + k] = soft_to_sym(si);
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(512) void k_demap_frame(EngineDev e, DevTables t)
     mean_value = block_sum(part, red, tid) * (1.0f / (float)K);
   }
 #pragma unroll
-  for (int q = 0; q < 3; q++) {
-    const int k = tid + 512 * q;
+  for (int q = 0; q < DEMAP_Q; q++) {
+    const int k = tid + DEMAP_THREADS * q;
     d.integ[(size_t)s * K + k] = cr[q].integ;
     d.mean_power[(size_t)s * K + k] = cr[q].mean_power;
     d.mean_sigma[(size_t)s * K + k] = cr[q].mean_sigma_sq;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const float2 x = rv.at(TG + tid + 256 * u);
-    an += cabsf_(x);
+    an += cabsf_level(x);
     v[u] = nco.mix(x);
     nco.step();
   }
@@ -653,7 +654,7 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
   mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
-  mk.begin(3, st); hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(512), 0, st, e, *t); mk.end(3, st);
+  mk.begin(3, st); hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t); mk.end(3, st);
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
   DABX_HIP(hipGetLastError());

@@ -122,3 +122,46 @@ def test_oracle_resampler_keeps_a_tone_in_place(family, rate):
     skip = 2048                                                   # the UFF flavour starts from a zero sample
     err = np.abs(y[skip:] * np.exp(-1j * np.angle(np.vdot(ref[skip:], y[skip:]))) - ref[skip:])
     assert err.max() < 0.03                                       # linear interpolation error at f0/rate ~ 0.05..0.07
+
+
+def test_probe_survives_malformed_headers(tmp_path):
+    """Truncated / hostile containers are refused (or clipped to the file) without reading out of bounds."""
+    rng = np.random.default_rng(11)
+    good = iqf.wav_bytes(bytes(400), 2048000, 16, extra_chunks=[(b"LIST", b"x" * 10)])
+    p = tmp_path / "m.wav"
+    for cut in list(range(0, 80)) + [len(good) - 1]:
+        p.write_bytes(good[:cut])
+        try:
+            f = dx.probe_iq_file(str(p))
+            assert f.data_offset + f.data_bytes <= cut
+        except dx.DabxError:
+            pass
+    for _ in range(200):                                          # random corruption of header bytes
+        b = bytearray(good)
+        for _ in range(3):
+            b[int(rng.integers(4, 60))] = int(rng.integers(0, 256))
+        p.write_bytes(bytes(b))
+        try:
+            f = dx.probe_iq_file(str(p))
+            assert 0 <= f.data_offset and f.data_offset + f.data_bytes <= len(b)
+        except dx.DabxError:
+            pass
+    hdr = iqf.uff_header(2048000, 16, "int16", "LSB", n_elements=100)
+    u = tmp_path / "m.uff"
+    for cut in (5, 40, 200, len(hdr) - 3, len(hdr)):
+        u.write_bytes(hdr[:cut])
+        try:
+            f = dx.probe_iq_file(str(u))
+            assert f.data_bytes == 0
+        except dx.DabxError:
+            pass
+    for _ in range(200):
+        b = bytearray(hdr + bytes(700) + bytes(rng.integers(0, 256, 64).astype(np.uint8)))
+        for _ in range(4):
+            b[int(rng.integers(5, len(hdr)))] = int(rng.integers(32, 127))
+        u.write_bytes(bytes(b))
+        try:
+            f = dx.probe_iq_file(str(u))
+            assert f.data_bytes == 0 or (0 <= f.data_offset and f.data_offset + f.data_bytes <= len(b))
+        except dx.DabxError:
+            pass

@@ -21,7 +21,7 @@ python3 - "$OUT" <<'PY'
 import csv, glob, sys, json, collections
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/p[34]/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(out + "/p[134]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0].replace("dabx::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
@@ -29,8 +29,10 @@ for k, v in acc.items():
     # full-size launches only (the 7-frame batches): take the maximum-valued half
     fs = sorted(v.get("FETCH_SIZE", [0])); ws = sorted(v.get("WRITE_SIZE", [0]))
     f = sum(fs[len(fs) // 2:]) / max(1, len(fs[len(fs) // 2:])); w = sum(ws[len(ws) // 2:]) / max(1, len(ws[len(ws) // 2:]))
-    res[k] = {"fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE doubled (gfx950), mean over full-size launches",
+    vs = sorted(v.get("SQ_INSTS_VALU", [0])); va = sum(vs[len(vs) // 2:]) / max(1, len(vs[len(vs) // 2:]))
+    res[k] = {"fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+              "valu_wave_insts_per_launch": va}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE doubled (gfx950), mean over full-size launches; SQ_INSTS_VALU = wave-level VALU instructions",
            "streams": 512, "kernels": res}, open(out + "/traffic.json", "w"), indent=1)
 PY
 cat $OUT/bench.json
