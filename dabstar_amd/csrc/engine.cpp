@@ -184,6 +184,7 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
   for (int j = 0; j < n; j++) {
     const dabx_subch_desc &q = desc[j];
     SubchDev sc{};
+    if (q.kbps == 0) { row[j] = sc; continue; }            // empty slot (keeps the indices of the others stable)
     const uint16_t *map = nullptr;
     int n_in = 0;
     if ((rc = get_profile_map(q.kbps, q.prot_level, q.short_form, &map, &n_in))) return rc;
@@ -197,7 +198,9 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
     max_kbps = std::max(max_kbps, q.kbps);
   }
   // (re)allocate output rings / scratch when the largest bit rate grows
+  bool rings_reset = false;
   if (max_kbps > e->max_kbps) {
+    rings_reset = true;
     e->max_kbps = max_kbps;
     d.msc_stride = 3 * max_kbps;
     d.sf_stride = ((110 * max_kbps / 8) + 15) & ~15;
@@ -213,8 +216,15 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
     for (int j = 0; j < d.max_subch; j++) {
       SubchDev sc = j < n ? row[j] : SubchDev{};
       sc.start_cif = ctl[s].cif_no;
+      // a slot whose description does not change keeps running (MscHandler::set_channel only adds a Backend,
+      // msc_handler.cpp:95-131): its de-interleaver history, super-frame state and counters stay
+      const SubchDev &old = e->subch_host[(size_t)s * d.max_subch + j];
+      const bool same = !rings_reset && old.active && sc.active && old.cu_start == sc.cu_start && old.cu_size == sc.cu_size &&
+                        old.kbps == sc.kbps && old.prot_level == sc.prot_level && old.short_form == sc.short_form &&
+                        old.dab_plus == sc.dab_plus && e->subch_id_host[(size_t)s * d.max_subch + j] == desc[j].subch_id;
+      if (same) continue;
       e->subch_host[(size_t)s * d.max_subch + j] = sc;
-      e->subch_id_host[(size_t)s * d.max_subch + j] = j < n ? desc[j].subch_id : -1;
+      e->subch_id_host[(size_t)s * d.max_subch + j] = (j < n && sc.active) ? desc[j].subch_id : -1;
       e->eti[s] = dabx_engine::EtiCursor{};
     }
   }
@@ -511,6 +521,17 @@ int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)
     out->sf_ok += sc[j].sf_ok; out->sf_fail += sc[j].sf_fail; out->rs_corrected += sc[j].rs_corr; out->rs_failed += sc[j].rs_fail;
     out->au_ok += sc[j].au_ok; out->au_bad += sc[j].au_bad; out->cifs_decoded += sc[j].cif_out;
   }
+  return 0;
+}
+
+int dabx_get_subch_stats(dabx_engine *e, int stream, int j, dabx_subch_stats *out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || j < 0 || j >= e->dev.max_subch || !out) return DABX_E_ARG;
+  SubchDev sc;
+  int rc = fetch_subch(e, stream, j, &sc);
+  if (rc) return rc;
+  *out = dabx_subch_stats{sc.start_cif, sc.cif_out, sc.sf_count, sc.sf_ok, sc.sf_fail, sc.rs_corr, sc.rs_fail, sc.fc_corr, sc.au_ok,
+                          sc.au_bad, sc.active, e->subch_id_host[(size_t)stream * e->dev.max_subch + j]};
   return 0;
 }
 

@@ -180,6 +180,11 @@ class SubchDesc(C.Structure):
                 ("prot_level", C.c_int32), ("short_form", C.c_int32), ("dab_plus", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SubchStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("start_cif", "cifs_decoded", "sf_count", "sf_ok", "sf_fail", "rs_corrected", "rs_failed",
+                                         "fc_corrected", "au_ok", "au_bad")] + [("active", C.c_int32), ("subch_id", C.c_int32)]
+
+
 class IqFormat(C.Structure):
     """dabx_iq_format: family 0 raw / 1 wav / 2 uff; container 0 u8, 1 s8, 2 i16, 3 i24, 4 i32, 5 f32."""
     _fields_ = [("family", C.c_int32), ("container", C.c_int32), ("big_endian", C.c_int32), ("swap_iq", C.c_int32),
@@ -280,6 +285,11 @@ class Engine:
         out = (SubchDesc * max_out)()
         n = check(load().dabx_discover_subchannels(self._h, stream, out, max_out))
         return [out[i] for i in range(n)]
+
+    def subch_stats(self, stream, j):
+        st = SubchStats()
+        check(load().dabx_get_subch_stats(self._h, stream, j, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in SubchStats._fields_}
 
     def read_eti(self, stream, max_frames=32):
         out = np.zeros((max_frames, 6144), np.uint8)

@@ -149,7 +149,9 @@ typedef struct {
 void dabx_default_config(dabx_config *cfg);
 int  dabx_create(const dabx_config *cfg, dabx_engine **out);
 void dabx_destroy(dabx_engine *e);
-/* MscHandler::set_channel equivalent for stream (or all streams when stream < 0). */
+/* MscHandler::set_channel / stop_service equivalent for stream (or all streams when stream < 0): d[j] describes slot j
+ * (kbps == 0: empty slot).  A slot whose description is unchanged keeps decoding without interruption; new or changed
+ * slots start their 16-CIF de-interleaver fill at the current CIF (growing the largest bit rate restarts all). */
 int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
 /* Host IQ -> device ring (IDeviceHandler::getSamples contract, common/device_handler_if.h:47-48).
  * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70) */
@@ -176,6 +178,15 @@ int  dabx_read_msc(dabx_engine *e, int stream, int subch_idx, int n_cifs, uint8_
 int  dabx_read_superframes(dabx_engine *e, int stream, int subch_idx, int n, uint8_t *bytes);
 int  dabx_read_soft(dabx_engine *e, int stream, int16_t *soft /* 75*3072 */);
 int  dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out);
+/* Per-slot counters (Backend / Mp4Processor members: backend.cpp:146-150 warm-up, mp4processor.h:106-112 signals). */
+typedef struct {
+  int64_t start_cif;         /* CIF index (since open) at which the slot was configured */
+  int64_t cifs_decoded;      /* logical frames produced so far; frame i belongs to CIF start_cif + 16 + i */
+  int64_t sf_count;          /* super frames written to the super-frame ring */
+  int64_t sf_ok, sf_fail, rs_corrected, rs_failed, fc_corrected, au_ok, au_bad;
+  int32_t active, subch_id;
+} dabx_subch_stats;
+int  dabx_get_subch_stats(dabx_engine *e, int stream, int subch_idx, dabx_subch_stats *out);
 /* Sum of the counters over all streams of this engine (the values one RCCL all-reduce combines). */
 int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
 /* Per-kernel timing with HIP events recorded on the engine's stream around every launch of a batch step

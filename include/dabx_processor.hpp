@@ -1,0 +1,249 @@
+// dabx_processor.hpp -- header-only C++17 adapter over the C ABI of libdabx with the method names of the reference's
+// DabProcessor (base/main/dab_processor.h:71-110), so that a front end written against that class can be pointed at
+// the MI355X back end (selection pattern: dab_processor.h:53-57 + a CMake option).
+//
+// No Qt: the reference's signals become std::function callbacks, QString becomes std::string, the QThread body
+// (DabProcessor::run, dab_processor.cpp:110-265) becomes run(), which the caller invokes from its own thread
+// whenever samples have been handed over.  One Processor = one ensemble = one stream of a one-stream engine; the
+// stream-batched engine API (dabx_create with n_streams > 1) is the one to use for many ensembles at once.
+#pragma once
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "dabx.h"
+
+namespace dabx {
+
+struct ProcessorParams {                    // ProcessParams subset (base/main/dab_processor.h / dabradio.cpp:86-101)
+  float threshold = 3.0f;          //   threshold
+  int soft_bit_type = 1;           //   ESoftBitType (1..3)
+  bool sync_on_strongest_peak = false;
+  int ring_frames = 12;            // IQ ring capacity in transmission frames
+  int max_services = 64;           // slots for concurrently decoded sub-channels
+  int fib_ring_frames = 8;         // frames of FIBs kept for callbacks / ETI
+};
+
+class Processor {
+public:
+  using Params = ProcessorParams;
+
+  // signals of the reference, as callbacks (all optional; called from run())
+  std::function<void(const uint8_t *fib32, bool crc_ok, int fib_no)> on_fib;                      // IFibDecoder::process_FIB
+  std::function<void(int subChId, const uint8_t *bytes, int n)> on_logical_frame;                 // FrameProcessor::add_to_frame
+  std::function<void(int subChId, const uint8_t *bytes, int n)> on_super_frame;                   // Mp4Processor: RS-corrected super frame
+  std::function<void(int ficPercent, float freqOffsBbHz, float clockErrHz, float snrDb)> on_status;   // slot_show_fic_status, ..._freq_corr_bb_Hz, ..._clock_error
+
+  explicit Processor(const Params &p = Params()) : params_(p)
+  {
+    dabx_config cfg;
+    dabx_default_config(&cfg);
+    cfg.n_streams = 1; cfg.ring_frames = p.ring_frames; cfg.max_subch = p.max_services; cfg.out_frames = p.fib_ring_frames;
+    cfg.sync_threshold = p.threshold; cfg.soft_bit_type = p.soft_bit_type; cfg.sync_strongest = p.sync_on_strongest_peak ? 1 : 0;
+    if (dabx_create(&cfg, &eng_) < 0) throw std::runtime_error(std::string("dabx_create: ") + dabx_last_error());
+    slots_.assign((size_t)p.max_services, dabx_subch_desc{});
+    delivered_.assign((size_t)p.max_services, 0);
+    sf_delivered_.assign((size_t)p.max_services, 0);
+  }
+  ~Processor()
+  {
+    stop_eti_generator();
+    if (feed_) dabx_feed_close(feed_);
+    if (eng_) dabx_destroy(eng_);
+  }
+  Processor(const Processor &) = delete;
+  Processor &operator=(const Processor &) = delete;
+
+  // ---- DabProcessor::start / stop -------------------------------------------------------------------------------
+  void start() { running_ = true; }
+  void stop() { running_ = false; }
+  bool is_sample_reader_running() const { return running_; }
+
+  // ---- sample hand-over: stands for IDeviceHandler::getSamples (common/device_handler_if.h:47-48) ----------------
+  void put_samples(const std::complex<float> *iq, size_t n) { check(dabx_push_iq(eng_, 0, iq, 0, n), "dabx_push_iq"); }
+  // recorded files (.raw/.iq, .sdr/.wav, .uff): bytes are decoded / resampled on the GPU
+  dabx_iq_format open_recording(const std::string &path)
+  {
+    dabx_iq_format fmt;
+    check(dabx_probe_iq_file(path.c_str(), &fmt), "dabx_probe_iq_file");
+    if (feed_) { dabx_feed_close(feed_); feed_ = nullptr; }
+    check(dabx_feed_open(eng_, 0, &fmt, &feed_), "dabx_feed_open");
+    return fmt;
+  }
+  long long put_file_bytes(const void *bytes, size_t n)
+  {
+    if (!feed_) throw std::logic_error("open_recording first");
+    const long long k = dabx_feed_bytes(feed_, bytes, n);
+    if (k < 0) throw std::runtime_error(std::string("dabx_feed_bytes: ") + dabx_last_error());
+    return k;
+  }
+
+  // ---- the body of DabProcessor::run for the frames that are available ---------------------------------------------
+  // returns the number of frames demodulated; fires the callbacks and appends to the ETI file
+  int run(int max_frames = 4)
+  {
+    if (!running_) return 0;
+    dabx_stats before, after;
+    check(dabx_get_stats(eng_, 0, &before), "dabx_get_stats");
+    check(dabx_process(eng_, max_frames, 1), "dabx_process");
+    check(dabx_get_stats(eng_, 0, &after), "dabx_get_stats");
+    const int frames = (int)(after.frames - before.frames);
+    if (frames > 0) {
+      deliver_fibs(frames);
+      deliver_services();
+      if (eti_ && any_service()) write_eti();     // like EtiGenerator: nothing before the FIC has named the sub-channels
+      if (on_status) on_status(after.fic_ratio_percent, after.freq_offs_bb_hz, after.clock_err_hz, after.snr_db_est);
+    }
+    return frames;
+  }
+
+  // ---- FIB decoder getters (IFibDecoder subset: fib_decoder.cpp:547-570, 673-691) ------------------------------------
+  std::vector<dabx_subch_desc> get_sub_channels()
+  {
+    std::vector<dabx_subch_desc> v(64);
+    const int n = dabx_discover_subchannels(eng_, 0, v.data(), 64);
+    check(n, "dabx_discover_subchannels");
+    v.resize((size_t)n);
+    return v;
+  }
+  int get_fic_decode_ratio_percent()
+  {
+    dabx_stats st;
+    check(dabx_get_stats(eng_, 0, &st), "dabx_get_stats");
+    return st.fic_ratio_percent;
+  }
+
+  // ---- MscHandler interface of DabProcessor (dab_processor.h:95-101) -------------------------------------------------
+  bool set_audio_channel(int subChId)          // SAudioData: looked up in the FIC like DabRadio does before calling
+  {
+    for (const auto &d : get_sub_channels())
+      if (d.subch_id == subChId) return set_channel(d);
+    return false;
+  }
+  bool set_channel(dabx_subch_desc d)
+  {
+    if (d.dab_plus < 0) d.dab_plus = 1;
+    int free_slot = -1;
+    for (size_t j = 0; j < slots_.size(); j++) {
+      if (slots_[j].kbps && slots_[j].subch_id == d.subch_id) return true;        // already running (msc_handler.cpp:100-108)
+      if (!slots_[j].kbps && free_slot < 0) free_slot = (int)j;
+    }
+    if (free_slot < 0) return false;
+    slots_[(size_t)free_slot] = d;
+    delivered_[(size_t)free_slot] = 0; sf_delivered_[(size_t)free_slot] = 0;
+    return apply();
+  }
+  void stop_service(int subChId)
+  {
+    for (auto &s : slots_) if (s.kbps && s.subch_id == subChId) s = dabx_subch_desc{};
+    apply();
+  }
+  void stop_all_services()
+  {
+    for (auto &s : slots_) s = dabx_subch_desc{};
+    apply();
+  }
+  bool is_service_running(int subChId) const
+  {
+    for (const auto &s : slots_) if (s.kbps && s.subch_id == subChId) return true;
+    return false;
+  }
+  // "decode everything the FIC announces" -- what EtiGenerator does on its own (eti_generator.cpp:132-134)
+  int set_all_channels()
+  {
+    int n = 0;
+    for (const auto &d : get_sub_channels()) n += set_channel(d) ? 1 : 0;
+    return n;
+  }
+
+  // ---- ETI (dab_processor.h:82-84) ----------------------------------------------------------------------------------
+  bool start_eti_generator(const std::string &path)
+  {
+    stop_eti_generator();
+    eti_ = std::fopen(path.c_str(), "wb");
+    return eti_ != nullptr;
+  }
+  void stop_eti_generator()
+  {
+    if (eti_) std::fclose(eti_);
+    eti_ = nullptr;
+  }
+  void reset_eti_generator() {}                // the engine re-primes by itself after a configuration change
+  long long eti_frames_written() const { return eti_frames_; }
+
+  dabx_engine *engine() { return eng_; }
+
+private:
+  Params params_;
+  dabx_engine *eng_ = nullptr;
+  dabx_feed *feed_ = nullptr;
+  bool running_ = false;
+  std::vector<dabx_subch_desc> slots_;
+  std::vector<long long> delivered_, sf_delivered_;
+  std::FILE *eti_ = nullptr;
+  long long eti_frames_ = 0;
+
+  bool any_service() const
+  {
+    for (const auto &s : slots_) if (s.kbps) return true;
+    return false;
+  }
+  static void check(long long rc, const char *what)
+  {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + dabx_last_error());
+  }
+  bool apply()
+  {
+    int n = 0;
+    for (size_t j = 0; j < slots_.size(); j++) if (slots_[j].kbps) n = (int)j + 1;
+    return dabx_set_subchannels(eng_, 0, slots_.data(), n) == 0;
+  }
+  void deliver_fibs(int frames)
+  {
+    if (!on_fib) return;
+    frames = frames > params_.fib_ring_frames ? params_.fib_ring_frames : frames;
+    std::vector<uint8_t> fibs((size_t)frames * 384), crc((size_t)frames * 12);
+    const int have = dabx_read_fibs(eng_, 0, frames, fibs.data(), crc.data());
+    for (int i = 0; i < have * 12; i++) on_fib(fibs.data() + 32 * i, crc[(size_t)i] != 0, i % 12);
+  }
+  void deliver_services()
+  {
+    if (!on_logical_frame && !on_super_frame) return;
+    std::vector<uint8_t> buf;
+    for (size_t j = 0; j < slots_.size(); j++) {
+      if (!slots_[j].kbps) continue;
+      dabx_subch_stats st;
+      if (dabx_get_subch_stats(eng_, 0, (int)j, &st) < 0 || !st.active) continue;
+      if (on_logical_frame && st.cifs_decoded > delivered_[j]) {
+        long long fresh = st.cifs_decoded - delivered_[j];
+        if (fresh > 32) fresh = 32;                                   // ring depth; older frames are gone
+        const int nb = 3 * slots_[j].kbps;
+        buf.resize((size_t)fresh * nb);
+        const int got = dabx_read_msc(eng_, 0, (int)j, (int)fresh, buf.data());
+        for (int i = 0; i < got; i++) on_logical_frame(slots_[j].subch_id, buf.data() + (size_t)i * nb, nb);
+        delivered_[j] = st.cifs_decoded;
+      }
+      if (on_super_frame && st.sf_count > sf_delivered_[j]) {
+        long long fresh = st.sf_count - sf_delivered_[j];
+        if (fresh > 4) fresh = 4;
+        const int nb = 110 * slots_[j].kbps / 8;
+        buf.resize((size_t)fresh * nb);
+        const int got = dabx_read_superframes(eng_, 0, (int)j, (int)fresh, buf.data());
+        for (int i = 0; i < got; i++) on_super_frame(slots_[j].subch_id, buf.data() + (size_t)i * nb, nb);
+        sf_delivered_[j] = st.sf_count;
+      }
+    }
+  }
+  void write_eti()
+  {
+    std::vector<uint8_t> frames((size_t)32 * DABX_ETI_FRAME_BYTES);
+    int32_t lost = 0;
+    const int n = dabx_read_eti(eng_, 0, 32, frames.data(), &lost);
+    if (n > 0) { std::fwrite(frames.data(), DABX_ETI_FRAME_BYTES, (size_t)n, eti_); eti_frames_ += n; }
+  }
+};
+
+}  // namespace dabx

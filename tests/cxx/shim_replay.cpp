@@ -1,0 +1,54 @@
+// shim_replay.cpp -- test program for include/dabx_processor.hpp: replays a recorded-IQ file through the
+// DabProcessor-shaped adapter exactly as a front end would (start, feed, discover services, select, ETI out) and prints
+// counters as one JSON line.  Built with plain g++ against libdabx.so (C ABI only); exit code 3 = no usable GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+#include "dabx_processor.hpp"
+
+int main(int argc, char **argv)
+{
+  if (argc < 3) { std::fprintf(stderr, "usage: shim_replay <recording> <out.eti> [subChId ...]\n"); return 2; }
+  try {
+    dabx::Processor::Params pp;
+    pp.max_services = 24;
+    dabx::Processor rx(pp);
+    long long fibs_ok = 0, fibs = 0, lf = 0, sf = 0;
+    std::map<int, long long> lf_per_service;
+    rx.on_fib = [&](const uint8_t *, bool ok, int) { fibs++; fibs_ok += ok; };
+    rx.on_logical_frame = [&](int id, const uint8_t *, int) { lf++; lf_per_service[id]++; };
+    rx.on_super_frame = [&](int, const uint8_t *, int) { sf++; };
+    const dabx_iq_format fmt = rx.open_recording(argv[1]);
+    rx.start();
+    if (!rx.start_eti_generator(argv[2])) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 2; }
+    std::FILE *fp = std::fopen(argv[1], "rb");
+    std::fseek(fp, (long)fmt.data_offset, SEEK_SET);
+    const size_t spb = (size_t)dabx_iq_sample_bytes(&fmt);
+    std::vector<uint8_t> block((size_t)(fmt.sample_rate / 1000) * 96 * 3 * spb);       // three frames' worth of recording
+    long long left = fmt.data_bytes, frames = 0;
+    bool configured = false;
+    while (left > 0) {
+      const size_t want = (size_t)std::min<long long>(left, (long long)block.size());
+      const size_t got = std::fread(block.data(), 1, want, fp);
+      if (got == 0) break;
+      left -= (long long)got;
+      rx.put_file_bytes(block.data(), got);
+      frames += rx.run(4);
+      if (!configured && rx.get_fic_decode_ratio_percent() >= 90) {
+        if (argc > 3) { configured = true; for (int i = 3; i < argc; i++) configured = rx.set_audio_channel(std::atoi(argv[i])) && configured; }
+        else configured = rx.set_all_channels() > 0;
+      }
+    }
+    std::fclose(fp);
+    rx.stop_eti_generator();
+    rx.stop();
+    std::printf("{\"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"services\": %zu, "
+                "\"eti_frames\": %lld}\n", frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written());
+    return 0;
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "shim_replay: %s\n", e.what());
+    return std::string(e.what()).find("dabx_create") == 0 ? 3 : 1;
+  }
+}
