@@ -298,3 +298,36 @@ def test_mixed_ensemble_uep_eep_a_b_bit_exact_and_discoverable():
             at = [i for i in range(len(sf_o) - 2) if np.array_equal(sf_o[i:i + 3], got_sf)]
             assert at and at[-1] >= len(sf_o) - 4, (j, at, len(sf_o))
     eng.close()
+
+
+def test_adding_a_service_does_not_disturb_running_ones():
+    """MscHandler::set_channel only adds a Backend (msc_handler.cpp:95-131): the slot that keeps its description decodes
+    straight through; the new slot starts its own 16-CIF fill; an emptied slot (kbps = 0) stops."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=52)
+    x = ds.channel(ens.iq, snr_db=21.0, cfo_hz=150.0, timing_offset=1234, seed=3, n_out=24 * ds.TF)
+    ora = _oracle_run(x, subch)
+    A, B = subch[4], subch[13]
+    mk = lambda c: dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0)   # noqa: E731
+    empty = dx.SubchDesc(0, 0, 0, 0, 0, 0, 0, 0)
+    eng = dx.Engine(n_streams=1, ring_frames=25, max_subch=4, out_frames=4)
+    eng.set_subchannels([mk(A)])
+    eng.push_iq(0, x)
+    eng.process(8)
+    a0 = eng.subch_stats(0, 0)
+    assert a0["cifs_decoded"] == 8 * 4 - 16 and a0["subch_id"] == A.subch_id
+    eng.set_subchannels([mk(A), empty, mk(B)])                   # B goes to slot 2, slot 1 stays empty
+    eng.process(9)
+    a1, b1, e1 = eng.subch_stats(0, 0), eng.subch_stats(0, 2), eng.subch_stats(0, 1)
+    assert a1["start_cif"] == a0["start_cif"] == 0 and a1["cifs_decoded"] == 17 * 4 - 16      # no restart, no gap
+    assert b1["start_cif"] == 32 and b1["cifs_decoded"] == 9 * 4 - 16 and not e1["active"]
+    eng.subch = [A, None, B]
+    oa = ora["msc"][4].reshape(-1, 192)
+    assert np.array_equal(eng.read_msc(0, 0, 32), oa[17 * 4 - 16 - 32:17 * 4 - 16])           # A: bit-exact across the change
+    ob = ora["msc"][13].reshape(-1, 192)
+    assert np.array_equal(eng.read_msc(0, 2, 20), ob[32:52])     # B's first logical frame is CIF 32 + 16 = the oracle's 33rd
+    eng.set_subchannels([empty, empty, mk(B)])                   # stop A
+    eng.process(3)
+    a2, b2 = eng.subch_stats(0, 0), eng.subch_stats(0, 2)
+    assert not a2["active"] and b2["cifs_decoded"] == 12 * 4 - 16 and b2["start_cif"] == 32
+    eng.close()
