@@ -11,6 +11,7 @@
 #include "crc.h"
 #include "freq_interleaver.h"
 #include "phasetable.h"
+#include "fib_table.h"          // cProtLevelTable: the short-form (UEP) sub-channel table of FIG 0/1
 #include <cstring>
 #include <vector>
 
@@ -102,6 +103,13 @@ void ref_phase_table(float * out4096)
 {
   OpenPhase p;
   memcpy(out4096, p.mRefTable.data(), sizeof(float) * 4096);
+}
+
+void ref_uep_table(int16_t * out192)     // 64 x {CU size, protection level, bit rate}, fib_table.h:51-117
+{
+  for (int i = 0; i < 64; i++) {
+    out192[3 * i] = cProtLevelTable[i].CUSize; out192[3 * i + 1] = cProtLevelTable[i].ProtLevel; out192[3 * i + 2] = cProtLevelTable[i].BitRate;
+  }
 }
 
 }  // extern "C"

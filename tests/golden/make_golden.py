@@ -28,7 +28,9 @@ def main():
     R.ref_freq_interleaver(perm)
     prs = np.zeros(4096, np.float32)
     R.ref_phase_table(prs)
-    out.update(pi_codes=pi, freq_perm=perm, prs_table=prs)
+    uep = np.zeros(192, np.int16)
+    R.ref_uep_table(uep)                                   # FIG 0/1 short-form table, fib_table.h
+    out.update(pi_codes=pi, freq_perm=perm, prs_table=prs, uep_table=uep.reshape(64, 3))
     maps = {}
     for kbps, prot in [(8, 0), (8, 1), (8, 2), (8, 3), (16, 1), (32, 2), (32, 4), (32, 7), (64, 0), (64, 2), (64, 3), (64, 5), (128, 1), (192, 3), (256, 4), (320, 2)]:
         m = np.zeros(96 * kbps + 24, np.int32)

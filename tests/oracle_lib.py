@@ -130,6 +130,7 @@ def ref():
     L.ref_check_crc_bytes.argtypes = [_u8p, C.c_int]
     L.ref_freq_interleaver.argtypes = [_i16p]
     L.ref_phase_table.argtypes = [_f32p]
+    L.ref_uep_table.argtypes = [_i16p]
     _ref = L
     return L
 

@@ -99,3 +99,22 @@ def test_random_fibs_never_crash_and_match_oracle():
         fibs[:, 0] &= 0x1F                                    # force FIG type 0 on the first FIG to reach the parsers often
         crc = np.ones(6, np.uint8)
         assert _dx_parse(fibs, crc) == _oracle_parse(fibs, crc)
+
+
+def test_short_form_table_is_the_references_own():
+    """tests/golden/ref_leaf_vectors.npz holds cProtLevelTable read out of the reference header (fib_table.h:51-117) through
+    oracle/_ref; every row must come back from dabx_parse_fibs and from the oracle walk."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_leaf_vectors.npz"))
+    table = G["uep_table"]
+    assert table.shape == (64, 3)
+    for idx, (cu, lvl, kbps) in enumerate(table.tolist()):
+        one = bytes([0x01]) + _fig01_short(idx, 100, idx)
+        f1 = _fib([bytes([len(one)]) + one])
+        got = _dx_parse(f1[None], np.ones(1, np.uint8))[0]
+        assert got == [(idx, 100, cu, kbps, lvl, 1, -1)], idx
+        assert _oracle_parse(f1[None], np.ones(1, np.uint8))[0] == got
+    if ol.have_ref():                                          # and the fixture is what the reference holds right now
+        live = np.zeros(192, np.int16)
+        ol.ref().ref_uep_table(live)
+        assert np.array_equal(live.reshape(64, 3), table)
