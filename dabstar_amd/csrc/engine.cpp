@@ -31,6 +31,8 @@ struct dabx_engine {
   std::vector<int> subch_id_host;              // [S][max_subch] SubChId (host only: ETI STC field)
   struct EtiCursor { long long next_cif = -1; int hi = -1, lo = -1; long long fib_frames_seen = 0; };
   std::vector<EtiCursor> eti;                  // [S]
+  std::vector<dabx_tii *> tii;                 // [S] detectors, created on first dabx_read_tii
+  std::vector<int> tii_epoch;                  // [S] reset epoch seen by the detector
   std::vector<void *> allocs;
   int max_kbps = 0;
   bool buffers_ready = false;
@@ -118,6 +120,10 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&e->snap_buf[0], S));
   A(e->alloc(&e->snap_buf[1], S));
   d.snap = e->snap_buf[0];
+  A(e->alloc(&d.tii_acc, (size_t)S * TU));
+  A(e->alloc(&d.tii_cnt, (size_t)S * 2));
+  e->tii.assign((size_t)S, nullptr);
+  e->tii_epoch.assign((size_t)S, 0);
   A(e->alloc(&d.cp_part, (size_t)S * 75));
   A(e->alloc(&d.abs_part, (size_t)S * 76));
   A(e->alloc(&d.fic_sym, (size_t)S * 3 * K2));
@@ -158,6 +164,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.b) { (void)hipStreamSynchronize(e->ss.b); (void)hipStreamDestroy(e->ss.b); }
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
+  for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
   for (void *p : e->allocs) (void)hipFree(p);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
@@ -483,6 +490,28 @@ int dabx_read_eti(dabx_engine *e, int stream, int max_frames, uint8_t *out, int3
     n++;
   }
   return n;
+}
+
+int dabx_read_tii(dabx_engine *e, int stream, int min_frames, int threshold_db, int collisions, int collision_sub_id,
+                  dabx_tii_result *out, int max_out, int32_t *frames_accumulated)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || (!out && max_out > 0) || max_out < 0) return DABX_E_ARG;
+  if (!e->dev.tii_acc) { set_error("dabx_read_tii: engine has no TII accumulator"); return DABX_E_STATE; }
+  if (int rc = sync_all(e)) return rc;
+  int32_t cnt[2];
+  DABX_HIP(hipMemcpy(cnt, e->dev.tii_cnt + 2 * stream, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (frames_accumulated) *frames_accumulated = cnt[0];
+  dabx_tii *&t = e->tii[(size_t)stream];
+  if (!t) { if (int rc = dabx_tii_create(&t)) return rc; e->tii_epoch[(size_t)stream] = cnt[1]; }
+  if (cnt[1] != e->tii_epoch[(size_t)stream]) { dabx_tii_reset(t); e->tii_epoch[(size_t)stream] = cnt[1]; }   // lock was lost meanwhile
+  if (cnt[0] < std::max(1, min_frames)) return 0;
+  std::vector<float> acc(2 * (size_t)TU);
+  DABX_HIP(hipMemcpy(acc.data(), e->dev.tii_acc + (size_t)stream * TU, sizeof(float2) * TU, hipMemcpyDeviceToHost));
+  DABX_HIP(hipMemset(e->dev.tii_acc + (size_t)stream * TU, 0, sizeof(float2) * TU));
+  DABX_HIP(hipMemset(e->dev.tii_cnt + 2 * stream, 0, sizeof(int32_t)));
+  dabx_tii_set_collisions(t, collisions, collision_sub_id);
+  dabx_tii_add(t, acc.data());
+  return dabx_tii_process(t, threshold_db, out, max_out);
 }
 
 int dabx_read_soft(dabx_engine *e, int stream, int16_t *soft)

@@ -85,6 +85,8 @@ struct EngineDev {
   uint8_t *sf_out;                // [S][max_subch][SF_SLOTS][sf_stride]
   int16_t *soft_cap;              // [S][75][3072] or null
   BatchSnap *snap;                // [S] counters of the MSC batch being decoded
+  float2 *tii_acc;                // [S][2048] sum of the FFTs of the TII null symbols (TiiDetector::mNullSymbolBufferVec)
+  int32_t *tii_cnt;               // [S][2] null symbols in the sum; detector-reset epoch (bumped on loss of lock)
 };
 
 // ---- uniform-profile fast path of the MSC decoder (vit_t.hip) -----------------------------------------------

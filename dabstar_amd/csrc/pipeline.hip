@@ -49,6 +49,10 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
     e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
   }
   for (int i = lane; i < TU; i += 64) e.demap.null_power[(size_t)s * TU + i] = 0.f;
+  if (e.tii_acc) {                     // mTiiDetector.reset(); mTiiCounter = 0 (dab_processor.cpp:150-152)
+    for (int i = lane; i < TU; i += 64) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
+    if (lane == 0) { e.tii_cnt[2 * s] = 0; e.tii_cnt[2 * s + 1]++; }
+  }
 
   __shared__ float chunk[256];
   __shared__ float env[64];
@@ -407,6 +411,14 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   an = block_sum(an, red, tid);
   fft2048<false>(v, lds, t.twiddle, tid);
   const bool is_tii = (c.cif_count & 7) >= 4;              // :274
+  if (is_tii && e.tii_acc) {                               // add_to_tii_buffer, dab_processor.cpp:287
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      float2 *a = &e.tii_acc[(size_t)s * TU + tid + 256 * u];
+      *a = make_float2(a->x + v[u].x, a->y + v[u].y);
+    }
+    if (tid == 0) e.tii_cnt[2 * s]++;
+  }
   if (!is_tii) {                                           // store_null_symbol_without_tii
     const float kMinNoisePower = (1.0f / 32767.0f) * (1.0f / 32767.0f);
 #pragma unroll

@@ -161,6 +161,13 @@ static float prs_phi(int k)
   return (float)(M_PI / 2.0) * (float)(kPrsH[i][(k - kp) & 15] + n);   // phasetable.cpp:122-135
 }
 
+// (h + n) mod 4 of carrier k (quarter turns of the phase reference), for the TII pair table (tii.cpp)
+int prs_quarter_turns(int k)
+{
+  if (k == 0 || k < -768 || k > 768) return 0;
+  return (int)lroundf(prs_phi(k) / (float)(M_PI / 2.0)) & 3;
+}
+
 static void host_dft(std::vector<double> &re, std::vector<double> &im, bool inverse)
 {
   const int N = TU;

@@ -30,6 +30,12 @@ def load(build_if_missing=True):
         raise DabxError("libdabx.so is missing: run `python -m dabstar_amd.build` (needs hipcc)")
     L = C.CDLL(lib_path())
     L.dabx_last_error.restype = C.c_char_p
+    for name in ("dabx_tii_destroy", "dabx_tii_reset"):
+        getattr(L, name).argtypes = [C.c_void_p]
+        getattr(L, name).restype = None
+    L.dabx_tii_set_collisions.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.dabx_tii_add.argtypes = [C.c_void_p, C.c_void_p]
+    L.dabx_tii_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     for name in ("dabx_convert_iq_bytes", "dabx_feed_bytes", "dabx_feed_bound"):
         getattr(L, name).restype = C.c_longlong
     L.dabx_feed_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -185,6 +191,49 @@ class SubchStats(C.Structure):
                                          "fc_corrected", "au_ok", "au_bad")] + [("active", C.c_int32), ("subch_id", C.c_int32)]
 
 
+class TiiResult(C.Structure):
+    _fields_ = [("main_id", C.c_uint8), ("sub_id", C.c_uint8), ("strength", C.c_float), ("phase_deg", C.c_float),
+                ("non_etsi_phase", C.c_int32)]
+
+    def as_tuple(self):
+        return (self.main_id, self.sub_id, self.strength, self.phase_deg, self.non_etsi_phase)
+
+
+class Tii:
+    """Host-side TII detector (dabx_tii_*): TiiDetector of the reference."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(load().dabx_tii_create(C.byref(self._h)))
+
+    def reset(self):
+        load().dabx_tii_reset(self._h)
+
+    def set_collisions(self, on, sub_id=0):
+        load().dabx_tii_set_collisions(self._h, int(on), int(sub_id))
+
+    def add(self, null_fft):
+        v = np.ascontiguousarray(null_fft, np.complex64)
+        assert v.size == 2048
+        check(load().dabx_tii_add(self._h, _p(v)))
+
+    def process(self, threshold_db, max_out=64):
+        out = (TiiResult * max_out)()
+        n = check(load().dabx_tii_process(self._h, int(threshold_db), out, max_out))
+        return [out[i].as_tuple() for i in range(n)]
+
+    def close(self):
+        if self._h and _LIB is not None:
+            _LIB.dabx_tii_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class IqFormat(C.Structure):
     """dabx_iq_format: family 0 raw / 1 wav / 2 uff; container 0 u8, 1 s8, 2 i16, 3 i24, 4 i32, 5 f32."""
     _fields_ = [("family", C.c_int32), ("container", C.c_int32), ("big_endian", C.c_int32), ("swap_iq", C.c_int32),
@@ -290,6 +339,13 @@ class Engine:
         st = SubchStats()
         check(load().dabx_get_subch_stats(self._h, stream, j, C.byref(st)))
         return {k: getattr(st, k) for k, _ in SubchStats._fields_}
+
+    def read_tii(self, stream, min_frames=1, threshold_db=6, collisions=False, collision_sub_id=0, max_out=64):
+        out = (TiiResult * max_out)()
+        acc = C.c_int32(0)
+        n = check(load().dabx_read_tii(self._h, stream, min_frames, threshold_db, int(collisions), collision_sub_id, out, max_out,
+                                       C.byref(acc)))
+        return [out[i].as_tuple() for i in range(n)], acc.value
 
     def read_eti(self, stream, max_frames=32):
         out = np.zeros((max_frames, 6144), np.uint8)

@@ -262,6 +262,29 @@ int  dabx_eti_frame(int cif_hi, int cif_lo, int minor, const dabx_subch_desc *sc
  * already left the rings: call at least every min(out_frames, 8) processed frames.  Returns the frame count. */
 int  dabx_read_eti(dabx_engine *e, int stream, int max_frames, uint8_t *out, int32_t *lost_cifs);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * TII: TiiDetector, base/ofdm/tii_detector.h:26-37, .cpp:149-240.  Host only: the engine
+ * accumulates the FFT of every TII null symbol ((CIF count & 7) >= 4, dab_processor.cpp:273-300) on the device;
+ * dabx_read_tii hands the sum to the stream's detector once `min_frames` of them are in (DabProcessor's
+ * tiiFramesToCount) and returns the transmitters found, strongest first. */
+typedef struct {
+  uint8_t main_id, sub_id;   /* STiiResult */
+  float strength, phase_deg;
+  int32_t non_etsi_phase;
+} dabx_tii_result;
+typedef struct dabx_tii dabx_tii;
+int  dabx_tii_create(dabx_tii **out);
+void dabx_tii_destroy(dabx_tii *t);
+void dabx_tii_reset(dabx_tii *t);
+void dabx_tii_set_collisions(dabx_tii *t, int on, int sub_id);       /* set_detect_collisions, set_subid_for_collision_search */
+int  dabx_tii_add(dabx_tii *t, const float *null_fft /* 2048 cf32 */);   /* add_to_tii_buffer */
+int  dabx_tii_process(dabx_tii *t, int threshold_db, dabx_tii_result *out, int max_out);   /* process_tii_data */
+/* Returns the number of results (0 while fewer than min_frames TII null symbols have been accumulated);
+ * *frames_accumulated (optional) = the count before the call.  A loss of lock resets the detector like
+ * dab_processor.cpp:150-152. */
+int  dabx_read_tii(dabx_engine *e, int stream, int min_frames, int threshold_db, int collisions, int collision_sub_id,
+                   dabx_tii_result *out, int max_out, int32_t *frames_accumulated);
+
 #ifdef __cplusplus
 }
 #endif

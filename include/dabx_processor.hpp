@@ -25,6 +25,7 @@ struct ProcessorParams {                    // ProcessParams subset (base/main/d
   int ring_frames = 12;            // IQ ring capacity in transmission frames
   int max_services = 64;           // slots for concurrently decoded sub-channels
   int fib_ring_frames = 8;         // frames of FIBs kept for callbacks / ETI
+  int tii_frames_to_count = 5;     //   tiiFramesToCount: TII null symbols summed before the detector runs
 };
 
 class Processor {
@@ -36,6 +37,8 @@ public:
   std::function<void(int subChId, const uint8_t *bytes, int n)> on_logical_frame;                 // FrameProcessor::add_to_frame
   std::function<void(int subChId, const uint8_t *bytes, int n)> on_super_frame;                   // Mp4Processor: RS-corrected super frame
   std::function<void(int ficPercent, float freqOffsBbHz, float clockErrHz, float snrDb)> on_status;   // slot_show_fic_status, ..._freq_corr_bb_Hz, ..._clock_error
+
+  std::function<void(const std::vector<dabx_tii_result> &)> on_tii;                                 // signal_show_tii
 
   explicit Processor(const Params &p = Params()) : params_(p)
   {
@@ -94,6 +97,7 @@ public:
     if (frames > 0) {
       deliver_fibs(frames);
       deliver_services();
+      if (tii_on_ && on_tii) deliver_tii();
       if (eti_ && any_service()) write_eti();     // like EtiGenerator: nothing before the FIC has named the sub-channels
       if (on_status) on_status(after.fic_ratio_percent, after.freq_offs_bb_hz, after.clock_err_hz, after.snr_db_est);
     }
@@ -159,6 +163,12 @@ public:
     return n;
   }
 
+  // ---- TII (dab_processor.h:106-109) ---------------------------------------------------------------------------------
+  void set_tii_processing(bool on) { tii_on_ = on; }
+  void set_tii_threshold(uint8_t db) { tii_threshold_ = db; }
+  void set_tii_sub_id(uint8_t sub_id) { tii_sub_id_ = sub_id; }
+  void set_tii_collisions(bool on) { tii_collisions_ = on; }
+
   // ---- ETI (dab_processor.h:82-84) ----------------------------------------------------------------------------------
   bool start_eti_generator(const std::string &path)
   {
@@ -185,6 +195,8 @@ private:
   std::vector<long long> delivered_, sf_delivered_;
   std::FILE *eti_ = nullptr;
   long long eti_frames_ = 0;
+  bool tii_on_ = false, tii_collisions_ = false;
+  int tii_threshold_ = 6, tii_sub_id_ = 0;
 
   bool any_service() const
   {
@@ -236,6 +248,12 @@ private:
         sf_delivered_[j] = st.sf_count;
       }
     }
+  }
+  void deliver_tii()
+  {
+    dabx_tii_result r[64];
+    const int n = dabx_read_tii(eng_, 0, params_.tii_frames_to_count, tii_threshold_, tii_collisions_ ? 1 : 0, tii_sub_id_, r, 64, nullptr);
+    if (n > 0) on_tii(std::vector<dabx_tii_result>(r, r + n));      // dab_processor.cpp:293-297: only non-empty lists are shown
   }
   void write_eti()
   {

@@ -21,6 +21,8 @@ struct ora_receiver {
   int16_t cif[ORA_CIF_BITS];
   ora_cf32 buf[ORA_TN];
   int16_t bits[ORA_2K];
+  /* TiiDetector::mNullSymbolBufferVec + DabProcessor::mTiiCounter (dab_processor.cpp:287-299, never processed here) */
+  ora_cf32 tii_acc[ORA_TU]; int tii_count;
   /* capture */
   ora_rx_capture cap; int cap_alloc; int want_soft;
 };
@@ -193,6 +195,10 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
   memcpy(fin, &r->buf[ORA_TG], sizeof(fin));
   ora_fft2048(fin, fout, 0);
   if (!is_tii) ora_demap_store_null(&r->dm, fout);
+  else {                                                          /* :282-300 add_to_tii_buffer */
+    for (int i = 0; i < ORA_TU; i++) { r->tii_acc[i].re += fout[i].re; r->tii_acc[i].im += fout[i].im; }
+    r->tii_count++;
+  }
 
   if (correction == 0) {                                          /* :246-251 */
     float ce = (float)ORA_INPUT_RATE * ((float)*sample_count / (float)ORA_TF - 1.0f);
@@ -214,6 +220,7 @@ int ora_rx_run(ora_receiver *r, const ora_cf32 *iq, size_t n_samples, int max_fr
     switch (state) {
     case WAIT_SYNC: {                                            /* :146-160 */
       ora_demap_reset(&r->dm);
+      memset(r->tii_acc, 0, sizeof(r->tii_acc)); r->tii_count = 0;   /* mTiiDetector.reset(), :150-152 */
       sample_count = 0; sync_thr = r->threshold;
       const int ok = time_sync(r);
       if (ok < 0) return frames;
@@ -255,4 +262,14 @@ int ora_rx_run(ora_receiver *r, const ora_cf32 *iq, size_t n_samples, int max_fr
     }
   }
   return frames;
+}
+
+/* accumulated TII null-symbol spectrum (2048 cf32) and the number of null symbols in it; clears both */
+int ora_rx_take_tii(ora_receiver *r, ora_cf32 *out)
+{
+  const int n = r->tii_count;
+  memcpy(out, r->tii_acc, sizeof(r->tii_acc));
+  memset(r->tii_acc, 0, sizeof(r->tii_acc));
+  r->tii_count = 0;
+  return n;
 }

@@ -11,6 +11,7 @@
 #include "crc.h"
 #include "freq_interleaver.h"
 #include "phasetable.h"
+#include "tii_detector.h"
 #include "fib_table.h"          // cProtLevelTable: the short-form (UEP) sub-channel table of FIG 0/1
 #include <cstring>
 #include <vector>
@@ -110,6 +111,34 @@ void ref_uep_table(int16_t * out192)     // 64 x {CU size, protection level, bit
   for (int i = 0; i < 64; i++) {
     out192[3 * i] = cProtLevelTable[i].CUSize; out192[3 * i + 1] = cProtLevelTable[i].ProtLevel; out192[3 * i + 2] = cProtLevelTable[i].BitRate;
   }
+}
+
+// ---- TiiDetector (base/ofdm/tii_detector.cpp, compiled unmodified) ----------------------------------------
+void * ref_tii_new() { return new TiiDetector(); }
+void ref_tii_free(void * p) { delete static_cast<TiiDetector *>(p); }
+void ref_tii_reset(void * p) { static_cast<TiiDetector *>(p)->reset(); }
+void ref_tii_set(void * p, int collisions, int sub_id)
+{
+  static_cast<TiiDetector *>(p)->set_detect_collisions(collisions != 0);
+  static_cast<TiiDetector *>(p)->set_subid_for_collision_search((u8)sub_id);
+}
+void ref_tii_add(void * p, const float * null_fft4096)
+{
+  TArrayTu v;
+  memcpy(v.data(), null_fft4096, sizeof(float) * 4096);
+  static_cast<TiiDetector *>(p)->add_to_tii_buffer(v);
+}
+// out: n x {mainId, subId, strength, phaseDeg, isNonEtsi} as 5 floats
+int ref_tii_process(void * p, int threshold_db, float * out, int max_out)
+{
+  const std::vector<STiiResult> r = static_cast<TiiDetector *>(p)->process_tii_data((i16)threshold_db);
+  int n = 0;
+  for (const auto & e : r) {
+    if (n >= max_out) break;
+    out[5 * n] = e.mainId; out[5 * n + 1] = e.subId; out[5 * n + 2] = e.strength; out[5 * n + 3] = e.phaseDeg; out[5 * n + 4] = e.isNonEtsiPhase ? 1.f : 0.f;
+    n++;
+  }
+  return n;
 }
 
 }  // extern "C"

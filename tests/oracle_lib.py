@@ -76,6 +76,7 @@ def oracle():
     L.ora_rx_run.argtypes = [C.c_void_p, _c64p, C.c_size_t, C.c_int]
     L.ora_rx_enable_soft_capture.argtypes = [C.c_void_p, C.c_int]
     L.ora_rx_get_capture.restype = C.POINTER(RxCapture)
+    L.ora_rx_take_tii.argtypes = [C.c_void_p, _c64p]
     L.ora_rx_get_capture.argtypes = [C.c_void_p]
     L.ora_rx_backend.restype = C.c_void_p
     L.ora_rx_backend.argtypes = [C.c_void_p, C.c_int]
@@ -131,6 +132,12 @@ def ref():
     L.ref_freq_interleaver.argtypes = [_i16p]
     L.ref_phase_table.argtypes = [_f32p]
     L.ref_uep_table.argtypes = [_i16p]
+    L.ref_tii_new.restype = C.c_void_p
+    L.ref_tii_free.argtypes = [C.c_void_p]
+    L.ref_tii_reset.argtypes = [C.c_void_p]
+    L.ref_tii_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ref_tii_add.argtypes = [C.c_void_p, _c64p]
+    L.ref_tii_process.argtypes = [C.c_void_p, C.c_int, _f32p, C.c_int]
     _ref = L
     return L
 

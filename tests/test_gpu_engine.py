@@ -331,3 +331,39 @@ def test_adding_a_service_does_not_disturb_running_ones():
     a2, b2 = eng.subch_stats(0, 0), eng.subch_stats(0, 2)
     assert not a2["active"] and b2["cifs_decoded"] == 12 * 4 - 16 and b2["start_cif"] == 32
     eng.close()
+
+
+def test_tii_null_symbols_are_accumulated_and_identified():
+    """TII (dab_processor.cpp:273-300): the engine sums the FFTs of the TII null symbols on the GPU; dabx_read_tii runs the
+    (reference-pinned) detector on the sum.  Same transmitters, strengths and counts as the detector fed by the oracle
+    receiver's sum; the accumulator restarts after a read."""
+    subch = ds.default_subchannels(18, 64)
+    tx = [(12, 5, 1.0, True), (40, 17, 0.6, True), (63, 20, 0.5, False)]
+    ens = ds.build_ensemble(10, subch, seed=61, tii=tx)
+    x = ds.channel(ens.iq, snr_db=25.0, cfo_hz=60.0, timing_offset=3000, seed=2, n_out=23 * ds.TF)
+    L = ol.oracle()
+    rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    n = L.ora_rx_run(rx, x, len(x), 20)
+    acc = np.zeros(2048, np.complex64)
+    n_tii = L.ora_rx_take_tii(rx, acc)
+    L.ora_rx_destroy(rx)
+    det = dx.Tii()
+    det.add(acc)
+    want = det.process(6)
+    det.close()
+    assert n == 20 and n_tii >= 8
+    assert {(m, c, e) for m, c, _, _, e in want} == {(12, 5, 0), (40, 17, 0), (63, 20, 1)}
+    eng = dx.Engine(n_streams=1, ring_frames=24, max_subch=18, out_frames=4)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    eng.process(12)
+    none, k = eng.read_tii(0, min_frames=100)
+    assert none == [] and 4 <= k <= 6                       # below min_frames: nothing consumed
+    eng.process(8)
+    got, k = eng.read_tii(0, min_frames=4, threshold_db=6)
+    assert k == n_tii
+    assert [(m, c, e) for m, c, _, _, e in got] == [(m, c, e) for m, c, _, _, e in want]
+    for g, w in zip(got, want):
+        assert abs(g[2] - w[2]) <= 2e-3 * w[2] and abs(((g[3] - w[3] + 180) % 360) - 180) < 0.5
+    assert eng.read_tii(0, min_frames=1)[1] == 0            # accumulator was cleared by the read
+    eng.close()

@@ -1,0 +1,119 @@
+"""TII detection (host, CPU): libdabx's dabx_tii_* vs the reference's own TiiDetector object code (oracle/_ref, compiled
+unmodified from base/ofdm/tii_detector.cpp) where /root/reference exists, and vs the golden fixture made from it
+(tests/golden/tii_vectors.npz, tests/golden/make_tii_golden.py) everywhere."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from dabstar_amd import lib as dx
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tools import dab_synth as ds  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "tii_vectors.npz")
+
+
+def scenarios():
+    """name -> (collisions, sub_id, threshold_db, list of rounds; a round = list of null-symbol spectra added before process)"""
+    rng = np.random.default_rng(2026)
+
+    def noise(s=0.02):
+        return (rng.standard_normal(2048) + 1j * rng.standard_normal(2048)) * s
+
+    def sp(*tx, s=0.02):
+        z = noise(s)
+        for (m, c, a, e) in tx:
+            z = z + ds.tii_null_spectrum(m, c, a, e) * np.exp(1j * rng.uniform(0, 2 * np.pi))
+        return z.astype(np.complex64)
+
+    sc = {}
+    sc["single"] = (0, 0, 6, [[sp((12, 5, 1.0, True)) for _ in range(4)] for _ in range(3)])
+    sc["three_tx"] = (0, 0, 6, [[sp((3, 1, 1.0, True), (40, 17, 0.6, True), (69, 23, 0.3, True)) for _ in range(5)] for _ in range(4)])
+    sc["non_etsi"] = (0, 0, 8, [[sp((25, 9, 1.0, False), (7, 2, 0.7, True)) for _ in range(3)] for _ in range(3)])
+    sc["collision_99"] = (1, 4, 6, [[sp((10, 6, 1.0, True), (33, 6, 0.8, True)) for _ in range(4)] for _ in range(3)])
+    sc["collision_list"] = (1, 6, 6, [[sp((10, 6, 1.0, True), (33, 6, 0.8, True)) for _ in range(4)] for _ in range(3)])
+    lone = sp((20, 11, 1.0, True))
+    lone[300] += 40.0                                           # a spur: one strong carrier, no partner in the other blocks
+    lone[301] += 40.0
+    sc["lone_carrier"] = (0, 0, 6, [[lone.copy() for _ in range(3)] for _ in range(2)])
+    sc["noise_only"] = (0, 0, 10, [[sp() for _ in range(4)] for _ in range(2)])
+    sc["weak_low_threshold"] = (0, 0, 2, [[sp((55, 0, 0.08, True), s=0.03) for _ in range(8)] for _ in range(4)])
+    return sc
+
+
+def run_dabx(collisions, sub_id, thr, rounds):
+    t = dx.Tii()
+    t.set_collisions(collisions, sub_id)
+    out = []
+    for r in rounds:
+        for z in r:
+            t.add(z)
+        out.append(t.process(thr))
+    t.close()
+    return out
+
+
+def run_ref(collisions, sub_id, thr, rounds):
+    R = ol.ref()
+    h = R.ref_tii_new()
+    R.ref_tii_set(h, collisions, sub_id)
+    out = []
+    for r in rounds:
+        for z in r:
+            R.ref_tii_add(h, np.ascontiguousarray(z, np.complex64))
+        buf = np.zeros(5 * 64, np.float32)
+        n = R.ref_tii_process(h, thr, buf, 64)
+        out.append([(int(buf[5 * i]), int(buf[5 * i + 1]), float(buf[5 * i + 2]), float(buf[5 * i + 3]), int(buf[5 * i + 4])) for i in range(n)])
+    R.ref_tii_free(h)
+    return out
+
+
+def same(a, b):
+    if len(a) != len(b):
+        return False
+    for x, y in zip(a, b):
+        if len(x) != len(y):
+            return False
+        for p, q in zip(x, y):
+            if p[:2] != q[:2] or p[4] != q[4] or np.float32(p[2]) != np.float32(q[2]) or np.float32(p[3]) != np.float32(q[3]):
+                return False
+    return True
+
+
+@pytest.mark.parametrize("name", sorted(scenarios()))
+def test_matches_the_reference_object_code(name):
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here): the golden test covers it")
+    c, s, thr, rounds = scenarios()[name]
+    got, want = run_dabx(c, s, thr, rounds), run_ref(c, s, thr, rounds)
+    assert same(got, want), (got[-1][:4], want[-1][:4])
+
+
+def test_matches_the_golden_fixture():
+    G = np.load(GOLD)
+    sc = scenarios()
+    assert sorted(sc) == sorted(str(n) for n in G["names"])
+    for name in sc:
+        c, s, thr, rounds = sc[name]
+        got = run_dabx(c, s, thr, rounds)
+        flat = np.array([(ri,) + t for ri, r in enumerate(got) for t in r], np.float64).reshape(-1, 6)
+        want = G["res_" + name]
+        assert flat.shape == want.shape, name
+        assert np.array_equal(flat[:, [0, 1, 2, 5]], want[:, [0, 1, 2, 5]]), name
+        assert np.array_equal(flat[:, 3:5].astype(np.float32), want[:, 3:5].astype(np.float32)), name
+
+
+def test_expected_transmitters_are_found():
+    got = run_dabx(*[scenarios()["three_tx"][i] for i in range(4)])
+    assert [(m, c) for m, c, *_ in got[-1]] == [(3, 1), (40, 17), (69, 23)] and all(t[4] == 0 for t in got[-1])
+    got = run_dabx(*[scenarios()["non_etsi"][i] for i in range(4)])
+    assert {(m, c, e) for m, c, _, _, e in got[-1]} == {(25, 9, 1), (7, 2, 0)}
+    got = run_dabx(*[scenarios()["collision_99"][i] for i in range(4)])
+    assert {(m, c) for m, c, *_ in got[-1]} >= {(99, 6)}
+    got = run_dabx(*[scenarios()["noise_only"][i] for i in range(4)])
+    assert got[-1] == []
+    got = run_dabx(*[scenarios()["lone_carrier"][i] for i in range(4)])
+    assert [(m, c) for m, c, *_ in got[-1]][:1] == [(20, 11)]

@@ -212,6 +212,28 @@ UEP_ROWS = [(k, l) for k, ls in [(32, (5, 4, 3, 2, 1)), (48, (5, 4, 3, 2, 1)), (
                                  (320, (5, 4, 2)), (384, (5, 3, 1))] for l in ls]
 
 
+TII_PATTERNS = [v for v in range(256) if bin(v).count("1") == 4]      # EN 300 401 table 43: 70 combinations, ascending
+
+
+def tii_null_spectrum(main_id: int, sub_id: int, amp: float = 1.0, etsi: bool = True) -> np.ndarray:
+    """FFT-order spectrum (2048 bins) of the TII signal of transmitter (main_id, sub_id), EN 300 401 14.8.1: in each of
+    the four 384-carrier blocks, carrier pairs (k, k+1) at pair index 24 g + sub_id for the four groups g of the pattern;
+    both carriers carry the phase-reference phase of the FIRST one (etsi) or each its own (the deviation some
+    transmitters show, which the reference detects as 'non-ETSI phase')."""
+    prs = prs_spectrum()
+    z = np.zeros(TU, np.complex128)
+    pat = TII_PATTERNS[main_id]
+    for b in range(4):
+        for g in range(8):
+            if pat & (0x80 >> g):
+                i = b * 192 + g * 24 + sub_id
+                k = -768 + 2 * i
+                f0 = k + TU if k < 0 else k + 1
+                z[f0] = amp * prs[f0]
+                z[f0 + 1] = amp * (prs[f0] if etsi else prs[f0 + 1])
+    return z
+
+
 def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndarray:
     """3 FIBs (one FIC group, 96 bytes) for the CIF with the given counter."""
     hi, lo = (cif_count // 250) % 20, cif_count % 250
@@ -267,7 +289,7 @@ class Ensemble:
 
 
 def build_ensemble(n_frames: int = 10, subch: list | None = None, seed: int = 0, cyclic: bool = True,
-                   cif_start: int = 0) -> Ensemble:
+                   cif_start: int = 0, tii: list | None = None) -> Ensemble:
     subch = default_subchannels() if subch is None else subch
     rng = np.random.default_rng(seed)
     n_cif = 4 * n_frames
@@ -321,7 +343,17 @@ def build_ensemble(n_frames: int = 10, subch: list | None = None, seed: int = 0,
     q = ((1 - 2.0 * tx_bits[:, :, :K]) + 1j * (1 - 2.0 * tx_bits[:, :, K:])) / np.sqrt(2)
     iq = np.zeros((n_frames, TF), np.complex64)
     scale = 1.0 / np.sqrt(K)          # unit mean power in the useful part
+    tii_z = None
+    if tii:                               # [(main_id, sub_id, amplitude, etsi)]: sum of the transmitters' TII signals
+        tii_z = sum(tii_null_spectrum(m, c, a, e) for (m, c, a, e) in tii)
     for f in range(n_frames):
+        # the null symbol that opens frame f closes frame f-1: it carries TII when the CIF counter of the last FIG 0/0
+        # of that frame has (count & 7) >= 4 (the receiver's rule, dab_processor.cpp:274)
+        if tii_z is not None and ((cif_start + 4 * ((f - 1) % n_frames if cyclic else f - 1) + 3) & 7) >= 4 and (cyclic or f > 0):
+            t = np.fft.ifft(tii_z) * TU * scale
+            iq[f, 0:TG] = t[-TG:]
+            iq[f, TG:TG + TU] = t
+            iq[f, TG + TU:TN] = t[:TN - TG - TU]
         z = prs.copy()
         pos = TN
         for l in range(L):
