@@ -115,45 +115,117 @@ static int probe_wav(FILE *fp, long long file_len, dabx_iq_format *out)
   }
 }
 
-// minimal XML scanning for the .uff header: find <Tag ...> elements and their attributes (no entities, no CDATA)
-static bool xml_attr(const std::string &elem, const char *name, std::string *val)
-{
+// ---- a small XML reader for the .uff header: element tree with attributes (what QDomDocument gives the reference).
+// Well-formedness is enforced the way QDomDocument::setContent does for these headers: a document that does not parse
+// yields no elements at all, i.e. the defaults and no data block (xml_descriptor.cpp:127-129, 240).
+namespace {
+struct XmlNode {
+  std::string name;
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<XmlNode> kids;
+  std::string attr(const char *key, const char *dflt) const
+  {
+    for (const auto &a : attrs) if (a.first == key) return a.second;
+    return dflt;
+  }
+};
+struct XmlParser {
+  const std::string &d;
   size_t p = 0;
-  const std::string key = std::string(name) + "=";
-  while ((p = elem.find(key, p)) != std::string::npos) {
-    if (p > 0 && !isspace((unsigned char)elem[p - 1])) { p += key.size(); continue; }
-    const size_t q = p + key.size();
-    if (q >= elem.size() || (elem[q] != '"' && elem[q] != '\'')) return false;
-    const size_t e = elem.find(elem[q], q + 1);
-    if (e == std::string::npos) return false;
-    *val = elem.substr(q + 1, e - q - 1);
-    return true;
-  }
-  return false;
-}
-static std::string attr_or(const std::string &elem, const char *name, const char *dflt)
-{
-  std::string v;
-  return xml_attr(elem, name, &v) ? v : std::string(dflt);
-}
-// next element start tag named `tag` at or after *pos; returns its text between '<' and '>' and advances *pos
-static bool xml_next(const std::string &doc, const char *tag, size_t *pos, std::string *elem)
-{
-  const std::string open = std::string("<") + tag;
-  size_t p = *pos;
-  while ((p = doc.find(open, p)) != std::string::npos) {
-    const char c = p + open.size() < doc.size() ? doc[p + open.size()] : '>';
-    if (c == '>' || c == '/' || isspace((unsigned char)c)) {
-      const size_t e = doc.find('>', p);
-      if (e == std::string::npos) return false;
-      *elem = doc.substr(p, e - p);
-      *pos = e + 1;
-      return true;
+  explicit XmlParser(const std::string &doc) : d(doc) {}
+  static bool name_char(char c) { return isalnum((unsigned char)c) || c == '_' || c == '-' || c == '.' || c == ':'; }
+  void skip_ws() { while (p < d.size() && isspace((unsigned char)d[p])) p++; }
+  bool skip_misc()      // whitespace, comments, processing instructions, DOCTYPE
+  {
+    for (;;) {
+      skip_ws();
+      if (d.compare(p, 4, "<!--") == 0) { const size_t e = d.find("-->", p + 4); if (e == std::string::npos) return false; p = e + 3; }
+      else if (d.compare(p, 2, "<?") == 0) { const size_t e = d.find("?>", p + 2); if (e == std::string::npos) return false; p = e + 2; }
+      else if (d.compare(p, 9, "<!DOCTYPE") == 0) { const size_t e = d.find('>', p); if (e == std::string::npos) return false; p = e + 1; }
+      else return true;
     }
-    p += open.size();
   }
-  return false;
-}
+  static std::string unescape(const std::string &v)
+  {
+    std::string o;
+    for (size_t i = 0; i < v.size(); i++) {
+      if (v[i] != '&') { o.push_back(v[i]); continue; }
+      static const char *ent[5][2] = {{"&amp;", "&"}, {"&lt;", "<"}, {"&gt;", ">"}, {"&quot;", "\""}, {"&apos;", "'"}};
+      bool hit = false;
+      for (auto &e : ent) if (v.compare(i, strlen(e[0]), e[0]) == 0) { o += e[1]; i += strlen(e[0]) - 1; hit = true; break; }
+      if (!hit) o.push_back('&');
+    }
+    return o;
+  }
+  // Parses one element into parent.kids.  Like Qt's SAX-driven QDomDocument builder, a node is attached as soon as its
+  // start tag is complete, and a later syntax error stops the parse but leaves everything attached so far in place.
+  bool element(XmlNode &parent, int depth)
+  {
+    if (depth > 32 || p >= d.size() || d[p] != '<') return false;
+    p++;
+    const size_t n0 = p;
+    while (p < d.size() && name_char(d[p])) p++;
+    if (p == n0) return false;
+    XmlNode n;
+    n.name = d.substr(n0, p - n0);
+    bool empty = false;
+    for (;;) {                                            // attributes
+      const size_t before = p;
+      skip_ws();
+      if (p >= d.size()) return false;
+      if (d[p] == '/') { if (p + 1 < d.size() && d[p + 1] == '>') { p += 2; empty = true; break; } return false; }
+      if (d[p] == '>') { p++; break; }
+      if (p == before) return false;                      // attributes must be separated by white space
+      const size_t a0 = p;
+      while (p < d.size() && name_char(d[p])) p++;
+      if (p == a0) return false;
+      const std::string key = d.substr(a0, p - a0);
+      skip_ws();
+      if (p >= d.size() || d[p] != '=') return false;
+      p++;
+      skip_ws();
+      if (p >= d.size() || (d[p] != '"' && d[p] != '\'')) return false;
+      const char q = d[p++];
+      const size_t e = d.find(q, p);
+      if (e == std::string::npos) return false;
+      const std::string val = d.substr(p, e - p);
+      if (val.find('<') != std::string::npos) return false;
+      for (const auto &a : n.attrs) if (a.first == key) return false;      // duplicate attribute
+      n.attrs.emplace_back(key, unescape(val));
+      p = e + 1;
+    }
+    parent.kids.push_back(std::move(n));
+    if (empty) return true;
+    const size_t me = parent.kids.size() - 1;
+    for (;;) {                                            // content
+      const size_t lt = d.find('<', p);
+      if (lt == std::string::npos) return false;
+      p = lt;
+      if (d.compare(p, 4, "<!--") == 0) { const size_t e = d.find("-->", p + 4); if (e == std::string::npos) return false; p = e + 3; continue; }
+      if (d.compare(p, 9, "<![CDATA[") == 0) { const size_t e = d.find("]]>", p); if (e == std::string::npos) return false; p = e + 3; continue; }
+      if (d.compare(p, 2, "<?") == 0) { const size_t e = d.find("?>", p + 2); if (e == std::string::npos) return false; p = e + 2; continue; }
+      if (d.compare(p, 2, "</") == 0) {
+        const std::string &name = parent.kids[me].name;
+        p += 2;
+        if (d.compare(p, name.size(), name) != 0 || (p + name.size() < d.size() && name_char(d[p + name.size()]))) return false;
+        p += name.size();
+        skip_ws();
+        if (p >= d.size() || d[p] != '>') return false;
+        p++;
+        return true;
+      }
+      if (!element(parent.kids[me], depth + 1)) return false;
+    }
+  }
+  // Fills doc.kids[0] with the root element (as far as the text is well formed); false if there is no root at all.
+  bool document(XmlNode &doc)
+  {
+    if (!skip_misc()) return false;
+    (void)element(doc, 0);
+    return !doc.kids.empty();
+  }
+};
+}  // namespace
 
 static int probe_uff(FILE *fp, long long file_len, dabx_iq_format *out)
 {
@@ -166,33 +238,48 @@ static int probe_uff(FILE *fp, long long file_len, dabx_iq_format *out)
     if (c) doc.push_back((char)c);
     if (doc.size() > (1u << 20)) break;
   }
-  // defaults of xml_descriptor.cpp:103-110 and of the attribute getters :160-190
-  int rate = 2048000, bits = 16;
-  std::string container = "i16", ordering = "MSB", iq_order = "IQ", e;
-  size_t p = 0;
-  if (xml_next(doc, "Samplerate", &p, &e)) {
-    const std::string unit = attr_or(e, "Unit", "Hz");
-    const int factor = unit == "Hz" ? 1 : (unit == "KHz" || unit == "Khz") ? 1000 : 1000000;
-    rate = atoi(attr_or(e, "Value", "2048000").c_str()) * factor;
-  }
-  p = 0;
-  if (xml_next(doc, "Channels", &p, &e)) {
-    bits = atoi(attr_or(e, "Bits", "8").c_str());
-    container = attr_or(e, "Container", "u8");
-    ordering = attr_or(e, "Ordering", "N/A");
-    if (atoi(attr_or(e, "Amount", "2").c_str()) != 2) { set_error("uff: only 2-channel recordings are supported"); return DABX_E_ARG; }
-    std::string first, second;
-    if (xml_next(doc, "Channel", &p, &e)) first = attr_or(e, "Value", "I");
-    if (xml_next(doc, "Channel", &p, &e)) second = attr_or(e, "Value", "I");
-    if (first == "I" && second == "Q") iq_order = "IQ";                     // xml_descriptor.cpp:58-75
-    else if (first != "I" && second == "I") iq_order = "QI";
-    else { set_error("uff: single-channel (I-only / Q-only) recordings are not supported"); return DABX_E_ARG; }
-  }
+  // defaults of xml_descriptor.cpp:103-110, attribute defaults of :160-190
+  int rate = 2048000, bits = 16, channels = 2, n_blocks = 0;
   long long n_elements = 0;
-  int n_blocks = 0;
-  p = 0;
-  while (xml_next(doc, "Datablock", &p, &e)) { n_elements += atoll(attr_or(e, "Count", "100").c_str()); n_blocks++; }
-  if (n_blocks == 0) { set_error("uff: no Datablock in the header"); return DABX_E_ARG; }   // xml_descriptor.cpp:240
+  std::string container = "i16", ordering = "MSB", iq_order = "IQ";
+  XmlNode tree;
+  XmlParser px(doc);
+  if (px.document(tree)) {
+    for (const XmlNode &comp : tree.kids[0].kids) {
+      if (comp.name == "Sample") {
+        for (const XmlNode &ch : comp.kids) {
+          if (ch.name == "Samplerate") {
+            const std::string unit = ch.attr("Unit", "Hz");
+            const int factor = unit == "Hz" ? 1 : (unit == "KHz" || unit == "Khz") ? 1000 : 1000000;
+            rate = atoi(ch.attr("Value", "2048000").c_str()) * factor;
+          } else if (ch.name == "Channels") {
+            channels = atoi(ch.attr("Amount", "2").c_str());
+            bits = atoi(ch.attr("Bits", "8").c_str());
+            container = ch.attr("Container", "u8");
+            ordering = ch.attr("Ordering", "N/A");
+            int k = 0;
+            for (const XmlNode &cc : ch.kids) {             // xml_descriptor.cpp:58-75
+              if (cc.name != "Channel") continue;
+              const std::string v = cc.attr("Value", "I");
+              if (k == 0) iq_order = v == "I" ? "I_ONLY" : "Q_ONLY";
+              else if (k == 1 && iq_order == "I_ONLY" && v == "Q") iq_order = "IQ";
+              else if (k == 1 && iq_order == "Q_ONLY" && v == "I") iq_order = "QI";
+              k++;
+            }
+          }
+        }
+      } else if (comp.name == "Datablocks") {
+        n_blocks = 0; n_elements = 0;
+        for (const XmlNode &b : comp.kids)
+          if (b.name == "Datablock") { n_elements += atoll(b.attr("Count", "100").c_str()); n_blocks++; }
+      }
+    }
+  }
+  if (n_blocks == 0) { set_error("uff: header does not parse or names no Datablock"); return DABX_E_ARG; }   // xml_descriptor.cpp:240
+  if (channels != 2 || (iq_order != "IQ" && iq_order != "QI")) {
+    set_error("uff: %d channel(s), order %s: only I+Q recordings are supported", channels, iq_order.c_str());
+    return DABX_E_ARG;
+  }
   memset(out, 0, sizeof(*out));
   out->family = DABX_FAMILY_UFF; out->sample_rate = rate; out->bits = bits;
   out->big_endian = ordering == "MSB"; out->swap_iq = iq_order == "QI";

@@ -12,6 +12,7 @@
 #include "freq_interleaver.h"
 #include "phasetable.h"
 #include "tii_detector.h"
+#include "xml_descriptor.h"     // .uff header parser (QtXml)
 #include "fib_table.h"          // cProtLevelTable: the short-form (UEP) sub-channel table of FIG 0/1
 #include <cstring>
 #include <vector>
@@ -139,6 +140,25 @@ int ref_tii_process(void * p, int threshold_db, float * out, int max_out)
     n++;
   }
   return n;
+}
+
+// ---- XmlDescriptor (devices/filereaders/xml_filereader/xml_descriptor.cpp, compiled unmodified) ----------------
+// ints: sampleRate, nrChannels, bitsperChannel, nrBlocks, ok ; strings (<= 15 chars + NUL each): container, byteOrder, iqOrder
+int ref_uff_describe(const char * path, int32_t * ints, char * strings48, long long * nr_elements)
+{
+  FILE * f = fopen(path, "rb");
+  if (!f) return -1;
+  bool ok = false;
+  XmlDescriptor d(f, &ok);
+  fclose(f);
+  ints[0] = d.sampleRate; ints[1] = d.nrChannels; ints[2] = d.bitsperChannel; ints[3] = ok ? d.nrBlocks : 0; ints[4] = ok ? 1 : 0;
+  memset(strings48, 0, 48);
+  strncpy(strings48, d.container.toUtf8().constData(), 15);
+  strncpy(strings48 + 16, d.byteOrder.toUtf8().constData(), 15);
+  strncpy(strings48 + 32, d.iqOrder.toUtf8().constData(), 15);
+  *nr_elements = 0;
+  if (ok) for (const auto & b : d.blockList) *nr_elements += b.nrElements;
+  return 0;
 }
 
 }  // extern "C"

@@ -132,6 +132,7 @@ def ref():
     L.ref_freq_interleaver.argtypes = [_i16p]
     L.ref_phase_table.argtypes = [_f32p]
     L.ref_uep_table.argtypes = [_i16p]
+    L.ref_uff_describe.argtypes = [C.c_char_p, _i32p, C.c_char_p, C.POINTER(C.c_longlong)]
     L.ref_tii_new.restype = C.c_void_p
     L.ref_tii_free.argtypes = [C.c_void_p]
     L.ref_tii_reset.argtypes = [C.c_void_p]

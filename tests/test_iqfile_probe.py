@@ -1,5 +1,6 @@
 """Recorded-IQ containers, host side (CPU): dabx_probe_iq_file on .raw/.iq, RIFF/WAVE and .uff headers, and the
 oracle's decode + 1-ms linear resampler (reference rules quoted in include/dabx.h)."""
+import ctypes as C
 import os
 import sys
 
@@ -165,3 +166,64 @@ def test_probe_survives_malformed_headers(tmp_path):
             assert f.data_bytes == 0 or (0 <= f.data_offset and f.data_offset + f.data_bytes <= len(b))
         except dx.DabxError:
             pass
+
+
+def _uff_expect_from_descriptor(ints, strs, n_elements, file_len):
+    """What dabx_probe_iq_file must answer given the reference's XmlDescriptor fields (None = refuse)."""
+    rate, nch, bits, n_blocks, ok = ints
+    cont, order, iq = strs
+    code = {"int8": 1, "uint8": 0, "int16": 2, "int24": 3, "int32": 4, "float32": 5}.get(cont)
+    if not ok or n_blocks == 0 or code is None or iq not in ("IQ", "QI") or nch != 2:
+        return None
+    bc = (1, 1, 2, 3, 4, 4)[code]
+    start = file_len - n_elements * bc
+    if start < 2048 or start > 1000000:
+        start = 2048
+    nbytes = max(0, file_len - start)
+    return (2, code, int(order == "MSB"), int(iq == "QI"), bits, rate, start, nbytes - nbytes % (2 * bc))
+
+
+def _uff_probe(path):
+    try:
+        return dx.probe_iq_file(path).as_tuple()
+    except dx.DabxError:
+        return None
+
+
+def _uff_files(tmp_path):
+    import uff_cases
+    for name, hdr in sorted(uff_cases.cases().items()):
+        p = tmp_path / (name + ".uff")
+        raw = hdr + bytes(max(600, 2048 - len(hdr))) + bytes(range(256)) * 8       # header, zero padding, 2048 payload bytes
+        p.write_bytes(raw)
+        yield name, str(p), len(raw)
+
+
+def test_uff_headers_match_the_reference_descriptor(tmp_path):
+    """xml_descriptor.cpp compiled unmodified into oracle/_ref (QtXml): every header variant is described the same way."""
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built here: the golden test covers it")
+    R = ol.ref()
+    for name, path, flen in _uff_files(tmp_path):
+        ints = np.zeros(5, np.int32)
+        strs = C.create_string_buffer(48)
+        nel = C.c_longlong(0)
+        if not (name.startswith("empty") or name.startswith("not_xml")):           # the probe dispatches on "<?xml" / "<SDR"
+            assert R.ref_uff_describe(path.encode(), ints, strs, C.byref(nel)) == 0
+            s3 = [strs.raw[i:i + 16].split(b"\0")[0].decode() for i in (0, 16, 32)]
+            want = _uff_expect_from_descriptor(ints.tolist(), s3, nel.value, flen)
+        else:
+            want = None
+        assert _uff_probe(path) == want, (name, ints.tolist())
+
+
+def test_uff_headers_match_the_golden_fixture(tmp_path):
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "uff_headers.json")))
+    seen = 0
+    for name, path, flen in _uff_files(tmp_path):
+        want = gold[name]
+        got = _uff_probe(path)
+        assert (list(got) if got else None) == want, name
+        seen += 1
+    assert seen == len(gold) >= 40
