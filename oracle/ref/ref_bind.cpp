@@ -151,13 +151,14 @@ int ref_uff_describe(const char * path, int32_t * ints, char * strings48, long l
   bool ok = false;
   XmlDescriptor d(f, &ok);
   fclose(f);
-  ints[0] = d.sampleRate; ints[1] = d.nrChannels; ints[2] = d.bitsperChannel; ints[3] = ok ? d.nrBlocks : 0; ints[4] = ok ? 1 : 0;
+  ints[0] = d.sampleRate; ints[1] = d.nrChannels; ints[2] = d.bitsperChannel; ints[3] = (int)d.blockList.size();      // nrBlocks itself is uninitialised when the header has no <Datablocks> element
+  ints[4] = ok ? 1 : 0;
   memset(strings48, 0, 48);
   strncpy(strings48, d.container.toUtf8().constData(), 15);
   strncpy(strings48 + 16, d.byteOrder.toUtf8().constData(), 15);
   strncpy(strings48 + 32, d.iqOrder.toUtf8().constData(), 15);
   *nr_elements = 0;
-  if (ok) for (const auto & b : d.blockList) *nr_elements += b.nrElements;
+  for (const auto & b : d.blockList) *nr_elements += b.nrElements;
   return 0;
 }
 

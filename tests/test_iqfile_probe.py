@@ -173,7 +173,8 @@ def _uff_expect_from_descriptor(ints, strs, n_elements, file_len):
     rate, nch, bits, n_blocks, ok = ints
     cont, order, iq = strs
     code = {"int8": 1, "uint8": 0, "int16": 2, "int24": 3, "int32": 4, "float32": 5}.get(cont)
-    if not ok or n_blocks == 0 or code is None or iq not in ("IQ", "QI") or nch != 2:
+    # `ok` is not used: XmlDescriptor::nrBlocks is uninitialised when there is no <Datablocks> element (ok = garbage > 0)
+    if n_blocks == 0 or code is None or iq not in ("IQ", "QI") or nch != 2:
         return None
     bc = (1, 1, 2, 3, 4, 4)[code]
     start = file_len - n_elements * bc
