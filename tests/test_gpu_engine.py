@@ -367,3 +367,57 @@ def test_tii_null_symbols_are_accumulated_and_identified():
         assert abs(g[2] - w[2]) <= 2e-3 * w[2] and abs(((g[3] - w[3] + 180) % 360) - 180) < 0.5
     assert eng.read_tii(0, min_frames=1)[1] == 0            # accumulator was cleared by the read
     eng.close()
+
+
+@pytest.mark.parametrize("gap_kind", ["silence", "noise", "shifted"])
+def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind):
+    """DabProcessor FSM (dab_processor.cpp:110-265): a drop-out in the middle of the stream -- PRS correlation fails, back to
+    the null-dip search, demapper reset, coarse CFO again -- must be walked exactly like the oracle receiver walks it:
+    same start indices, same FIB bytes / CRC flags frame by frame, same number of frames."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=71)
+    x = ds.channel(ens.iq, snr_db=18.0, cfo_hz=-1333.0, timing_offset=5555, seed=7, n_out=34 * ds.TF).copy()
+    rng = np.random.default_rng(5)
+    a, b = int(11.3 * ds.TF), int(13.1 * ds.TF)
+    if gap_kind == "silence":
+        x[a:b] = 0
+    elif gap_kind == "noise":
+        x[a:b] = ((rng.standard_normal(b - a) + 1j * rng.standard_normal(b - a)) * 0.2).astype(np.complex64)
+    else:                                                   # the transmitter jumps: 0.37 frame of samples vanish
+        x = np.concatenate([x[:a], x[a + int(0.37 * ds.TF):]])
+    ora = _oracle_run(x, subch)
+    eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=18, out_frames=4)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    fibs, crc, starts, fbbs, idle, steps = [], [], [], [], 0, 0
+    while idle < 4 and steps < 400:                         # a step without a frame is an acquisition pass: keep going
+        before = eng.stats(0)
+        eng.process(1)
+        st = eng.stats(0)
+        steps += 1
+        idle = idle + 1 if st["samples_consumed"] == before["samples_consumed"] else 0
+        if st["frames"] > before["frames"]:
+            f, c = eng.read_fibs(0, 1)
+            fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
+    fibs, crc, starts, fbbs = np.array(fibs), np.array(crc), np.array(starts), np.array(fbbs)
+    n = min(len(fibs), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 24, (len(fibs), ora["n"], steps)
+    assert eng.counters()["sync_lost"] >= 1
+    # The null-dip search after the loss compares against SampleReader's signal level, a per-sample IIR over every sample
+    # ever read (sample_reader.cpp:246-248); the engine tracks it per symbol chunk (DESIGN 3, k_frame_tail), so the search
+    # may stop a sample or two earlier or later.  The PRS correlation then lands on the SAME absolute sample: the start
+    # index of that one frame moves by the same amount and everything decoded from it is identical.
+    d = starts[:n].astype(int) - ora["start"][:n].astype(int)
+    first_after = 11                                         # frames 0..10 precede the drop-out
+    assert np.all(d[np.arange(n) != first_after] == 0) and abs(d[first_after]) <= 2, d
+    assert np.array_equal(crc[:n], ora["crc"][:n])
+    assert np.array_equal(fibs[:n], ora["fibs"][:n])
+    assert abs(fbbs[n - 1] - ora["fbb"][n - 1]) < 1.0 and abs(fbbs[n - 1] + 1333.0) < 2.0     # same CFO estimate at the end
+    assert crc[n - 6:n].all() and not crc[:n].all()         # locked again at the end
+    if len(fibs) == ora["n"]:                               # the back ends ran straight through the drop-out on both sides
+        k = 4 * ora["n"] - 16
+        for j in (0, 8, 17):
+            o = ora["msc"][j].reshape(-1, 192)
+            if len(o) == k:
+                assert np.array_equal(eng.read_msc(0, j, 24), o[k - 24:k]), j
+    eng.close()
