@@ -92,8 +92,14 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
           level += a - env[(idx - 50) & 63];
           ++idx;
           ++counter;
-          if (phase == 2 && counter > TF) { s_done = 1; s_ok = 0; }                       // NO_DIP_FOUND
-          else if (phase == 3 && counter > TN + 50 + 20) { s_done = 1; s_ok = 0; }       // NO_END_OF_DIP_FOUND
+          if ((phase == 2 && counter > TF) || (phase == 3 && counter > TN + 50 + 20)) {   // NO_DIP_FOUND / NO_END_OF_DIP_FOUND
+            // dab_processor.cpp:154-160 tries again at once.  Do the same inside this step while the next attempt's
+            // worst case is still in the ring and less than a frame has gone by: a stream in a drop-out then walks
+            // through it at the pace of the others (one attempt is only T_n + 121 samples long in silence).
+            if (avail - (unsigned long long)consumed >= (unsigned long long)ACQ_NEED && consumed < TF) {
+              phase = 1; remain = 50; counter = 0; idx = 0; level = 0.f;
+            } else { s_done = 1; s_ok = 0; }
+          }
         }
       }
       s_consumed = consumed;

@@ -23,7 +23,7 @@ void ora_fft2048(const ora_cf32 *in, ora_cf32 *out, int inverse)
     for (int i = 0; i < N / 2; i++) { g_tw_re[i] = cos(2.0 * M_PI * i / N); g_tw_im[i] = -sin(2.0 * M_PI * i / N); }
     g_tw_ready = 1;
   }
-  static double re[ORA_TU], im[ORA_TU];
+  double re[ORA_TU], im[ORA_TU];          /* on the stack: receivers may run on several threads (bench cpu_baseline) */
   for (int i = 0; i < N; i++) {
     unsigned r = 0;
     for (int b = 0; b < LOGN; b++) r |= ((i >> b) & 1u) << (LOGN - 1 - b);
@@ -78,8 +78,8 @@ void ora_phaseref_init(ora_phaseref *p)
 /* phasereference.cpp:87-213 */
 int ora_phaseref_correlate(ora_phaseref *p, const ora_cf32 *v, float threshold)
 {
-  static ora_cf32 a[ORA_TU], b[ORA_TU];
-  static float peak[ORA_TU];
+  ora_cf32 a[ORA_TU], b[ORA_TU];
+  float peak[ORA_TU];
   ora_fft2048(v, a, 0);
   for (int i = 0; i < ORA_TU; i++) {       /* X * conj(ref), :97-100 */
     b[i].re = a[i].re * p->ref[i].re + a[i].im * p->ref[i].im;
@@ -112,7 +112,7 @@ int ora_phaseref_correlate(ora_phaseref *p, const ora_cf32 *v, float threshold)
 /* phasereference.cpp:223-280 */
 int ora_phaseref_coarse_cfo(ora_phaseref *p, const ora_cf32 *fft_sym0)
 {
-  static ora_cf32 a[ORA_TU], b[ORA_TU];
+  ora_cf32 a[ORA_TU], b[ORA_TU];
   int index = ORA_IDX_NOT_FOUND;
   float max = 0, avg = 0;
   relative_phase(a, fft_sym0);

@@ -148,7 +148,7 @@ static void msc_process_block(ora_receiver *r, const int16_t *bits, int blk)
 /* dab_processor.cpp:191-265 + :304-367 + :267-302 ; returns 0 at end of input */
 static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_no)
 {
-  static ora_cf32 fin[ORA_TU], fout[ORA_TU];
+  ora_cf32 fin[ORA_TU], fout[ORA_TU];
   memcpy(fin, r->buf, sizeof(fin));
   ora_fft2048(fin, fout, 0);
   ora_demap_store_ref(&r->dm, fout);                              /* :199-202 */

@@ -421,3 +421,52 @@ def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind):
             if len(o) == k:
                 assert np.array_equal(eng.read_msc(0, j, 24), o[k - 24:k]), j
     eng.close()
+
+
+def test_streams_in_different_states_and_configurations_do_not_interact():
+    """One engine, four streams: a different ensemble and sub-channel set on each (per-stream dabx_set_subchannels), one
+    stream that receives its samples late, one with a drop-out, one left without any samples.  Every stream must produce
+    exactly what a single-stream engine produces on the same samples."""
+    mixed = _mixed_subchannels()
+    full = ds.default_subchannels(18, 64)
+    few = [full[2], full[9]]
+    cfgs = [full, mixed, few, full]
+    xs = []
+    for s, cfg in enumerate(cfgs[:3]):
+        ens = ds.build_ensemble(10, full if cfg is few else cfg, seed=80 + s)
+        xs.append(ds.channel(ens.iq, snr_db=17.0 + 3 * s, cfo_hz=500.0 * (s - 1), timing_offset=40000 * s + 77, seed=30 + s, n_out=21 * ds.TF).copy())
+    xs[2][int(8.2 * ds.TF):int(9.9 * ds.TF)] = 0                      # stream 2 loses lock for a while
+    late = 6 * ds.TF                                                   # stream 1 gets nothing for the first 6 steps
+    eng = dx.Engine(n_streams=4, ring_frames=22, max_subch=18, out_frames=4)
+    for s in range(4):
+        eng.set_subchannels(cfgs[s], stream=s)
+    eng.push_iq(0, xs[0])
+    eng.push_iq(2, xs[2])
+    eng.process(6)
+    assert eng.stats(1)["frames"] == 0 and eng.stats(3)["frames"] == 0 and eng.stats(0)["frames"] >= 4
+    eng.push_iq(1, xs[1])
+    for _ in range(30):
+        eng.process(3)
+    del late
+    for s in range(3):
+        ref = dx.Engine(n_streams=1, ring_frames=22, max_subch=18, out_frames=4)
+        ref.set_subchannels(cfgs[s])
+        ref.push_iq(0, xs[s])
+        for _ in range(32):
+            ref.process(3)
+        a, b = eng.stats(s), ref.stats(0)
+        for key in ("frames", "samples_consumed", "fib_ok", "fib_total", "sf_ok", "sf_fail", "rs_corrected", "au_ok", "au_bad",
+                    "cifs_decoded", "last_start_index", "cif_count"):
+            assert a[key] == b[key], (s, key, a[key], b[key])
+        assert a["frames"] >= 15, (s, a["frames"], a["state"])
+        fa, fb = eng.read_fibs(s, 4), ref.read_fibs(0, 4)
+        assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1]), s
+        eng.subch = ref.subch = list(cfgs[s])
+        for j in range(len(cfgs[s])):
+            assert np.array_equal(eng.read_msc(s, j, 16), ref.read_msc(0, j, 16)), (s, j)
+            if getattr(cfgs[s][j], "dab_plus", 1):
+                assert np.array_equal(eng.read_superframes(s, j, 2), ref.read_superframes(0, j, 2)), (s, j)
+            assert eng.subch_stats(s, j) == ref.subch_stats(0, j), (s, j)
+        ref.close()
+    assert eng.stats(3)["frames"] == 0 and eng.stats(3)["samples_consumed"] == 0
+    eng.close()
