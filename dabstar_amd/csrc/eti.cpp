@@ -28,6 +28,14 @@ extern "C" int dabx_eti_frame(int cif_hi, int cif_lo, int minor, const dabx_subc
     set_error("dabx_eti_frame: bad argument");
     return DABX_E_ARG;
   }
+  for (int i = 0; i < n_subch; i++) {
+    const dabx_subch_desc &q = sc[i];
+    const bool lvl_ok = q.short_form ? (q.prot_level >= 1 && q.prot_level <= 5) : (q.prot_level >= 0 && q.prot_level <= 7);
+    if (!lvl_ok || q.subch_id < 0 || q.subch_id > 63 || q.cu_start < 0 || q.cu_start > 863 || q.kbps <= 0 || q.kbps > 1023 || !msc[i]) {
+      set_error("dabx_eti_frame: sub-channel %d is not a legal description", i);
+      return DABX_E_ARG;
+    }
+  }
   int fl = 0, mst = 96;
   for (int i = 0; i < n_subch; i++) { fl += sc[i].kbps * 3 / 4; mst += sc[i].kbps * 3; }
   if (4 + 4 + 4 * n_subch + 4 + mst + 8 > 6144) { set_error("dabx_eti_frame: %d bytes of sub-channel data do not fit an ETI frame", mst); return DABX_E_ARG; }

@@ -85,6 +85,7 @@ static void walk_fib(const uint8_t *fib, FibTable &t)
         int used = 2;
         while (used <= len) {
           int o = used * 8 + (pd ? 32 : 16);
+          if (o / 8 + 1 > len + 1) break;                   // service header (SId + component count) runs past the FIG
           const int ncomp = (int)bits(d, o + 4, 4);
           o += 8;
           for (int c = 0; c < ncomp; c++, o += 16) {

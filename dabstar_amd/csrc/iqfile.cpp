@@ -251,7 +251,8 @@ static int probe_uff(FILE *fp, long long file_len, dabx_iq_format *out)
           if (ch.name == "Samplerate") {
             const std::string unit = ch.attr("Unit", "Hz");
             const int factor = unit == "Hz" ? 1 : (unit == "KHz" || unit == "Khz") ? 1000 : 1000000;
-            rate = atoi(ch.attr("Value", "2048000").c_str()) * factor;
+            const long long r = (long long)atoi(ch.attr("Value", "2048000").c_str()) * factor;   // the reference multiplies in int
+            rate = (r < 0 || r > 2000000000ll) ? 0 : (int)r;                                        // 0: refused at feed time
           } else if (ch.name == "Channels") {
             channels = atoi(ch.attr("Amount", "2").c_str());
             bits = atoi(ch.attr("Bits", "8").c_str());

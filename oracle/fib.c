@@ -78,6 +78,7 @@ int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, 
           int used = 2;
           while (used <= (int)len) {
             int o = used * 8 + (pd ? 32 : 16);
+            if (o / 8 + 1 > (int)len + 1) break;            /* service header runs past the FIG */
             const int ncomp = (int)gb(d, o + 4, 4);
             o += 8;
             for (int c = 0; c < ncomp; c++, o += 16) {

@@ -85,3 +85,12 @@ def test_adapter_replays_a_recording_to_eti(tmp_path, select):
         assert last_q is None or q == (last_q + 1) % 40                    # consecutive CIFs, none lost or repeated
         last_q = q
         assert _crc(f[mst:pos]) == (f[pos] << 8 | f[pos + 1])
+
+
+def test_host_parsers_are_clean_under_asan_and_ubsan():
+    """tests/cxx/san_host.cpp: FIB walk, ETI assembly, container probing on mutated headers and the TII detector, built with
+    g++ -fsanitize=address,undefined from the library's own host sources (GPU sanitizers are not available on the pool)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cxx"), "san"], check=True)
+    p = subprocess.run([os.path.join(ROOT, "tests", "cxx", "_build", "san_host")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert p.returncode == 0 and "san_host ok" in p.stdout, (p.returncode, p.stderr[-2000:])
