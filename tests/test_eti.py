@@ -34,7 +34,7 @@ def _random_case(rng, n):
         kbps = int(rng.choice([32, 48, 64, 96, 128]))
         lvl = int(rng.integers(1, 6)) if short else int(rng.integers(0, 8))
         subch.append(dx.SubchDesc(int(rng.integers(0, 64)), start, 48, kbps, lvl, short, 1, 0))
-        start += int(rng.integers(48, 200))
+        start = min(start + int(rng.integers(48, 200)), 815)
     msc = [rng.integers(0, 256, 3 * s.kbps).astype(np.uint8) for s in subch]
     return subch, rng.integers(0, 256, 96).astype(np.uint8), msc
 
