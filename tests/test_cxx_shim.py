@@ -94,3 +94,18 @@ def test_host_parsers_are_clean_under_asan_and_ubsan():
     p = subprocess.run([os.path.join(ROOT, "tests", "cxx", "_build", "san_host")], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert p.returncode == 0 and "san_host ok" in p.stdout, (p.returncode, p.stderr[-2000:])
+
+
+def test_oracle_receiver_is_clean_under_asan_and_ubsan(tmp_path):
+    """The parity checker itself: whole receiver chain (acquisition, drop-out, FIC, MSC, DAB+ stage, TII sum) on a noisy
+    synthetic recording, built -fsanitize=address,undefined (oracle/Makefile target `san`)."""
+    from tools import dab_synth as ds
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(5, subch, seed=9, tii=[(5, 3, 1.0, True)])
+    x = ds.channel(ens.iq, snr_db=14.0, cfo_hz=911.0, timing_offset=31000, seed=4, n_out=16 * ds.TF).copy()
+    x[int(9.1 * ds.TF):int(10.2 * ds.TF)] = 0
+    path = str(tmp_path / "x.cf32")
+    x.astype(np.complex64).tofile(path)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "san"], check=True)
+    p = subprocess.run([os.path.join(ROOT, "oracle", "_build", "ora_san"), path, "18"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ora_san ok: 1" in p.stdout, (p.returncode, p.stdout, p.stderr[-2000:])
