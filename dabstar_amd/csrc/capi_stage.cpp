@@ -1,4 +1,5 @@
 // capi_stage.cpp -- stage-level C ABI (host-pointer entry points mirroring single reference functions).
+#include <algorithm>
 #include "dabx_internal.h"
 #include <cstring>
 
@@ -56,6 +57,19 @@ int dabx_profile_input_bits(int kbps, int prot_level, int short_form)
   int n = 0;
   const int rc = host_profile_map(kbps, prot_level, short_form, m, &n);
   return rc ? rc : n;
+}
+
+// Host only: the depuncture index list itself (mother-code bit i <- transmitted bit map[i], 0xFFFF = punctured), the table
+// the device kernels gather through; length 96*kbps + 24.  Returns the number of transmitted bits.
+int dabx_profile_map(int kbps, int prot_level, int short_form, uint16_t *map, int max_entries)
+{
+  std::vector<uint16_t> m;
+  int n = 0;
+  const int rc = host_profile_map(kbps, prot_level, short_form, m, &n);
+  if (rc) return rc;
+  if (!map || max_entries < (int)m.size()) { set_error("dabx_profile_map: need room for %d entries", (int)m.size()); return DABX_E_ARG; }
+  std::copy(m.begin(), m.end(), map);
+  return n;
 }
 
 int dabx_deconvolve(const int16_t *in, int in_stride, int kbps, int prot_level, int short_form, int batch, uint8_t *bits)

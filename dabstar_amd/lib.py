@@ -72,6 +72,19 @@ def viterbi(soft, nbits):
     return out
 
 
+def profile_input_bits(kbps, prot_level, short_form=0):
+    return check(load().dabx_profile_input_bits(kbps, prot_level, short_form))
+
+
+def profile_map(kbps, prot_level, short_form=0):
+    """Host only: (transmitted bits, index list as int32 with -1 for punctured positions)."""
+    m = np.zeros(96 * kbps + 24, np.uint16)
+    n = check(load().dabx_profile_map(kbps, prot_level, short_form, _p(m), m.size))
+    out = m.astype(np.int32)
+    out[m == 0xFFFF] = -1
+    return n, out
+
+
 def deconvolve(soft, kbps, prot_level, short_form=0):
     """soft: [batch, cu_size*64] int16 -> [batch, 24*kbps] uint8 (Protection::deconvolve)."""
     n_in = check(load().dabx_profile_input_bits(kbps, prot_level, short_form))

@@ -62,6 +62,10 @@ int dabx_deconvolve(const int16_t *in, int in_stride, int kbps, int prot_level, 
                     uint8_t *bits);
 /* Size in soft bits (cu_size*64) of a legal profile, or DABX_E_PROFILE. */
 int dabx_profile_input_bits(int kbps, int prot_level, int short_form);
+/* Host only: the depuncture index list of a profile (96*kbps + 24 entries: mother-code bit i comes from transmitted bit
+ * map[i], 0xFFFF = punctured) -- EepProtection / UepProtection constructors, eep_protection.cpp:43-150,
+ * uep_protection.cpp:136-196.  Returns the number of transmitted bits. */
+int dabx_profile_map(int kbps, int prot_level, int short_form, uint16_t *map, int max_entries);
 
 /* FicDecoder::process_block x3 (base/decoder/fic_decoder.h:49, .cpp:143-262): soft = batch x 9216
  * int16 (OFDM symbols 1..3); fibs = batch x 12 x 32 bytes (packed, de-dispersed);

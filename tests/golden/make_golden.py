@@ -16,6 +16,14 @@ sys.path.insert(0, os.path.dirname(HERE))
 import oracle_lib as ol  # noqa: E402
 
 
+def viterbi_big_inputs(n):
+    """Seeded soft-bit rows for the long trellises: random, small (many ties), saturating mix, hard +-127."""
+    rng = np.random.default_rng(7000 + n)
+    m = 4 * (n + 6)
+    return np.stack([rng.integers(-200, 201, m), rng.integers(-3, 4, m), rng.choice([-32768, 32767, 300, -300, 0, 127, -127], m),
+                     rng.choice([-127, 127], m)]).astype(np.int16)
+
+
 def main():
     R = ol.ref()
     rng = np.random.default_rng(20261002)
@@ -103,6 +111,33 @@ def main():
         msgs[i, 30], msgs[i, 31] = (c >> 8) & 0xFF, c & 0xFF
     out.update(crc_msgs=msgs, crc_bytes_ok=np.array([R.ref_check_crc_bytes(m_, 30) for m_ in msgs], np.uint8),
                crc_bits_ok=np.array([R.ref_check_crc_bits(np.unpackbits(m_[:32]), 256) for m_ in msgs], np.uint8))
+    # G1 extended: the depuncture map of EVERY profile the reference can hold (EN 300 401 11.3: EEP-A in steps of 8 kbit/s,
+    # EEP-B in steps of 32, the UEP rows of table 8) as (transmitted bits, SHA-256 of the index list).  Above 341 kbit/s the
+    # reference's i16 indices wrap (96 * kbps + 24 > 32767) and its constructors write out of bounds: those are left out.
+    allmaps = {}
+    for kbps in range(8, 337, 8):
+        for prot in range(8):
+            if prot >= 4 and kbps % 32:
+                continue
+            m = np.zeros(96 * kbps + 24, np.int32)
+            n = R.ref_eep_map(kbps, prot, m)
+            allmaps["eep_%d_%d" % (kbps, prot)] = (n, hashlib.sha256(m.tobytes()).hexdigest())
+    for cu, lvl, kbps in uep.reshape(64, 3).tolist():
+        if kbps > 336:
+            continue
+        m = np.zeros(96 * kbps + 24, np.int32)
+        n = R.ref_uep_map(kbps, lvl, m)
+        allmaps["uep_%d_%d" % (kbps, lvl)] = (n, hashlib.sha256(m.tobytes()).hexdigest())
+    out["allmap_names"] = np.array(sorted(allmaps))
+    out["allmap_n_in"] = np.array([allmaps[k][0] for k in sorted(allmaps)], np.int32)
+    out["allmap_sha256"] = np.array([allmaps[k][1] for k in sorted(allmaps)])
+    # G2 extended: 128 and 384 kbit/s trellises; the inputs are regenerated from the seed by the tests (viterbi_big_inputs)
+    for n in (3072, 9216):
+        soft = viterbi_big_inputs(n)
+        bits = np.zeros((len(soft), n), np.uint8)
+        for i in range(len(soft)):
+            R.ref_viterbi(soft[i], n, bits[i])
+        out["vitbig%d_bits" % n] = np.packbits(bits, axis=1)
     np.savez_compressed(os.path.join(HERE, "ref_leaf_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "ref_leaf_vectors.npz"), os.path.getsize(os.path.join(HERE, "ref_leaf_vectors.npz")), "bytes")
 

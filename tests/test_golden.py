@@ -34,6 +34,31 @@ def test_oracle_viterbi_matches_golden(n):
         assert np.array_equal(ol.ora_viterbi(soft[i], n), bits[i]), i
 
 
+@pytest.mark.parametrize("n", [3072, 9216])
+def test_oracle_viterbi_long_trellises_match_golden(n):
+    from golden.make_golden import viterbi_big_inputs
+    soft, bits = viterbi_big_inputs(n), np.unpackbits(G["vitbig%d_bits" % n], axis=1)[:, :n]
+    for i in range(len(soft)):
+        assert np.array_equal(ol.ora_viterbi(soft[i], n), bits[i]), i
+
+
+def test_oracle_maps_of_every_legal_profile_match_golden():
+    assert len(G["allmap_names"]) == 42 * 4 + 10 * 4 + 61         # <= 336 kbit/s: the reference's i16 indices wrap above 341
+    for name, n_in, sha in zip(G["allmap_names"], G["allmap_n_in"], G["allmap_sha256"]):
+        kind, kbps, prot = str(name).split("_")
+        n, m = (ol.ora_eep_map if kind == "eep" else ol.ora_uep_map)(int(kbps), int(prot))
+        assert n == n_in and hashlib.sha256(m.tobytes()).hexdigest() == str(sha), name
+
+
+def test_libdabx_maps_of_every_legal_profile_match_golden():
+    """The product's own depuncture tables (host side, what the kernels gather through) against the reference digests."""
+    from dabstar_amd import lib as dx
+    for name, n_in, sha in zip(G["allmap_names"], G["allmap_n_in"], G["allmap_sha256"]):
+        kind, kbps, prot = str(name).split("_")
+        n, m = dx.profile_map(int(kbps), int(prot), int(kind == "uep"))
+        assert n == n_in and hashlib.sha256(m.tobytes()).hexdigest() == str(sha), name
+
+
 def test_oracle_fec_matches_golden():
     L = ol.oracle()
     for i in range(len(G["rs_in"])):
@@ -55,6 +80,10 @@ def test_hip_matches_golden():
     for n in (768, 1536, 192):
         soft, bits = G["vit%d_soft" % n], np.unpackbits(G["vit%d_bits" % n], axis=1)[:, :n]
         assert np.array_equal(dx.viterbi(soft, n), bits), n
+    from golden.make_golden import viterbi_big_inputs
+    for n in (3072, 9216):
+        bits = np.unpackbits(G["vitbig%d_bits" % n], axis=1)[:, :n]
+        assert np.array_equal(dx.viterbi(viterbi_big_inputs(n), n), bits), n
     for name, kbps, prot, short in (("eep64_2", 64, 2, 0), ("eep32_4", 32, 4, 0), ("uep64_3", 64, 3, 1)):
         bits = np.unpackbits(G["dec_%s_bits" % name], axis=1)[:, :24 * kbps]
         assert np.array_equal(dx.deconvolve(G["dec_%s_soft" % name], kbps, prot, short), bits), name
