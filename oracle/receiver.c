@@ -106,6 +106,15 @@ ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch)
   return r;
 }
 
+/* ProcessParams::threshold (dabradio.cpp:92), sync on strongest peak (configuration.cpp:65), soft-bit type (glob_enums.h:49-56) */
+void ora_rx_configure(ora_receiver *r, float threshold, int sync_strongest, int soft_bit_type)
+{
+  r->threshold = threshold;
+  r->sync_strongest = sync_strongest;
+  ora_phaseref_set_strongest(&r->pr, sync_strongest);
+  ora_demap_set_type(&r->dm, soft_bit_type);
+}
+
 void ora_rx_destroy(ora_receiver *r)
 {
   if (!r) return;

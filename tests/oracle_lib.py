@@ -73,6 +73,7 @@ def oracle():
     L.ora_rx_create.restype = C.c_void_p
     L.ora_rx_create.argtypes = [C.POINTER(SubchDesc), C.c_int]
     L.ora_rx_destroy.argtypes = [C.c_void_p]
+    L.ora_rx_configure.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
     L.ora_rx_run.argtypes = [C.c_void_p, _c64p, C.c_size_t, C.c_int]
     L.ora_rx_enable_soft_capture.argtypes = [C.c_void_p, C.c_int]
     L.ora_rx_get_capture.restype = C.POINTER(RxCapture)

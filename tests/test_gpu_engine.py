@@ -18,9 +18,11 @@ from tools import dab_synth as ds  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_run(x, subch, want_soft=False):
+def _oracle_run(x, subch, want_soft=False, config=None):
     L = ol.oracle()
     rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    if config:
+        L.ora_rx_configure(rx, *config)
     L.ora_rx_enable_soft_capture(rx, int(want_soft))
     n = L.ora_rx_run(rx, x, len(x), 10000)
     cap = L.ora_rx_get_capture(rx).contents
@@ -469,4 +471,29 @@ def test_streams_in_different_states_and_configurations_do_not_interact():
             assert eng.subch_stats(s, j) == ref.subch_stats(0, j), (s, j)
         ref.close()
     assert eng.stats(3)["frames"] == 0 and eng.stats(3)["samples_consumed"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("threshold,strongest,soft_type", [(3.0, 0, 2), (3.0, 0, 3), (4.5, 1, 1), (2.0, 1, 3)])
+def test_receiver_options_follow_the_oracle(threshold, strongest, soft_type):
+    """ProcessParams: sync threshold, sync on the strongest peak, soft-bit generator 1..3 (ofdm_decoder.cpp:231-251) -- through
+    the whole engine: start indices, FIB bytes, MSC bytes bit-exact; soft bits within the demapper tolerance."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=90 + soft_type)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=700.0, timing_offset=66000, seed=11, n_out=22 * ds.TF)
+    ora = _oracle_run(x, subch, want_soft=True, config=(threshold, strongest, soft_type))
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"], sync_threshold=threshold, sync_strongest=bool(strongest),
+                                                    soft_bit_type=soft_type, capture_soft=True)
+    n = min(len(fibs), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 18
+    assert np.array_equal(starts[:n], ora["start"][:n])
+    assert np.array_equal(crc[:n], ora["crc"][:n]) and np.array_equal(fibs[:n], ora["fibs"][:n])
+    assert crc[6:n].all()
+    k = eng.stats(0)["frames"] * 4 - 16
+    for j in (1, 10, 16):
+        o = ora["msc"][j].reshape(-1, 192)
+        assert np.array_equal(eng.read_msc(0, j, 16), o[k - 16:k]), j
+    if len(fibs) == ora["n"]:                               # soft bits of the last frame, same frame on both sides
+        d = np.abs(eng.read_soft(0).astype(int) - ora["soft"][ora["n"] - 1].astype(int))
+        assert d.max() <= 3 and np.mean(d > 1) < 2e-3, (d.max(), np.mean(d > 1))
     eng.close()
