@@ -530,3 +530,42 @@ def test_sample_clock_offset_is_tracked_like_the_oracle(ppm):
     for j in (0, 9, 17):
         assert np.array_equal(eng.read_msc(0, j, 16), ora["msc"][j].reshape(-1, 192)[k - 16:k]), j
     eng.close()
+
+
+@pytest.mark.parametrize("snr", [5.0, 3.8])
+def test_low_snr_error_paths_follow_the_oracle(snr):
+    """Close to the threshold: FIB CRC failures, fire-code misses, RS corrections and RS failures (which leave partially
+    corrected data, reed_solomon.cpp:140-439), bad AU CRCs, super-frame resynchronisation -- every counter of every
+    sub-channel and every byte as in the oracle."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=120)
+    # the recording ends 30 000 samples into a frame: too short for the oracle to finish another CIF, so both sides have
+    # decoded exactly the same CIFs and every counter is comparable
+    x = ds.channel(ens.iq, snr_db=snr, cfo_hz=333.0, timing_offset=20000, seed=17, n_out=25 * ds.TF + 20000 + 30000)
+    ora = _oracle_run(x, subch)
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"])
+    n = min(len(fibs), ora["n"])
+    assert len(fibs) == ora["n"] and n >= 18
+    assert np.array_equal(starts[:n], ora["start"][:n])
+    assert np.array_equal(crc[:n], ora["crc"][:n]) and np.array_equal(fibs[:n], ora["fibs"][:n])
+    compared = 0
+    seen = dict(rs_corrected=0, rs_failed=0, au_bad=0, sf_fail=0)
+    for j in range(18):
+        st, o = eng.subch_stats(0, j), ora["stats"][j]
+        assert st["cifs_decoded"] == o["cif_out"], (j, st["cifs_decoded"], o["cif_out"])
+        compared += 1
+        for a, b in (("sf_ok", "sf_ok"), ("sf_fail", "sf_fail"), ("rs_corrected", "rs_corr"), ("rs_failed", "rs_fail"),
+                     ("fc_corrected", "fc_corr"), ("au_ok", "au_ok"), ("au_bad", "au_bad")):
+            assert st[a] == o[b], (j, a, st[a], o[b])
+        for key in seen:
+            seen[key] += st[key]
+        k = st["cifs_decoded"]
+        assert np.array_equal(eng.read_msc(0, j, 16), ora["msc"][j].reshape(-1, 192)[k - 16:k]), j
+        sf_o = ora["sf"][j].reshape(-1, 880)
+        got = eng.read_superframes(0, j, 3)
+        if len(sf_o) >= 3:
+            assert np.array_equal(got, sf_o[len(sf_o) - 3:]), j
+    assert compared == 18 and seen["rs_corrected"] > 0     # the paths were exercised
+    if snr < 4:
+        assert seen["rs_failed"] + seen["au_bad"] + seen["sf_fail"] > 0, seen
+    eng.close()
