@@ -160,13 +160,14 @@ def test_fic_decode_stage_matches_oracle():
     assert np.array_equal(fibs[0], ens.fibs[0])
 
 
-def test_many_streams_fast_msc_path_matches_single_stream_path(monkeypatch):
+@pytest.mark.parametrize("snr", [18.0, 4.2])
+def test_many_streams_fast_msc_path_matches_single_stream_path(monkeypatch, snr):
     """Lane-per-trellis MSC decoder (vit_t.hip, uniform configuration) vs the wave-per-trellis kernel:
     same IQ through a 24-stream engine forced onto the fast path and through single-stream engines."""
     subch = ds.default_subchannels(18, 64)
     ens = ds.build_ensemble(10, subch, seed=21)
     n_streams, n_frames = 24, 26
-    xs = [ds.channel(ens.iq, snr_db=18.0, cfo_hz=200.0 * (s - 12), timing_offset=7919 * s + 11, seed=100 + s,
+    xs = [ds.channel(ens.iq, snr_db=snr, cfo_hz=200.0 * (s - 12), timing_offset=7919 * s + 11, seed=100 + s,
                      n_out=(n_frames + 3) * ds.TF) for s in range(n_streams)]
     monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "1024")
     eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=18)
@@ -181,7 +182,7 @@ def test_many_streams_fast_msc_path_matches_single_stream_path(monkeypatch):
         ref.push_iq(0, xs[s])
         ref.process(n_frames)
         a, b = eng.stats(s), ref.stats(0)
-        for key in ("frames", "fib_ok", "sf_ok", "sf_fail", "rs_corrected", "au_ok", "cifs_decoded", "last_start_index"):
+        for key in ("frames", "fib_ok", "sf_ok", "sf_fail", "rs_corrected", "rs_failed", "au_ok", "au_bad", "cifs_decoded", "last_start_index"):
             assert a[key] == b[key], (s, key, a[key], b[key])
         assert a["frames"] >= n_frames - 2 and a["sf_ok"] > 0
         for j in (0, 9, 17):
