@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
 __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
 {
   __shared__ float2 lds[FFT_LDS_FLOAT2];
-  __shared__ float red[8];
+  __shared__ float red3[3][4];
   const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;   // l = symbol index - 1
   const StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
@@ -222,11 +222,17 @@ __global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
     v[u] = nco.mix(x);
     nco.step();
   }
-  cre = block_sum(cre, red, tid);
-  cim = block_sum(cim, red, tid);
-  asum = block_sum(asum, red, tid);
-  if (tid == 0) { e.cp_part[(size_t)s * 75 + l] = make_float2(cre, cim); e.abs_part[(size_t)s * 76 + l] = asum; }
+  // the three block sums ride on the FFT's barriers: per-wave partials go to LDS now, thread 0 adds them (in wave order,
+  // as block_sum does) once the transform has synchronised the block
+  cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
+  if ((tid & 63) == 0) { red3[0][tid >> 6] = cre; red3[1][tid >> 6] = cim; red3[2][tid >> 6] = asum; }
   fft2048<false>(v, lds, t.twiddle, tid);                 // :337-338
+  if (tid == 0) {
+    float r[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { float a = 0.f; for (int w = 0; w < 4; w++) a += red3[q][w]; r[q] = a; }
+    e.cp_part[(size_t)s * 75 + l] = make_float2(r[0], r[1]); e.abs_part[(size_t)s * 76 + l] = r[2];
+  }
   float2 *dst = e.spectra + ((size_t)s * 76 + l) * TU;
 #pragma unroll
   for (int u = 0; u < 8; u++) dst[tid + 256 * u] = v[u];
