@@ -35,6 +35,7 @@ struct DevTables {
   uint16_t *fc_syndrome;    // [65536] fire-code burst table                           firecode_checker.cpp:61-144
   uint16_t *fc_crctab;      // [256] CRC table poly 0x782F
   uint16_t *crc_ccitt;      // [256] CRC table poly 0x1021
+  uint16_t *crc_xpow;       // [1024] x^(8 m) mod the CCITT polynomial (a CRC state advanced over m zero bytes)
   uint8_t *gf_exp;          // [512] alpha^i (doubled), [255] = 0 handled in code
   uint8_t *gf_log;          // [256]
 };

@@ -18,6 +18,20 @@ __device__ __forceinline__ bool crc16_check_bytes(const uint8_t *msg, int len, c
   return crc16_ccitt(msg, len, tab) == (uint16_t)((msg[len] << 8) | msg[len + 1]);
 }
 
+// a(x) b(x) mod x^16 + x^12 + x^5 + 1 (carry-less, Horner over the bits of a): moves a CRC-16-CCITT register value over
+// n message bytes when b = x^(8 n) mod P
+__device__ __forceinline__ unsigned crc_mulmod(unsigned a, unsigned b)
+{
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 15; i >= 0; i--) {
+    r <<= 1;
+    if (r & 0x10000u) r ^= 0x11021u;
+    if ((a >> i) & 1u) r ^= b;
+  }
+  return r;
+}
+
 // FirecodeChecker::crc16 (base/backend/firecode_checker.cpp:146-160): bytes 2..10 then 0..1
 template <class Get> __device__ __forceinline__ uint16_t firecode_syndrome(Get get, const uint16_t *fctab)
 {

@@ -535,6 +535,7 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
   long long sf_count = sc.sf_count, sf_ok = 0, sf_fail = 0, rs_corr = 0, rs_fail = 0, fc_corr = 0, au_ok = 0, au_bad = 0;
   __shared__ __attribute__((aligned(16))) uint8_t win[120 * 48 + 16];   // 5 logical frames (<= 384 kbit/s)
   __shared__ uint8_t gexp[512], glog[256];
+  __shared__ uint16_t s_crc[256];                           // CCITT CRC table (serial look-up chains: keep it in LDS)
   __shared__ unsigned syn_or[48];                           // != 0: some syndrome of the code word is non-zero
   __shared__ uint8_t hdr0[12];
   __shared__ int s_flag;
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
     __syncthreads();
     if (!tables_ready) {
       for (int i = lane; i < 512; i += 64) gexp[i] = t.gf_exp[i];
-      for (int i = lane; i < 256; i += 64) glog[i] = t.gf_log[i];
+      for (int i = lane; i < 256; i += 64) { glog[i] = t.gf_log[i]; s_crc[i] = t.crc_ccitt[i]; }
       tables_ready = true;
     }
     for (int f = 0; f < 5; f++) {
@@ -565,19 +566,33 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
       uint32_t *dst = reinterpret_cast<uint32_t *>(win + f * nbytes);
       for (int i = lane; i < nbytes / 4; i += 64) dst[i] = src[i];
     }
-    for (int i = lane; i < R; i += 64) syn_or[i] = 0;
     if (lane < 12) hdr0[lane] = 0;
     __syncthreads();
     if (lane < 11) hdr0[lane] = win[lane];
-    // ---- syndromes: pair p = (root, code word), reed_solomon.cpp:254-290 (Horner, leading zeros skipped)
-    for (int p = lane; p < 10 * R; p += 64) {
-      const int cw = p % R, root = p / R;
-      int sy = 0;
-      for (int k = 0; k < 120; k++) {
-        const int b = win[cw + k * R];
-        sy = (sy == 0) ? b : (b ^ gexp[glog[sy] + root]);
+    // ---- syndromes S_r(j) = XOR_k c_k alpha^(r (119 - k)), r < 10: the Horner recursion of reed_solomon.cpp:254-290 written
+    //      as a sum, lanes over the byte index k (no 120-step dependent look-up chain); only "all ten are zero" is needed
+    //      here, the full decoder below recomputes them for the code words that are not clean
+    for (int j = 0; j < R; j++) {
+      unsigned a0 = 0, a1 = 0, a2 = 0;                        // ten 8-bit sums packed into three words
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = lane + 64 * h;
+        const int b = k < 120 ? win[j + k * R] : 0;
+        if (b) {
+          const int lg = glog[b], m = 119 - k;
+          int ex = 0;
+#pragma unroll
+          for (int r = 0; r < 10; r++) {
+            const unsigned v = gexp[lg + ex];
+            if (r < 4) a0 ^= v << (8 * r); else if (r < 8) a1 ^= v << (8 * (r - 4)); else a2 ^= v << (8 * (r - 8));
+            ex += m;
+            if (ex >= 255) ex -= 255;
+          }
+        }
       }
-      if (sy) atomicOr(&syn_or[cw], 1u);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { a0 ^= __shfl_xor(a0, o); a1 ^= __shfl_xor(a1, o); a2 ^= __shfl_xor(a2, o); }
+      if (lane == 0) syn_or[j] = a0 | a1 | a2;
     }
     __syncthreads();
     // ---- full decoder only where needed (one lane per dirty code word)
@@ -624,14 +639,24 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
       if (flag & 2) fc_corr++;
       sf_sync = 4; sf_ok++;
       const int n_au = s_au[7];
+      // :318-333 AU CRCs.  The CRC register is linear in the message: every lane runs the table recursion over its own
+      // slice from state 0, the slice results are moved to the end of the AU by multiplying with x^(8 n) mod P
+      // (t.crc_xpow) and XOR-ed together with the contribution of the 0xFFFF start value -- calc_crc (crc.cpp:75-86)
+      // without a several-hundred-step look-up chain on one lane.
       int good = 0, bad = 0;
-      if (lane < n_au) {                     // :318-333 AU CRCs, one lane per AU
-        const int st = s_au[lane], len = s_au[lane + 1] - st - 2;
-        if (len > 960 || len < 0 || st + len + 2 > 110 * R) bad = 1;
-        else if (crc16_check_bytes(win + st, len, t.crc_ccitt)) good = 1; else bad = 1;
-      }
+      for (int a = 0; a < n_au; a++) {
+        const int st = s_au[a], len = s_au[a + 1] - st - 2;
+        if (len > 960 || len < 0 || st + len + 2 > 110 * R) { bad++; continue; }
+        const int per = (len + 63) >> 6, from = lane * per, to = min(len, from + per);
+        unsigned crc = 0;
+        for (int i = from; i < to; i++) crc = (s_crc[(win[st + i] ^ (crc >> 8)) & 0xFF] ^ (crc << 8)) & 0xFFFFu;
+        unsigned acc = from < to ? crc_mulmod(crc, t.crc_xpow[len - to]) : 0u;
+        if (lane == 0) acc ^= crc_mulmod(0xFFFFu, t.crc_xpow[len]);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { good += __shfl_xor(good, o); bad += __shfl_xor(bad, o); }
+        for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o);
+        const unsigned want = ((unsigned)win[st + len] << 8) | win[st + len + 1];
+        if (((~acc) & 0xFFFFu) == want) good++; else bad++;
+      }
       au_ok += good; au_bad += bad;
       uint8_t *sfo = e.sf_out + (((size_t)s * e.max_subch + j) * SF_SLOTS + (size_t)(sf_count % SF_SLOTS)) * e.sf_stride;
       for (int i = lane; i < (110 * R + 3) / 4; i += 64)

@@ -299,6 +299,12 @@ static int build_tables(DevTables &t)
   if ((rc = upload(&t.fc_syndrome, syn))) return rc;
   if ((rc = upload(&t.fc_crctab, fctab))) return rc;
   if ((rc = upload(&t.crc_ccitt, cctab))) return rc;
+  {
+    std::vector<uint16_t> xp(1024);
+    uint16_t st = 1;
+    for (int m = 0; m < 1024; m++) { xp[m] = st; st = (uint16_t)(cctab[st >> 8] ^ (uint16_t)(st << 8)); }
+    if ((rc = upload(&t.crc_xpow, xp))) return rc;
+  }
   if ((rc = upload(&t.gf_exp, gexp))) return rc;
   if ((rc = upload(&t.gf_log, glog))) return rc;
   return 0;
