@@ -535,12 +535,16 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
   long long sf_count = sc.sf_count, sf_ok = 0, sf_fail = 0, rs_corr = 0, rs_fail = 0, fc_corr = 0, au_ok = 0, au_bad = 0;
   __shared__ __attribute__((aligned(16))) uint8_t win[120 * 48 + 16];   // 5 logical frames (<= 384 kbit/s)
   __shared__ uint8_t gexp[512], glog[256];
-  __shared__ uint16_t s_crc[256];                           // CCITT CRC table (serial look-up chains: keep it in LDS)
+  __shared__ uint16_t s_crc[256], s_fc[256];                // CCITT and fire-code CRC tables (serial look-up chains: keep them in LDS)
   __shared__ unsigned syn_or[48];                           // != 0: some syndrome of the code word is non-zero
   __shared__ uint8_t hdr0[12];
   __shared__ int s_flag;
   __shared__ int s_au[8];
-  bool tables_ready = false;
+  if (sc.dab_plus) {
+    for (int i = lane; i < 512; i += 64) gexp[i] = t.gf_exp[i];
+    for (int i = lane; i < 256; i += 64) { glog[i] = t.gf_log[i]; s_crc[i] = t.crc_ccitt[i]; s_fc[i] = t.fc_crctab[i]; }
+  }
+  __syncthreads();
   for (long long n = 0; n < n_new; n++) {
     const long long newest = cif_out;        // index of the logical frame just added
     cif_out++;
@@ -550,17 +554,12 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
     const long long oldest = newest - 4;
     if (sf_sync == 0) {                      // :132-142: fire code over the first 11 bytes of the oldest frame
       const uint8_t *f0 = ring + (size_t)(oldest % MSC_SLOTS) * e.msc_stride;
-      const bool ok = firecode_syndrome([&](int i) { return f0[i]; }, t.fc_crctab) == 0;
+      const bool ok = firecode_syndrome([&](int i) { return f0[i]; }, s_fc) == 0;
       if (ok) sf_sync = 4; else { blocks_in_buf = 4; continue; }
     }
     blocks_in_buf = 0;                       // :147
     // ---- stage the window (coalesced 4-byte loads) and the GF tables
     __syncthreads();
-    if (!tables_ready) {
-      for (int i = lane; i < 512; i += 64) gexp[i] = t.gf_exp[i];
-      for (int i = lane; i < 256; i += 64) { glog[i] = t.gf_log[i]; s_crc[i] = t.crc_ccitt[i]; }
-      tables_ready = true;
-    }
     for (int f = 0; f < 5; f++) {
       const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + (size_t)((oldest + f) % MSC_SLOTS) * e.msc_stride);
       uint32_t *dst = reinterpret_cast<uint32_t *>(win + f * nbytes);
@@ -609,7 +608,7 @@ __global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
     if (lane == 0) {
       uint8_t hdr[12];
       for (int i = 0; i < 12; i++) hdr[i] = win[i];
-      const bool ok = firecode_check_and_correct(hdr, t.fc_crctab, t.fc_syndrome);   // :230-240
+      const bool ok = firecode_check_and_correct(hdr, s_fc, t.fc_syndrome);   // :230-240
       int flag = ok ? 1 : 0;
       if (ok) {
         bool changed = false;

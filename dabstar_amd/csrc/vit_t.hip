@@ -21,7 +21,7 @@ __device__ __forceinline__ int bitrev4(int v) { return ((v & 1) << 3) | ((v & 2)
 // with lanes ALONG the run (coalesced; a lane-per-job read would touch 64 different lines per instruction) into
 // LDS; (2) lane = job, pg = plane group: 4 planes x 1 dword -> 4x4 byte transpose in registers (8 v_perm) ->
 // 4 idx-ordered dwords, stored as inT[q][job] (256-B coalesced rows).
-constexpr int PCH = 32;                       // positions per chunk (bytes per plane run); 33 KB of LDS -> 4 blocks per CU
+constexpr int PCH = 32;                       // positions per chunk (bytes per plane run); 33 KB of LDS -> 4 blocks per CU (64: fewer sectors, but 2 blocks per CU is slower)
 constexpr int PJS = 16 * PCH + 4;             // LDS job stride in bytes (+4: conflict-free ds_read across jobs)
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_in, uint32_t *inT)
 {
