@@ -56,20 +56,30 @@ __device__ __forceinline__ int vit_pat_off(int lane, int c)
   return (c0 * 4 + c1 * 2 + c2) * 2;
 }
 
-template <int C> __device__ __forceinline__ int vit_exchange(int m, int bperm_addr32)
+template <int C> __device__ __forceinline__ int vit_exchange(int m, int lane)
 {
-  // partner lane = lane ^ (1 << ((5 - C) % 6))
+  // partner lane = lane ^ (1 << ((5 - C) % 6)); all six exchanges stay in the VALU (DPP, and gfx950's permlane swaps for the
+  // two that cross a 16-lane row) -- no trip through the LDS crossbar on the add-compare-select chain
   if constexpr (C == 5) return __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, true);        // xor 1  quad_perm [1,0,3,2]
   else if constexpr (C == 4) return __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, true);   // xor 2  quad_perm [2,3,0,1]
-  else if constexpr (C == 3) return __builtin_amdgcn_ds_swizzle(m, 0x101F);                    // xor 4
+  else if constexpr (C == 3) {                                                                 // xor 4 = (i ^ 7) ^ 3
+    const int hm = __builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, true);                   //   row_half_mirror: i -> 7 - i
+    return __builtin_amdgcn_update_dpp(0, hm, 0x1B, 0xF, 0xF, true);                           //   quad_perm [3,2,1,0]: i -> i ^ 3
+  }
   else if constexpr (C == 2) return __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, true);  // xor 8  row_ror:8
-  else if constexpr (C == 1) return __builtin_amdgcn_ds_swizzle(m, 0x401F);                    // xor 16
-  else return __builtin_amdgcn_ds_bpermute(bperm_addr32, m);                                   // xor 32
+  else if constexpr (C == 1) {                                                                 // xor 16
+    const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);                       //   odd rows of [0] <-> even rows of [1]
+    return (lane & 16) ? (int)r[0] : (int)r[1];
+  }
+  else {                                                                                       // xor 32
+    const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false);                       //   upper half of [0] <-> lower half of [1]
+    return (lane & 32) ? (int)r[0] : (int)r[1];
+  }
 }
 
 struct VitLaneConst {
   int pat[6];        // LDS byte offset of this lane's branch metric within a step row, per class
-  int bperm32;       // (lane ^ 32) * 4
+  int lane;
 };
 
 __device__ __forceinline__ VitLaneConst vit_lane_const(int lane)
@@ -79,7 +89,7 @@ __device__ __forceinline__ VitLaneConst vit_lane_const(int lane)
   for (int c = 0; c < 6; c++) {
     k.pat[c] = vit_pat_off(lane, c);
   }
-  k.bperm32 = (lane ^ 32) * 4;
+  k.lane = lane;
   return k;
 }
 
@@ -91,7 +101,7 @@ __device__ __forceinline__ void vit_step(int &m, unsigned &acc, const char *wrow
                                   : C == 2 ? 0xFF00FF00FF00FF00ull : C == 3 ? 0xF0F0F0F0F0F0F0F0ull
                                   : C == 4 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;
   const int w = *reinterpret_cast<const int16_t *>(wrow + k.pat[C]);
-  const int partner = vit_exchange<C>(m, k.bperm32);
+  const int partner = vit_exchange<C>(m, k.lane);
   const int co = m + w, cp = partner - w;
   // decision = (value through predecessor i) > (value through predecessor i+32), viterbi_scalar.h:25-26;
   // a lower lane owns predecessor i (co), an upper lane owns predecessor i+32.
@@ -110,11 +120,17 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
 {
   int m = lane == 0 ? 0 : 2000;                 // viterbi_spiral.cpp:98-101 (0 / 1000), doubled
   const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
+  // The symbols of block b + 1 (two dependent global loads: depuncture map, then the soft symbols) are requested before
+  // the 60 add-compare-select steps of block b run and only consumed afterwards: their latency is off the chain.
+  VitSyms s = {0, 0, 0, 0};
+  if (lane < VIT_BLK && lane < nsteps) s = src(lane);
   for (int b = 0; b < nblk; b++) {
+    VitSyms sn = {0, 0, 0, 0};
+    {
+      const int tn = (b + 1) * VIT_BLK + lane;
+      if (lane < VIT_BLK && tn < nsteps) sn = src(tn);
+    }
     if (lane < VIT_BLK) {
-      const int t = b * VIT_BLK + lane;
-      VitSyms s = {0, 0, 0, 0};
-      if (t < nsteps) s = src(t);
       const int y0 = s.x0 + s.x3;
       short v[8];
 #pragma unroll
@@ -146,6 +162,7 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
       acc = 0;
     }
     __builtin_amdgcn_wave_barrier();
+    s = sn;
   }
 }
 
