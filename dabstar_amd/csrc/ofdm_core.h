@@ -262,8 +262,9 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
   const float F_RAD_PER_DEG = 0.01745329251994329577f, F_SQRT1_2 = 0.70710678118654752440f;
   const float2 pr = c.prev;
-  const float pr_abs = __builtin_amdgcn_sqrtf(pr.x * pr.x + pr.y * pr.y);
-  const float pr_inv = __builtin_amdgcn_rcpf(pr_abs);
+  const float pr_sq = pr.x * pr.x + pr.y * pr.y;
+  const float pr_inv = __builtin_amdgcn_rsqf(pr_sq);             // 1 / |prev| and |prev| from one v_rsq_f32
+  const float pr_abs = pr_sq * pr_inv;
   float2 raw;                                                   // :188-189
   raw.x = (x.x * pr.x + x.y * pr.y) * pr_inv;
   raw.y = (x.y * pr.x - x.x * pr.y) * pr_inv;
@@ -290,24 +291,23 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   c.mean_sigma_sq += ALPHA * (sigma_sq - c.mean_sigma_sq);
   float signal_power = c.mean_power - c.null_power;             // :225-226
   if (signal_power <= 0.0f) signal_power = 0.1f;
-  float2 r1;
+  // r1 = b * w1 with a real weight w1 >= 0, so |r1| (:256, the summand of mMeanValue) is |b| * w1: one square root
+  // serves both; the quotients of the weight share one reciprocal
+  const float babs = __builtin_amdgcn_sqrtf(power);
+  const float nsr = c.null_power * __builtin_amdgcn_rcpf(signal_power) + 0.7f;
+  float w1;
   if (soft_type == 3) {                                         // :231-235
-    r1 = make_float2(b.x * pr_abs, b.y * pr_abs);
+    w1 = pr_abs;
   } else if (soft_type == 2) {                                  // :236-242
-    float w1 = pr_abs * __builtin_amdgcn_rcpf(c.mean_sigma_sq);
-    w1 *= __builtin_amdgcn_rcpf(c.null_power * __builtin_amdgcn_rcpf(signal_power) + 0.7f);
-    r1 = make_float2(b.x * w1, b.y * w1);
+    w1 = pr_abs * __builtin_amdgcn_rcpf(c.mean_sigma_sq * nsr);
   } else {                                                      // :243-251
-    const float babs = __builtin_amdgcn_sqrtf(power);
-    float w1 = __builtin_amdgcn_sqrtf(babs * pr_abs) * mean_level;
-    w1 *= __builtin_amdgcn_rcpf(c.null_power * __builtin_amdgcn_rcpf(signal_power) + 0.7f);
-    w1 *= __builtin_amdgcn_rcpf(c.mean_sigma_sq * babs);
-    r1 = make_float2(b.x * w1, b.y * w1);
+    w1 = __builtin_amdgcn_sqrtf(babs * pr_abs) * mean_level * __builtin_amdgcn_rcpf(nsr * (c.mean_sigma_sq * babs));
   }
+  const float2 r1 = make_float2(b.x * w1, b.y * w1);
   soft_re = cvt_i16_x86(r1.x * w2);                             // :254-255, w2 = -100 (-140) / mMeanValue
   soft_im = cvt_i16_x86(r1.y * w2);
   c.prev = x;                                                   // :354
-  return __builtin_amdgcn_sqrtf(r1.x * r1.x + r1.y * r1.y);     // :256
+  return babs * w1;
 }
 __device__ __forceinline__ float demap_w2(float mean_value, int soft_type)
 {
