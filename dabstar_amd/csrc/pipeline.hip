@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
 // ------------------------------------------------------------------------------------------------ symbols
 // grid (76, S): x = 0..74 -> OFDM symbols 1..75.  (The null symbol is handled by k_frame_tail: it needs the
 // fine-CFO update that depends on all 75 cyclic-prefix correlations.)
-__global__ __launch_bounds__(256) void k_symbols(EngineDev e, DevTables t)
+__global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
 {
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red3[3][4];
