@@ -146,7 +146,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DABX_BENCH_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)     # RCCL
