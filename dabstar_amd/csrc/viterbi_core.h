@@ -79,6 +79,7 @@ template <int C> __device__ __forceinline__ int vit_exchange(int m, int lane)
 
 struct VitLaneConst {
   int pat[6];        // LDS byte offset of this lane's branch metric within a step row, per class
+  int sgn[6];        // +1 where this lane holds the lower predecessor of its butterfly in class c, -1 where the upper
   int lane;
 };
 
@@ -88,6 +89,7 @@ __device__ __forceinline__ VitLaneConst vit_lane_const(int lane)
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     k.pat[c] = vit_pat_off(lane, c);
+    k.sgn[c] = ((lane >> ((5 - c) % 6)) & 1) ? -1 : 1;
   }
   k.lane = lane;
   return k;
@@ -96,21 +98,17 @@ __device__ __forceinline__ VitLaneConst vit_lane_const(int lane)
 template <int C>
 __device__ __forceinline__ void vit_step(int &m, unsigned &acc, const char *wrow, const VitLaneConst &k)
 {
-  // lanes holding the upper (i+32) predecessor in class C: bit (5 - C) % 6 of the lane index is set
-  constexpr unsigned long long UM = C == 0 ? 0xFFFFFFFF00000000ull : C == 1 ? 0xFFFF0000FFFF0000ull
-                                  : C == 2 ? 0xFF00FF00FF00FF00ull : C == 3 ? 0xF0F0F0F0F0F0F0F0ull
-                                  : C == 4 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;
   const int w = *reinterpret_cast<const int16_t *>(wrow + k.pat[C]);
   const int partner = vit_exchange<C>(m, k.lane);
   const int co = m + w, cp = partner - w;
-  // decision = (value through predecessor i) > (value through predecessor i+32), viterbi_scalar.h:25-26;
-  // a lower lane owns predecessor i (co), an upper lane owns predecessor i+32.
-  const unsigned long long gt = __builtin_amdgcn_ballot_w64(co > cp);
-  const unsigned long long lt = __builtin_amdgcn_ballot_w64(cp > co);
-  const unsigned long long dm = (gt & ~UM) | (lt & UM);
+  // decision = (value through predecessor i) > (value through predecessor i+32), viterbi_scalar.h:25-26.  A lower lane of
+  // the pair owns predecessor i (co), an upper lane owns predecessor i+32: the test is co > cp below and cp > co above,
+  // i.e. (co - cp) * (+1 | -1) > 0 with the lane's sign for this step class (the metric spread of a K = 7 trellis with
+  // |branch metric| <= 1020 stays below 2^15, so the 24-bit multiply is exact).  One compare into vcc, consumed as the
+  // carry-in of acc = 2 acc + decision: the whole step stays in the VALU (no ballot masks merged on the scalar unit).
+  const int dd = __mul24(co - cp, k.sgn[C]);
   m = co < cp ? co : cp;
-  // acc = 2*acc + decision: one VALU op with the decision mask as carry-in
-  asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(acc) : "v"(acc), "s"(dm) : "vcc");
+  asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
 }
 
 // Forward pass.  wtab: this wave's LDS area, VIT_BLK rows of 8 int16.  dec: u32[vit_blocks*2][64].
