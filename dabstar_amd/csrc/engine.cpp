@@ -294,6 +294,17 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
     return DABX_E_ARG;
   }
   if (n == 0) return 0;
+  {                                       // never overwrite samples the receiver has not read yet
+    if (int rc0 = sync_all(e)) return rc0;
+    StreamCtl c;
+    DABX_HIP(hipMemcpy(&c, e->dev.ctl + stream, sizeof(StreamCtl), hipMemcpyDeviceToHost));
+    const unsigned long long used = e->wr_host[stream] - c.rd;
+    if (used + n > (unsigned long long)e->dev.ring_len) {
+      set_error("dabx_push_iq: ring of stream %d has room for %llu samples, %zu offered (call dabx_process first)", stream,
+                (unsigned long long)e->dev.ring_len - used, n);
+      return DABX_E_STATE;
+    }
+  }
   static const int bps[3] = {8, 4, 2};
   void *stage = nullptr;
   DABX_HIP(hipMalloc(&stage, n * bps[fmt]));

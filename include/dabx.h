@@ -159,7 +159,7 @@ void dabx_destroy(dabx_engine *e);
 int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
 /* Host IQ -> device ring (IDeviceHandler::getSamples contract, common/device_handler_if.h:47-48).
  * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70) */
-int  dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_samples);
+int  dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_samples);   /* DABX_E_STATE: would overwrite unread samples */
 /* Device-resident producers: ring base (cf32, capacity ring_frames*T_F) and commit of n new samples. */
 int  dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *capacity_samples);
 int  dabx_commit_iq(dabx_engine *e, int stream /* <0: all */, size_t n_samples);

@@ -570,3 +570,16 @@ def test_low_snr_error_paths_follow_the_oracle(snr):
     if snr < 4:
         assert seen["rs_failed"] + seen["au_bad"] + seen["sf_fail"] > 0, seen
     eng.close()
+
+
+def test_push_refuses_to_overwrite_unread_samples():
+    eng = dx.Engine(n_streams=2, ring_frames=3, max_subch=0, fic_only=True)
+    x = np.zeros(2 * ds.TF, np.complex64)
+    eng.push_iq(0, x)
+    with pytest.raises(dx.DabxError):
+        eng.push_iq(0, x)                                   # 4 frames into a 3-frame ring
+    eng.push_iq(1, x)                                       # the other stream is independent
+    eng.push_iq(0, x[:ds.TF])                               # exactly full is fine
+    with pytest.raises(dx.DabxError):
+        eng.push_iq(0, x[:1])
+    eng.close()
