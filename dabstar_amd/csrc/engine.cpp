@@ -101,8 +101,10 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   DABX_HIP(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, pa));
   e->ss.a = e->stream;
   DABX_HIP(hipStreamCreateWithPriority(&e->ss.b, hipStreamNonBlocking, pb));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming));
+  // both HIP streams live on this device: a device-scope release is all the dependency needs (the default system-scope
+  // release writes the caches back for host visibility on every record)
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
   const int S = cfg->n_streams;
   EngineDev &d = e->dev;
   d.n_streams = S; d.max_subch = cfg->max_subch; d.out_frames = cfg->out_frames;

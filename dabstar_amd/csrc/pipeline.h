@@ -119,7 +119,8 @@ struct Marker {
   size_t open_ev[N_STEP_KERNELS] = {0};
   size_t take(hipStream_t st)
   {
-    if (used == pool.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); pool.push_back(ev); }
+    // device-scope release: these events only time kernels, nothing on the host reads device memory behind them
+    if (used == pool.size()) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventReleaseToDevice); pool.push_back(ev); }
     (void)hipEventRecord(pool[used], st);
     return used++;
   }
