@@ -1,4 +1,6 @@
 """GPU parity: HIP Viterbi / deconvolve through the C ABI vs the CPU oracle (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,3 +54,22 @@ def test_deconvolve_matches_oracle(kbps, prot, short):
         exp = np.zeros(24 * kbps, np.uint8)
         ol.oracle().ora_deconvolve(soft[b], m, kbps, exp)
         assert np.array_equal(got[b], exp), (kbps, prot, short, b)
+
+
+def test_deconvolve_every_legal_profile_matches_oracle():
+    """Protection::deconvolve through the C ABI for every profile of EN 300 401 11.3 (EEP-A 8..384 kbit/s, EEP-B in steps of
+    32, the 64 UEP rows): depuncture map built on the host, gathered on the device, decoded by the Viterbi kernel."""
+    rng = np.random.default_rng(99)
+    L = ol.oracle()
+    profiles = [(k, p, 0) for k in range(8, 385, 8) for p in range(8) if p < 4 or k % 32 == 0]
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_leaf_vectors.npz"))
+    profiles += [(int(k), int(l), 1) for _, l, k in G["uep_table"].tolist()]
+    assert len(profiles) == 48 * 4 + 12 * 4 + 64
+    for kbps, prot, short in profiles:
+        n_in, m = (ol.ora_uep_map if short else ol.ora_eep_map)(kbps, prot)
+        soft = rng.integers(-160, 161, (2, n_in)).astype(np.int16)
+        want = np.zeros((2, 24 * kbps), np.uint8)
+        for i in range(2):
+            L.ora_deconvolve(soft[i], m, kbps, want[i])
+        got = dx.deconvolve(soft, kbps, prot, short)
+        assert np.array_equal(got, want), (kbps, prot, short)
