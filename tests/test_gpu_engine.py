@@ -583,3 +583,29 @@ def test_push_refuses_to_overwrite_unread_samples():
     with pytest.raises(dx.DabxError):
         eng.push_iq(0, x[:1])
     eng.close()
+
+
+def test_largest_and_smallest_subchannels():
+    """Sizes at both ends: a 320 kbit/s DAB+ sub-channel (240 CU, 40 RS code words per super frame, 960-byte logical
+    frames, AUs of up to 960 bytes) beside an 8 kbit/s one (1 code word, 24-byte frames) -- bit-exact vs the oracle."""
+    subch = [ds.SubCh(1, 0, 240, 320, 2, 0), ds.SubCh(2, 300, 12, 8, 0, 0)]
+    ens = ds.build_ensemble(10, subch, seed=131)
+    x = ds.channel(ens.iq, snr_db=15.0, cfo_hz=410.0, timing_offset=7777, seed=19, n_out=23 * ds.TF + 50000)
+    ora = _oracle_run(x, subch)
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"])
+    n = min(len(fibs), ora["n"])
+    assert len(fibs) == ora["n"] and n >= 20
+    assert np.array_equal(crc[:n], ora["crc"][:n]) and np.array_equal(fibs[:n], ora["fibs"][:n])
+    for j, c in enumerate(subch):
+        st, o = eng.subch_stats(0, j), ora["stats"][j]
+        assert st["cifs_decoded"] == o["cif_out"] and st["cifs_decoded"] >= 60
+        for a, b in (("sf_ok", "sf_ok"), ("sf_fail", "sf_fail"), ("rs_corrected", "rs_corr"), ("rs_failed", "rs_fail"),
+                     ("au_ok", "au_ok"), ("au_bad", "au_bad")):
+            assert st[a] == o[b], (j, a, st[a], o[b])
+        assert st["sf_ok"] >= 10
+        k, nb = st["cifs_decoded"], 3 * c.kbps
+        assert np.array_equal(eng.read_msc(0, j, 16), ora["msc"][j].reshape(-1, nb)[k - 16:k]), j
+        sf_o = ora["sf"][j].reshape(-1, 110 * c.kbps // 8)
+        assert np.array_equal(eng.read_superframes(0, j, 3), sf_o[len(sf_o) - 3:]), j
+        assert any(np.array_equal(sf_o[-1], ens.superframes[j][q]) for q in range(8)), j
+    eng.close()

@@ -190,11 +190,22 @@ def build_superframe(kbps: int, rng: np.random.Generator) -> np.ndarray:
     s = kbps // 8
     n = 110 * s
     sf = rng.integers(0, 256, n).astype(np.uint8)
-    # header: dac_rate=1, sbr=1 -> 3 AUs, first starts at 6
-    sf[2] = (1 << 6) | (1 << 5) | (1 << 4)
-    a0, a1, a2 = 6, 6 + (n - 6) // 3, 6 + 2 * ((n - 6) // 3)
-    sf[3], sf[4], sf[5] = a1 >> 4, ((a1 & 0xF) << 4) | (a2 >> 8), a2 & 0xFF
-    for st, en in ((a0, a1), (a1, a2), (a2, n)):
+    if n // 3 <= 900:
+        # header: dac_rate=1, sbr=1 -> 3 AUs, first starts at 6
+        sf[2] = (1 << 6) | (1 << 5) | (1 << 4)
+        a0, a1, a2 = 6, 6 + (n - 6) // 3, 6 + 2 * ((n - 6) // 3)
+        sf[3], sf[4], sf[5] = a1 >> 4, ((a1 & 0xF) << 4) | (a2 >> 8), a2 & 0xFF
+        bounds = (a0, a1, a2, n)
+    else:
+        # high bit rates: dac_rate=1, sbr=0 -> 6 AUs (each must stay <= 960 bytes), first starts at 11
+        sf[2] = (1 << 6) | (1 << 4)
+        step = (n - 11) // 6
+        a = [11 + i * step for i in range(6)]
+        sf[3], sf[4], sf[5] = a[1] >> 4, ((a[1] & 0xF) << 4) | (a[2] >> 8), a[2] & 0xFF
+        sf[6], sf[7], sf[8] = a[3] >> 4, ((a[3] & 0xF) << 4) | (a[4] >> 8), a[4] & 0xFF
+        sf[9], sf[10] = a[5] >> 4, (a[5] & 0xF) << 4
+        bounds = tuple(a) + (n,)
+    for st, en in zip(bounds[:-1], bounds[1:]):
         c = crc16(bytes(sf[st:en - 2]))
         sf[en - 2], sf[en - 1] = c >> 8, c & 0xFF
     fc = firecode_parity(bytes(sf[2:11]))
