@@ -34,6 +34,8 @@ struct dabx_engine {
   std::vector<dabx_tii *> tii;                 // [S] detectors, created on first dabx_read_tii
   std::vector<int> tii_epoch;                  // [S] reset epoch seen by the detector
   std::vector<void *> allocs;
+  void *stage = nullptr;                       // host -> device staging of dabx_push_iq
+  size_t stage_cap = 0;
   int max_kbps = 0;
   bool buffers_ready = false;
   Marker mk;
@@ -167,6 +169,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
+  if (e->stage) (void)hipFree(e->stage);
   for (void *p : e->allocs) (void)hipFree(p);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
@@ -308,13 +311,17 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
     }
   }
   static const int bps[3] = {8, 4, 2};
-  void *stage = nullptr;
-  DABX_HIP(hipMalloc(&stage, n * bps[fmt]));
-  DABX_HIP(hipMemcpyAsync(stage, iq, n * bps[fmt], hipMemcpyHostToDevice, e->stream));
-  int rc = launch_convert_iq(stage, fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, e->stream);
+  const size_t bytes = n * bps[fmt];
+  if (bytes > e->stage_cap) {                   // one staging buffer per engine, grown on demand
+    if (e->stage) DABX_HIP(hipFree(e->stage));
+    e->stage = nullptr; e->stage_cap = 0;
+    DABX_HIP(hipMalloc(&e->stage, bytes));
+    e->stage_cap = bytes;
+  }
+  DABX_HIP(hipMemcpyAsync(e->stage, iq, bytes, hipMemcpyHostToDevice, e->stream));
+  int rc = launch_convert_iq(e->stage, fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, e->stream);
   if (!rc) rc = dabx_commit_iq(e, stream, n);
-  DABX_HIP(hipStreamSynchronize(e->stream));
-  DABX_HIP(hipFree(stage));
+  DABX_HIP(hipStreamSynchronize(e->stream));   // the caller's buffer and the staging buffer are free again
   return rc;
 }
 
