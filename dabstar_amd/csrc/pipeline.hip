@@ -323,9 +323,11 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
   __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
   __shared__ uint32_t raw[4][32];           // chain-back output, 30 bits per word (26 words + padding)
   __shared__ uint8_t crc_ok[12];
+  __shared__ uint16_t s_crc[256];           // CCITT table: the 30-step look-up chain of a FIB's CRC stays in LDS
   const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
+  s_crc[threadIdx.x] = t.crc_ccitt[threadIdx.x];
   {
     SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + wave * FIC_IN, t.fic_map};
     uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + wave) * (size_t)e.vit_stride;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
   if (threadIdx.x < 12) {                    // one lane per FIB: CRC (crc.cpp:98-132 == CCITT over 30 bytes vs the last 2)
     const int fibi = threadIdx.x;
     const uint8_t *b = reinterpret_cast<const uint8_t *>(&fibw[fibi / 3][0]) + (fibi % 3) * 32;
-    crc_ok[fibi] = crc16_check_bytes(b, 30, t.crc_ccitt);
+    crc_ok[fibi] = crc16_check_bytes(b, 30, s_crc);
   }
   for (int i = threadIdx.x; i < 96; i += 256) reinterpret_cast<uint32_t *>(fo)[i] = fibw[i / 24][i % 24];
   __syncthreads();
