@@ -243,6 +243,7 @@ constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers pe
 __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t)
 {
   __shared__ float red[16];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
   const int s = blockIdx.x, tid = threadIdx.x;
   const StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
@@ -271,10 +272,25 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[bin[q]];
   }
+  // The 3072 Viterbi symbols of an OFDM symbol leave through LDS: every thread drops its four bytes into a tile that is
+  // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barriers of
+  // the mean-value reduction each of the 768 threads stores ONE aligned dword -- 48 consecutive dwords per plane --
+  // instead of four scattered byte stores with their address arithmetic.  Two tiles: a fast thread may already fill the
+  // next symbol's tile while a slow one still drains this one.
+  static_assert(DEMAP_THREADS == 768 && DEMAP_Q == 2, "tile <-> thread mapping below");
+  int tpos[2 * DEMAP_Q];                                   // tile byte offsets of (re, im) of this thread's carriers
+#pragma unroll
+  for (int q = 0; q < DEMAP_Q; q++) {
+    const int k = tid + DEMAP_THREADS * q;
+    tpos[2 * q] = (k & 15) * 192 + (k >> 4);
+    tpos[2 * q + 1] = ((K + k) & 15) * 192 + ((K + k) >> 4);
+  }
+  const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
   for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
     const float2 *X = e.spectra + ((size_t)s * 76 + (l < 74 ? l + 1 : l)) * TU;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, d.soft_type);
+    uint8_t *tl = tile[l & 1];
     float2 xc[DEMAP_Q];
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[bin[q]]; }
@@ -283,17 +299,20 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     for (int q = 0; q < DEMAP_Q; q++) {
       int16_t sr, si;
       part += demap_one(cr[q], xc[q], rel[q], ce, w2, d.soft_type, sr, si);
-      const int k = tid + DEMAP_THREADS * q;
-      if (l < 3) {                                        // symbols 1..3 -> FIC
-        fic[l * K2 + k] = soft_to_sym(sr);
-        fic[l * K2 + K + k] = soft_to_sym(si);
-      } else {                                            // MSC -> planar time-de-interleaver ring
-        tdi[tdi_off(cif0 + cif, blk * K2 + k)] = soft_to_sym(sr);
-        tdi[tdi_off(cif0 + cif, blk * K2 + K + k)] = soft_to_sym(si);
-      }
-      if (cap) { cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
+      tl[tpos[2 * q]] = soft_to_sym(sr);
+      tl[tpos[2 * q + 1]] = soft_to_sym(si);
+      if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
     }
-    mean_value = block_sum(part, red, tid) * (1.0f / (float)K);
+    mean_value = block_sum(part, red, tid) * (1.0f / (float)K);   // two barriers: the tile is complete behind them
+    if (l < 3) {                                            // symbols 1..3 -> FIC, linear: bytes 4 tid .. 4 tid + 3
+      uint32_t v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) { const int i = 4 * tid + b; v |= (uint32_t)tl[(i & 15) * 192 + (i >> 4)] << (8 * b); }
+      reinterpret_cast<uint32_t *>(fic + l * K2)[tid] = v;
+    } else {                                                // MSC -> planar time-de-interleaver ring
+      const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * 192 + 4 * out_dw);
+      *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
+    }
   }
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
