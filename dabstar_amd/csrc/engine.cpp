@@ -119,7 +119,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.iq, (size_t)S * d.ring_len, false));
   A(e->alloc(&d.wr, S));
   A(e->alloc(&d.ctl, S));
-  A(e->alloc(&d.spectra, (size_t)S * 76 * TU, false));
+  A(e->alloc(&d.spectra, (size_t)S * 75 * K, false));
   A(e->alloc(&d.nco_tid, (size_t)S * 256));
   A(e->alloc(&e->snap_buf[0], S));
   A(e->alloc(&e->snap_buf[1], S));

@@ -71,7 +71,7 @@ struct EngineDev {
   unsigned long long *wr;         // [S] absolute index one past the last committed sample
   StreamCtl *ctl;                 // [S]
   DemapDev demap;
-  float2 *spectra;                // [S][76][2048]: symbols 1..75, then the null symbol
+  float2 *spectra;                // [S][75][1536]: symbols 1..75 in CARRIER order (frequency de-interleaved by k_symbols)
   double2 *nco_tid;               // [S][256] e^{-j 2 pi f tid / fs} of the current frame (k_frame_head -> k_symbols)
   float2 *cp_part;                // [S][75] cyclic-prefix correlation partial sums
   float *abs_part;                // [S][76] sum |x| of the samples read per symbol (level tracking)

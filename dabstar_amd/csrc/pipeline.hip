@@ -233,9 +233,18 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
     for (int q = 0; q < 3; q++) { float a = 0.f; for (int w = 0; w < 4; w++) a += red3[q][w]; r[q] = a; }
     e.cp_part[(size_t)s * 75 + l] = make_float2(r[0], r[1]); e.abs_part[(size_t)s * 76 + l] = r[2];
   }
-  float2 *dst = e.spectra + ((size_t)s * 76 + l) * TU;
+  // Frequency de-interleaving rides on the way out (freq_interleaver.cpp:40-76): each bin goes to its carrier index in LDS
+  // (the transform's exchange buffer is free again), the 1536 used carriers are then stored contiguously.  The demapper
+  // reads carrier k of every symbol with coalesced loads; the 512 unused bins are never written.
 #pragma unroll
-  for (int u = 0; u < 8; u++) dst[tid + 256 * u] = v[u];
+  for (int u = 0; u < 8; u++) {
+    const int kk = t.bin_to_k[tid + 256 * u];
+    if (kk >= 0) lds[kk] = v[u];
+  }
+  __syncthreads();
+  float2 *dst = e.spectra + ((size_t)s * 75 + l) * K;
+#pragma unroll
+  for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
 }
 
 // -------------------------------------------------------------------------------------------------- demap
@@ -268,9 +277,9 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
   float2 xn[DEMAP_Q];                                           // spectrum values of the next symbol (gather latency off the chain)
   {
-    const float2 *X0 = e.spectra + (size_t)s * 76 * TU;
+    const float2 *X0 = e.spectra + (size_t)s * 75 * K;
 #pragma unroll
-    for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[bin[q]];
+    for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[tid + DEMAP_THREADS * q];
   }
   // The 3072 Viterbi symbols of an OFDM symbol leave through LDS: every thread drops its four bytes into a tile that is
   // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barriers of
@@ -287,13 +296,13 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   }
   const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
   for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
-    const float2 *X = e.spectra + ((size_t)s * 76 + (l < 74 ? l + 1 : l)) * TU;
+    const float2 *X = e.spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, d.soft_type);
     uint8_t *tl = tile[l & 1];
     float2 xc[DEMAP_Q];
 #pragma unroll
-    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[bin[q]]; }
+    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[tid + DEMAP_THREADS * q]; }
     float part = 0.f;
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) {

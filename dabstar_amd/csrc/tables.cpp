@@ -290,6 +290,11 @@ static int build_tables(DevTables &t)
   }
   int rc;
   if ((rc = upload(&t.perm_bin, bin))) return rc;
+  {
+    std::vector<int16_t> inv(TU, (int16_t)-1);
+    for (int k = 0; k < K; k++) inv[bin[k]] = (int16_t)k;
+    if ((rc = upload(&t.bin_to_k, inv))) return rc;
+  }
   if ((rc = upload(&t.perm_rel, rel))) return rc;
   if ((rc = upload(&t.prs_ref, prs))) return rc;
   if ((rc = upload(&t.prs_arg_conj, argc))) return rc;
