@@ -5,13 +5,16 @@
 // Thread `tid` enters with x[tid + 256 u] (u = 0..7: eight coalesced 2-KB loads of the T_u slice) and
 // leaves with X[tid + 256 u]: input and output use the same strided register layout, so element-wise
 // stages before/after the transform (NCO mix, x conj(PRS), |.|) never touch LDS.  Twiddles come from a
-// 2048-entry table computed in double on the host (16 KB, L1/L2 resident).
+// table computed in double on the host (16 KB, L1/L2 resident), laid out per pass so that a wave's 64 lanes read
+// consecutive entries (tables.cpp): a gather through the natural e^{-j 2 pi i/2048} order cost up to 64 cache lines
+// per load in the third pass.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace dabx {
 
 constexpr int FFT_LDS_FLOAT2 = 2048 + 2048 / 16;   // padded: one extra slot per 16
+constexpr int FFT_TW_P2 = 0, FFT_TW_P3 = 56, FFT_TW_P4 = 56 + 448;   // twiddle table sections: [7][8], [7][64], [3][512]
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
@@ -55,7 +58,7 @@ template <bool INV, int NS> __device__ __forceinline__ void fft_pass8(float2 v[8
   const int k = j & (NS - 1);
   if (NS > 1) {
 #pragma unroll
-    for (int t = 1; t < 8; t++) v[t] = cmul(v[t], tw_dir<INV>(tw[t * k * (2048 / (NS * 8))]));
+    for (int t = 1; t < 8; t++) v[t] = cmul(v[t], tw_dir<INV>(tw[(NS == 8 ? FFT_TW_P2 : FFT_TW_P3) + (t - 1) * NS + k]));
   }
   dft8<INV>(v);
   const int base = (j - k) * 8 + k;
@@ -83,9 +86,9 @@ template <bool INV> __device__ __forceinline__ void fft2048(float2 v[8], float2 
   for (int h = 0; h < 2; h++) {
     const int j = tid + 256 * h;
     float2 a = lds[fft_pad(j)], b = lds[fft_pad(j + 512)], c = lds[fft_pad(j + 1024)], d = lds[fft_pad(j + 1536)];
-    b = cmul(b, tw_dir<INV>(tw[j]));
-    c = cmul(c, tw_dir<INV>(tw[2 * j]));
-    d = cmul(d, tw_dir<INV>(tw[3 * j]));
+    b = cmul(b, tw_dir<INV>(tw[FFT_TW_P4 + j]));
+    c = cmul(c, tw_dir<INV>(tw[FFT_TW_P4 + 512 + j]));
+    d = cmul(d, tw_dir<INV>(tw[FFT_TW_P4 + 1024 + j]));
     dft4<INV>(a, b, c, d);
     v[h] = a; v[h + 2] = b; v[h + 4] = c; v[h + 6] = d;     // X[j + 512 t] -> register u = 2 t + h
   }

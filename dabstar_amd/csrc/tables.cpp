@@ -221,8 +221,16 @@ static int build_tables(DevTables &t)
     host_dft(re, im, true);
     for (int i = 0; i < TU; i++) argc[i] = make_float2((float)re[i], -(float)im[i]);
   }
-  std::vector<float2> tw(TU);
-  for (int i = 0; i < TU; i++) tw[i] = make_float2((float)cos(2.0 * M_PI * i / TU), (float)-sin(2.0 * M_PI * i / TU));
+  // Twiddles e^{-j 2 pi i / 2048} (double, rounded once), stored in the order the passes of fft_core.h read them so that
+  // the 64 lanes of a wave always load consecutive entries: [7][8] for the second pass (i = 32 t k), [7][64] for the third
+  // (i = 4 t k), [3][512] for the last (i = m j).
+  std::vector<float2> tw;
+  tw.reserve(TU);
+  auto W = [](int i) { i &= TU - 1; return make_float2((float)cos(2.0 * M_PI * i / TU), (float)-sin(2.0 * M_PI * i / TU)); };
+  for (int t = 1; t < 8; t++) for (int k = 0; k < 8; k++) tw.push_back(W(32 * t * k));
+  for (int t = 1; t < 8; t++) for (int k = 0; k < 64; k++) tw.push_back(W(4 * t * k));
+  for (int m = 1; m < 4; m++) for (int j = 0; j < 512; j++) tw.push_back(W(m * j));
+  tw.resize(TU, make_float2(0.f, 0.f));
   std::vector<uint16_t> ficm;
   host_fic_map(ficm);
   // PRBS x^9+x^5+1, all ones (fic_decoder.cpp:59-73, backend.cpp:72-84), packed MSB-first
