@@ -17,33 +17,37 @@ namespace dabx {
 __device__ __forceinline__ int bitrev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
 
 // ---------------------------------------------------------------------------------------------------- prepare
-// grid = groups, 256 threads.  Per chunk of PCH ring positions: (1) every (job, plane) run of PCH bytes is read
-// with lanes ALONG the run (coalesced; a lane-per-job read would touch 64 different lines per instruction) into
-// LDS; (2) lane = job, pg = plane group: 4 planes x 1 dword -> 4x4 byte transpose in registers (8 v_perm) ->
-// 4 idx-ordered dwords, stored as inT[q][job] (256-B coalesced rows).
-constexpr int PCH = 32;                       // positions per chunk (bytes per plane run); 33 KB of LDS -> 4 blocks per CU (64: fewer sectors, but 2 blocks per CU is slower)
-constexpr int PJS = 16 * PCH + 4;             // LDS job stride in bytes (+4: conflict-free ds_read across jobs)
+// grid = ceil(jobs / PJB), 256 threads; a block prepares PJB = 32 consecutive jobs (half of a decoder wave).
+// Per chunk of PCH = 64 ring positions: (1) every (job, plane) run of 64 bytes -- exactly one HBM line -- is read with
+// lanes ALONG the run into LDS (32-byte pieces made the kernel fetch every line twice to four times: the two halves
+// were a whole chunk iteration apart, too far for the L2); (2) thread = (job, plane group, half of the chunk):
+// 4 planes x 1 dword -> 4x4 byte transpose in registers (8 v_perm) -> 4 idx-ordered dwords, stored to inT[q][lane]
+// (the 32 jobs are 32 adjacent lanes: 128-B pieces of a row).
+constexpr int PJB = 32;                       // jobs per block
+constexpr int PCH = 64;                       // positions per chunk (bytes per plane run)
+constexpr int PJS = 16 * PCH + 4;             // LDS job stride in bytes (+4: conflict-free ds_read across jobs); 33 KB per block
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_in, uint32_t *inT)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[64 * PJS];
-  __shared__ const uint8_t *s_base[64];      // per job: stream ring + cu_start*4 (nullptr = invalid job)
-  __shared__ long long s_r[64];
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, pg = tid >> 6;
-  if (tid < 64) {
-    const MscJob q = msc_job(e, g * 64 + tid, cifs);
+  __shared__ __attribute__((aligned(16))) uint8_t tile[PJB * PJS];
+  __shared__ const uint8_t *s_base[PJB];     // per job: stream ring + cu_start*4 (nullptr = invalid job)
+  __shared__ long long s_r[PJB];
+  const int tid = threadIdx.x, job0 = blockIdx.x * PJB;
+  if (tid < PJB) {
+    const MscJob q = msc_job(e, job0 + tid, cifs);
     s_base[tid] = q.valid ? e.tdi + (size_t)q.s * TDI_SLOTS * CIF_BITS + e.subch[(size_t)q.s * e.max_subch + q.j].cu_start * 4 : nullptr;
     s_r[tid] = q.r;
   }
   const int rows = n_in / 4 + 1;
-  uint32_t *dst = inT + (size_t)g * rows * 64 + lane;
-  if (pg == 0) dst[(size_t)(rows - 1) * 64] = 0x7F7F7F7Fu;        // punctured soft bit = 0 -> symbol 127
+  const int jl = tid & (PJB - 1), pg = (tid >> 5) & 3, qd = tid >> 7;      // job in block, plane group, half of the chunk
+  uint32_t *dst = inT + (size_t)(job0 >> 6) * rows * 64 + (job0 & 63) + jl;
+  if (pg == 0 && qd == 0) dst[(size_t)(rows - 1) * 64] = 0x7F7F7F7Fu;      // punctured soft bit = 0 -> symbol 127
   __syncthreads();
   const int npos = n_in / 16;                                      // ring positions per plane of one job
   for (int p0 = 0; p0 < npos; p0 += PCH) {
     const int cw = (npos - p0 < PCH ? npos - p0 : PCH) / 4;       // dwords per run in this chunk (npos % 4 == 0)
     // (1) coalesced load: item = (job, plane, dword)
     const bool full = cw == PCH / 4;
-    for (int it = tid; it < 64 * 16 * cw; it += 256) {
+    for (int it = tid; it < PJB * 16 * cw; it += 256) {
       int d, jp;
       if (full) { d = it & (PCH / 4 - 1); jp = it / (PCH / 4); }   // shifts/masks for whole chunks
       else { d = it % cw; jp = it / cw; }
@@ -58,9 +62,9 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_i
       *reinterpret_cast<uint32_t *>(tile + job * PJS + pl * PCH + 4 * d) = v;
     }
     __syncthreads();
-    // (2) lane = job: transpose 4 planes x 4 positions, write idx-ordered dwords
-    const uint8_t *mine = tile + lane * PJS + (4 * pg) * PCH;
-    for (int d = 0; d < cw; d++) {
+    // (2) transpose 4 planes x 4 positions, write idx-ordered dwords
+    const uint8_t *mine = tile + jl * PJS + (4 * pg) * PCH;
+    for (int d = qd; d < cw; d += 2) {
       const uint32_t m0 = *reinterpret_cast<const uint32_t *>(mine + 0 * PCH + 4 * d), m1 = *reinterpret_cast<const uint32_t *>(mine + 1 * PCH + 4 * d);
       const uint32_t m2 = *reinterpret_cast<const uint32_t *>(mine + 2 * PCH + 4 * d), m3 = *reinterpret_cast<const uint32_t *>(mine + 3 * PCH + 4 * d);
       const uint32_t a = __builtin_amdgcn_perm(m1, m0, 0x05010400u), b = __builtin_amdgcn_perm(m1, m0, 0x07030602u);
@@ -215,7 +219,7 @@ int launch_msc_prep(const EngineDev &e, int cifs, int n_in, uint32_t *inT, hipSt
 {
   const int jobs = e.n_streams * cifs * e.max_subch, groups = (jobs + 63) / 64;
   mk.begin(6, st);
-  hipLaunchKernelGGL(k_msc_prep, dim3(groups), dim3(256), 0, st, e, cifs, n_in, inT);
+  hipLaunchKernelGGL(k_msc_prep, dim3(groups * (64 / PJB)), dim3(256), 0, st, e, cifs, n_in, inT);
   mk.end(6, st);
   DABX_HIP(hipGetLastError());
   return 0;
