@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
 
 // -------------------------------------------------------------------------------------------------- demap
 constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
+template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
 __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t)
 {
   __shared__ float red[16];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
     const float2 *X = e.spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
-    const float w2 = demap_w2(mean_value, d.soft_type);
+    const float w2 = demap_w2(mean_value, SOFT_TYPE);
     uint8_t *tl = tile[l & 1];
     float2 xc[DEMAP_Q];
 #pragma unroll
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) {
       int16_t sr, si;
-      part += demap_one(cr[q], xc[q], rel[q], ce, w2, d.soft_type, sr, si);
+      part += demap_one(cr[q], xc[q], rel[q], ce, w2, SOFT_TYPE, sr, si);
       tl[tpos[2 * q]] = soft_to_sym(sr);
       tl[tpos[2 * q + 1]] = soft_to_sym(si);
       if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
@@ -732,7 +733,11 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
   mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
-  mk.begin(3, st); hipLaunchKernelGGL(k_demap_frame, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t); mk.end(3, st);
+  mk.begin(3, st);
+  if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+  else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+  else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+  mk.end(3, st);
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
   DABX_HIP(hipGetLastError());
