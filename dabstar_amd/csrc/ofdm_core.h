@@ -309,6 +309,91 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   c.prev = x;                                                   // :354
   return babs * w1;
 }
+
+// ---- the same demapper on TWO carriers at once, as 2-vectors: every add / sub / mul of demap_one becomes one packed
+// v_pk_*_f32 (IEEE, same rounding as the scalar op; -ffp-contract=off holds for vectors too), the transcendentals,
+// selects and conversions stay per component.  Same operations in the same order as demap_one: identical results.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+struct DemapPair {           // state of two carriers (DemapCarrier x 2, component-wise)
+  v2f prev_re, prev_im, integ, mean_power, mean_sigma_sq, null_power;
+};
+__device__ __forceinline__ v2f v2_rsq(v2f a) { return (v2f){__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
+__device__ __forceinline__ v2f v2_sqrt(v2f a) { return (v2f){__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; }
+__device__ __forceinline__ v2f v2_rcp(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f v2_abs(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
+__device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ v2f atan2_as2(v2f y, v2f x)
+{
+  const v2f ax = v2_abs(x), ay = v2_abs(y);
+  const v2f mx = (v2f){fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)}, mnv = (v2f){fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+  const v2f t = mnv * v2_rcp(mx);
+  const v2f z = t * t;
+  v2f p = (v2f)(0.0028662257f);
+  p = v2_fma(p, z, (v2f)(-0.0161657367f));
+  p = v2_fma(p, z, (v2f)(0.0429096138f));
+  p = v2_fma(p, z, (v2f)(-0.0752896400f));
+  p = v2_fma(p, z, (v2f)(0.1065626393f));
+  p = v2_fma(p, z, (v2f)(-0.1420889944f));
+  p = v2_fma(p, z, (v2f)(0.1999355085f));
+  p = v2_fma(p, z, (v2f)(-0.3333314528f));
+  v2f r = v2_fma(p * z, t, t);
+  r = (mx == 0.0f) ? (v2f)(0.0f) : r;
+  r = (ay > ax) ? 1.57079632679489661923f - r : r;
+  r = (x < 0.0f) ? 3.14159265358979323846f - r : r;
+  return (y < 0.0f) ? -r : r;
+}
+
+template <int SOFT_TYPE>
+__device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f rel_f, float clock_err, float w2,
+                                          int16_t (&soft_re)[2], int16_t (&soft_im)[2])
+{
+  constexpr float ALPHA = 0.005f;
+  const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
+  const float F_RAD_PER_DEG = 0.01745329251994329577f, F_SQRT1_2 = 0.70710678118654752440f;
+  const v2f pr_re = c.prev_re, pr_im = c.prev_im;
+  const v2f pr_sq = pr_re * pr_re + pr_im * pr_im;
+  const v2f pr_inv = v2_rsq(pr_sq);
+  const v2f pr_abs = pr_sq * pr_inv;
+  const v2f raw_re = (x_re * pr_re + x_im * pr_im) * pr_inv;      // :188-189
+  const v2f raw_im = (x_im * pr_re - x_re * pr_im) * pr_inv;
+  const v2f phase_err = clock_err * (F_PI / 1024.0f / (float)(K / 2)) * rel_f + c.integ;   // :192, rel_f = (float)(K/2 - rel)
+  const v2f xx = -phase_err, x2 = xx * xx;                        // cmplx_from_phase2, :70-88
+  const v2f sine = xx * (x2 * -0.16034401953220367431640625f + 0.99903142452239990234375f);
+  const v2f cosine = 0.9994032382965087890625f + x2 * (x2 * 3.679168224334716796875e-2f + -0.495580852031707763671875f);
+  const v2f b_re = raw_re * cosine - raw_im * sine;
+  const v2f b_im = raw_re * sine + raw_im * cosine;
+  v2f ph = atan2_as2(b_im, b_re);                                 // :197
+  ph = (ph < 0.0f) ? ph + F_PI : ph;                              // glob_defs.h:173-182
+  const v2f aph = (ph < F_PI_2) ? ph : ((ph < F_PI) ? ph - F_PI_2 : ph - F_PI);
+  v2f integ = c.integ + 0.2f * ALPHA * (aph - F_PI_4);            // :201-202
+  const float lim = F_RAD_PER_DEG * 20.0f;
+  integ = (integ > lim) ? (v2f)(lim) : ((integ < -lim) ? (v2f)(-lim) : integ);
+  c.integ = integ;
+  const v2f power = b_re * b_re + b_im * b_im;                    // :211-213
+  c.mean_power += ALPHA * (power - c.mean_power);
+  const v2f mean_level = v2_sqrt(c.mean_power);                   // :217-223
+  const v2f at_axis = mean_level * F_SQRT1_2;
+  const v2f rd = v2_abs(b_re) - at_axis, id = v2_abs(b_im) - at_axis;
+  const v2f sigma_sq = rd * rd + id * id;
+  c.mean_sigma_sq += ALPHA * (sigma_sq - c.mean_sigma_sq);
+  v2f signal_power = c.mean_power - c.null_power;                 // :225-226
+  signal_power = (signal_power <= 0.0f) ? (v2f)(0.1f) : signal_power;
+  const v2f babs = v2_sqrt(power);
+  const v2f nsr = c.null_power * v2_rcp(signal_power) + 0.7f;
+  v2f w1;
+  if (SOFT_TYPE == 3) w1 = pr_abs;                                // :231-235
+  else if (SOFT_TYPE == 2) w1 = pr_abs * v2_rcp(c.mean_sigma_sq * nsr);   // :236-242
+  else w1 = v2_sqrt(babs * pr_abs) * mean_level * v2_rcp(nsr * (c.mean_sigma_sq * babs));   // :243-251
+  const v2f r1_re = b_re * w1, r1_im = b_im * w1;
+  const v2f s_re = r1_re * w2, s_im = r1_im * w2;                 // :254-255
+  soft_re[0] = cvt_i16_x86(s_re.x); soft_re[1] = cvt_i16_x86(s_re.y);
+  soft_im[0] = cvt_i16_x86(s_im.x); soft_im[1] = cvt_i16_x86(s_im.y);
+  c.prev_re = x_re; c.prev_im = x_im;                             // :354
+  return babs * w1;
+}
+
 __device__ __forceinline__ float demap_w2(float mean_value, int soft_type)
 {
   return (soft_type == 1 ? -100.0f : -140.0f) * __builtin_amdgcn_rcpf(mean_value);

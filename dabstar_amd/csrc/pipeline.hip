@@ -258,17 +258,20 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   const StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   DemapDev &d = e.demap;
-  DemapCarrier cr[DEMAP_Q];
-  int bin[DEMAP_Q], rel[DEMAP_Q];
+  DemapPair cr;                                            // the thread's two carriers, component-wise (demap_pair)
+  int bin[DEMAP_Q];
+  v2f rel_f;
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
     const int k = tid + DEMAP_THREADS * q;
-    bin[q] = t.perm_bin[k]; rel[q] = t.perm_rel[k];
-    cr[q].prev = d.phase_ref[(size_t)s * TU + bin[q]];
-    cr[q].integ = d.integ[(size_t)s * K + k];
-    cr[q].mean_power = d.mean_power[(size_t)s * K + k];
-    cr[q].mean_sigma_sq = d.mean_sigma[(size_t)s * K + k];
-    cr[q].null_power = d.null_power[(size_t)s * TU + bin[q]];
+    bin[q] = t.perm_bin[k];
+    rel_f[q] = (float)(K / 2 - t.perm_rel[k]);
+    const float2 pr = d.phase_ref[(size_t)s * TU + bin[q]];
+    cr.prev_re[q] = pr.x; cr.prev_im[q] = pr.y;
+    cr.integ[q] = d.integ[(size_t)s * K + k];
+    cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
+    cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
+    cr.null_power[q] = d.null_power[(size_t)s * TU + bin[q]];
   }
   float mean_value = d.mean_value[s];
   const float ce = c.clock_err;                           // mClockErrHz of the previous frame, dab_processor.cpp:342
@@ -304,14 +307,14 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     float2 xc[DEMAP_Q];
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[tid + DEMAP_THREADS * q]; }
-    float part = 0.f;
+    int16_t sr[2], si[2];
+    const v2f mag = demap_pair<SOFT_TYPE>(cr, (v2f){xc[0].x, xc[1].x}, (v2f){xc[0].y, xc[1].y}, rel_f, ce, w2, sr, si);
+    const float part = mag.x + mag.y;
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) {
-      int16_t sr, si;
-      part += demap_one(cr[q], xc[q], rel[q], ce, w2, SOFT_TYPE, sr, si);
-      tl[tpos[2 * q]] = soft_to_sym(sr);
-      tl[tpos[2 * q + 1]] = soft_to_sym(si);
-      if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr; cap[(size_t)l * K2 + K + k] = si; }
+      tl[tpos[2 * q]] = soft_to_sym(sr[q]);
+      tl[tpos[2 * q + 1]] = soft_to_sym(si[q]);
+      if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[q]; cap[(size_t)l * K2 + K + k] = si[q]; }
     }
     mean_value = block_sum(part, red, tid) * (1.0f / (float)K);   // two barriers: the tile is complete behind them
     if (l < 3) {                                            // symbols 1..3 -> FIC, linear: bytes 4 tid .. 4 tid + 3
@@ -327,9 +330,9 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
     const int k = tid + DEMAP_THREADS * q;
-    d.integ[(size_t)s * K + k] = cr[q].integ;
-    d.mean_power[(size_t)s * K + k] = cr[q].mean_power;
-    d.mean_sigma[(size_t)s * K + k] = cr[q].mean_sigma_sq;
+    d.integ[(size_t)s * K + k] = cr.integ[q];
+    d.mean_power[(size_t)s * K + k] = cr.mean_power[q];
+    d.mean_sigma[(size_t)s * K + k] = cr.mean_sigma_sq[q];
   }
   if (tid == 0) d.mean_value[s] = mean_value;
 }
