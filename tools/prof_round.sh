@@ -18,12 +18,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$FILT" -d $OUT
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$FILT" -d $OUT/p4 --output-format csv -- python3 bench.py $ARGS > $OUT/p4.log 2>&1
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, json, collections
+import csv, glob, sys, json, collections, re
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p[134]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0].replace("dabx::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[re.sub(r"<.*>$", "", r["Kernel_Name"].split("(")[0].replace("dabx::", "").replace("void ", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in acc.items():
     # full-size launches only (the 7-frame batches): take the maximum-valued half
