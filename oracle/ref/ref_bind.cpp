@@ -6,6 +6,7 @@
 #include "protTables.h"
 #include "eep_protection.h"
 #include "uep_protection.h"
+#include "backend_deconvolver.h"
 #include "reed_solomon.h"
 #include "firecode_checker.h"
 #include "crc.h"
@@ -68,6 +69,14 @@ int ref_uep_deconvolve(int kbps, int prot, const int16_t * in, int n_in, uint8_t
 {
   UepProtection p((i16)kbps, (i16)prot);
   return p.deconvolve(in, n_in, out) ? 0 : -1;
+}
+void ref_backend_deconvolve(int short_form, int kbps, int prot, const int16_t * in, int n_in, uint8_t * out)   // backend_deconvolver.h:29-31
+{
+  SDescriptorType d{};
+  d.shortForm = short_form != 0;
+  d.bitRate = (i16)kbps;
+  d.protLevel = (i16)prot;
+  BackendDeconvolver(&d).deconvolve(in, n_in, out);
 }
 
 int ref_rs_dec(const uint8_t * in120, uint8_t * out110)   // reed_solomon.h:28, params mp4processor.cpp:63,203

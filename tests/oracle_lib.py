@@ -123,6 +123,8 @@ def ref():
         f.argtypes = [C.c_int, C.c_int, _i32p]
     for f in (L.ref_eep_deconvolve, L.ref_uep_deconvolve):
         f.argtypes = [C.c_int, C.c_int, _i16p, C.c_int, _u8p]
+    L.ref_backend_deconvolve.argtypes = [C.c_int, C.c_int, C.c_int, _i16p, C.c_int, _u8p]
+    L.ref_backend_deconvolve.restype = None
     L.ref_rs_dec.argtypes = [_u8p, _u8p]
     L.ref_rs_enc.argtypes = [_u8p, _u8p]
     L.ref_firecode_check.argtypes = [_u8p]

@@ -111,6 +111,20 @@ def test_uep_deconvolve():
         assert np.array_equal(o, r)
 
 
+def test_backend_deconvolver_selects_profile_family():
+    """BackendDeconvolver (backend_deconvolver.cpp:35-52): shortForm -> UEP, else EEP; one pass per profile."""
+    rng = np.random.default_rng(5)
+    for short, profs in ((0, EEP), (1, UEP)):
+        for kbps, prot in profs:
+            n_in, m = (ol.ora_uep_map if short else ol.ora_eep_map)(kbps, prot)
+            soft = rng.integers(-140, 141, n_in).astype(np.int16)
+            r = np.zeros(24 * kbps, np.uint8)
+            o = np.zeros(24 * kbps, np.uint8)
+            ol.ref().ref_backend_deconvolve(short, kbps, prot, soft, n_in, r)
+            ol.oracle().ora_deconvolve(soft, m, kbps, o)
+            assert np.array_equal(o, r), (short, kbps, prot)
+
+
 def test_rs():
     rng = np.random.default_rng(11)
     for trial in range(300):
