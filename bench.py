@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=300)
     ap.add_argument("--fic-only", action="store_true", help="BASELINE config 2 instead of config 4")
+    ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
+                    help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
+                         "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
     return ap.parse_args()
 
 
@@ -61,6 +64,23 @@ def hip():
     return L
 
 
+def mixed_multiplex():
+    """A 16-service DAB+ multiplex as found on air: 32..128 kbit/s, EEP 2-A/3-A/3-B, 782 of 864 CU."""
+    from tools import dab_synth as ds
+    rows = [(64, 2, 48)] * 4 + [(48, 2, 36)] * 3 + [(80, 2, 60)] * 2 + [(96, 2, 72)] * 2 + [(128, 2, 96)] + [(32, 2, 24)] * 2 + \
+           [(56, 1, 56)] + [(32, 6, 18)]
+    out, cu = [], 0
+    for i, (kbps, prot, size) in enumerate(rows):
+        out.append(ds.SubCh(i + 1, cu, size, kbps, prot, 0))
+        cu += size
+    return out
+
+
+def layout_of(args, subch, e):
+    """Sub-channel layout of base ensemble e (streams use ensemble s % args.ensembles)."""
+    return mixed_multiplex() if getattr(args, "layout", "uniform") == "mixed" and e % 2 == 1 else subch
+
+
 def fill_rings(eng, torch, dev, args, rank, subch):
     """Synthetic IQ for every stream, generated on the GPU from a few clean cyclic ensembles (10 frames each)."""
     from tools import dab_synth as ds
@@ -68,7 +88,7 @@ def fill_rings(eng, torch, dev, args, rank, subch):
     n_frames = 10
     base = []
     for e in range(args.ensembles):
-        ens = ds.build_ensemble(n_frames, subch, seed=1000 * rank + e, cyclic=True)
+        ens = ds.build_ensemble(n_frames, layout_of(args, subch, e), seed=1000 * rank + e, cyclic=True)
         base.append(torch.from_numpy(ens.iq).to(dev))
     n = n_frames * TF
     t = torch.arange(n, device=dev, dtype=torch.float64)
@@ -157,7 +177,11 @@ def main():
     subch = ds.default_subchannels(18, 64)
     eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, fic_only=args.fic_only)
     if not args.fic_only:
-        eng.set_subchannels(subch)
+        if args.layout == "mixed":
+            for s_ in range(args.streams):
+                eng.set_subchannels(layout_of(args, subch, s_ % args.ensembles), stream=s_)
+        else:
+            eng.set_subchannels(subch)
     ring_frames = fill_rings(eng, torch, dev, args, rank, subch)
 
     def barrier():
@@ -250,7 +274,10 @@ def main():
                       "frac_of_hbm_peak": round(value / world * A_FRAME / HBM_PEAK, 6),
                       "kernel_ms_per_step_warmup": {k: round(v, 4) for k, v in share.items()}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.layout == "mixed":       # the byte model above is the uniform layout's: no roofline claim for this variant
+            out["config"]["workload"] = out["config"]["workload"].replace("18x64 kbit/s EEP 3-A DAB+ each", "alternating 18x64 kbit/s EEP 3-A and a 16-service multiplex of 7 profiles (32..128 kbit/s, EEP 2-A/3-A/3-B)")
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline and args.layout == "uniform":
             out["cpu_baseline"] = cpu_baseline(args, subch)
         print(json.dumps(out))
     eng.close()

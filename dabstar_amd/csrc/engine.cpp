@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <tuple>
 #include <vector>
 
 namespace dabx {
@@ -45,6 +47,10 @@ struct dabx_engine {
   bool have_fast = false;
   MscFast fast{};
 
+  std::vector<void *> fast_allocs;             // buffers of the current MSC classes (replaced on reconfiguration)
+  bool classes_dirty = false;
+  int build_msc_classes();
+
   template <class T> int alloc(T **p, size_t count, bool zero = true)
   {
     void *q = nullptr;
@@ -56,6 +62,92 @@ struct dabx_engine {
     return 0;
   }
 };
+
+// Groups the active (stream, slot) pairs by protection profile for the lane-per-trellis decoder (vit_t.hip): every
+// class gets its depuncture map, pair list and transposed-symbol / decision scratch.  Up to MSC_MAX_CLASSES classes,
+// largest first; classes too small to fill a few waves and anything beyond stay with the wave-per-trellis kernel.
+int dabx_engine::build_msc_classes()
+{
+  const EngineDev &d = dev;
+  have_fast = false;
+  fast = MscFast{};
+  for (void *q : fast_allocs) {
+    (void)hipFree(q);
+    allocs.erase(std::remove(allocs.begin(), allocs.end(), q), allocs.end());
+  }
+  fast_allocs.clear();
+  for (auto &sc : subch_host) sc.fast_class = 0;
+  if (d.max_subch <= 0) return 0;
+  struct Key { int kbps, prot, shortf, cu; bool operator<(const Key &o) const { return std::tie(kbps, prot, shortf, cu) < std::tie(o.kbps, o.prot, o.shortf, o.cu); } };
+  std::map<Key, std::vector<uint32_t>> groups;
+  int active = 0;
+  for (int s = 0; s < d.n_streams; s++)
+    for (int j = 0; j < d.max_subch; j++) {
+      const SubchDev &sc = subch_host[(size_t)s * d.max_subch + j];
+      if (!sc.active) continue;
+      active++;
+      groups[Key{sc.kbps, sc.prot_level, sc.short_form, sc.cu_size}].push_back(((uint32_t)s << 8) | (uint32_t)j);
+    }
+  std::vector<std::pair<Key, std::vector<uint32_t>>> order(groups.begin(), groups.end());
+  std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) {
+    return (long long)a.second.size() * a.first.kbps > (long long)b.second.size() * b.first.kbps; });
+  // 64 trellises per wave: pays once there are >= ~512 waves per launch; DABX_MSC_FAST_MIN_JOBS overrides (tests)
+  size_t min_jobs = 64 * 512;
+  if (const char *ev = getenv("DABX_MSC_FAST_MIN_JOBS")) min_jobs = (size_t)atoll(ev);
+  size_t class_min_jobs = 256;                                     // fewer than 4 decoder waves per full batch: not worth a class
+  if (const char *ev = getenv("DABX_MSC_CLASS_MIN_JOBS")) class_min_jobs = (size_t)atoll(ev);
+  const int max_cifs = 4 * MSC_BATCH_FRAMES;
+  long long jobs_total = 0;
+  std::vector<std::vector<uint32_t>> host_pairs;
+  int rc;
+  auto falloc = [&](auto **p, size_t count) {
+    int r = alloc(p, count, false);
+    if (!r) fast_allocs.push_back(*p);
+    return r;
+  };
+  for (const auto &kv : order) {
+    if (fast.n_cls >= MSC_MAX_CLASSES) break;
+    const Key &k = kv.first;
+    const std::vector<uint32_t> &pairs = kv.second;
+    if (pairs.size() * (size_t)max_cifs < class_min_jobs) continue;
+    std::vector<uint16_t> m;
+    int n_in = 0;
+    if ((rc = host_profile_map(k.kbps, k.prot, k.shortf, m, &n_in))) return rc;
+    if (n_in % 64 != 0 || n_in != k.cu * 64) continue;
+    for (auto &v : m) if (v == PUNCT) v = (uint16_t)n_in;
+    MscClass c{};
+    c.n_in = n_in; c.nbits = 24 * k.kbps; c.n_pairs = (int)pairs.size();
+    uint16_t *map2 = nullptr;
+    uint32_t *pr = nullptr;
+    if ((rc = falloc(&map2, m.size()))) return rc;
+    if ((rc = falloc(&pr, pairs.size()))) return rc;
+    DABX_HIP(hipMemcpy(map2, m.data(), m.size() * 2, hipMemcpyHostToDevice));
+    DABX_HIP(hipMemcpy(pr, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+    c.map2 = map2; c.pairs = pr;
+    const size_t ngroups = (pairs.size() * (size_t)max_cifs + 63) / 64;
+    if ((rc = falloc(&c.inT[0], ngroups * (size_t)(n_in / 4 + 1) * 64))) return rc;
+    if ((rc = falloc(&c.inT[1], ngroups * (size_t)(n_in / 4 + 1) * 64))) return rc;
+    if ((rc = falloc(&c.decT, ngroups * (size_t)(c.nbits + 6) * 64))) return rc;
+    fast.cls[fast.n_cls++] = c;
+    host_pairs.push_back(pairs);
+    jobs_total += (long long)pairs.size() * max_cifs;
+  }
+  // launch order: longest trellises first, so that the short ones fill in behind them
+  std::vector<int> idx(fast.n_cls);
+  for (int i = 0; i < fast.n_cls; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return fast.cls[a].nbits > fast.cls[b].nbits; });
+  MscFast sorted = fast;
+  for (int i = 0; i < fast.n_cls; i++) {
+    sorted.cls[i] = fast.cls[idx[i]];
+    for (uint32_t q : host_pairs[idx[i]]) subch_host[(size_t)(q >> 8) * d.max_subch + (q & 255u)].fast_class = i + 1;
+  }
+  fast = sorted;
+  fast.min_jobs = (int)std::min<size_t>(min_jobs, 0x7fffffff);
+  fast.slots_active = active;
+  have_fast = fast.n_cls > 0 && (size_t)jobs_total >= min_jobs;
+  DABX_HIP(hipMemcpy(d.subch, subch_host.data(), sizeof(SubchDev) * subch_host.size(), hipMemcpyHostToDevice));
+  return 0;
+}
 
 static int sync_all(dabx_engine *e)
 {
@@ -241,38 +333,8 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
     }
   }
   DABX_HIP(hipMemcpy(d.subch, e->subch_host.data(), sizeof(SubchDev) * e->subch_host.size(), hipMemcpyHostToDevice));
-  // Uniform configuration (every slot of every stream active with one and the same profile): lane-per-trellis decoder
   e->have_fast = false;
-  if (d.max_subch > 0) {
-    const SubchDev &f0 = e->subch_host[0];
-    bool uniform = f0.active != 0;
-    for (const auto &sc : e->subch_host)
-      uniform = uniform && sc.active && sc.kbps == f0.kbps && sc.prot_level == f0.prot_level && sc.short_form == f0.short_form &&
-                sc.cu_size == f0.cu_size;
-    const size_t jobs = (size_t)d.n_streams * 4 * MSC_BATCH_FRAMES * d.max_subch;
-    // 64 trellises per wave: pays once there are >= ~512 waves per launch; DABX_MSC_FAST_MIN_JOBS overrides (tests)
-    size_t min_jobs = 64 * 512;
-    if (const char *ev = getenv("DABX_MSC_FAST_MIN_JOBS")) min_jobs = (size_t)atoll(ev);
-    if (uniform && jobs >= min_jobs) {
-      std::vector<uint16_t> m;
-      int n_in = 0;
-      if ((rc = host_profile_map(f0.kbps, f0.prot_level, f0.short_form, m, &n_in))) return rc;
-      if (n_in % 64 == 0 && n_in == f0.cu_size * 64) {
-        for (auto &v : m) if (v == PUNCT) v = (uint16_t)n_in;
-        uint16_t *map2 = nullptr;
-        if ((rc = e->alloc(&map2, m.size(), false))) return rc;
-        DABX_HIP(hipMemcpy(map2, m.data(), m.size() * 2, hipMemcpyHostToDevice));
-        const size_t groups = (jobs + 63) / 64;
-        MscFast f{};
-        f.n_in = n_in; f.nbits = 24 * f0.kbps; f.min_jobs = (int)min_jobs; f.map2 = map2;
-        if ((rc = e->alloc(&f.inT[0], groups * (size_t)(n_in / 4 + 1) * 64, false))) return rc;
-        if ((rc = e->alloc(&f.inT[1], groups * (size_t)(n_in / 4 + 1) * 64, false))) return rc;
-        if ((rc = e->alloc(&f.decT, groups * (size_t)(f.nbits + 6) * 64, false))) return rc;
-        e->fast = f;
-        e->have_fast = true;
-      }
-    }
-  }
+  e->classes_dirty = true;            // the decoder classes are rebuilt by the next dabx_process (one rebuild for a series of per-stream calls)
   return 0;
 }
 
@@ -360,6 +422,10 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
   // The front end (sync, FFT, demap, FIC) has frame-to-frame feedback and runs once per frame; the MSC decoder
   // has none, so its CIFs are decoded MSC_BATCH_FRAMES frames at a time (more trellises per launch) and always
   // before this call returns.
+  if (e->classes_dirty) {
+    if (int rc = e->build_msc_classes()) return rc;
+    e->classes_dirty = false;
+  }
   for (int i = 0; i < max_frames; i++) {
     int rc = launch_front_step(e->dev, e->stream, e->mk);
     if (rc) return rc;

@@ -46,6 +46,7 @@ struct SubchDev {
   int32_t cu_start, cu_size, kbps, prot_level, short_form, dab_plus;
   int32_t nbits;                  // 24 * kbps
   int32_t active;
+  int32_t fast_class, pad_;       // 1 + index of the lane-per-trellis class this slot belongs to, 0 = none (vit_t.hip)
   const uint16_t *map;            // depuncture map, device
   long long start_cif;            // cif_no when the sub-channel was configured (Backend construction)
   long long cif_out;              // logical frames decoded so far
@@ -89,14 +90,27 @@ struct EngineDev {
   int32_t *tii_cnt;               // [S][2] null symbols in the sum; detector-reset epoch (bumped on loss of lock)
 };
 
-// ---- uniform-profile fast path of the MSC decoder (vit_t.hip) -----------------------------------------------
-struct MscFast {
+// ---- lane-per-trellis path of the MSC decoder (vit_t.hip) ------------------------------------------------------
+// The sub-channels of ALL streams are grouped into classes of equal protection profile (same depuncture map and
+// trellis length): the 64 lanes of a decoder wave then share the map and step count whatever ensemble they come from.
+constexpr int MSC_MAX_CLASSES = 16;
+struct MscClass {
   int n_in, nbits;          // soft bits per job (cu_size*64), decoded bits (24*kbps)
-  int min_jobs;             // below this the wave-per-trellis kernel is used
+  int n_pairs;              // (stream, slot) pairs in the class
   const uint16_t *map2;     // depuncture map with punctured entries remapped to n_in
+  const uint32_t *pairs;    // [n_pairs] (stream << 8) | slot, sorted
   uint32_t *inT[2];         // [groups][n_in/4 + 1][64] transposed de-interleaved symbols, double-buffered per batch
   uint2 *decT;              // [groups][nbits + 6][64] decision words
 };
+struct MscFast {
+  int n_cls;
+  int min_jobs;             // below this many trellises per batch the wave-per-trellis kernel is used for everything
+  int slots_active;         // active (stream, slot) pairs in total (> sum of n_pairs: the rest goes wave-per-trellis)
+  MscClass cls[MSC_MAX_CLASSES];
+};
+// what one batch launches (by value): classes in launch order with their first decoder group
+struct MscLaunchCls { int n_in, nbits, n_pairs, g0; const uint16_t *map2; const uint32_t *pairs; uint32_t *inT; uint2 *decT; };
+struct MscLaunch { int n, groups; MscLaunchCls c[MSC_MAX_CLASSES]; };
 
 // HIP streams/events of the engine: front end on `a`; the long lane-per-trellis decode of batch n runs on `b`
 // while `a` already demodulates the frames of batch n+1.
@@ -153,6 +167,24 @@ __device__ __forceinline__ MscJob msc_job(const EngineDev &e, int J, int cifs)
   const long long valid_from = sc.start_cif + 16;                 // de-interleaver filled, backend.cpp:146-150
   q.valid = sc.active && q.r < c.cif_no && q.r >= valid_from;
   q.out_idx = sc.cif_out + (q.r - (c.msc_done > valid_from ? c.msc_done : valid_from));
+  return q;
+}
+// job J of a class: adjacent jobs = adjacent (stream, slot) pairs of one pending CIF
+__device__ __forceinline__ MscJob msc_class_job(const EngineDev &e, const MscLaunchCls &c, int J, int cifs)
+{
+  MscJob q;
+  q.k = J / c.n_pairs;
+  const int pi = J - q.k * c.n_pairs;
+  q.valid = false; q.r = 0; q.out_idx = 0; q.s = 0; q.j = 0;
+  if (q.k >= cifs) return q;
+  const uint32_t pr = c.pairs[pi];
+  q.s = (int)(pr >> 8); q.j = (int)(pr & 255u);
+  const BatchSnap b = e.snap[q.s];
+  const SubchDev &sc = e.subch[(size_t)q.s * e.max_subch + q.j];
+  q.r = b.msc_done + q.k;
+  const long long valid_from = sc.start_cif + 16;
+  q.valid = sc.active && q.r < b.cif_no && q.r >= valid_from;
+  q.out_idx = sc.cif_out + (q.r - (b.msc_done > valid_from ? b.msc_done : valid_from));
   return q;
 }
 // TDI ring, planar: within a CIF slot soft bit i lives at plane (i & 15), position (i >> 4)

@@ -521,7 +521,8 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
   }
 };
 
-__global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, int cifs)
+// fast_mask: bit c set = class c + 1 is decoded by the lane-per-trellis kernels in this batch (vit_t.hip)
+__global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, int cifs, unsigned fast_mask)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t raw[4][VIT_RAW_WORDS];
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, 
   if (!q.valid) return;
   const int s = q.s, j = q.j;
   const SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
+  if (sc.fast_class && ((fast_mask >> (sc.fast_class - 1)) & 1u)) return;
   const long long r = q.r, out_idx = q.out_idx;
   SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64};
   uint32_t *dec = e.vit_scratch + ((size_t)e.n_streams * 4 + (size_t)job) * (size_t)e.vit_stride;
@@ -747,9 +749,8 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
   return 0;
 }
 
-int launch_msc_prep(const EngineDev &e, int cifs, int n_in, uint32_t *inT, hipStream_t st, Marker &mk);
-int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, const uint32_t *inT, uint2 *decT,
-                    hipStream_t st, Marker &mk);
+int launch_msc_prep(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_t st, Marker &mk);
+int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_t st, Marker &mk);
 
 // MSC decode of the CIFs produced by the last `frames` front-end steps (<= MSC_BATCH_FRAMES) + DAB+ stage.
 // `e.snap` must point at the snapshot buffer of this batch.
@@ -764,12 +765,36 @@ int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, Engine
   // the previous batch (stream b) owns SubchDev / msc_done_cif until it has finished
   if (ss.msc_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0)); ss.msc_in_flight = false; }
   hipLaunchKernelGGL(k_msc_snap, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e, cifs);
-  if (fast && jobs >= fast->min_jobs && ss.b) {
-    uint32_t *inT = fast->inT[ss.batch_parity];
-    if ((rc = launch_msc_prep(e, cifs, fast->n_in, inT, ss.a, mk))) return rc;
+  // classes worth a lane-per-trellis launch in this batch (pipeline.h, MscClass)
+  MscLaunch L{};
+  unsigned fast_mask = 0;
+  long long fast_jobs = 0, fast_pairs = 0;
+  if (fast && ss.b) {
+    for (int c = 0; c < fast->n_cls; c++) fast_jobs += (long long)fast->cls[c].n_pairs * cifs;
+    if (fast_jobs >= fast->min_jobs)
+      for (int c = 0; c < fast->n_cls; c++) {
+        const MscClass &k = fast->cls[c];
+        MscLaunchCls &o = L.c[L.n++];
+        o.n_in = k.n_in; o.nbits = k.nbits; o.n_pairs = k.n_pairs; o.g0 = L.groups;
+        o.map2 = k.map2; o.pairs = k.pairs; o.inT = k.inT[ss.batch_parity]; o.decT = k.decT;
+        L.groups += (int)(((long long)k.n_pairs * cifs + 63) / 64);
+        fast_mask |= 1u << c;
+        fast_pairs += k.n_pairs;
+      }
+  }
+  if (L.n > 0) {
+    if ((rc = launch_msc_prep(e, cifs, L, ss.a, mk))) return rc;
     DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
     DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
-    if ((rc = launch_msc_vitT(e, cifs, fast->n_in, fast->nbits, fast->map2, inT, fast->decT, ss.b, mk))) return rc;
+    if ((rc = launch_msc_vitT(e, cifs, L, ss.b, mk))) return rc;
+    if (fast_pairs < fast->slots_active) {
+      // the remaining sub-channels: wave per trellis, on the front-end stream (it reads the TDI ring in place)
+      mk.begin(8, ss.a);
+      hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs, fast_mask);
+      mk.end(8, ss.a);
+      DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
+      DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+    }
     mk.begin(9, ss.b);
     hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.b, e, *t);
     hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.b, e);
@@ -778,7 +803,7 @@ int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, Engine
     ss.msc_in_flight = true;
   } else {
     mk.begin(8, ss.a);
-    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs);
+    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs, 0u);
     mk.end(8, ss.a);
     mk.begin(9, ss.a);
     hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.a, e, *t);

@@ -8,7 +8,10 @@
 //               scalar tie rule) + PRBS + byte packing for 64 jobs per wave.  The 64 path metrics of a trellis
 //               live in 32 VGPRs as packed int16 pairs; butterflies are v_pk_add/sub/min on register pairs in
 //               place (tools/gen_vit_t.py, vit_t_gen.h); ~3 VALU per trellis step instead of ~8 for the
-//               wave-per-trellis kernel (viterbi_core.h), which remains the path for small or mixed batches.
+//               wave-per-trellis kernel (viterbi_core.h), which remains the path for small batches.
+// Jobs are grouped in CLASSES of equal protection profile across all streams (pipeline.h, MscClass): one launch
+// covers every class, a block finds its class from its group index, so ensembles with different and mixed
+// sub-channel layouts are decoded together.
 #include "pipeline.h"
 #include "vit_t_gen.h"
 
@@ -26,14 +29,25 @@ __device__ __forceinline__ int bitrev4(int v) { return ((v & 1) << 3) | ((v & 2)
 constexpr int PJB = 32;                       // jobs per block
 constexpr int PCH = 64;                       // positions per chunk (bytes per plane run)
 constexpr int PJS = 16 * PCH + 4;             // LDS job stride in bytes (+4: conflict-free ds_read across jobs); 33 KB per block
-__global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, int n_in, uint32_t *inT)
+__device__ __forceinline__ int msc_class_of_group(const MscLaunch &L, int g)
+{
+  int c = 0;
+  while (c + 1 < L.n && g >= L.c[c + 1].g0) c++;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaunch L)
 {
   __shared__ __attribute__((aligned(16))) uint8_t tile[PJB * PJS];
   __shared__ const uint8_t *s_base[PJB];     // per job: stream ring + cu_start*4 (nullptr = invalid job)
   __shared__ long long s_r[PJB];
-  const int tid = threadIdx.x, job0 = blockIdx.x * PJB;
+  const int ci = msc_class_of_group(L, blockIdx.x / (64 / PJB));
+  const MscLaunchCls &cl = L.c[ci];
+  const int n_in = cl.n_in;
+  uint32_t *inT = cl.inT;
+  const int tid = threadIdx.x, job0 = (blockIdx.x - cl.g0 * (64 / PJB)) * PJB;      // job within the class
   if (tid < PJB) {
-    const MscJob q = msc_job(e, job0 + tid, cifs);
+    const MscJob q = msc_class_job(e, cl, job0 + tid, cifs);
     s_base[tid] = q.valid ? e.tdi + (size_t)q.s * TDI_SLOTS * CIF_BITS + e.subch[(size_t)q.s * e.max_subch + q.j].cu_start * 4 : nullptr;
     s_r[tid] = q.r;
   }
@@ -133,16 +147,18 @@ __device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int
 }
 
 // grid = groups, 64 threads.  map: depuncture map with PUNCT remapped to n_in (the 0x7F row).
-__global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, int n_in, int nbits, const uint16_t *map,
-                                                 const uint32_t *inT, uint2 *decT, const uint32_t *prbs)
+__global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs)
 {
   __shared__ unsigned char pos_tab[6][64];
-  const int g = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, blockIdx.x)];
+  const int g = blockIdx.x - cl.g0;                               // decoder group within the class
+  const uint16_t *map = cl.map2;
   for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
-  const MscJob q = msc_job(e, g * 64 + lane, cifs);
-  const int nsteps = nbits + 6, rows = n_in / 4 + 1;
-  const uint32_t *in_lane = inT + (size_t)g * rows * 64 + lane;
-  uint2 *dec_lane = decT + (size_t)g * nsteps * 64 + lane;
+  const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
+  const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
+  const uint32_t *in_lane = cl.inT + (size_t)g * rows * 64 + lane;
+  uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
 
   vt::s2 R[32];
 #pragma unroll
@@ -215,24 +231,21 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, int n_in
 
 // ---------------------------------------------------------------------------------------------------- launch
 // prep on stream a (reads the TDI ring before the front end moves on), decode on stream b.
-int launch_msc_prep(const EngineDev &e, int cifs, int n_in, uint32_t *inT, hipStream_t st, Marker &mk)
+int launch_msc_prep(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_t st, Marker &mk)
 {
-  const int jobs = e.n_streams * cifs * e.max_subch, groups = (jobs + 63) / 64;
   mk.begin(6, st);
-  hipLaunchKernelGGL(k_msc_prep, dim3(groups * (64 / PJB)), dim3(256), 0, st, e, cifs, n_in, inT);
+  hipLaunchKernelGGL(k_msc_prep, dim3(L.groups * (64 / PJB)), dim3(256), 0, st, e, cifs, L);
   mk.end(6, st);
   DABX_HIP(hipGetLastError());
   return 0;
 }
-int launch_msc_vitT(const EngineDev &e, int cifs, int n_in, int nbits, const uint16_t *map2, const uint32_t *inT, uint2 *decT,
-                    hipStream_t st, Marker &mk)
+int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_t st, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
-  const int jobs = e.n_streams * cifs * e.max_subch, groups = (jobs + 63) / 64;
   mk.begin(7, st);
-  hipLaunchKernelGGL(k_msc_vitT, dim3(groups), dim3(64), 0, st, e, cifs, n_in, nbits, map2, inT, decT, t->prbs_words);
+  hipLaunchKernelGGL(k_msc_vitT, dim3(L.groups), dim3(64), 0, st, e, cifs, L, t->prbs_words);
   mk.end(7, st);
   DABX_HIP(hipGetLastError());
   return 0;

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm ships its own HIP runtime.  Load it before libdabx.so pulls in /opt/rocm's (same SONAME, the loader then
+# shares one instance), as bench.py and __graft_entry__.smoke() do: tests that build their input on the device with torch
+# (test_gpu_fullsize.py) must see the very runtime the library allocates with, whatever order the test files run in.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

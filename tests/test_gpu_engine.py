@@ -192,6 +192,60 @@ def test_many_streams_fast_msc_path_matches_single_stream_path(monkeypatch, snr)
     eng.close()
 
 
+def _kernel_launches(eng):
+    ms = (C.c_double * 16)(); cnt = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
+    nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
+    return {names[i].decode(): int(cnt[i]) for i in range(nk)}
+
+
+@pytest.mark.parametrize("class_min", [1, 256])
+def test_profile_classes_decode_mixed_and_per_stream_layouts_lane_per_trellis(monkeypatch, class_min):
+    """Lane-per-trellis MSC decoder on a population of DIFFERENT ensembles: the sub-channels of all streams are grouped
+    into classes of equal protection profile (UEP, EEP-A, EEP-B, 32..128 kbit/s here), one launch decodes every class.
+    class_min = 1: every class goes lane-per-trellis (no wave-per-trellis launch at all); class_min = 256: the small
+    classes stay wave-per-trellis and both kernels share a batch.  Reference: single-stream engines on the
+    wave-per-trellis kernel."""
+    mixed, full = _mixed_subchannels(), ds.default_subchannels(18, 64)
+    n_streams, n_frames = 10, 26
+    cfgs = [full if s % 2 == 0 else mixed for s in range(n_streams)]
+    ens = {id(full): ds.build_ensemble(10, full, seed=41), id(mixed): ds.build_ensemble(10, mixed, seed=42)}
+    xs = [ds.channel(ens[id(cfgs[s])].iq, snr_db=15.0 + s, cfo_hz=150.0 * (s - 5), timing_offset=6151 * s + 5, seed=200 + s,
+                     n_out=(n_frames + 3) * ds.TF) for s in range(n_streams)]
+    monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "64")
+    monkeypatch.setenv("DABX_MSC_CLASS_MIN_JOBS", str(class_min))
+    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=18)
+    for s in range(n_streams):
+        eng.set_subchannels(cfgs[s], stream=s)
+    for s in range(n_streams):
+        eng.push_iq(s, xs[s])
+    dx.check(dx.load().dabx_set_profiling(eng._h, 1))
+    eng.process(n_frames)
+    launches = _kernel_launches(eng)
+    dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+    assert launches["k_msc_vitT"] >= 4 and launches["k_msc_prep"] == launches["k_msc_vitT"]
+    assert (launches["k_msc_frame"] == 0) == (class_min == 1), launches
+    monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "1000000000")
+    for s in (0, 1, 6, 9):
+        ref = dx.Engine(n_streams=1, ring_frames=n_frames + 4, max_subch=18)
+        ref.set_subchannels(cfgs[s])
+        ref.push_iq(0, xs[s])
+        ref.process(n_frames)
+        a, b = eng.stats(s), ref.stats(0)
+        for key in ("frames", "fib_ok", "sf_ok", "sf_fail", "rs_corrected", "rs_failed", "au_ok", "au_bad", "cifs_decoded", "last_start_index"):
+            assert a[key] == b[key], (s, key, a[key], b[key])
+        assert a["frames"] >= n_frames - 2 and a["sf_ok"] > 0
+        eng.subch = list(cfgs[s])
+        for j in range(len(cfgs[s])):
+            assert np.array_equal(eng.read_msc(s, j, 32), ref.read_msc(0, j, 32)), (s, j)
+            if cfgs[s][j].dab_plus:
+                assert np.array_equal(eng.read_superframes(s, j, 4), ref.read_superframes(0, j, 4)), (s, j)
+            assert eng.subch_stats(s, j) == ref.subch_stats(0, j), (s, j)
+        ref.close()
+    # reconfiguration rebuilds the classes: stream 1 switches to the uniform layout and keeps decoding
+    eng.set_subchannels(full, stream=1)
+    eng.close()
+
+
 def test_subchannels_discovered_from_the_decoded_fic_then_decoded():
     """no configuration from outside -- FIG 0/1 + 0/2 from the engine's own FIBs select the
     sub-channels (what FibDecoder hands DabRadio::set_audio_channel), which then decode cleanly."""
