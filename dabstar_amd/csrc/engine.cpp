@@ -38,6 +38,10 @@ struct dabx_engine {
   std::vector<void *> allocs;
   void *stage = nullptr;                       // host -> device staging of dabx_push_iq
   size_t stage_cap = 0;
+  hipStream_t ingest = nullptr;                // dabx_push_iq: copy + format conversion, concurrent with the receiver streams
+  hipEvent_t ingest_done = nullptr;
+  std::vector<unsigned long long> rd_seen;     // [S] read index of every stream when last looked at (lower bound)
+  std::vector<StreamCtl> ctl_peek;
   int max_kbps = 0;
   bool buffers_ready = false;
   Marker mk;
@@ -199,6 +203,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   // release writes the caches back for host visibility on every record)
   DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  DABX_HIP(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
+  DABX_HIP(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  e->rd_seen.assign(cfg->n_streams, 0);
   const int S = cfg->n_streams;
   EngineDev &d = e->dev;
   d.n_streams = S; d.max_subch = cfg->max_subch; d.out_frames = cfg->out_frames;
@@ -261,6 +268,8 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
+  if (e->ingest) { (void)hipStreamSynchronize(e->ingest); (void)hipStreamDestroy(e->ingest); }
+  if (e->ingest_done) (void)hipEventDestroy(e->ingest_done);
   if (e->stage) (void)hipFree(e->stage);
   for (void *p : e->allocs) (void)hipFree(p);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
@@ -361,16 +370,20 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
     return DABX_E_ARG;
   }
   if (n == 0) return 0;
-  {                                       // never overwrite samples the receiver has not read yet
-    if (int rc0 = sync_all(e)) return rc0;
-    StreamCtl c;
-    DABX_HIP(hipMemcpy(&c, e->dev.ctl + stream, sizeof(StreamCtl), hipMemcpyDeviceToHost));
-    const unsigned long long used = e->wr_host[stream] - c.rd;
-    if (used + n > (unsigned long long)e->dev.ring_len) {
+  // never overwrite samples the receiver has not read yet.  rd only grows, so the value seen at the last look is a safe
+  // bound: the pipeline is drained (and rd read again) only when that bound says the ring is full
+  for (int attempt = 0; e->wr_host[stream] - e->rd_seen[stream] + n > (unsigned long long)e->dev.ring_len; attempt++) {
+    if (attempt == 2) {
       set_error("dabx_push_iq: ring of stream %d has room for %llu samples, %zu offered (call dabx_process first)", stream,
-                (unsigned long long)e->dev.ring_len - used, n);
+                (unsigned long long)e->dev.ring_len - (e->wr_host[stream] - e->rd_seen[stream]), n);
       return DABX_E_STATE;
     }
+    // first a look at the counters while the receiver keeps running (any value read is a valid lower bound), then,
+    // if that is not enough, with the pipeline drained
+    if (attempt == 1) { if (int rc0 = sync_all(e)) return rc0; }
+    e->ctl_peek.resize(e->dev.n_streams);
+    DABX_HIP(hipMemcpy(e->ctl_peek.data(), e->dev.ctl, sizeof(StreamCtl) * e->dev.n_streams, hipMemcpyDeviceToHost));
+    for (int s = 0; s < e->dev.n_streams; s++) e->rd_seen[s] = std::max(e->rd_seen[s], e->ctl_peek[s].rd);
   }
   static const int bps[3] = {8, 4, 2};
   const size_t bytes = n * bps[fmt];
@@ -380,10 +393,15 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
     DABX_HIP(hipMalloc(&e->stage, bytes));
     e->stage_cap = bytes;
   }
-  DABX_HIP(hipMemcpyAsync(e->stage, iq, bytes, hipMemcpyHostToDevice, e->stream));
-  int rc = launch_convert_iq(e->stage, fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, e->stream);
-  if (!rc) rc = dabx_commit_iq(e, stream, n);
-  DABX_HIP(hipStreamSynchronize(e->stream));   // the caller's buffer and the staging buffer are free again
+  // copy + conversion on the ingest stream, next to whatever the receiver streams are computing: the samples land
+  // beyond the committed write index, which no queued kernel reads; only the commit is ordered into the front-end stream
+  DABX_HIP(hipMemcpyAsync(e->stage, iq, bytes, hipMemcpyHostToDevice, e->ingest));
+  int rc = launch_convert_iq(e->stage, fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, e->ingest);
+  if (rc) return rc;
+  DABX_HIP(hipEventRecord(e->ingest_done, e->ingest));
+  DABX_HIP(hipStreamWaitEvent(e->stream, e->ingest_done, 0));
+  rc = dabx_commit_iq(e, stream, n);
+  DABX_HIP(hipStreamSynchronize(e->ingest));   // the caller's buffer and the staging buffer are free again
   return rc;
 }
 
