@@ -155,10 +155,14 @@ int  dabx_create(const dabx_config *cfg, dabx_engine **out);
 void dabx_destroy(dabx_engine *e);
 /* MscHandler::set_channel / stop_service equivalent for stream (or all streams when stream < 0): d[j] describes slot j
  * (kbps == 0: empty slot).  A slot whose description is unchanged keeps decoding without interruption; new or changed
- * slots start their 16-CIF de-interleaver fill at the current CIF (growing the largest bit rate restarts all). */
+ * slots start their 16-CIF de-interleaver fill at the current CIF (growing the largest bit rate restarts all).
+ * Streams may carry different layouts: the decoder groups the slots of all streams by protection profile (rebuilt by the
+ * next dabx_process after a series of calls). */
 int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
 /* Host IQ -> device ring (IDeviceHandler::getSamples contract, common/device_handler_if.h:47-48).
- * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70) */
+ * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70).
+ * Returns when the caller's buffer is free again; copy and conversion run on their own HIP stream next to frames still
+ * being decoded (the receiver is drained only if the ring looks full). */
 int  dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_samples);   /* DABX_E_STATE: would overwrite unread samples */
 /* Device-resident producers: ring base (cf32, capacity ring_frames*T_F) and commit of n new samples. */
 int  dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *capacity_samples);
