@@ -246,6 +246,59 @@ def test_profile_classes_decode_mixed_and_per_stream_layouts_lane_per_trellis(mo
     eng.close()
 
 
+def test_more_profiles_than_decoder_classes(monkeypatch):
+    """8 streams with random layouts drawn from 26 protection profiles (EEP-A 1..4, EEP-B, UEP; 16..160 kbit/s): more
+    distinct profiles than the lane-per-trellis decoder has classes (16), so the largest classes go lane-per-trellis and
+    the rest wave-per-trellis within the same batch.  Every stream must equal a single-stream engine."""
+    rng = np.random.default_rng(2024)
+    pool = [(k, p, 0) for k in (16, 32, 48, 64, 96) for p in (0, 1, 2, 3)] + [(32, 4, 0), (64, 6, 0), (96, 5, 0), (160, 2, 0)] + \
+           [(32, 2, 1), (64, 3, 1)]
+    uep_mask = lambda k, l: (ol.ora_uep_map(k, l)[1] >= 0).astype(np.uint8)                 # noqa: E731
+    n_streams, n_frames = 8, 24
+    cfgs = []
+    for s in range(n_streams):
+        order = rng.permutation(len(pool))
+        cu, lay = 0, []
+        for i in order:
+            k, p, sh = pool[i]
+            size = (ol.ora_uep_map if sh else ol.ora_eep_map)(k, p)[0] // 64
+            if cu + size > 864 or len(lay) == 9:
+                continue
+            lay.append(ds.SubCh(len(lay) + 1 + 8 * s % 50, cu, size, k, p, sh, mask=uep_mask(k, p) if sh else None))
+            cu += size
+        cfgs.append(lay)
+    assert len({(c.kbps, c.prot_level, c.short_form) for lay in cfgs for c in lay}) > 16
+    xs = [ds.channel(ds.build_ensemble(10, cfgs[s], seed=300 + s).iq, snr_db=22.0, cfo_hz=90.0 * s - 300, timing_offset=3001 * s + 17,
+                     seed=400 + s, n_out=(n_frames + 3) * ds.TF) for s in range(n_streams)]
+    monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "64")
+    monkeypatch.setenv("DABX_MSC_CLASS_MIN_JOBS", "1")
+    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=9)
+    for s in range(n_streams):
+        eng.set_subchannels(cfgs[s], stream=s)
+        eng.push_iq(s, xs[s])
+    dx.check(dx.load().dabx_set_profiling(eng._h, 1))
+    eng.process(n_frames)
+    launches = _kernel_launches(eng)
+    dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+    assert launches["k_msc_vitT"] >= 4 and launches["k_msc_frame"] == launches["k_msc_vitT"], launches
+    monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "1000000000")
+    for s in range(n_streams):
+        ref = dx.Engine(n_streams=1, ring_frames=n_frames + 4, max_subch=9)
+        ref.set_subchannels(cfgs[s])
+        ref.push_iq(0, xs[s])
+        ref.process(n_frames)
+        a, b = eng.stats(s), ref.stats(0)
+        for key in ("frames", "fib_ok", "sf_ok", "sf_fail", "rs_corrected", "rs_failed", "au_ok", "au_bad", "cifs_decoded"):
+            assert a[key] == b[key], (s, key, a[key], b[key])
+        assert a["frames"] >= n_frames - 2 and a["sf_ok"] > 0, (s, a)
+        eng.subch = list(cfgs[s])
+        for j in range(len(cfgs[s])):
+            assert np.array_equal(eng.read_msc(s, j, 32), ref.read_msc(0, j, 32)), (s, j)
+            assert np.array_equal(eng.read_superframes(s, j, 4), ref.read_superframes(0, j, 4)), (s, j)
+        ref.close()
+    eng.close()
+
+
 def test_subchannels_discovered_from_the_decoded_fic_then_decoded():
     """no configuration from outside -- FIG 0/1 + 0/2 from the engine's own FIBs select the
     sub-channels (what FibDecoder hands DabRadio::set_audio_channel), which then decode cleanly."""
