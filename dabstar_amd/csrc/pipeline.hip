@@ -144,7 +144,20 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
   const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
   __syncthreads();
   if (start < 0) {                                         // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER
+    // the T_u samples just read went through SampleReader's level tracker (sample_reader.cpp:245-248): run it exactly,
+    // sample by sample -- right after start-up the level is still far from settled (it starts at 0.1) and the null-dip
+    // detector of the next attempt compares against it
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); peak[tid + 256 * u] = sqrtf(x.x * x.x + x.y * x.y); }
+    __syncthreads();
     if (tid == 0) {
+      float s_level = c.s_level, peak_level = c.peak_level;
+      for (int i = 0; i < TU; i++) {
+        const float a = peak[i];
+        if (a > peak_level) peak_level = a;
+        s_level += 0.00001f * (a - s_level);
+      }
+      c.s_level = s_level; c.peak_level = peak_level;
       c.rd = rd + TU;
       c.nco_phase = nco_advance(phase0, f, TU);
       c.state = ST_WAIT_SYNC;
