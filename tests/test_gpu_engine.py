@@ -126,6 +126,64 @@ def test_input_level_extremes_follow_the_oracle(gain):
     eng.close()
 
 
+@pytest.mark.parametrize("strongest", [0, 1])
+def test_multipath_channel_follows_the_oracle(strongest):
+    """Two echoes (+37 and +210 samples, -4 and -9 dB, rotated) inside the guard interval: several correlation peaks for
+    the first-peak / strongest-peak selection (phasereference.cpp:136-212), frequency-selective carriers for the demapper."""
+    subch = ds.default_subchannels(9, 64)
+    ens = ds.build_ensemble(10, subch, seed=61)
+    x = ds.channel(ens.iq, snr_db=19.0, cfo_hz=-455.0, timing_offset=101010, seed=61, n_out=24 * ds.TF)
+    y = x.copy()
+    y[37:] += np.complex64(0.63 * np.exp(1j * 1.1)) * x[:-37]
+    y[210:] += np.complex64(0.35 * np.exp(-1j * 2.3)) * x[:-210]
+    y = y.astype(np.complex64)
+    cfg = (3.0, strongest, 1)
+    ora = _oracle_run(y, subch, config=cfg)
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(y, subch, ora["n"], sync_threshold=cfg[0], sync_strongest=bool(strongest))
+    n = min(len(fibs), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 18
+    assert np.array_equal(starts[:n], ora["start"][:n])
+    assert np.array_equal(crc[:n], ora["crc"][:n]) and np.array_equal(fibs[:n], ora["fibs"][:n])
+    assert crc[6:n].all()
+    k = eng.stats(0)["frames"] * 4 - 16
+    for j in range(len(subch)):
+        assert np.array_equal(eng.read_msc(0, j, 16), ora["msc"][j].reshape(-1, 192)[k - 16:k]), j
+    eng.close()
+
+
+def test_arbitrary_push_sizes_give_the_same_result():
+    """IDeviceHandler::getSamples hands over whatever the device has: the stream pushed in random pieces (1 .. 300 000
+    samples) with a dabx_process call after each, through a ring of only 3 frames, must decode exactly like the same
+    stream pushed at once."""
+    subch = ds.default_subchannels(5, 64)
+    ens = ds.build_ensemble(10, subch, seed=71)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=1500.0, timing_offset=5555, seed=71, n_out=21 * ds.TF)
+    ref, fibs_ref, crc_ref, _, starts_ref, _ = _engine_run(x, subch, 21)
+    rng = np.random.default_rng(5)
+    eng = dx.Engine(n_streams=1, ring_frames=3, max_subch=len(subch), out_frames=4)
+    eng.set_subchannels(subch)
+    pos, fibs, crc = 0, [], []
+    while pos < len(x):
+        n = int(min(len(x) - pos, rng.choice([1, 7, 1000, 50021, 196608, 300000])))
+        eng.push_iq(0, x[pos:pos + n])
+        pos += n
+        while True:
+            before = eng.stats(0)["frames"]
+            eng.process(1)
+            if eng.stats(0)["frames"] == before:
+                break
+            f, c = eng.read_fibs(0, 1)
+            fibs.append(f[0]); crc.append(c[0])
+    a, b = eng.stats(0), ref.stats(0)
+    for key in ("frames", "samples_consumed", "fib_ok", "sf_ok", "sf_fail", "rs_corrected", "au_ok", "cifs_decoded", "last_start_index"):
+        assert a[key] == b[key], (key, a[key], b[key])
+    assert np.array_equal(np.array(fibs), fibs_ref[:len(fibs)]) and np.array_equal(np.array(crc), crc_ref[:len(crc)])
+    for j in range(len(subch)):
+        assert np.array_equal(eng.read_msc(0, j, 16), ref.read_msc(0, j, 16)), j
+        assert np.array_equal(eng.read_superframes(0, j, 2), ref.read_superframes(0, j, 2)), j
+    eng.close(); ref.close()
+
+
 def test_soft_bits_within_tolerance_and_transmitted_data_recovered():
     subch = ds.default_subchannels(18, 64)
     ens = ds.build_ensemble(10, subch, seed=7)
