@@ -447,6 +447,53 @@ def test_eti_frames_carry_the_fic_and_the_logical_frames_of_each_cif():
     eng.close()
 
 
+def test_sixty_four_subchannels_discovered_decoded_and_packed_into_eti():
+    """The most sub-channels an ensemble can carry (SubChId is 6 bits): 64 x 8 kbit/s EEP 3-A DAB+.  Discovery from the FIC
+    (the FIG 0/1 / 0/2 description is spread over several FIBs and frames), decode of all 64 slots, per-slot counters and
+    ETI frames with 64 stream-characterisation entries -- all equal to the oracle's."""
+    import test_eti as te
+    subch = [ds.SubCh(i, 6 * i, 6, 8, 2, 0) for i in range(64)]
+    ens = ds.build_ensemble(10, subch, seed=88)
+    x = ds.channel(ens.iq, snr_db=18.0, cfo_hz=-120.0, timing_offset=1234, seed=88, n_out=22 * ds.TF)
+    ora = _oracle_run(x, subch)
+    eng = dx.Engine(n_streams=1, ring_frames=23, max_subch=64, out_frames=8)
+    eng.push_iq(0, x)
+    eng.process(6)
+    found = eng.discover_subchannels(0)                # in order of arrival: the rotation is entered wherever lock came
+    assert sorted((f.subch_id, f.cu_start, f.cu_size, f.kbps, f.prot_level, f.short_form, f.dab_plus) for f in found) == \
+           [(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1) for c in subch]
+    eng.close()
+    eng = dx.Engine(n_streams=1, ring_frames=23, max_subch=64, out_frames=8)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    eng.process(ora["n"])
+    frames, lost = eng.read_eti(0, 64)
+    st = eng.stats(0)
+    assert lost == 0 and st["frames"] >= ora["n"] - 1
+    k = st["frames"] * 4 - 16
+    for j in range(64):
+        assert np.array_equal(eng.read_msc(0, j, 16), ora["msc"][j].reshape(-1, 24)[k - 16:k]), j
+        sub, o = eng.subch_stats(0, j), ora["stats"][j]
+        if sub["cifs_decoded"] == o["cif_out"]:
+            assert (sub["sf_ok"], sub["rs_corrected"], sub["au_ok"], sub["au_bad"]) == (o["sf_ok"], o["rs_corr"], o["au_ok"], o["au_bad"]), j
+        assert sub["sf_ok"] >= 8, (j, sub)
+    descs = [dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0) for c in subch]
+    assert len(frames) == min(32, k)                                      # the rings keep the newest 32 CIFs (8 frames of FIBs)
+    first = k - len(frames)                                               # index of the first logical frame returned
+    for i in (0, 1, len(frames) - 1):
+        r = 16 + first + i
+        F, q = divmod(r, 4)
+        fib = ora["fibs"][F].reshape(-1)
+        hi, lo = int(fib[4] & 0x1F), int(fib[5])
+        for g in range(4):
+            if ora["crc"][F][3 * g]:
+                hi, lo = int(ora["fibs"][F][3 * g][4] & 0x1F), int(ora["fibs"][F][3 * g][5])
+        msc = [ora["msc"][j].reshape(-1, 24)[r - 16] for j in range(64)]
+        want, _ = te._ora_frame(hi, lo, q, descs, fib[96 * q:96 * q + 96], msc)
+        assert np.array_equal(frames[i], want), i
+    eng.close()
+
+
 def _mixed_subchannels():
     uep = lambda k, l: (ol.ora_uep_map(k, l)[1] >= 0).astype(np.uint8)                   # noqa: E731
     return [ds.SubCh(3, 0, 24, 32, 3, 1, mask=uep(32, 3), dab_plus=0),                   # UEP 32k level 3, MP2-style payload

@@ -271,7 +271,16 @@ def build_fibs(subch: list[SubCh], cif_count: int, eid: int = 0x10F2) -> np.ndar
 
     fig00 = bytes([0x05, 0x00, eid >> 8, eid & 0xFF, hi & 0x1F, lo])
     phase = cif_count % 4                 # FIG 0/1 on even CIFs, FIG 0/2 on odd ones (15 + 3 services)
-    if phase in (0, 2):
+    if len(subch) > 18:                   # large ensembles: the description rotates through the CIFs (19 / 14 entries each)
+        n, turn = len(subch), cif_count // 2
+        take = lambda o, k: [subch[(o + i) % n] for i in range(k)]      # noqa: E731
+        if cif_count % 2 == 0:
+            o = (19 * turn) % n
+            payloads = [fig01(take(o, 5)), fig01(take(o + 5, 7)), fig01(take(o + 12, 7))]
+        else:
+            o = (14 * turn) % n
+            payloads = [fig02(take(o, 4)), fig02(take(o + 4, 5)), fig02(take(o + 9, 5))]
+    elif phase in (0, 2):
         payloads = [fig01(subch[0:5]), fig01(subch[5:12]), fig01(subch[12:18])]
     elif phase == 1:
         payloads = [fig02(subch[0:4]), fig02(subch[4:9]), fig02(subch[9:14])]
