@@ -95,8 +95,9 @@ int dabx_engine::build_msc_classes()
   std::vector<std::pair<Key, std::vector<uint32_t>>> order(groups.begin(), groups.end());
   std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) {
     return (long long)a.second.size() * a.first.kbps > (long long)b.second.size() * b.first.kbps; });
-  // 64 trellises per wave: pays once there are >= ~512 waves per launch; DABX_MSC_FAST_MIN_JOBS overrides (tests)
-  size_t min_jobs = 64 * 512;
+  // 64 trellises per wave, decoded on the second HIP stream: measured break-even against the wave-per-trellis kernel at
+  // ~320 waves per batch (40-48 streams of 18 sub-channels); DABX_MSC_FAST_MIN_JOBS overrides (tests)
+  size_t min_jobs = 64 * 320;
   if (const char *ev = getenv("DABX_MSC_FAST_MIN_JOBS")) min_jobs = (size_t)atoll(ev);
   size_t class_min_jobs = 256;                                     // fewer than 4 decoder waves per full batch: not worth a class
   if (const char *ev = getenv("DABX_MSC_CLASS_MIN_JOBS")) class_min_jobs = (size_t)atoll(ev);
