@@ -152,6 +152,18 @@ def cpu_baseline(args, subch):
             L.ora_rx_destroy(r)
         out["all_cores"] = {"value": round(sum(done) / dt, 3), "unit": "frames/s", "cores": ncpu,
                             "sample": "%d threads x %d frames, one receiver each" % (ncpu, n2)}
+    # the reference's OWN object code where it could be built (oracle/_ref, viterbi_spiral.cpp scalar): its Viterbi alone,
+    # as a frame rate (72 MSC blocks of 1542 steps + 4 FIC blocks of 774 per frame)
+    if ol.have_ref():
+        R = ol.ref()
+        rng = np.random.default_rng(0)
+        soft = rng.integers(-127, 128, 4 * 1542).astype(np.int16)
+        bits = np.zeros(1536, np.uint8)
+        reps = 3000
+        us = R.ref_viterbi_seconds(soft, 1536, bits, reps) * 1e6
+        out["reference_viterbi"] = {"us_per_1542_step_block": round(us, 2), "frames_per_s_viterbi_only": round(1e6 / (us * (72 + 4 * 774 / 1542.0)), 2),
+                                    "cores": 1, "kind": "reference",
+                                    "sample": "%d x ViterbiSpiral::deconvolve (scalar build of the reference's own source), 1536 bits" % reps}
     return out
 
 

@@ -15,6 +15,7 @@
 #include "tii_detector.h"
 #include "xml_descriptor.h"     // .uff header parser (QtXml)
 #include "fib_table.h"          // cProtLevelTable: the short-form (UEP) sub-channel table of FIG 0/1
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -39,6 +40,15 @@ int ref_viterbi(const int16_t * soft, int nbits, uint8_t * out)   // viterbi_spi
   ViterbiSpiral v((short)nbits, true);
   v.deconvolve(soft, out);
   return 0;
+}
+
+// one decoder object, `reps` decodes of the same block: seconds per decode (CPU baseline of bench.py)
+double ref_viterbi_seconds(const int16_t * soft, int nbits, uint8_t * out, int reps)
+{
+  ViterbiSpiral v((short)nbits, true);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < reps; i++) v.deconvolve(soft, out);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
 }
 
 int ref_viterbi_ber(const int16_t * soft, uint8_t * punct, const uint8_t * bits, int nbits, int * io_bits, int * io_err)

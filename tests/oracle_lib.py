@@ -117,6 +117,8 @@ def ref():
         return _ref
     L = C.CDLL(REF_SO)
     L.ref_viterbi.argtypes = [_i16p, C.c_int, _u8p]
+    L.ref_viterbi_seconds.argtypes = [_i16p, C.c_int, _u8p, C.c_int]
+    L.ref_viterbi_seconds.restype = C.c_double
     L.ref_viterbi_ber.argtypes = [_i16p, _u8p, _u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ref_pi_codes.argtypes = [C.c_int, _i8p]
     for f in (L.ref_eep_map, L.ref_uep_map):
