@@ -155,15 +155,18 @@ def cpu_baseline(args, subch):
     # the reference's OWN object code where it could be built (oracle/_ref, viterbi_spiral.cpp scalar): its Viterbi alone,
     # as a frame rate (72 MSC blocks of 1542 steps + 4 FIC blocks of 774 per frame)
     if ol.have_ref():
-        R = ol.ref()
         rng = np.random.default_rng(0)
         soft = rng.integers(-127, 128, 4 * 1542).astype(np.int16)
         bits = np.zeros(1536, np.uint8)
         reps = 3000
-        us = R.ref_viterbi_seconds(soft, 1536, bits, reps) * 1e6
-        out["reference_viterbi"] = {"us_per_1542_step_block": round(us, 2), "frames_per_s_viterbi_only": round(1e6 / (us * (72 + 4 * 774 / 1542.0)), 2),
-                                    "cores": 1, "kind": "reference",
-                                    "sample": "%d x ViterbiSpiral::deconvolve (scalar build of the reference's own source), 1536 bits" % reps}
+        ref = {"cores": 1, "kind": "reference", "unit": "frames/s (Viterbi only)",
+               "sample": "%d x ViterbiSpiral::deconvolve of 1536 bits per build variant of the reference's own viterbi_spiral.cpp" % reps}
+        for name, lib in (("scalar", ol.ref()), ("sse2", ol.ref_viterbi_variant("sse2")), ("avx2", ol.ref_viterbi_variant("avx2"))):
+            if lib is None:
+                continue
+            us = lib.ref_viterbi_seconds(soft, 1536, bits, reps) * 1e6
+            ref[name] = {"us_per_1542_step_block": round(us, 2), "value": round(1e6 / (us * (72 + 4 * 774 / 1542.0)), 2)}
+        out["reference_viterbi"] = ref
     return out
 
 

@@ -107,6 +107,24 @@ def oracle():
     return L
 
 
+def ref_viterbi_variant(name):
+    """The reference's Viterbi built with its SIMD option (name = "sse2" | "avx2"), or None (not built / CPU lacks it)."""
+    path = os.path.join(os.path.dirname(REF_SO), "libdabref_vit_%s.so" % name)
+    if not os.path.exists(path):
+        return None
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        flags = ""
+    if (name == "avx2" and " avx2" not in flags) or (name == "sse2" and " sse4_1" not in flags):
+        return None
+    L = C.CDLL(path)
+    L.ref_viterbi.argtypes = [_i16p, C.c_int, _u8p]
+    L.ref_viterbi_seconds.argtypes = [_i16p, C.c_int, _u8p, C.c_int]
+    L.ref_viterbi_seconds.restype = C.c_double
+    return L
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 

@@ -74,6 +74,25 @@ def test_viterbi(n):
         assert np.array_equal(o, r), name
 
 
+@pytest.mark.parametrize("variant", ["sse2", "avx2"])
+def test_reference_simd_viterbi_builds_decode_like_the_scalar_one(variant):
+    """The reference's VITERBI_SSE2 / VITERBI_AVX2 builds (u16 saturating metrics with renormalisation, used as CPU baseline
+    by bench.py): same decoded bits as the canonical scalar build / the oracle on coded blocks with noise."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from tools import dab_synth as ds
+    L = ol.ref_viterbi_variant(variant)
+    if L is None:
+        pytest.skip("variant not built or not supported by this CPU")
+    rng = np.random.default_rng(11)
+    for n, sigma in ((768, 30.0), (1536, 45.0), (3072, 20.0)):
+        msg = rng.integers(0, 2, n).astype(np.uint8)
+        soft = ((ds.conv_encode(msg).astype(np.int16) * 2 - 1) * 60 + rng.normal(0, sigma, 4 * (n + 6))).astype(np.int16)
+        out = np.zeros(n, np.uint8)
+        L.ref_viterbi(soft, n, out)
+        assert np.array_equal(out, ol.ora_viterbi(soft, n)), (variant, n)
+
+
 def test_viterbi_ber():
     rng = np.random.default_rng(5)
     n = 768
