@@ -151,8 +151,18 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
 {
   __shared__ unsigned char pos_tab[6][64];
   const int lane = threadIdx.x;
-  const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, blockIdx.x)];
-  const int g = blockIdx.x - cl.g0;                               // decoder group within the class
+  // Groups are ordered longest trellis first.  All waves of a launch are resident at once (<= 4 per SIMD), so the work of
+  // a SIMD is the sum over the ~4 "rounds" of 1024 blocks that landed on it: walk every second round backwards
+  // (boustrophedon) so that long and short trellises pair up on the same SIMD.
+  int gg = blockIdx.x;
+  {
+    constexpr int ROUND = 1024;                                    // 256 CUs x 4 SIMDs
+    const int r = gg / ROUND, base = r * ROUND;
+    const int len = ML.groups - base < ROUND ? ML.groups - base : ROUND;
+    if (r & 1) gg = base + (len - 1 - (gg - base));
+  }
+  const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, gg)];
+  const int g = gg - cl.g0;                                       // decoder group within the class
   const uint16_t *map = cl.map2;
   for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
   const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
