@@ -39,7 +39,7 @@ struct StreamCtl {
   float snr_db;
   // counters (summed across streams / GPUs by dabx_get_counters)
   long long fib_ok, fib_total, sync_lost;
-  int32_t pad[2];
+  float head_abs_a, head_abs_b;   // sum |x| over the T_u correlation window / the start_index samples read after it (level tracker)
 };
 
 struct SubchDev {

@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
   Nco nco;
   nco.init(phase0, f, tid);
   const RingView rv(ring, e.ring_len, rd);
+  float abs_a = 0.f, abs_b = 0.f;                          // level tracker: sum |x| of what this frame head reads
 #pragma unroll
-  for (int u = 0; u < 8; u++) { v[u] = nco.mix(rv.at(tid + 256 * u)); nco.step(); }
+  for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); abs_a += cabsf_level(x); v[u] = nco.mix(x); nco.step(); }
   const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
   __syncthreads();
   if (start < 0) {                                         // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER
@@ -168,7 +169,13 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
   // symbol 0 = samples [start, start + Tu) of the same (mixed) stream, :402-411
   nco.init(phase0, f, (long long)start + tid);
 #pragma unroll
-  for (int u = 0; u < 8; u++) { v[u] = nco.mix(rv.at(start + tid + 256 * u)); nco.step(); }
+  for (int u = 0; u < 8; u++) {
+    const float2 x = rv.at(start + tid + 256 * u);
+    if (start + tid + 256 * u >= TU) abs_b += cabsf_level(x);   // the start_index samples read beyond the correlation window
+    v[u] = nco.mix(x); nco.step();
+  }
+  abs_a = block_sum(abs_a, red, tid);
+  abs_b = block_sum(abs_b, red, tid);
   fft2048<false>(v, lds, t.twiddle, tid);                 // dab_processor.cpp:199-201
 #pragma unroll
   for (int u = 0; u < 8; u++) e.demap.phase_ref[(size_t)s * TU + tid + 256 * u] = v[u];   // store_reference_symbol_0
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
   e.nco_tid[(size_t)s * 256 + tid] = Nco::tid_factor((int)roundf(f_bb), tid);
   if (tid == 0) {
     c.start_index = start;
+    c.head_abs_a = abs_a; c.head_abs_b = abs_b;
     c.sample_count = start + TU;
     c.sym0_pos = rd + start;
     c.phase_sym1 = nco_advance(phase0, f, (long long)start + TU);
@@ -430,11 +438,11 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   // fine CFO from the 75 cyclic-prefix correlations (dab_processor.cpp:366, 236-242)
-  float cre = 0.f, cim = 0.f, asum = 0.f;
-  if (tid < 75) { const float2 p = e.cp_part[(size_t)s * 75 + tid]; cre = p.x; cim = p.y; asum = e.abs_part[(size_t)s * 76 + tid]; }
+  __shared__ float s_abs[75];
+  float cre = 0.f, cim = 0.f;
+  if (tid < 75) { const float2 p = e.cp_part[(size_t)s * 75 + tid]; cre = p.x; cim = p.y; s_abs[tid] = e.abs_part[(size_t)s * 76 + tid]; }
   cre = block_sum(cre, red, tid);
   cim = block_sum(cim, red, tid);
-  asum = block_sum(asum, red, tid);
   const int f = c.f_frame;
   if (tid == 0) {
     // the reference correlates NCO-mixed samples: x'[i] conj(x'[i-Tu]) = x[i] conj(x[i-Tu]) e^{-j 2 pi f Tu / fs}
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     v[u] = nco.mix(x);
     nco.step();
   }
+  for (int i = tid; i < TN - TU; i += 256) an += cabsf_level(rv.at(i < TG ? i : i + TU));   // the rest of the T_n samples read
   an = block_sum(an, red, tid);
   fft2048<false>(v, lds, t.twiddle, tid);
   const bool is_tii = (c.cif_count & 7) >= 4;              // :274
@@ -497,11 +506,22 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
       if (ce > 307.2f) ce = 307.2f; else if (ce < -307.2f) ce = -307.2f;
       c.clock_err += 0.1f * (ce - c.clock_err);
     }
-    // level IIR of SampleReader over the samples of this frame, applied per chunk with the chunk mean
-    // (approximation of sample_reader.cpp:246-248; only used by the out-of-lock dip detector)
-    const int nread = sample_count;
-    const float mean_abs = (asum + an * ((float)TN / (float)TU)) / (float)(75 * TS + TN);
-    c.s_level += (1.0f - __expf((float)nread * -0.00001f)) * (mean_abs - c.s_level);
+    // Level IIR of SampleReader (sample_reader.cpp:246-248: s += 1e-5 (|x| - s) for every sample read) over the samples of
+    // this frame, chunk by chunk in the order they were read: the T_u correlation window, the start_index samples after
+    // it, symbols 1..75, the null symbol.  Within a chunk the samples are weighted equally (chunk mean); across chunks the
+    // decay q^n is exact -- the null symbol, read last, keeps its full weight.  Only the out-of-lock dip detector reads it.
+    {
+      const float LNQ = -1.00000500003333e-5f;               // ln(1 - 1e-5)
+      float lv = c.s_level;
+      auto upd = [&lv](float sum, int n, float qn) { lv += (1.0f - qn) * (sum / (float)n - lv); };
+      const int start = c.start_index;
+      upd(c.head_abs_a, TU, __expf((float)TU * LNQ));
+      if (start > 0) upd(c.head_abs_b, start, __expf((float)start * LNQ));
+      const float q_ts = __expf((float)TS * LNQ);
+      for (int l = 0; l < 75; l++) upd(s_abs[l], TS, q_ts);
+      upd(an, TN, __expf((float)TN * LNQ));
+      c.s_level = lv;
+    }
     c.sample_count = sample_count;
     c.rd = base + TN;
     c.nco_phase = nco_advance(phase_null, f2, TN);

@@ -1,0 +1,122 @@
+"""GPU differential test: randomly drawn channels and layouts, engine vs the CPU oracle receiver, stream by stream.
+
+24 streams in ONE engine, each with its own SNR (3.5 .. 28 dB), carrier offset (up to +-36 kHz, i.e. also beyond the
++-35 kHz the reference follows), timing, level (-60 .. +30 dB), an echo, a drop-out, and one of three sub-channel layouts.
+Whatever the reference's state machine does with such an input -- late lock, loss of lock, no lock at all -- the engine must
+do the same: FIBs and CRC flags of every frame, the logical frames and the super frames of every sub-channel."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from dabstar_amd import lib as dx
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tools import dab_synth as ds  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N_CASES, N_FRAMES = 24, 22
+
+
+def _layouts():
+    uep = lambda k, l: (ol.ora_uep_map(k, l)[1] >= 0).astype(np.uint8)                   # noqa: E731
+    mixed = [ds.SubCh(3, 0, 24, 32, 3, 1, mask=uep(32, 3), dab_plus=0), ds.SubCh(7, 30, 48, 32, 0, 0),
+             ds.SubCh(12, 80, 128, 128, 1, 0), ds.SubCh(20, 210, 54, 96, 6, 0), ds.SubCh(21, 270, 24, 48, 3, 0),
+             ds.SubCh(33, 300, 48, 64, 2, 0), ds.SubCh(40, 350, 54, 64, 4, 0), ds.SubCh(63, 410, 116, 128, 2, 1, mask=uep(128, 2))]
+    full = ds.default_subchannels(18, 64)
+    return [full, mixed, [full[1], full[8], full[17]]]
+
+
+def _oracle(x, subch):
+    L = ol.oracle()
+    rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    n = L.ora_rx_run(rx, x, len(x), 10000)
+    cap = L.ora_rx_get_capture(rx).contents
+    res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (max(n, 1), 12, 32))[:n].copy(),
+               crc=np.ctypeslib.as_array(cap.fib_crc, (max(n, 1), 12))[:n].copy(),
+               msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
+               sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
+               stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
+    L.ora_rx_destroy(rx)
+    return res
+
+
+def test_random_channels_and_layouts_follow_the_oracle():
+    layouts = _layouts()
+    base = [ds.build_ensemble(10, lay, seed=500 + i) for i, lay in enumerate(layouts)]
+    rng = np.random.default_rng(int(os.environ.get("DABX_FUZZ_SEED", "20260101")))      # other seeds: hunting runs
+    cases, xs = [], []
+    for i in range(N_CASES):
+        li = int(rng.integers(0, 3))
+        snr = float(rng.uniform(3.5, 28.0))
+        cfo = float(rng.uniform(-36000.0, 36000.0)) if i % 3 == 0 else float(rng.uniform(-2500.0, 2500.0))
+        toff = int(rng.integers(0, ds.TF))
+        gain = float(10 ** rng.uniform(-3.0, 1.5)) * 0.25
+        x = ds.channel(base[li].iq, snr_db=snr, cfo_hz=cfo, timing_offset=toff, gain=gain, seed=700 + i, n_out=(N_FRAMES + 2) * ds.TF)
+        if i % 4 == 1:                                    # an echo inside the guard interval
+            d = int(rng.integers(5, 400))
+            x[d:] += np.complex64(rng.uniform(0.2, 0.8) * np.exp(1j * rng.uniform(0, 6.28))) * x[:-d].copy()
+        if i % 5 == 2:                                    # a drop-out of 0.3 .. 2.5 frames somewhere after lock
+            a = int(rng.uniform(7, 12) * ds.TF)
+            x[a:a + int(rng.uniform(0.3, 2.5) * ds.TF)] *= np.float32(1e-3)
+        xs.append(np.ascontiguousarray(x, np.complex64))
+        cases.append((li, snr, cfo, toff, gain))
+
+    eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=4)
+    for s, (li, *_rest) in enumerate(cases):
+        eng.set_subchannels(layouts[li], stream=s)
+        eng.push_iq(s, xs[s])
+    fibs = [[] for _ in range(N_CASES)]
+    crcs = [[] for _ in range(N_CASES)]
+    frames_seen = [0] * N_CASES
+    for _ in range(N_FRAMES + 40):                        # failed acquisition attempts cost steps too
+        eng.process(1)
+        for s in range(N_CASES):
+            f = eng.stats(s)["frames"]
+            if f != frames_seen[s]:
+                frames_seen[s] = f
+                a, b = eng.read_fibs(s, 1)
+                fibs[s].append(a[0]); crcs[s].append(b[0])
+
+    locked = n_bad = n_bad_diff = compared = 0
+    for s, (li, snr, cfo, toff, gain) in enumerate(cases):
+        tag = (s, li, round(snr, 1), round(cfo), toff, gain)
+        subch = layouts[li]
+        ora = _oracle(xs[s], subch)
+        n = len(fibs[s])
+        assert abs(n - ora["n"]) <= 1, (tag, n, ora["n"])           # the oracle also counts a last, partially read frame
+        n = min(n, ora["n"])
+        if n == 0:
+            continue
+        assert np.array_equal(np.array(crcs[s])[:n], ora["crc"][:n]), tag
+        ef, of, okm = np.array(fibs[s])[:n], ora["fibs"][:n], ora["crc"][:n].astype(bool)
+        assert np.array_equal(ef[okm], of[okm]), tag                  # every FIB that passes its CRC: identical bytes
+        # FIBs that fail the CRC are the decoder's answer to noise; with the float demapper equal only within tolerance
+        #  a few of them may differ -- they must stay rare and confined to frames without a good FIB
+        bad_diff = (ef != of).any(axis=2) & ~okm
+        n_bad_diff += int(bad_diff.sum()); n_bad += int((~okm).sum())
+        if os.environ.get("DABX_FUZZ_VERBOSE") and bad_diff.any():
+            print("garbage FIBs differ:", tag, "frames", np.nonzero(bad_diff.any(axis=1))[0].tolist(), "of", n, "crc ok per frame", okm.sum(axis=1).tolist())
+        locked += int(ora["crc"][:n].sum() > 12 * n // 2)
+        if n < 7 or not okm[n - 7:].all():
+            continue                                       # MSC bytes are compared where the signal is decodable: the newest 16 logical
+        eng.subch = list(subch)                            # frames reach back 32 CIFs = 8 frames, of which the last 7 are clean here
+        compared += 1
+        for j, c in enumerate(subch):
+            st = eng.subch_stats(s, j)
+            k, nb = st["cifs_decoded"], 3 * c.kbps
+            o = ora["msc"][j].reshape(-1, nb)
+            assert k <= len(o), (tag, j)
+            m = min(16, k)
+            if m:
+                assert np.array_equal(eng.read_msc(s, j, m), o[k - m:k]), (tag, j)
+            if c.dab_plus and st["sf_ok"]:
+                o_sf = ora["sf"][j].reshape(-1, 110 * c.kbps // 8)
+                q = min(4, st["sf_ok"])
+                assert np.array_equal(eng.read_superframes(s, j, q), o_sf[st["sf_ok"] - q:st["sf_ok"]]), (tag, j)
+    assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
+    assert n_bad_diff <= max(2, n_bad // 10), (n_bad_diff, n_bad)
+    eng.close()
