@@ -1,7 +1,9 @@
 """GPU differential test: randomly drawn channels and layouts, engine vs the CPU oracle receiver, stream by stream.
 
 24 streams in ONE engine, each with its own SNR (3.5 .. 28 dB), carrier offset (up to +-36 kHz, i.e. also beyond the
-+-35 kHz the reference follows), timing, level (-60 .. +30 dB), an echo, a drop-out, and one of three sub-channel layouts.
++-35 kHz the reference follows), timing, level (-60 .. +30 dB), an echo, a drop-out, a sample-clock offset (+-90 ppm) and one
+of three sub-channel layouts.  DABX_FUZZ_SEED / DABX_FUZZ_CFG (threshold, strongest-peak sync, soft-bit generator) and the
+decoder knobs of INTEGRATION.md 7 select other draws, receiver options and the lane-per-trellis MSC path for hunting runs.
 Whatever the reference's state machine does with such an input -- late lock, loss of lock, no lock at all -- the engine must
 do the same: FIBs and CRC flags of every frame, the logical frames and the super frames of every sub-channel."""
 import os
@@ -30,13 +32,14 @@ def _layouts():
     return [full, mixed, [full[1], full[8], full[17]]]
 
 
-def _oracle(x, subch):
+def _oracle(x, subch, cfg):
     L = ol.oracle()
     rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    L.ora_rx_configure(rx, *cfg)
     n = L.ora_rx_run(rx, x, len(x), 10000)
     cap = L.ora_rx_get_capture(rx).contents
-    res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (max(n, 1), 12, 32))[:n].copy(),
-               crc=np.ctypeslib.as_array(cap.fib_crc, (max(n, 1), 12))[:n].copy(),
+    res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy() if n else np.zeros((0, 12, 32), np.uint8),
+               crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy() if n else np.zeros((0, 12), np.uint8),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
                sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
                stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
@@ -48,6 +51,8 @@ def test_random_channels_and_layouts_follow_the_oracle():
     layouts = _layouts()
     base = [ds.build_ensemble(10, lay, seed=500 + i) for i, lay in enumerate(layouts)]
     rng = np.random.default_rng(int(os.environ.get("DABX_FUZZ_SEED", "20260101")))      # other seeds: hunting runs
+    # receiver options (sync threshold, strongest-peak sync, soft-bit generator 1..3): DABX_FUZZ_CFG="4.0,1,2"
+    thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), os.environ.get("DABX_FUZZ_CFG", "3.0,0,1").split(","))]
     cases, xs = [], []
     for i in range(N_CASES):
         li = int(rng.integers(0, 3))
@@ -62,10 +67,16 @@ def test_random_channels_and_layouts_follow_the_oracle():
         if i % 5 == 2:                                    # a drop-out of 0.3 .. 2.5 frames somewhere after lock
             a = int(rng.uniform(7, 12) * ds.TF)
             x[a:a + int(rng.uniform(0.3, 2.5) * ds.TF)] *= np.float32(1e-3)
+        if i % 6 == 3:                                    # sample-clock offset up to +-90 ppm (linear interpolation)
+            t = np.arange(len(x) - 1000, dtype=np.float64) * (1.0 + rng.uniform(-90e-6, 90e-6))    # 90 ppm of 4.7 M = 425 samples
+            i0 = np.floor(t).astype(np.int64)
+            fr = (t - i0).astype(np.float32)
+            x = np.concatenate([(x[i0] * (1 - fr) + x[i0 + 1] * fr).astype(np.complex64), x[-1000:]])
         xs.append(np.ascontiguousarray(x, np.complex64))
         cases.append((li, snr, cfo, toff, gain))
 
-    eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=4)
+    eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=4, sync_threshold=thr,
+                    sync_strongest=bool(strongest), soft_bit_type=soft_type)
     for s, (li, *_rest) in enumerate(cases):
         eng.set_subchannels(layouts[li], stream=s)
         eng.push_iq(s, xs[s])
@@ -85,7 +96,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
         tag = (s, li, round(snr, 1), round(cfo), toff, gain)
         subch = layouts[li]
-        ora = _oracle(xs[s], subch)
+        ora = _oracle(xs[s], subch, (thr, strongest, soft_type))
         n = len(fibs[s])
         assert abs(n - ora["n"]) <= 1, (tag, n, ora["n"])           # the oracle also counts a last, partially read frame
         n = min(n, ora["n"])
