@@ -75,7 +75,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
         xs.append(np.ascontiguousarray(x, np.complex64))
         cases.append((li, snr, cfo, toff, gain))
 
-    eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=4, sync_threshold=thr,
+    eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr,
                     sync_strongest=bool(strongest), soft_bit_type=soft_type)
     for s, (li, *_rest) in enumerate(cases):
         eng.set_subchannels(layouts[li], stream=s)
@@ -83,14 +83,19 @@ def test_random_channels_and_layouts_follow_the_oracle():
     fibs = [[] for _ in range(N_CASES)]
     crcs = [[] for _ in range(N_CASES)]
     frames_seen = [0] * N_CASES
-    for _ in range(N_FRAMES + 40):                        # failed acquisition attempts cost steps too
-        eng.process(1)
+    steps = 0
+    while steps < N_FRAMES + 40:                          # failed acquisition attempts cost steps too
+        m = int(rng.integers(1, 10)) if steps >= 3 else 1 # frames per dabx_process call: 1..9 (MSC batches of 7 + remainder)
+        eng.process(m)
+        steps += m
         for s in range(N_CASES):
             f = eng.stats(s)["frames"]
-            if f != frames_seen[s]:
+            new = f - frames_seen[s]
+            if new:
                 frames_seen[s] = f
-                a, b = eng.read_fibs(s, 1)
-                fibs[s].append(a[0]); crcs[s].append(b[0])
+                a, b = eng.read_fibs(s, new)
+                assert len(a) == new
+                fibs[s].extend(a); crcs[s].extend(b)
 
     locked = n_bad = n_bad_diff = compared = 0
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
