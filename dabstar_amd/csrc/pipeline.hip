@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
 }
 
 // --------------------------------------------------------------------------------------------- frame head
-__global__ __launch_bounds__(256) void k_frame_head(EngineDev e, DevTables t)
+__global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 {
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float peak[TU];
@@ -438,11 +438,16 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   // fine CFO from the 75 cyclic-prefix correlations (dab_processor.cpp:366, 236-242)
-  __shared__ float s_abs[75];
-  float cre = 0.f, cim = 0.f;
-  if (tid < 75) { const float2 p = e.cp_part[(size_t)s * 75 + tid]; cre = p.x; cim = p.y; s_abs[tid] = e.abs_part[(size_t)s * 76 + tid]; }
+  const float LNQ = -1.00000500003333e-5f;                 // ln(1 - 1e-5): decay of the level tracker per sample
+  float cre = 0.f, cim = 0.f, sym_w = 0.f;
+  if (tid < 75) {
+    const float2 p = e.cp_part[(size_t)s * 75 + tid]; cre = p.x; cim = p.y;
+    // level tracker (see the end of this kernel): chunk mean of symbol tid + 1, weighted by the decay over the symbols after it
+    sym_w = e.abs_part[(size_t)s * 76 + tid] * (1.0f / (float)TS) * __expf((float)((74 - tid) * TS) * LNQ);
+  }
   cre = block_sum(cre, red, tid);
   cim = block_sum(cim, red, tid);
+  sym_w = block_sum(sym_w, red, tid);
   const int f = c.f_frame;
   if (tid == 0) {
     // the reference correlates NCO-mixed samples: x'[i] conj(x'[i-Tu]) = x[i] conj(x[i-Tu]) e^{-j 2 pi f Tu / fs}
@@ -511,15 +516,14 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     // it, symbols 1..75, the null symbol.  Within a chunk the samples are weighted equally (chunk mean); across chunks the
     // decay q^n is exact -- the null symbol, read last, keeps its full weight.  Only the out-of-lock dip detector reads it.
     {
-      const float LNQ = -1.00000500003333e-5f;               // ln(1 - 1e-5)
       float lv = c.s_level;
-      auto upd = [&lv](float sum, int n, float qn) { lv += (1.0f - qn) * (sum / (float)n - lv); };
+      auto upd = [&lv](float mean, float qn) { lv += (1.0f - qn) * (mean - lv); };
       const int start = c.start_index;
-      upd(c.head_abs_a, TU, __expf((float)TU * LNQ));
-      if (start > 0) upd(c.head_abs_b, start, __expf((float)start * LNQ));
-      const float q_ts = __expf((float)TS * LNQ);
-      for (int l = 0; l < 75; l++) upd(s_abs[l], TS, q_ts);
-      upd(an, TN, __expf((float)TN * LNQ));
+      upd(c.head_abs_a * (1.0f / (float)TU), __expf((float)TU * LNQ));
+      if (start > 0) upd(c.head_abs_b / (float)start, __expf((float)start * LNQ));
+      // symbols 1..75: lv <- lv q^75 + (1 - q) sum_l q^(74-l) mean_l, the weighted sum taken in parallel above
+      lv = lv * __expf((float)(75 * TS) * LNQ) + (1.0f - __expf((float)TS * LNQ)) * sym_w;
+      upd(an * (1.0f / (float)TN), __expf((float)TN * LNQ));
       c.s_level = lv;
     }
     c.sample_count = sample_count;
