@@ -136,3 +136,58 @@ def test_random_channels_and_layouts_follow_the_oracle():
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
     assert n_bad_diff <= 2, (n_bad_diff, n_bad)
     eng.close()
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_random_service_start_stop_schedules(monkeypatch, fast):
+    """MscHandler::set_channel / stop_service at random times (msc_handler.cpp:95-146): 5 streams of one engine, each with
+    its own channel; between dabx_process calls a random stream gets a new random subset of the 18 services.  A service that
+    keeps running is never disturbed, one that (re)starts at CIF c delivers exactly the oracle's logical frames c, c+1, ...
+    (its 16-CIF de-interleaver fill starts at c).  fast = 1 routes the MSC through the lane-per-trellis classes, which are
+    rebuilt after every change."""
+    if fast:
+        monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "64")
+        monkeypatch.setenv("DABX_MSC_CLASS_MIN_JOBS", "1")
+    rng = np.random.default_rng(77 + fast)
+    subch = ds.default_subchannels(18, 64)
+    n_streams, n_frames = 5, 30
+    ens = ds.build_ensemble(10, subch, seed=90)
+    xs = [ds.channel(ens.iq, snr_db=16.0 + 2 * s, cfo_hz=300.0 * (s - 2), timing_offset=30011 * s + 9, seed=900 + s,
+                     n_out=(n_frames + 3) * ds.TF) for s in range(n_streams)]
+    oras = [_oracle(x, subch, (3.0, 0, 1)) for x in xs]
+    mk = lambda c: dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0)   # noqa: E731
+    empty = dx.SubchDesc(0, 0, 0, 0, 0, 0, 0, 0)
+    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=18, out_frames=4)
+    active = [set(int(j) for j in rng.choice(18, 6, replace=False)) for _ in range(n_streams)]
+    for s in range(n_streams):
+        eng.set_subchannels([mk(subch[j]) if j in active[s] else empty for j in range(18)], stream=s)
+        eng.push_iq(s, xs[s])
+    done = 0
+    while done < n_frames:
+        m = int(rng.integers(1, 6))
+        eng.process(m)
+        done += m
+        for _ in range(int(rng.integers(0, 3))):                      # 0..2 changes between calls
+            s = int(rng.integers(0, n_streams))
+            keep = {j for j in active[s] if rng.random() < 0.7}
+            new = set(int(j) for j in rng.choice(18, int(rng.integers(0, 5)), replace=False))
+            active[s] = keep | new
+            eng.set_subchannels([mk(subch[j]) if j in active[s] else empty for j in range(18)], stream=s)
+    checked = 0
+    for s in range(n_streams):
+        st = eng.stats(s)
+        assert st["frames"] >= n_frames - 2 and st["frames"] * 4 == oras[s]["crc"][:st["frames"]].shape[0] * 4
+        eng.subch = list(subch)
+        for j in range(18):
+            sub = eng.subch_stats(s, j)
+            assert bool(sub["active"]) == (j in active[s]), (s, j)
+            if not sub["active"] or sub["cifs_decoded"] == 0:
+                continue
+            c0, k = sub["start_cif"], sub["cifs_decoded"]
+            assert k == st["frames"] * 4 - c0 - 16, (s, j, c0, k)
+            o = oras[s]["msc"][j].reshape(-1, 192)
+            m = min(16, k)
+            assert np.array_equal(eng.read_msc(s, j, m), o[c0 + k - m:c0 + k]), (s, j, c0, k)
+            checked += 1
+    assert checked >= 10
+    eng.close()
