@@ -97,7 +97,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
                 assert len(a) == new
                 fibs[s].extend(a); crcs[s].extend(b)
 
-    locked = n_bad = n_bad_diff = compared = 0
+    locked = n_bad = n_bad_diff = compared = eti_checked = 0
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
         tag = (s, li, round(snr, 1), round(cfo), toff, gain)
         subch = layouts[li]
@@ -133,6 +133,27 @@ def test_random_channels_and_layouts_follow_the_oracle():
                 o_sf = ora["sf"][j].reshape(-1, 110 * c.kbps // 8)
                 q = min(4, st["sf_ok"])
                 assert np.array_equal(eng.read_superframes(s, j, q), o_sf[st["sf_ok"] - q:st["sf_ok"]]), (tag, j)
+        # ETI-NI frames of the newest CIFs (eti_generator.cpp:169-308): header with the FIG 0/0 counter, stream characterisation of
+        # the layout (UEP / EEP-A / EEP-B TPL fields), FIC, MST, CRCs -- against the oracle's assembly of the oracle's bytes
+        kmin = min(eng.subch_stats(s, j)["cifs_decoded"] for j in range(len(subch)))
+        frames_eti, _lost = eng.read_eti(s, 32)                    # everything the rings still hold: the last one is the newest CIF
+        if kmin >= 16 and len(frames_eti) >= 4 and all(eng.subch_stats(s, j)["cifs_decoded"] == kmin for j in range(len(subch))):
+            import test_eti as te
+            descs = [dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, int(c.dab_plus), 0) for c in subch]
+            Lf = len(frames_eti)
+            for i in range(Lf - 4, Lf):
+                r = 16 + (kmin - Lf + i)
+                F, q = divmod(r, 4)
+                fib = of[F].reshape(-1)
+                hi, lo = int(fib[4] & 0x1F), int(fib[5])              # FIG 0/0 leads FIB 0 of every CIF of the synthetic ensembles;
+                for g in range(4):                                    # the counter state after a frame is that of its last good group
+                    if okm[F][3 * g]:
+                        hi, lo = int(of[F][3 * g][4] & 0x1F), int(of[F][3 * g][5])
+                msc_r = [ora["msc"][j].reshape(-1, 3 * c.kbps)[r - 16] for j, c in enumerate(subch)]
+                want, _ = te._ora_frame(hi, lo, q, descs, fib[96 * q:96 * q + 96], msc_r)
+                assert np.array_equal(frames_eti[i], want), (tag, i, r)
+            eti_checked += 1
+    assert eti_checked >= N_CASES // 4
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
     assert n_bad_diff <= 2, (n_bad_diff, n_bad)
     eng.close()
