@@ -203,8 +203,8 @@ def test_soft_bits_within_tolerance_and_transmitted_data_recovered():
                 d = np.abs(got - exp)
                 # 1 Hz steps of round(f_bb) can differ between the two float pipelines while the loop converges,
                 # so the tight bound is asserted once it has settled; signs must agree wherever |soft| > 8.
-                if done >= 6:
-                    assert (d > 2).mean() < 2e-3, (done, (d > 2).mean(), d.max())
+                if done >= 6:          # measured (tools/soft_diff_stats.py): 2-4 soft bits in 1e5 differ, always by one LSB
+                    assert d.max() <= 1 and (d > 0).mean() < 3e-4, (done, (d > 0).mean(), d.max())
                 strong = np.abs(exp) > 8
                 assert np.array_equal(got[strong] > 0, exp[strong] > 0)
     # transmitted FIBs recovered
