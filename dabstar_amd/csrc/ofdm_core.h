@@ -29,6 +29,18 @@ __device__ __forceinline__ float block_sum(float v, float *red /* >= 8 floats of
   for (int w = 0; w < nw; w++) s += red[w];
   return s;
 }
+// two sums in one pass for blocks of at most 4 waves (red[0..3] / red[4..7]); same summation order as block_sum
+__device__ __forceinline__ void block_sum2(float &a, float &b, float *red /* >= 8 floats of LDS */, int tid)
+{
+  a = wave_sum(a); b = wave_sum(b);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = b; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float sa = 0.f, sb = 0.f;
+  for (int w = 0; w < nw; w++) { sa += red[w]; sb += red[4 + w]; }
+  a = sa; b = sb;
+}
 __device__ __forceinline__ int block_min_int(int v, int *red, int tid)
 {
 #pragma unroll

@@ -174,8 +174,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
     if (start + tid + 256 * u >= TU) abs_b += cabsf_level(x);   // the start_index samples read beyond the correlation window
     v[u] = nco.mix(x); nco.step();
   }
-  abs_a = block_sum(abs_a, red, tid);
-  abs_b = block_sum(abs_b, red, tid);
+  block_sum2(abs_a, abs_b, red, tid);
   fft2048<false>(v, lds, t.twiddle, tid);                 // dab_processor.cpp:199-201
 #pragma unroll
   for (int u = 0; u < 8; u++) e.demap.phase_ref[(size_t)s * TU + tid + 256 * u] = v[u];   // store_reference_symbol_0
@@ -445,8 +444,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     // level tracker (see the end of this kernel): chunk mean of symbol tid + 1, weighted by the decay over the symbols after it
     sym_w = e.abs_part[(size_t)s * 76 + tid] * (1.0f / (float)TS) * __expf((float)((74 - tid) * TS) * LNQ);
   }
-  cre = block_sum(cre, red, tid);
-  cim = block_sum(cim, red, tid);
+  block_sum2(cre, cim, red, tid);
   sym_w = block_sum(sym_w, red, tid);
   const int f = c.f_frame;
   if (tid == 0) {
