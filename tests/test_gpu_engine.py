@@ -381,6 +381,40 @@ def test_more_profiles_than_decoder_classes(monkeypatch):
     eng.close()
 
 
+def test_two_engines_driven_from_two_threads():
+    """A handle is thread-compatible (one caller at a time), different handles are independent: two engines decoding
+    different ensembles from two host threads at once give what each gives alone (shared constant tables behind a mutex,
+    per-thread error strings, separate HIP streams)."""
+    import threading
+    layouts = [ds.default_subchannels(18, 64), _mixed_subchannels()]
+    xs = [ds.channel(ds.build_ensemble(10, lay, seed=140 + i).iq, snr_db=18.0, cfo_hz=-700.0 + 900 * i, timing_offset=4000 + 999 * i,
+                     seed=140 + i, n_out=21 * ds.TF) for i, lay in enumerate(layouts)]
+
+    def run(i, out):
+        eng = dx.Engine(n_streams=1, ring_frames=22, max_subch=18, out_frames=4)
+        eng.set_subchannels(layouts[i])
+        eng.push_iq(0, xs[i])
+        for _ in range(12):
+            eng.process(2)
+        eng.subch = list(layouts[i])
+        out[i] = (eng.stats(0), eng.read_fibs(0, 4), [eng.read_msc(0, j, 16) for j in range(len(layouts[i]))])
+        eng.close()
+
+    alone, together = {}, {}
+    for i in range(2):
+        run(i, alone)
+    th = [threading.Thread(target=run, args=(i, together)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert set(together) == {0, 1} and together[i][0] == alone[i][0] and alone[i][0]["frames"] >= 18
+        assert np.array_equal(together[i][1][0], alone[i][1][0]) and np.array_equal(together[i][1][1], alone[i][1][1])
+        for a, b in zip(together[i][2], alone[i][2]):
+            assert np.array_equal(a, b)
+
+
 def test_subchannels_discovered_from_the_decoded_fic_then_decoded():
     """no configuration from outside -- FIG 0/1 + 0/2 from the engine's own FIBs select the
     sub-channels (what FibDecoder hands DabRadio::set_audio_channel), which then decode cleanly."""
