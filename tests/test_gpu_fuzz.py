@@ -172,7 +172,7 @@ def test_random_service_start_stop_schedules(monkeypatch, fast):
     if fast:
         monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "64")
         monkeypatch.setenv("DABX_MSC_CLASS_MIN_JOBS", "1")
-    rng = np.random.default_rng(77 + fast)
+    rng = np.random.default_rng(int(os.environ.get("DABX_FUZZ_SEED", "77")) + fast)
     subch = ds.default_subchannels(18, 64)
     n_streams, n_frames = 5, 30
     ens = ds.build_ensemble(10, subch, seed=90)
