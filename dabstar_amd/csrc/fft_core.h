@@ -16,8 +16,29 @@ namespace dabx {
 constexpr int FFT_LDS_FLOAT2 = 2048 + 2048 / 16;   // padded: one extra slot per 16
 constexpr int FFT_TW_P2 = 0, FFT_TW_P3 = 56, FFT_TW_P4 = 56 + 448;   // twiddle table sections: [7][8], [7][64], [3][512]
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+// Complex products as three packed instructions: two v_pk_mul_f32 whose op_sel picks (a.x, a.x) x (b.x, b.y) and
+// (a.y, a.y) x (b.y, b.x), and one v_pk_add_f32 with a per-half negation -- the rounding of the scalar formula
+// (four products rounded, then one add/subtract each).  hipcc finds the multiplies by itself but forms sum AND difference
+// as two packed adds plus a move; the add is therefore spelled out.
+typedef float fft_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)        // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+{
+  const fft_v2f A = {a.x, a.y}, W = {b.x, b.y};
+  const fft_v2f t1 = __builtin_shufflevector(A, A, 0, 0) * W;
+  const fft_v2f t2 = __builtin_shufflevector(A, A, 1, 1) * __builtin_shufflevector(W, W, 1, 0);
+  fft_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(t1), "v"(t2));
+  return make_float2(r.x, r.y);
+}
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)   // a * conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+{
+  const fft_v2f A = {a.x, a.y}, W = {b.x, b.y};
+  const fft_v2f t1 = __builtin_shufflevector(A, A, 0, 0) * W;
+  const fft_v2f t2 = __builtin_shufflevector(A, A, 1, 1) * __builtin_shufflevector(W, W, 1, 0);
+  fft_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(t2), "v"(t1));
+  return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 template <bool INV> __device__ __forceinline__ float2 mul_mj(float2 a)   // forward: * (-j); inverse: * (+j)

@@ -102,7 +102,7 @@ struct Nco {
   __device__ float2 mix(float2 v) const
   {
     const float cr = (float)br, ci = (float)bi;
-    return make_float2(v.x * cr - v.y * ci, v.x * ci + v.y * cr);   // v * table[p]
+    return cmul(v, make_float2(cr, ci));                            // v * table[p]
   }
   __device__ void step()
   {
