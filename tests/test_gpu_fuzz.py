@@ -68,7 +68,8 @@ def test_random_channels_and_layouts_follow_the_oracle():
             a = int(rng.uniform(7, 12) * ds.TF)
             x[a:a + int(rng.uniform(0.3, 2.5) * ds.TF)] *= np.float32(1e-3)
         if i % 6 == 3:                                    # sample-clock offset up to +-90 ppm (linear interpolation)
-            t = np.arange(len(x) - 1000, dtype=np.float64) * (1.0 + rng.uniform(-90e-6, 90e-6))    # 90 ppm of 4.7 M = 425 samples
+            ppm = float(os.environ.get("DABX_FUZZ_PPM", "90")) * 1e-6                            # 90 ppm of 4.7 M = 425 samples
+            t = np.arange(len(x) - 1000, dtype=np.float64) * (1.0 + rng.uniform(-ppm, ppm))
             i0 = np.floor(t).astype(np.int64)
             fr = (t - i0).astype(np.float32)
             x = np.concatenate([(x[i0] * (1 - fr) + x[i0 + 1] * fr).astype(np.complex64), x[-1000:]])
