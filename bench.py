@@ -8,7 +8,10 @@ FIC (4 Viterbi + 12 CRC), MSC (72 time-deinterleave + depuncture + Viterbi), RS(
 value = frames/s summed over all GPUs (weak scaling: 512 streams per GPU).
 
 Launch: python bench.py --gpus 1            (single process)
+        python bench.py --gpus N            (no launcher: this process starts N ranks of itself, one per GPU, before it
+                                             touches the GPU, and relays rank 0's JSON line)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   (one rank per GPU)
+        python bench.py --gpus 2 --dry-launch   (CPU: the same launcher and N>1 control flow over gloo, no engine)
 """
 import argparse
 import ctypes as C
@@ -24,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 TF = 196608
 A_FRAME = 2115456          # algorithmic HBM bytes per frame, SURVEY.md 8(d)
+A_FRAME_FIC = 1659264      # the same for config 2 (FIC only)
 # per-kernel share of those bytes (DESIGN.md "Kernels"): what each kernel must move at least
 A_KERNEL = {
     "k_msc_prep": 2 * 4 * 55296,                       # planar TDI read, transposed symbols written
@@ -37,7 +41,8 @@ A_KERNEL = {
     "k_msc_frame": 4 * 55296 + 4 * 3456,              # time-deinterleaver read, packed logical frames out
     "k_dabplus": 4 * 3456 * 5 // 5 + 18 * 880 * 4 // 5,
 }
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4      # wave64 VALU instructions per second, whole chip (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2      # fallback only: wave64 VALU instructions per second at 2 cycles each (MI355X_MICROARCH.md); the
+                                           # figure used is the MEASURED one of tools/valu_peak.hip (load_valu_peak)
 HBM_PEAK = 8.0e12
 
 
@@ -52,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=300)
     ap.add_argument("--fic-only", action="store_true", help="BASELINE config 2 instead of config 4")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="CPU check of the N>1 control flow: ranks join a gloo group, a counting stand-in replaces the engine "
+                         "(no decode, no roofline); prints the same JSON line with \"dry\": true")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
                     help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
                          "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
@@ -170,40 +178,160 @@ def cpu_baseline(args, subch):
     return out
 
 
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start N ranks of this script -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment as torch.distributed.run would set them -- BEFORE anything in this process touches the GPU
+    (the parent never initialises HIP), relay rank 0's JSON line, and fail if any rank fails."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("DABX_BENCH_LAUNCH_TIMEOUT", "3000"))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = "rank %d exited with code %d" % (r, p.returncode)
+        if time.time() > deadline:
+            failed = "ranks still running after the launch timeout"
+        if procs[0].poll() is not None and failed is None and all(p.poll() is not None for p in procs):
+            break
+        time.sleep(0.05)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = "rank %d exited with code %d" % (r, p.returncode)
+    if failed is not None:
+        for p in procs:                       # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        raise SystemExit("bench.py --gpus %d: %s" % (args.gpus, failed))
+    line = procs[0].stdout.read().decode()
+    rec = [ln for ln in line.splitlines() if ln.startswith("{")]
+    if len(rec) != 1 or json.loads(rec[0]).get("n_gpus") != args.gpus:
+        raise SystemExit("bench.py --gpus %d: rank 0 did not report %d joined ranks: %r" % (args.gpus, args.gpus, line[-300:]))
+    print(rec[0])
+
+
+class DryEngine:
+    """--dry-launch stand-in for dabx.Engine: counts the frames the calls would have decoded (CPU, no decode)."""
+
+    def __init__(self, streams):
+        self.streams, self.frames = streams, 0
+
+    def commit(self, n):
+        pass
+
+    def process(self, m, sync=False):
+        self.frames += m * self.streams
+
+    def synchronize(self):
+        pass
+
+    def counters(self):
+        f = self.frames
+        return {"frames": f, "fib_ok": 12 * f, "fib_total": 12 * f, "sf_ok": 0, "sf_fail": 0, "msc_bytes": 0, "streams_locked": self.streams}
+
+    def close(self):
+        pass
+
+
+def load_traffic(dom):
+    """HBM bytes and VALU instructions per FRAME of kernel `dom` from the committed rocprofv3 --pmc passes (tools/prof_round.sh)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if dom not in tj.get("kernels", {}):
+            continue
+        k = tj["kernels"][dom]
+        fpl = k.get("frames_per_launch") or tj["streams"] * (7 if dom.startswith("k_msc") or dom == "k_dabplus" else 1)
+        return {"file": "profiles/" + name, "streams": tj["streams"], "hbm_bytes_per_frame": k["hbm_bytes_per_launch"] / fpl,
+                "valu_per_frame": (k.get("valu_wave_insts_per_launch") or 0) / fpl}
+    return None
+
+
+def load_valu_peak():
+    """Measured chip-wide wave64 VALU issue rate (tools/valu_peak.hip -> profiles/r02_valu_peak.json): the rate of the
+    decoder's own instruction mix at 4 waves per SIMD; falls back to the guide's 2 cycles per wave64 instruction."""
+    try:
+        vj = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_peak.json")))
+        rows = [r for r in vj["rows"] if r["inst"].startswith("mix: butterfly pair + decisions") and r["waves_per_simd"] == 4]
+        return float(rows[0]["wave_insts_per_s"]), "profiles/r02_valu_peak.json: decoder instruction mix, 4 waves/SIMD, all CUs (measured)"
+    except Exception:
+        return VALU_ISSUE_PEAK, "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md; not measured)"
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_launch
+    if dry and os.environ.get("DABX_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies before joining the group
+        raise SystemExit(3)
+    if dry:
+        dev = torch.device("cpu")
+        sync_dev = lambda: None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync_dev = torch.cuda.synchronize
     dist = None
     if world > 1 or os.environ.get("DABX_BENCH_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)     # RCCL
-    from dabstar_amd import lib as dx
-    from tools import dab_synth as ds
-    dx.check(dx.load().dabx_set_device(local_rank))
-
-    subch = ds.default_subchannels(18, 64)
-    eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, fic_only=args.fic_only)
-    if not args.fic_only:
-        if args.layout == "mixed":
-            for s_ in range(args.streams):
-                eng.set_subchannels(layout_of(args, subch, s_ % args.ensembles), stream=s_)
+        if dry:
+            dist.init_process_group("gloo")
         else:
-            eng.set_subchannels(subch)
-    ring_frames = fill_rings(eng, torch, dev, args, rank, subch)
+            dist.init_process_group("nccl", device_id=dev)     # RCCL
+    n_joined = dist.get_world_size() if dist is not None else 1
+    if n_joined != args.gpus:
+        raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (n_joined, args.gpus))
+    from tools import dab_synth as ds
+    subch = ds.default_subchannels(18, 64)
+    dx = None
+    if dry:
+        eng = DryEngine(args.streams)
+        ring_frames = 10
+    else:
+        from dabstar_amd import lib as dx
+        dx.check(dx.load().dabx_set_device(local_rank))
+        eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, fic_only=args.fic_only)
+        if not args.fic_only:
+            if args.layout == "mixed":
+                for s_ in range(args.streams):
+                    eng.set_subchannels(layout_of(args, subch, s_ % args.ensembles), stream=s_)
+            else:
+                eng.set_subchannels(subch)
+        ring_frames = fill_rings(eng, torch, dev, args, rank, subch)
 
     def barrier():
-        torch.cuda.synchronize()
+        sync_dev()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_dev()
 
     def step(n=1):
         # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch, so the
@@ -219,20 +347,22 @@ def main():
     eng.commit(ring_frames * TF - TF)
     step(40)
     eng.synchronize()
-    c0 = eng.counters()
     # warm-up with every kernel instrumented: finds the dominant kernel and the per-kernel breakdown; the timed region
     # then instruments only that kernel (one HIP event pair per launch on the stream it runs on)
     ms = (C.c_double * 16)(); cnt = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
-    dx.check(dx.load().dabx_set_profiling(eng._h, 1))
+    if not dry:
+        dx.check(dx.load().dabx_set_profiling(eng._h, 1))
     step(args.warmup)
     eng.synchronize()
-    nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
-    share = {names[i].decode(): ms[i] / max(1, args.warmup) for i in range(nk) if cnt[i]}      # ms per step (warm-up)
-    dom = max(share, key=share.get) if share else "k_symbols"
-    dom_idx = [names[i].decode() for i in range(nk)].index(dom)
+    share, dom, nk = {}, None, 0
+    if not dry:
+        nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
+        share = {names[i].decode(): ms[i] / max(1, args.warmup) for i in range(nk) if cnt[i]}      # ms per step (warm-up)
+        dom = max(share, key=share.get) if share else "k_symbols"
+        dom_idx = [names[i].decode() for i in range(nk)].index(dom)
+        dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
     c1 = eng.counters()
 
-    dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
     barrier()
     t0 = time.perf_counter()
     step(args.steps)
@@ -240,8 +370,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     c2 = eng.counters()
-    nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
-    dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+    if not dry:
+        nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
+        dx.check(dx.load().dabx_set_profiling(eng._h, 0))
 
     frames = c2["frames"] - c1["frames"]
     fib_ok, fib_tot = c2["fib_ok"] - c1["fib_ok"], c2["fib_total"] - c1["fib_total"]
@@ -253,48 +384,55 @@ def main():
 
     if rank == 0:
         value = frames / dt
-        kern = {names[i].decode(): (ms[i] / cnt[i]) for i in range(nk) if cnt[i]}          # average launch duration (timed region)
-        launches = {names[i].decode(): int(cnt[i]) for i in range(nk) if cnt[i]}
-        units = args.streams * args.steps / launches[dom]      # frames one launch of that kernel processes
-        achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
-        traffic = valu = None
-        try:        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/prof_round.sh)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("streams") == args.streams and dom in tj["kernels"] and units == args.streams * (7 if dom.startswith("k_msc") else 1):
-                traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"])
-                vi = tj["kernels"][dom].get("valu_wave_insts_per_launch")
-                if vi:      # issue-rate view of the same launch: wave64 VALU instructions / (1024 SIMDs x 2.4 GHz / 4 cycles)
-                    valu = {"wave_insts_per_launch": int(vi), "issue_peak_per_s": VALU_ISSUE_PEAK,
-                            "util": round(vi / (kern[dom] * 1e-3) / VALU_ISSUE_PEAK, 4)}
-        except Exception:
-            traffic = valu = None
+        roofline = None
+        if not dry:
+            kern = {names[i].decode(): (ms[i] / cnt[i]) for i in range(nk) if cnt[i]}          # average launch duration (timed region)
+            launches = {names[i].decode(): int(cnt[i]) for i in range(nk) if cnt[i]}
+            units = args.streams * args.steps / launches[dom]      # frames one launch of that kernel processes (average)
+            achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
+            traffic = valu = traffic_src = None
+            tj = load_traffic(dom)
+            if tj is not None and tj["streams"] == args.streams:
+                # counters are per frame of work (collected at whole 7-frame batches), scaled to this run's average launch
+                traffic = int(tj["hbm_bytes_per_frame"] * units)
+                traffic_src = tj["file"] + " (per frame x %.1f frames per launch)" % units
+                if tj["valu_per_frame"]:    # issue-rate view of the same launch: wave64 VALU instructions / measured issue peak
+                    peak, peak_src = load_valu_peak()
+                    vi = tj["valu_per_frame"] * units
+                    valu = {"wave_insts_per_launch": int(vi), "issue_peak_per_s": peak, "issue_peak_source": peak_src,
+                            "util": round(vi / (kern[dom] * 1e-3) / peak, 4)}
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": round(units, 2),
+                        "avg_launch_ms": round(kern[dom], 4), "valu": valu}
+        a_frame = A_FRAME_FIC if args.fic_only else A_FRAME
         out = {
             "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32+i32", "data": "synthetic",
             "config": {"workload": ("FIC only, " if args.fic_only else "") +
                        "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
                        "AWGN %g dB, per-stream CFO/timing" % (args.streams, args.snr),
-                       "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
-                       "x_realtime_per_gpu": round(value / world / (2048000.0 / TF), 1),
+                       "streams_per_gpu": args.streams, "frames_per_step": args.streams * n_joined,
+                       "x_realtime_per_gpu": round(value / n_joined / (2048000.0 / TF), 1),
                        "msamples_per_s": round(value * TF / 1e6, 1)},
             "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
             "streams_locked": locked, "superframes_ok": sf_ok, "superframes_failed": sf_fail, "msc_bytes": msc_bytes,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": units,
-                         "avg_launch_ms": round(kern[dom], 4), "valu": valu},
-            "chain": {"algorithmic_bytes_per_frame": A_FRAME, "achieved_GBps": round(value / world * A_FRAME / 1e9, 2),
-                      "frac_of_hbm_peak": round(value / world * A_FRAME / HBM_PEAK, 6),
+            "roofline": roofline,
+            "chain": {"algorithmic_bytes_per_frame": a_frame, "achieved_GBps": round(value / n_joined * a_frame / 1e9, 2),
+                      "frac_of_hbm_peak": round(value / n_joined * a_frame / HBM_PEAK, 6),
                       "kernel_ms_per_step_warmup": {k: round(v, 4) for k, v in share.items()}},
         }
+        if dry:
+            out["dry"] = True
+            out["data"] = "none (dry launch: control flow only)"
         if args.layout == "mixed":       # the byte model above is the uniform layout's: no roofline claim for this variant
             out["config"]["workload"] = out["config"]["workload"].replace("18x64 kbit/s EEP 3-A DAB+ each", "alternating 18x64 kbit/s EEP 3-A and a 16-service multiplex of 7 profiles (32..128 kbit/s, EEP 2-A/3-A/3-B)")
             out["roofline"] = None
-        if world == 1 and not args.no_cpu_baseline and args.layout == "uniform":
+        if n_joined == 1 and not dry and not args.no_cpu_baseline and args.layout == "uniform":
             out["cpu_baseline"] = cpu_baseline(args, subch)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -98,16 +98,30 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
 // byte lane of every symbol (2 bits each).  Fetched one cycle ahead so no memory latency sits on the ACS chain.
 struct VtCycle { uint32_t w[24]; unsigned long long sh; };
 
-__device__ __forceinline__ void vt_fetch(VtCycle &c, const uint32_t *in_lane, const uint16_t *map, int t0)
+// The depuncture map is written once by the host (engine.cpp, build_msc_classes) and never by a kernel: read through the
+// CONSTANT address space its entries come in over the scalar cache (s_load_dwordx2 per trellis step, lgkmcnt) instead of
+// as vector loads + v_readfirstlane, which sat in the same in-order vmcnt queue as the symbol loads and decision stores and
+// forced a full s_waitcnt vmcnt(0) round trip per 6-step cycle.
+typedef unsigned vt_u2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) vt_u2 *vt_cmap;
+
+// in_grp: buffer resource over the group's transposed symbols [row][64 lanes]: the row offset is wave-uniform and goes
+// into the instruction's scalar offset, the lane is the only vector part of the address (no 64-bit VALU address math)
+typedef __amdgpu_buffer_rsrc_t vt_rsrc;
+__device__ __forceinline__ vt_rsrc vt_make_rsrc(const uint32_t *base, unsigned bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword format (gfx9 / CDNA)
+}
+__device__ __forceinline__ void vt_fetch(VtCycle &c, vt_rsrc in_grp, int lane, vt_cmap map, int t0)
 {
   c.sh = 0;
 #pragma unroll
   for (int s6 = 0; s6 < 6; s6++) {
-    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * (t0 + s6));   // wave-uniform
-    const unsigned idx[4] = {m.x, m.y, m.z, m.w};
+    const vt_u2 m = map[t0 + s6];                                    // 4 x uint16 indices of step t0 + s6, wave-uniform
+    const unsigned idx[4] = {m.x & 0xFFFFu, m.x >> 16, m.y & 0xFFFFu, m.y >> 16};
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      c.w[4 * s6 + p] = in_lane[(size_t)(idx[p] >> 2) * 64];
+      c.w[4 * s6 + p] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(in_grp, lane * 4, (int)((idx[p] >> 2) * 256u), 0);
       c.sh |= (unsigned long long)(idx[p] & 3) << (2 * (4 * s6 + p));
     }
   }
@@ -167,28 +181,37 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
   const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
   const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
-  const uint32_t *in_lane = cl.inT + (size_t)g * rows * 64 + lane;
+  const vt_rsrc in_grp = vt_make_rsrc(cl.inT + (size_t)g * rows * 64, (unsigned)rows * 256u);
   uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
+  const vt_cmap cmap = (vt_cmap)(const void *)map;
 
   vt::s2 R[32];
 #pragma unroll
   for (int r = 0; r < 32; r++) R[r] = vt::pk(2000, 2000);          // viterbi_spiral.cpp:98-101 (0 / 1000), doubled
   R[0] = vt::pk(0, 2000);
+  // Two 6-step cycles of symbols are always in flight, fetched UNCONDITIONALLY one cycle ahead (beyond the end the last
+  // cycle is fetched again): with no branch around a fetch the number of outstanding loads is static and the compiler
+  // waits with s_waitcnt vmcnt(N) for exactly the cycle it is about to consume instead of draining the queue.
+  const int last = nsteps - 6;                                     // nsteps is a multiple of 6, >= 12
   VtCycle ca, cb;
-  vt_fetch(ca, in_lane, map, 0);
-  for (int t = 0; t < nsteps; t += 12) {                           // nsteps is a multiple of 6
-    const bool second = t + 6 < nsteps;
-    if (second) vt_fetch(cb, in_lane, map, t + 6);
-    {                                                              // re-centre every 12 steps on the metric of label 0
-      const vt::s2 ref = vt::pk(R[0].x, R[0].x);
+  vt_fetch(ca, in_grp, lane, cmap, 0);
+  vt_fetch(cb, in_grp, lane, cmap, 6);
+  auto recentre = [&R]() {                                         // every 12 steps on the metric of label 0
+    const vt::s2 ref = vt::pk(R[0].x, R[0].x);
 #pragma unroll
-      for (int r = 0; r < 32; r++) R[r] = R[r] - ref;
-    }
+    for (int r = 0; r < 32; r++) R[r] = R[r] - ref;
+  };
+  int t = 0;
+  for (; t + 12 <= nsteps; t += 12) {
+    recentre();
     vt_cycle(R, ca, t, dec_lane);
-    if (second) {
-      if (t + 12 < nsteps) vt_fetch(ca, in_lane, map, t + 12);
-      vt_cycle(R, cb, t + 6, dec_lane);
-    }
+    vt_fetch(ca, in_grp, lane, cmap, t + 12 < last ? t + 12 : last);
+    vt_cycle(R, cb, t + 6, dec_lane);
+    vt_fetch(cb, in_grp, lane, cmap, t + 18 < last ? t + 18 : last);
+  }
+  if (t < nsteps) {                                                // odd number of cycles
+    recentre();
+    vt_cycle(R, ca, t, dec_lane);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);

@@ -50,13 +50,21 @@ def class_plan(c):
             dlist += [("a", k), ("b", k)]
             labels[("a", k)] = (ra, ra | 32)
             labels[("b", k)] = (rb, rb | 32)
-    # perm j takes S0 = dlist[2j], S1 = dlist[2j+1]; result bytes: [S1.lo, S1.hi, S0.lo, S0.hi] sign bytes
+    # c != 0: perm j takes S0 = a-difference, S1 = b-difference of pair j; result bytes [S1.lo, S1.hi, S0.lo, S0.hi] as
+    # 0x00 / 0xFF, folded with mask 0x01010101 << (j % 8) into word j // 8.  c == 0: register r goes to bytes (0, 1)
+    # (r even) or (2, 3) (r odd) = labels (r, r | 32) of perm j = r // 2.
     pos = [None] * 64
-    for j in range(16):
-        a, k = j // 8, j % 8
-        s0, s1 = dlist[2 * j], dlist[2 * j + 1]
-        for b, lab in enumerate((labels[s1][0], labels[s1][1], labels[s0][0], labels[s0][1])):
-            pos[lab] = 32 * a + 8 * b + 7 - k
+    if c == 0:
+        for r in range(32):
+            j, base = r // 2, 2 * (r % 2)
+            pos[r] = 32 * (j // 8) + 8 * base + j % 8
+            pos[r | 32] = 32 * (j // 8) + 8 * (base + 1) + j % 8
+    else:
+        for j in range(16):
+            a, k = j // 8, j % 8
+            s0, s1 = dlist[2 * j], dlist[2 * j + 1]
+            for b, lab in enumerate((labels[s1][0], labels[s1][1], labels[s0][0], labels[s0][1])):
+                pos[lab] = 32 * a + 8 * b + k
     plan["dlist"] = dlist
     plan["pos"] = pos
     return plan
@@ -155,14 +163,22 @@ def emit():
     A("__device__ __forceinline__ unsigned u(s2 v) { return __builtin_bit_cast(unsigned, v); }")
     A("__device__ __forceinline__ s2 s(unsigned v) { return __builtin_bit_cast(s2, v); }")
     A("__device__ __forceinline__ s2 pk(int lo, int hi) { return s(__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u)); }")
-    A("__device__ __forceinline__ s2 swp(s2 v) { return s(__builtin_amdgcn_alignbit(u(v), u(v), 16)); }")
     A("__device__ __forceinline__ s2 mn(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }")
-    A("// sign bytes of two packed difference registers -> bits 7,15,23,31 = [s1.lo, s1.hi, s0.lo, s0.hi]")
-    A("__device__ __forceinline__ unsigned sg(s2 s0, s2 s1) { return __builtin_amdgcn_perm(u(s0), u(s1), 0x07050301u); }")
+    A("// VOP3P op_sel forms (class 0: the butterfly partner is the other half of the same register)")
+    A("__device__ __forceinline__ s2 mn_x(s2 a, s2 b)      // (min(a.lo, b.hi), min(a.hi, b.lo))")
+    A("{ s2 r; asm(\"v_pk_min_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\" : \"=v\"(r) : \"v\"(a), \"v\"(b)); return r; }")
+    A("__device__ __forceinline__ s2 sub_hl(s2 a, s2 b)    // (a.hi - b.lo, a.lo - b.hi)")
+    A("{ s2 r; asm(\"v_pk_sub_i16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]\" : \"=v\"(r) : \"v\"(a), \"v\"(b)); return r; }")
+    A("__device__ __forceinline__ s2 sub_lh(s2 a, s2 b)    // (a.lo - b.hi, a.hi - b.lo)")
+    A("{ s2 r; asm(\"v_pk_sub_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\" : \"=v\"(r) : \"v\"(a), \"v\"(b)); return r; }")
+    A("// v_perm_b32 selectors 8..11 = sign of S1.lo, S1.hi, S0.lo, S0.hi replicated over the byte (0x00 / 0xFF); 12 = 0x00")
+    A("__device__ __forceinline__ unsigned sg(s2 s0, s2 s1) { return __builtin_amdgcn_perm(u(s0), u(s1), 0x0B0A0908u); }")
+    A("__device__ __forceinline__ unsigned sg_even(s2 dd, s2 ee) { return __builtin_amdgcn_perm(u(dd), u(ee), 0x0C0C090Au); }   // [dd.lo, ee.hi, 0, 0]")
+    A("__device__ __forceinline__ unsigned sg_odd(s2 dd, s2 ee) { return __builtin_amdgcn_perm(u(dd), u(ee), 0x090A0C0Cu); }    // [0, 0, dd.lo, ee.hi]")
     A("template <int K> __device__ __forceinline__ void fold(unsigned &acc, unsigned p)")
-    A("{ constexpr unsigned M = 0x80808080u >> K;   // shift + v_and_or_b32 per perm (hipcc splits the and/or otherwise)")
+    A("{ constexpr unsigned M = 0x01010101u << K;   // one v_and_or_b32 per gather (hipcc splits the and/or otherwise)")
     A("  if (K == 0) acc = p & M;")
-    A("  else { const unsigned t = p >> K; asm(\"v_and_or_b32 %0, %1, %2, %0\" : \"+v\"(acc) : \"v\"(t), \"s\"(M)); } }")
+    A("  else asm(\"v_and_or_b32 %0, %1, %2, %0\" : \"+v\"(acc) : \"v\"(p), \"s\"(M)); }")
     A("")
     A("// exchange bit of each step class and decision bit position of every label (chain-back tables)")
     A("__device__ constexpr unsigned char VT_P[6] = {%s};" % ", ".join(str(pl["p"]) for pl in PLANS))
@@ -180,17 +196,16 @@ def emit():
             qs = sorted(set(min(q, 7 - q) for _, q in pl["regs"]))
             for q in qs:
                 A("  const s2 M%d = pk(W[%d], W[%d]);" % (q, q, q))
-            for r, q in pl["regs"]:
-                cq, flip = (q, False) if q < 4 else (7 - q, True)
-                A("  { const s2 t1 = R[%d] %s M%d, t2 = swp(R[%d] %s M%d);" % (r, "-" if flip else "+", cq, r, "+" if flip else "-", cq))
-                A("    R[%d] = mn(t1, t2); const s2 dd = t2 - t1, ee = t1 - t2;" % r)
-                A("    const s2 m%d = s(__builtin_amdgcn_perm(u(ee), u(dd), 0x07060100u));" % r)   # (dd.lo, ee.hi)
-                if r % 2 == 1:
-                    j = r // 2
-                    A("    fold<%d>(acc%d, sg(m%d, m%d)); }" % (j % 8, j // 8, r - 1, r))
-                else:
-                    A("  }" if False else "    (void)0; }")
-            # the m registers of even r must outlive their block: re-emit with explicit declarations
+            for j in range(16):
+                names = []
+                for r in (2 * j, 2 * j + 1):
+                    q = pl["regs"][r][1]
+                    cq, flip = (q, False) if q < 4 else (7 - q, True)
+                    # t1 = (a0, b1), t2 = (a1, b0): new = (min(a0, b0), min(b1, a1)), d0 = b0 - a0, d1 = b1 - a1
+                    A("  const s2 t1_%d = R[%d] %s M%d, t2_%d = R[%d] %s M%d;" % (r, r, "-" if flip else "+", cq, r, r, "+" if flip else "-", cq))
+                    A("  R[%d] = mn_x(t1_%d, t2_%d);" % (r, r, r))
+                    names.append((r, "sub_hl(t2_%d, t1_%d)" % (r, r), "sub_lh(t1_%d, t2_%d)" % (r, r)))
+                A("  fold<%d>(acc%d, sg_even(%s, %s) | sg_odd(%s, %s));" % (j % 8, j // 8, names[0][1], names[0][2], names[1][1], names[1][2]))
         else:
             combos = {}
             for ra, rb, ql, qh in pl["pairs"]:
@@ -212,35 +227,10 @@ def emit():
     return "\n".join(o) + "\n"
 
 
-def emit_fixed():
-    """Class 0 needs the merged difference registers of two consecutive registers in one perm: emit it flat."""
-    txt = emit()
-    # rebuild step0 body cleanly
-    pl = PLANS[0]
-    body = ["__device__ __forceinline__ void step0(s2 (&R)[32], const int (&W)[8], unsigned &acc0, unsigned &acc1)", "{"]
-    qs = sorted(set(min(q, 7 - q) for _, q in pl["regs"]))
-    for q in qs:
-        body.append("  const s2 M%d = pk(W[%d], W[%d]);" % (q, q, q))
-    for j in range(16):
-        names = []
-        for r in (2 * j, 2 * j + 1):
-            q = pl["regs"][r][1]
-            cq, flip = (q, False) if q < 4 else (7 - q, True)
-            body.append("  const s2 t1_%d = R[%d] %s M%d, t2_%d = swp(R[%d] %s M%d);" % (r, r, "-" if flip else "+", cq, r, r, "+" if flip else "-", cq))
-            body.append("  R[%d] = mn(t1_%d, t2_%d);" % (r, r, r))
-            body.append("  const s2 m_%d = s(__builtin_amdgcn_perm(u(t1_%d - t2_%d), u(t2_%d - t1_%d), 0x07060100u));" % (r, r, r, r, r))
-            names.append("m_%d" % r)
-        body.append("  fold<%d>(acc%d, sg(%s, %s));" % (j % 8, j // 8, names[0], names[1]))
-    body.append("}")
-    a = txt.index("__device__ __forceinline__ void step0(")
-    b = txt.index("__device__ __forceinline__ void step1(")
-    return txt[:a] + "\n".join(body) + "\n\n" + txt[b:]
-
-
 if __name__ == "__main__" and "--emit" in sys.argv:
     import os
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dabstar_amd", "csrc", "vit_t_gen.h")
-    open(out, "w").write(emit_fixed())
+    open(out, "w").write(emit())
     print("wrote", os.path.normpath(out))
     for pl in PLANS[1:]:
         combos = set((ql, qh) if ql < 4 else (7 - ql, 7 - qh) for _, _, ql, qh in pl["pairs"])
