@@ -12,11 +12,12 @@
 
 namespace dabx {
 int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk);
-int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, EngineStreams &ss, Marker &mk);
+int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk);
+int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
 extern const char *const kStepKernelNames[10];
 int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st);
 int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st);
-int launch_fic_only(const EngineDev &e, hipStream_t st);
+int launch_fic_only(const EngineDev &e, hipStream_t st, int first, int count);
 int launch_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n, hipStream_t st);
 }  // namespace dabx
 using namespace dabx;
@@ -154,8 +155,19 @@ int dabx_engine::build_msc_classes()
   return 0;
 }
 
+// Engine calls may come from any host thread: bind the thread to the engine's device first (allocations, launches and
+// copies below otherwise go to whatever device the calling thread happens to have current).
+static int use_device(const dabx_engine *e)
+{
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == e->device) return 0;
+  DABX_HIP(hipSetDevice(e->device));
+  return 0;
+}
+
 static int sync_all(dabx_engine *e)
 {
+  if (int rc = use_device(e)) return rc;
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
   return 0;
@@ -264,6 +276,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
 void dabx_destroy(dabx_engine *e)
 {
   if (!e) return;
+  (void)use_device(e);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->ss.b) { (void)hipStreamSynchronize(e->ss.b); (void)hipStreamDestroy(e->ss.b); }
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
@@ -306,24 +319,39 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
       set_error("sub-channel %d: %d CU at %d do not hold %d coded bits", j, q.cu_size, q.cu_start, n_in);
       return DABX_E_PROFILE;
     }
+    // the DAB+ stage (k_dabplus) holds a super frame of at most 384 kbit/s (RS interleaving depth kbps / 8 <= 48) in LDS;
+    // ETSI TS 102 563 defines DAB+ sub-channels in multiples of 8 kbit/s only
+    if (q.dab_plus && (q.kbps > 384 || q.kbps % 8 != 0)) {
+      set_error("sub-channel %d: %d kbit/s is not a DAB+ rate (multiples of 8 up to 384); configure it with dab_plus = 0", j, q.kbps);
+      return DABX_E_PROFILE;
+    }
     sc.cu_start = q.cu_start; sc.cu_size = q.cu_size; sc.kbps = q.kbps; sc.prot_level = q.prot_level;
     sc.short_form = q.short_form; sc.dab_plus = q.dab_plus; sc.nbits = 24 * q.kbps; sc.active = 1; sc.map = map;
     row[j] = sc;
     max_kbps = std::max(max_kbps, q.kbps);
   }
-  // (re)allocate output rings / scratch when the largest bit rate grows
-  bool rings_reset = false;
+  // When the largest bit rate grows the output rings get wider slots.  Running services are not disturbed
+  // (MscHandler::set_channel only adds a Backend, msc_handler.cpp:95-131): the rings are re-strided with their contents,
+  // every counter and ring index stays valid, the superseded buffers are freed.
   if (max_kbps > e->max_kbps) {
-    rings_reset = true;
+    const int old_msc = d.msc_stride, old_sf = d.sf_stride;
+    uint8_t *old_msc_out = d.msc_out, *old_sf_out = d.sf_out;
+    uint32_t *old_scratch = d.vit_scratch;
     e->max_kbps = max_kbps;
     d.msc_stride = 3 * max_kbps;
     d.sf_stride = ((110 * max_kbps / 8) + 15) & ~15;
     d.vit_stride = (int)std::max(vit_scratch_words(FIC_OUT), vit_scratch_words(24 * max_kbps));
-    if ((rc = e->alloc(&d.msc_out, (size_t)d.n_streams * d.max_subch * MSC_SLOTS * d.msc_stride))) return rc;
-    if ((rc = e->alloc(&d.sf_out, (size_t)d.n_streams * d.max_subch * SF_SLOTS * d.sf_stride))) return rc;
+    const size_t msc_rows = (size_t)d.n_streams * d.max_subch * MSC_SLOTS, sf_rows = (size_t)d.n_streams * d.max_subch * SF_SLOTS;
+    if ((rc = e->alloc(&d.msc_out, msc_rows * d.msc_stride))) return rc;
+    if ((rc = e->alloc(&d.sf_out, sf_rows * d.sf_stride))) return rc;
     if ((rc = e->alloc(&d.vit_scratch, (size_t)d.n_streams * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * d.vit_stride, false))) return rc;
-    // sub-channels configured earlier restart their output rings
-    for (auto &sc : e->subch_host) { sc.cif_out = 0; sc.blocks_in_buf = 0; sc.sf_sync = 0; sc.sf_count = 0; }
+    if (old_msc_out && old_msc > 0)
+      DABX_HIP(hipMemcpy2DAsync(d.msc_out, d.msc_stride, old_msc_out, old_msc, old_msc, msc_rows, hipMemcpyDeviceToDevice, e->stream));
+    if (old_sf_out && old_sf > 0)
+      DABX_HIP(hipMemcpy2DAsync(d.sf_out, d.sf_stride, old_sf_out, old_sf, old_sf, sf_rows, hipMemcpyDeviceToDevice, e->stream));
+    DABX_HIP(hipStreamSynchronize(e->stream));
+    for (void *q : {(void *)old_msc_out, (void *)old_sf_out, (void *)old_scratch})
+      if (q) { (void)hipFree(q); e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), q), e->allocs.end()); }
   }
   for (int s = 0; s < d.n_streams; s++) {
     if (stream >= 0 && s != stream) continue;
@@ -333,7 +361,7 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
       // a slot whose description does not change keeps running (MscHandler::set_channel only adds a Backend,
       // msc_handler.cpp:95-131): its de-interleaver history, super-frame state and counters stay
       const SubchDev &old = e->subch_host[(size_t)s * d.max_subch + j];
-      const bool same = !rings_reset && old.active && sc.active && old.cu_start == sc.cu_start && old.cu_size == sc.cu_size &&
+      const bool same = old.active && sc.active && old.cu_start == sc.cu_start && old.cu_size == sc.cu_size &&
                         old.kbps == sc.kbps && old.prot_level == sc.prot_level && old.short_form == sc.short_form &&
                         old.dab_plus == sc.dab_plus && e->subch_id_host[(size_t)s * d.max_subch + j] == desc[j].subch_id;
       if (same) continue;
@@ -359,6 +387,7 @@ int dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *cap)
 int dabx_commit_iq(dabx_engine *e, int stream, size_t n)
 {
   if (!e || stream >= e->dev.n_streams) return DABX_E_ARG;
+  if (int rc = use_device(e)) return rc;
   for (int s = 0; s < e->dev.n_streams; s++)
     if (stream < 0 || s == stream) e->wr_host[s] += n;
   return launch_commit(e->dev, stream, n, e->stream);
@@ -371,6 +400,7 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
     return DABX_E_ARG;
   }
   if (n == 0) return 0;
+  if (int rc = use_device(e)) return rc;
   // never overwrite samples the receiver has not read yet.  rd only grows, so the value seen at the last look is a safe
   // bound: the pipeline is drained (and rd read again) only when that bound says the ring is full
   for (int attempt = 0; e->wr_host[stream] - e->rd_seen[stream] + n > (unsigned long long)e->dev.ring_len; attempt++) {
@@ -438,6 +468,7 @@ int dabx_internal_ring_info(dabx_engine *e, int stream, float2 **ring, int *ring
 int dabx_process(dabx_engine *e, int max_frames, int sync)
 {
   if (!e || max_frames < 0) return DABX_E_ARG;
+  if (int rc = use_device(e)) return rc;
   // The front end (sync, FFT, demap, FIC) has frame-to-frame feedback and runs once per frame; the MSC decoder
   // has none, so its CIFs are decoded MSC_BATCH_FRAMES frames at a time (more trellises per launch) and always
   // before this call returns.
@@ -450,7 +481,7 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     if (rc) return rc;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
       e->dev.snap = e->snap_buf[e->ss.batch_parity];
-      rc = launch_msc_batch(e->dev, e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk);
+      rc = launch_msc_batch(e->dev, 4 * e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk);
       if (rc) return rc;
       e->pending_frames = 0;
     }
@@ -735,6 +766,7 @@ int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_
     // avoid the (large) IQ ring for big batches: temporarily shrink via a dedicated light-weight allocation
     e = new dabx_engine();
     e->cfg = cfg;
+    (void)hipGetDevice(&e->device);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DABX_E_HIP; }
     e->ss.a = e->stream;
     EngineDev &d = e->dev;
@@ -753,7 +785,7 @@ int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_
     A(e->alloc(&dsoft, (size_t)batch * 3 * K2, false));
     DABX_HIP(hipMemcpyAsync(dsoft, soft, sizeof(int16_t) * (size_t)batch * 3 * K2, hipMemcpyHostToDevice, e->stream));
     A(launch_i16_to_sym(dsoft, d.fic_sym, (size_t)batch * 3 * K2, e->stream));
-    A(launch_fic_only(d, e->stream));
+    A(launch_fic_only(d, e->stream, 0, 4));
 #undef A
     DABX_HIP(hipStreamSynchronize(e->stream));
     DABX_HIP(hipMemcpy(fibs, d.fib_out, (size_t)batch * 384, hipMemcpyDeviceToHost));
@@ -761,6 +793,274 @@ int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_
   }
   dabx_destroy(e);
   return 0;
+}
+
+}  // extern "C"
+
+// ====================================================================================================================
+// Per-symbol, stateful stage entries: the GPU side of the reference's FicDecoder and MscHandler CLASS surface
+// (fic_decoder.h:42-58, msc_handler.h:36-47).  Both reuse the engine's kernels on the state of a one-stream engine: what
+// the frame-batched path does for 512 ensembles at once these do for one ensemble, one OFDM symbol per call.
+// ====================================================================================================================
+struct dabx_fic {
+  dabx_engine *eng = nullptr;        // light-weight: control record, FIC symbols, FIB outputs, Viterbi scratch only
+  int16_t *soft_dev = nullptr;       // staging of one symbol's soft bits
+  bool running = true;               // mIsRunning (the shim calls restart() from DabProcessor::start like the reference)
+  int index = 0, fic_idx = 0;        // mIndex / mFicIdx: soft bits collected of the current FIC block, next block
+};
+
+extern "C" {
+
+int dabx_fic_create(dabx_fic **out)
+{
+  if (!out) { set_error("dabx_fic_create: bad argument"); return DABX_E_ARG; }
+  int rc = need_device_e();
+  if (rc) return rc;
+  auto *f = new dabx_fic();
+  auto *e = f->eng = new dabx_engine();
+  (void)hipGetDevice(&e->device);
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; delete f; return DABX_E_HIP; }
+  e->ss.a = e->stream;
+  EngineDev &d = e->dev;
+  d.n_streams = 1; d.max_subch = 0; d.out_frames = 1; d.fic_only = 1;
+  d.vit_stride = (int)vit_scratch_words(FIC_OUT);
+#define A(x) if ((rc = (x))) { dabx_fic_destroy(f); return rc; }
+  A(e->alloc(&d.ctl, 1));
+  A(e->alloc(&d.fic_sym, (size_t)3 * K2));
+  A(e->alloc(&d.fib_out, 384));
+  A(e->alloc(&d.fib_crc, 12));
+  A(e->alloc(&d.vit_scratch, (size_t)4 * d.vit_stride, false));
+  A(e->alloc(&f->soft_dev, (size_t)K2, false));
+#undef A
+  StreamCtl c;
+  memset(&c, 0, sizeof(c));
+  c.frame_ok = 1;
+  DABX_HIP(hipMemcpyAsync(d.ctl, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  *out = f;
+  return 0;
+}
+
+void dabx_fic_destroy(dabx_fic *f)
+{
+  if (!f) return;
+  dabx_destroy(f->eng);
+  delete f;
+}
+
+int dabx_fic_process_block(dabx_fic *f, const int16_t *soft, int sym_idx, int *first_fic)
+{
+  if (!f || !soft || sym_idx < 1 || sym_idx > 3) { set_error("dabx_fic_process_block: bad argument"); return DABX_E_ARG; }
+  dabx_engine *e = f->eng;
+  if (int rc = use_device(e)) return rc;
+  if (sym_idx == 1) { f->index = 0; f->fic_idx = 0; }            // fic_decoder.cpp:148-152
+  // the 3072 soft bits continue the running FIC block; blocks complete at 2304-bit boundaries (:154-165)
+  const int pos0 = f->fic_idx * FIC_IN + f->index;               // position in the frame's 9216 FIC soft bits
+  if (pos0 + K2 > 3 * K2) { set_error("dabx_fic_process_block: symbols out of order"); return DABX_E_STATE; }
+  const int done_before = f->fic_idx;
+  const int total = f->index + K2;
+  const int completed = total / FIC_IN;
+  f->index = total % FIC_IN;
+  f->fic_idx += completed;
+  if (first_fic) *first_fic = done_before;
+  if (!f->running) return 0;                                     // :182-185: _process_fic_input returns at once
+  DABX_HIP(hipMemcpyAsync(f->soft_dev, soft, sizeof(int16_t) * K2, hipMemcpyHostToDevice, e->stream));
+  int rc = launch_i16_to_sym(f->soft_dev, e->dev.fic_sym + pos0, (size_t)K2, e->stream);
+  if (rc) return rc;
+  if (completed > 0 && (rc = launch_fic_only(e->dev, e->stream, done_before, completed))) return rc;
+  DABX_HIP(hipStreamSynchronize(e->stream));
+  return completed;
+}
+
+int dabx_fic_get_fibs(dabx_fic *f, int fic_idx, uint8_t fibs[96], uint8_t crc_ok[3])
+{
+  if (!f || fic_idx < 0 || fic_idx > 3 || !fibs || !crc_ok) return DABX_E_ARG;
+  if (int rc = sync_all(f->eng)) return rc;
+  DABX_HIP(hipMemcpy(fibs, f->eng->dev.fib_out + 96 * fic_idx, 96, hipMemcpyDeviceToHost));
+  DABX_HIP(hipMemcpy(crc_ok, f->eng->dev.fib_crc + 3 * fic_idx, 3, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int dabx_fic_get_fib_bits(dabx_fic *f, uint8_t *bits, uint8_t *valid)
+{
+  if (!f || !bits || !valid) return DABX_E_ARG;
+  if (int rc = sync_all(f->eng)) return rc;
+  uint8_t packed[384], crc[12];
+  DABX_HIP(hipMemcpy(packed, f->eng->dev.fib_out, 384, hipMemcpyDeviceToHost));
+  DABX_HIP(hipMemcpy(crc, f->eng->dev.fib_crc, 12, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 3072; i++) bits[i] = (uint8_t)((packed[i >> 3] >> (7 - (i & 7))) & 1);
+  for (int g = 0; g < 4; g++) valid[g] = (uint8_t)(crc[3 * g] && crc[3 * g + 1] && crc[3 * g + 2]);
+  return 0;
+}
+
+static int fic_ctl(dabx_fic *f, StreamCtl *c)
+{
+  if (int rc = sync_all(f->eng)) return rc;
+  DABX_HIP(hipMemcpy(c, f->eng->dev.ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost));
+  return 0;
+}
+int dabx_fic_get_decode_ratio_percent(dabx_fic *f)
+{
+  if (!f) return DABX_E_ARG;
+  StreamCtl c;
+  if (int rc = fic_ctl(f, &c)) return rc;
+  return c.fic_ratio * 10;
+}
+int dabx_fic_get_cif_count(dabx_fic *f)
+{
+  if (!f) return DABX_E_ARG;
+  StreamCtl c;
+  if (int rc = fic_ctl(f, &c)) return rc;
+  return c.cif_count;
+}
+int dabx_fic_reset_decode_success_ratio(dabx_fic *f)
+{
+  if (!f) return DABX_E_ARG;
+  StreamCtl c;
+  if (int rc = fic_ctl(f, &c)) return rc;
+  c.fic_ratio = 0;
+  DABX_HIP(hipMemcpy(f->eng->dev.ctl, &c, sizeof(StreamCtl), hipMemcpyHostToDevice));
+  return 0;
+}
+int dabx_fic_stop(dabx_fic *f) { if (!f) return DABX_E_ARG; f->running = false; return 0; }
+int dabx_fic_restart(dabx_fic *f)
+{
+  if (!f) return DABX_E_ARG;
+  if (int rc = dabx_fic_reset_decode_success_ratio(f)) return rc;
+  f->running = true;
+  return 0;
+}
+
+}  // extern "C"
+
+struct dabx_msc {
+  dabx_engine *eng = nullptr;              // one-stream engine: TDI ring, sub-channel slots, output rings, DAB+ stage
+  int16_t *soft_dev = nullptr;
+  std::vector<dabx_subch_desc> slots;      // kbps == 0: free
+  std::vector<long long> frames_seen, sf_seen;   // per slot: logical / super frames that existed before the CIF just closed
+  std::vector<long long> frames_now, sf_now;
+};
+
+static int msc_apply(dabx_msc *m)
+{
+  return dabx_set_subchannels(m->eng, 0, m->slots.data(), (int)m->slots.size());
+}
+
+extern "C" {
+
+int dabx_msc_create(int max_services, dabx_msc **out)
+{
+  if (!out || max_services < 1 || max_services > MAX_SUBCH) { set_error("dabx_msc_create: bad argument"); return DABX_E_ARG; }
+  dabx_config cfg;
+  dabx_default_config(&cfg);
+  cfg.n_streams = 1; cfg.ring_frames = 2; cfg.max_subch = max_services; cfg.out_frames = 1;
+  auto *m = new dabx_msc();
+  int rc = dabx_create(&cfg, &m->eng);
+  if (rc) { delete m; return rc; }
+  if ((rc = m->eng->alloc(&m->soft_dev, (size_t)K2, false))) { dabx_msc_destroy(m); return rc; }
+  m->slots.assign((size_t)max_services, dabx_subch_desc{});
+  m->frames_seen.assign((size_t)max_services, 0); m->sf_seen.assign((size_t)max_services, 0);
+  m->frames_now.assign((size_t)max_services, 0); m->sf_now.assign((size_t)max_services, 0);
+  *out = m;
+  return 0;
+}
+
+void dabx_msc_destroy(dabx_msc *m)
+{
+  if (!m) return;
+  dabx_destroy(m->eng);
+  delete m;
+}
+
+int dabx_msc_set_channel(dabx_msc *m, const dabx_subch_desc *d)
+{
+  if (!m || !d || d->kbps <= 0) { set_error("dabx_msc_set_channel: bad argument"); return DABX_E_ARG; }
+  int slot = -1;
+  for (size_t j = 0; j < m->slots.size() && slot < 0; j++) if (!m->slots[j].kbps) slot = (int)j;
+  if (slot < 0) { set_error("dabx_msc_set_channel: all %zu service slots in use", m->slots.size()); return DABX_E_STATE; }
+  m->slots[(size_t)slot] = *d;
+  if (m->slots[(size_t)slot].dab_plus < 0) m->slots[(size_t)slot].dab_plus = (d->kbps <= 384 && d->kbps % 8 == 0) ? 1 : 0;
+  const int rc = msc_apply(m);
+  if (rc) { m->slots[(size_t)slot] = dabx_subch_desc{}; return rc; }
+  m->frames_seen[(size_t)slot] = m->sf_seen[(size_t)slot] = m->frames_now[(size_t)slot] = m->sf_now[(size_t)slot] = 0;
+  return slot;
+}
+
+int dabx_msc_stop_service(dabx_msc *m, int slot)
+{
+  if (!m || slot < 0 || slot >= (int)m->slots.size()) return DABX_E_ARG;
+  m->slots[(size_t)slot] = dabx_subch_desc{};
+  return msc_apply(m);
+}
+
+int dabx_msc_stop_all_services(dabx_msc *m)
+{
+  if (!m) return DABX_E_ARG;
+  for (auto &s : m->slots) s = dabx_subch_desc{};
+  return msc_apply(m);
+}
+
+int dabx_msc_is_service_running(dabx_msc *m, int slot)
+{
+  if (!m || slot < 0 || slot >= (int)m->slots.size()) return DABX_E_ARG;
+  return m->slots[(size_t)slot].kbps != 0;
+}
+
+int dabx_msc_process_block(dabx_msc *m, const int16_t *soft, int blk_nr)
+{
+  if (!m || !soft || blk_nr < 4 || blk_nr >= L) { set_error("dabx_msc_process_block: bad argument"); return DABX_E_ARG; }
+  dabx_engine *e = m->eng;
+  if (int rc = use_device(e)) return rc;
+  if (e->classes_dirty) {                       // one stream never reaches the lane-per-trellis path, but the slots' class tags must be current
+    if (int rc = e->build_msc_classes()) return rc;
+    e->classes_dirty = false;
+  }
+  const int cur = (blk_nr - 4) % 18;            // msc_handler.cpp:145
+  const bool closes = cur == 17;
+  DABX_HIP(hipMemcpyAsync(m->soft_dev, soft, sizeof(int16_t) * K2, hipMemcpyHostToDevice, e->stream));
+  int rc = launch_stage_msc_block(e->dev, m->soft_dev, cur, closes, e->stream);
+  if (rc) return rc;
+  if (!closes) { DABX_HIP(hipStreamSynchronize(e->stream)); return 0; }
+  // a full CIF: every back end runs (msc_handler.cpp:155-167)
+  e->dev.snap = e->snap_buf[e->ss.batch_parity];
+  if ((rc = launch_msc_batch(e->dev, 1, nullptr, e->ss, e->mk))) return rc;
+  if ((rc = sync_all(e))) return rc;
+  std::vector<SubchDev> sc(m->slots.size());
+  DABX_HIP(hipMemcpy(sc.data(), e->dev.subch, sizeof(SubchDev) * sc.size(), hipMemcpyDeviceToHost));
+  for (size_t j = 0; j < sc.size(); j++) {
+    m->frames_seen[j] = m->frames_now[j]; m->sf_seen[j] = m->sf_now[j];
+    m->frames_now[j] = sc[j].active ? sc[j].cif_out : 0;
+    m->sf_now[j] = sc[j].active ? sc[j].sf_count : 0;
+  }
+  return 1;
+}
+
+int dabx_msc_get_frame(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes)
+{
+  if (!m || slot < 0 || slot >= (int)m->slots.size() || !bytes) return DABX_E_ARG;
+  const size_t j = (size_t)slot;
+  if (!m->slots[j].kbps || m->frames_now[j] == m->frames_seen[j]) return 0;       // de-interleaver still filling / no new CIF
+  const int nb = 3 * m->slots[j].kbps;
+  if (max_bytes < nb) { set_error("dabx_msc_get_frame: %d bytes needed", nb); return DABX_E_ARG; }
+  const int got = dabx_read_msc(m->eng, 0, slot, 1, bytes);
+  return got < 0 ? got : (got == 1 ? nb : 0);
+}
+
+int dabx_msc_get_superframe(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes)
+{
+  if (!m || slot < 0 || slot >= (int)m->slots.size() || !bytes) return DABX_E_ARG;
+  const size_t j = (size_t)slot;
+  if (!m->slots[j].kbps || m->sf_now[j] == m->sf_seen[j]) return 0;
+  const int nb = 110 * m->slots[j].kbps / 8;
+  if (max_bytes < nb) { set_error("dabx_msc_get_superframe: %d bytes needed", nb); return DABX_E_ARG; }
+  const int got = dabx_read_superframes(m->eng, 0, slot, 1, bytes);
+  return got < 0 ? got : (got == 1 ? nb : 0);
+}
+
+int dabx_msc_get_stats(dabx_msc *m, int slot, dabx_subch_stats *out)
+{
+  if (!m) return DABX_E_ARG;
+  return dabx_get_subch_stats(m->eng, 0, slot, out);
 }
 
 }  // extern "C"

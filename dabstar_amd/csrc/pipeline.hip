@@ -369,7 +369,11 @@ struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depun
   }
 };
 
-__global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
+// FIC blocks [first, first + count) of the frame: the engine decodes all four at once (first = 0, count = 4); the
+// per-symbol stage entry dabx_fic_process_block decodes each block as soon as its 2304 soft bits are complete, like
+// FicDecoder::process_block does (fic_decoder.cpp:155-165): block 0 with OFDM symbol 1, block 1 with symbol 2, blocks 2
+// and 3 with symbol 3.
+__global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int first, int count)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
@@ -380,9 +384,10 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
   StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   s_crc[threadIdx.x] = t.crc_ccitt[threadIdx.x];
-  {
-    SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + wave * FIC_IN, t.fic_map};
-    uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + wave) * (size_t)e.vit_stride;
+  const int fic = first + wave;             // this wave's FIC block
+  if (wave < count) {
+    SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + fic * FIC_IN, t.fic_map};
+    uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + fic) * (size_t)e.vit_stride;
     const VitLaneConst k = vit_lane_const(lane);
     vit_forward(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -390,23 +395,24 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
     vit_traceback(dec, FIC_OUT, lane, raw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 24) fibw[wave][lane] = vit_output_word(raw[wave], lane) ^ t.prbs_words[lane];   // fic_decoder.cpp:219-222
+    if (lane < 24) fibw[fic][lane] = vit_output_word(raw[wave], lane) ^ t.prbs_words[lane];   // fic_decoder.cpp:219-222
   }
   __syncthreads();
   const int slot = (int)(c.frames % e.out_frames);
   uint8_t *fo = e.fib_out + ((size_t)s * e.out_frames + slot) * 12 * 32;
-  if (threadIdx.x < 12) {                    // one lane per FIB: CRC (crc.cpp:98-132 == CCITT over 30 bytes vs the last 2)
-    const int fibi = threadIdx.x;
+  const int fib0 = 3 * first, nfib = 3 * count;
+  if ((int)threadIdx.x < nfib) {              // one lane per FIB: CRC (crc.cpp:98-132 == CCITT over 30 bytes vs the last 2)
+    const int fibi = fib0 + threadIdx.x;
     const uint8_t *b = reinterpret_cast<const uint8_t *>(&fibw[fibi / 3][0]) + (fibi % 3) * 32;
     crc_ok[fibi] = crc16_check_bytes(b, 30, s_crc);
   }
-  for (int i = threadIdx.x; i < 96; i += 256) reinterpret_cast<uint32_t *>(fo)[i] = fibw[i / 24][i % 24];
+  for (int i = threadIdx.x; i < 24 * count; i += 256) reinterpret_cast<uint32_t *>(fo)[24 * first + i] = fibw[first + i / 24][i % 24];
   __syncthreads();
   if (threadIdx.x == 0) {
     // per-FIB bookkeeping in FIB order (fic_decoder.cpp:234-261) + FIG walk for the CIF counter
     int ratio = c.fic_ratio, cif_count = c.cif_count;
     long long ok = 0;
-    for (int fibi = 0; fibi < 12; fibi++) {
+    for (int fibi = fib0; fibi < fib0 + nfib; fibi++) {
       e.fib_crc[((size_t)s * e.out_frames + slot) * 12 + fibi] = crc_ok[fibi];
       if (crc_ok[fibi]) {
         ok++;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t)
       } else if (ratio > 0) ratio--;
     }
     c.fic_ratio = ratio; c.cif_count = cif_count;
-    c.fib_ok += ok; c.fib_total += 12;
+    c.fib_ok += ok; c.fib_total += nfib;
   }
 }
 
@@ -778,7 +784,7 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
   else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
   else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
   mk.end(3, st);
-  mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(4, st);
+  mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
   DABX_HIP(hipGetLastError());
   return 0;
@@ -787,15 +793,14 @@ int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
 int launch_msc_prep(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_t st, Marker &mk);
 int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_t st, Marker &mk);
 
-// MSC decode of the CIFs produced by the last `frames` front-end steps (<= MSC_BATCH_FRAMES) + DAB+ stage.
+// MSC decode of the newest `cifs` CIFs (4 per front-end step, <= 4 * MSC_BATCH_FRAMES; 1 for the per-symbol stage entry) + DAB+ stage.
 // `e.snap` must point at the snapshot buffer of this batch.
-int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, EngineStreams &ss, Marker &mk)
+int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
   if (e.fic_only || e.max_subch <= 0 || !e.msc_out) return 0;
-  const int cifs = 4 * frames;
   const int jobs = e.n_streams * cifs * e.max_subch;
   // the previous batch (stream b) owns SubchDev / msc_done_cif until it has finished
   if (ss.msc_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0)); ss.msc_in_flight = false; }
@@ -850,12 +855,12 @@ int launch_msc_batch(const EngineDev &e, int frames, const MscFast *fast, Engine
   return 0;
 }
 
-int launch_fic_only(const EngineDev &e, hipStream_t st)
+int launch_fic_only(const EngineDev &e, hipStream_t st, int first, int count)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t);
+  hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, first, count);
   DABX_HIP(hipGetLastError());
   return 0;
 }
@@ -868,6 +873,25 @@ __global__ void k_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n)
 int launch_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n, hipStream_t st)
 {
   hipLaunchKernelGGL(k_i16_to_sym, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, soft, sym, n);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+// Per-symbol stage entry (dabx_msc_process_block == MscHandler::process_block, msc_handler.cpp:148-168): the 3072 soft bits
+// of OFDM symbol blk (0..17 within the CIF) go into the planar time-de-interleaver ring as Viterbi symbols; closing the
+// CIF advances the CIF counter, exactly what k_demap_frame / k_frame_tail do for a whole frame.
+__global__ void k_stage_msc_block(EngineDev e, const int16_t *soft, int blk)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K2) return;
+  uint8_t *tdi = e.tdi;                                     // stream 0
+  tdi[tdi_off(e.ctl[0].cif_no, blk * K2 + i)] = soft_to_sym(soft[i]);
+}
+__global__ void k_stage_cif_done(EngineDev e) { e.ctl[0].cif_no += 1; }
+int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_stage_msc_block, dim3(K2 / 256), dim3(256), 0, st, e, soft_dev, blk);
+  if (closes_cif) hipLaunchKernelGGL(k_stage_cif_done, dim3(1), dim3(1), 0, st, e);
   DABX_HIP(hipGetLastError());
   return 0;
 }

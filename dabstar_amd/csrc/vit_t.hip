@@ -160,11 +160,52 @@ __device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int
   vt_one<5>(R, cy, t0 + 5, dec_lane);
 }
 
+// ---- chain-back helpers: one 6-step cycle of decision words in named registers
+struct VtDec6 { uint2 w0, w1, w2, w3, w4, w5; };
+__device__ __forceinline__ VtDec6 vt_load_dec(const uint2 *dec_lane, int t0)
+{
+  VtDec6 d;
+  d.w0 = dec_lane[(size_t)(t0 + 0) * 64]; d.w1 = dec_lane[(size_t)(t0 + 1) * 64]; d.w2 = dec_lane[(size_t)(t0 + 2) * 64];
+  d.w3 = dec_lane[(size_t)(t0 + 3) * 64]; d.w4 = dec_lane[(size_t)(t0 + 4) * 64]; d.w5 = dec_lane[(size_t)(t0 + 5) * 64];
+  return d;
+}
+// step t of class C (viterbi_spiral.cpp:114-125 in label space): the decision of label L is bit pos_c[L] of the word; it
+// replaces bit p = 5 - C of the label and is output bit t - 6 (PRBS, backend.cpp:155-158, and byte packing on the way out)
+template <int C>
+__device__ __forceinline__ void vt_back_one(const uint2 w, int t, unsigned &L, unsigned &outw, uint32_t *out, const uint32_t *prbs,
+                                            const unsigned char *pos_c)
+{
+  constexpr unsigned p = 5 - C;                                   // VT_P[C]
+  const unsigned pos = pos_c[L];
+  const unsigned long long ww = ((unsigned long long)w.y << 32) | w.x;
+  const unsigned bit = (unsigned)(ww >> pos) & 1u;
+  const int qb = t - 6;
+  outw |= bit << (((qb >> 3) & 3) * 8 + 7 - (qb & 7));
+  L = (L & ~(1u << p)) | (bit << p);
+  if ((qb & 31) == 0) {                                           // wave-uniform
+    // PRBS word over the scalar cache (constant table): a vector load here would wait for vmcnt(0), i.e. drain the
+    // prefetched decision words, every 32 steps
+    const unsigned pw = ((const __attribute__((address_space(4))) uint32_t *)(const void *)prbs)[qb >> 5];
+    if (out) out[qb >> 5] = outw ^ pw;
+    outw = 0;
+  }
+}
+
+// Diagnostic (tools/vit_timeline.py): when a buffer is registered through dabx_internal_set_vt_timeline every decoder wave
+// records where it ran (HW_ID, XCC_ID) and when (100-MHz real-time counter: start, end of the forward pass, end).  Null
+// in normal operation: one scalar load per wave.
+__device__ unsigned long long *g_vt_timeline = nullptr;
+__device__ unsigned g_vt_timeline_cap = 0;
+__device__ unsigned g_vt_timeline_n = 0;
+
 // grid = groups, 64 threads.  map: depuncture map with PUNCT remapped to n_in (the 0x7F row).
 __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs)
 {
   __shared__ unsigned char pos_tab[6][64];
   const int lane = threadIdx.x;
+  unsigned long long *const tl = g_vt_timeline;
+  unsigned long long tl0 = 0, tl1 = 0;
+  if (tl) tl0 = __builtin_amdgcn_s_memrealtime();
   // Groups are ordered longest trellis first.  All waves of a launch are resident at once (<= 4 per SIMD), so the work of
   // a SIMD is the sum over the ~4 "rounds" of 1024 blocks that landed on it: walk every second round backwards
   // (boustrophedon) so that long and short trellises pair up on the same SIMD.
@@ -216,50 +257,52 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  if (tl) tl1 = __builtin_amdgcn_s_memrealtime();
 
   // chain-back per lane (viterbi_spiral.cpp:114-125 in label space) + PRBS (backend.cpp:155-158) + byte packing
   uint32_t *out = nullptr;
   if (q.valid)
     out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)q.s * e.max_subch + q.j) * MSC_SLOTS + (size_t)(q.out_idx % MSC_SLOTS)) * e.msc_stride);
-  int L = 0;
-  unsigned outw = 0;
-  // decision words are fetched two 6-step cycles ahead of their use: the load address does not depend on the path,
-  // only the bit that is picked does, so the HBM/L2 latency of the (long since written) words is off the chain
-  uint2 wa[6], wb[6];
-  int tc = nsteps - 6;                                            // first step of the cycle being consumed
-#pragma unroll
-  for (int i = 0; i < 6; i++) wa[i] = dec_lane[(size_t)(tc + i) * 64];
-  auto consume = [&](const uint2 (&w)[6], int t0) {
-#pragma unroll
-    for (int c = 5; c >= 0; --c) {
-      const int t = t0 + c, p = 5 - c;                            // VT_P[c] = (5 - c) % 6
-      if (t < 6) continue;
-      const int pos = pos_tab[c][L];
-      const unsigned bit = (((pos & 32) ? w[c].y : w[c].x) >> (pos & 31)) & 1u;
-      const int qb = t - 6;
-      outw |= bit << (((qb >> 3) & 3) * 8 + 7 - (qb & 7));
-      L = (L & ~(1 << p)) | ((int)bit << p);
-      if ((qb & 31) == 0) {
-        if (out) out[qb >> 5] = outw ^ prbs[qb >> 5];
-        outw = 0;
-      }
-    }
-  };
-  while (tc >= 0) {
-    if (tc >= 6) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) wb[i] = dec_lane[(size_t)(tc - 6 + i) * 64];
-    }
-    consume(wa, tc);
-    tc -= 6;
-    if (tc < 0) break;
-    if (tc >= 6) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) wa[i] = dec_lane[(size_t)(tc - 6 + i) * 64];
-    }
-    consume(wb, tc);
-    tc -= 6;
+  // The chain is one LDS look-up (bit position of the label's decision in the step's word) and three VALU operations per
+  // step and lane; the decision words themselves are fetched two 6-step cycles ahead of their use -- their addresses do not
+  // depend on the path, only the bit that is picked does -- so no memory latency sits on the chain.  (Kept in NAMED
+  // registers: as arrays indexed through a lambda the compiler had put one set in scratch and one in LDS, and the chain
+  // then ran at ~1150 cycles per step, a third of the kernel.)
+  unsigned L = 0, outw = 0;
+  VtDec6 cur = vt_load_dec(dec_lane, nsteps - 6);
+  VtDec6 nx1 = vt_load_dec(dec_lane, nsteps - 12);                // nsteps >= 18 for every legal profile (24 * 8 + 6 = 198 at least)
+  for (int tc = nsteps - 6; tc >= 6; tc -= 6) {
+    const int tf = tc - 12 > 6 ? tc - 12 : 6;                      // beyond the start: fetch a valid cycle again (never consumed)
+    const VtDec6 nx2 = vt_load_dec(dec_lane, tf);
+    vt_back_one<5>(cur.w5, tc + 5, L, outw, out, prbs, pos_tab[5]);
+    vt_back_one<4>(cur.w4, tc + 4, L, outw, out, prbs, pos_tab[4]);
+    vt_back_one<3>(cur.w3, tc + 3, L, outw, out, prbs, pos_tab[3]);
+    vt_back_one<2>(cur.w2, tc + 2, L, outw, out, prbs, pos_tab[2]);
+    vt_back_one<1>(cur.w1, tc + 1, L, outw, out, prbs, pos_tab[1]);
+    vt_back_one<0>(cur.w0, tc + 0, L, outw, out, prbs, pos_tab[0]);
+    cur = nx1; nx1 = nx2;
   }
+  if (tl && lane == 0) {
+    const unsigned slot = atomicAdd(&g_vt_timeline_n, 1u);
+    if (slot < g_vt_timeline_cap) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long *o = tl + (size_t)slot * 4;
+      o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tl0; o[2] = tl1; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+}
+
+// not part of include/dabx.h: registers (or clears, buf == nullptr) the diagnostic wave-timeline buffer of k_msc_vitT
+extern "C" int dabx_internal_set_vt_timeline(void *buf, unsigned capacity_records)
+{
+  unsigned long long *p = reinterpret_cast<unsigned long long *>(buf);
+  unsigned zero = 0;
+  DABX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vt_timeline_cap), &capacity_records, sizeof(unsigned)));
+  DABX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vt_timeline_n), &zero, sizeof(unsigned)));
+  DABX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vt_timeline), &p, sizeof(p)));
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------- launch

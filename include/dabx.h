@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DABX_ABI_VERSION 1
+#define DABX_ABI_VERSION 2
 
 typedef enum {
   DABX_OK = 0,
@@ -71,6 +71,55 @@ int dabx_profile_map(int kbps, int prot_level, int short_form, uint16_t *map, in
  * int16 (OFDM symbols 1..3); fibs = batch x 12 x 32 bytes (packed, de-dispersed);
  * crc_ok = batch x 12 flags. */
 int dabx_fic_decode(const int16_t *soft, int batch, uint8_t *fibs, uint8_t *crc_ok);
+
+/* ---- FicDecoder, per OFDM symbol and stateful (base/decoder/fic_decoder.h:42-58) -------------------------------------
+ * The handle is the GPU-side FicDecoder of ONE ensemble: what the `FicDecoder` class of the HIP build of the reference
+ * (shim/fic_decoder_hip.h) binds to.  dabx_fic_process_block == FicDecoder::process_block(iOfdmSoftBits, iOfdmSymbIdx)
+ * (.cpp:143-167): sym_idx = 1, 2, 3; soft = the 3072 int16 soft bits of that symbol.  A FIC block is decoded as soon as
+ * its 2304 soft bits are complete, exactly when the reference calls _process_fic_input: block 0 during symbol 1, block 1
+ * during symbol 2, blocks 2 and 3 during symbol 3.  Returns the number of FIC blocks this call completed (0..2; 0 also
+ * while stopped); *first_fic (optional) = index of the first of them.  Their FIBs -- what the reference hands to
+ * IFibDecoder::process_FIB for every FIB whose CRC holds (.cpp:234-261) -- are read with dabx_fic_get_fibs.          */
+typedef struct dabx_fic dabx_fic;
+int  dabx_fic_create(dabx_fic **out);
+void dabx_fic_destroy(dabx_fic *f);
+int  dabx_fic_process_block(dabx_fic *f, const int16_t *soft /* 3072 */, int sym_idx, int *first_fic);
+/* FIC block fic_idx (0..3) of the current frame: 3 FIBs x 32 packed bytes (de-dispersed) + 3 CRC flags. */
+int  dabx_fic_get_fibs(dabx_fic *f, int fic_idx, uint8_t fibs[96], uint8_t crc_ok[3]);
+/* FicDecoder::get_fib_bits(u8 *, bool *) (.cpp:310-321): mFibBitsEntireFrame as 3072 bytes holding one bit each and
+ * mFicValid[4] (all three FIBs of the block passed their CRC). */
+int  dabx_fic_get_fib_bits(dabx_fic *f, uint8_t *bits /* 3072 */, uint8_t *valid /* 4 */);
+int  dabx_fic_get_decode_ratio_percent(dabx_fic *f);        /* get_fic_decode_ratio_percent, .cpp:323-326 */
+int  dabx_fic_reset_decode_success_ratio(dabx_fic *f);      /* fic_decoder.h:53 */
+int  dabx_fic_stop(dabx_fic *f);                            /* stop(): process_block becomes a no-op, .cpp:182-185, 264-268 */
+int  dabx_fic_restart(dabx_fic *f);                         /* restart(): ratio = 0, running, .cpp:270-275 */
+/* FibDecoder::get_cif_count as the FIG 0/0 walk of the decoded FIBs left it (fib_decoder_fig0.cpp:89-101): hi * 250 + lo */
+int  dabx_fic_get_cif_count(dabx_fic *f);
+
+/* ---- MscHandler, per OFDM symbol and stateful (base/backend/msc_handler.h:36-47, backend.cpp:60-161) --------------
+ * The handle is the GPU-side MscHandler of ONE ensemble with up to max_services back ends: the CIF buffer, every back
+ * end's 16-CIF time de-interleaver history, depuncture + Viterbi + energy de-dispersal and (for DAB+ services) the
+ * Mp4Processor's super-frame synchronisation + RS(120,110) live on the device.
+ * dabx_msc_set_channel == MscHandler::set_channel (msc_handler.cpp:123-135): adds a back end for the sub-channel; its
+ * de-interleaver starts filling with the next CIF (Backend ctor, backend.cpp:60-84).  Returns the service slot (>= 0).
+ * dabx_msc_process_block == MscHandler::process_block(iSoftBits, iBlockNr) (msc_handler.cpp:140-168): blk_nr = 4..75;
+ * the block that completes a CIF ((blk_nr - 4) % 18 == 17) runs every back end and returns 1, the others return 0.
+ * dabx_msc_get_frame: the logical frame Backend::_process_segment hands to BackendDriver::add_to_frame for that CIF
+ * (backend.cpp:140-160) as 3 * kbps PACKED bytes (the reference's outV holds the same 24 * kbps bits one per byte, MSB of
+ * byte 0 first); returns the byte count, or 0 while the service's de-interleaver is still filling (first 16 CIFs).
+ * dabx_msc_get_superframe: the RS-corrected DAB+ super frame completed by that CIF, if any (110 * kbps / 8 bytes, else 0). */
+typedef struct dabx_msc dabx_msc;
+int  dabx_msc_create(int max_services, dabx_msc **out);
+void dabx_msc_destroy(dabx_msc *m);
+int  dabx_msc_set_channel(dabx_msc *m, const struct dabx_subch_desc_s *d);
+int  dabx_msc_stop_service(dabx_msc *m, int slot);          /* stop_service, msc_handler.cpp:77-103 (the shim maps SubChId + flag to the slot) */
+int  dabx_msc_stop_all_services(dabx_msc *m);               /* msc_handler.cpp:105-118 */
+int  dabx_msc_is_service_running(dabx_msc *m, int slot);
+int  dabx_msc_process_block(dabx_msc *m, const int16_t *soft /* 3072 */, int blk_nr);
+int  dabx_msc_get_frame(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes);
+int  dabx_msc_get_superframe(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes);
+struct dabx_subch_stats_s;
+int  dabx_msc_get_stats(dabx_msc *m, int slot, struct dabx_subch_stats_s *out);
 
 /* ReedSolomon::dec(in, out, 135) with (8,0435,0,1,10) (base/backend/reed_solomon.h:28, mp4processor.cpp:63,203):
  * in = batch x 120, out = batch x 110, ret = batch x int16 (#corrected | 0 | -1). */
@@ -187,7 +236,7 @@ int  dabx_read_superframes(dabx_engine *e, int stream, int subch_idx, int n, uin
 int  dabx_read_soft(dabx_engine *e, int stream, int16_t *soft /* 75*3072 */);
 int  dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out);
 /* Per-slot counters (Backend / Mp4Processor members: backend.cpp:146-150 warm-up, mp4processor.h:106-112 signals). */
-typedef struct {
+typedef struct dabx_subch_stats_s {
   int64_t start_cif;         /* CIF index (since open) at which the slot was configured */
   int64_t cifs_decoded;      /* logical frames produced so far; frame i belongs to CIF start_cif + 16 + i */
   int64_t sf_count;          /* super frames written to the super-frame ring */

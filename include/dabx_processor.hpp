@@ -129,7 +129,9 @@ public:
   }
   bool set_channel(dabx_subch_desc d)
   {
-    if (d.dab_plus < 0) d.dab_plus = 1;
+    // FIG 0/2 has not classified the component yet: treat it as DAB+ only if the bit rate can be one (multiples of
+    // 8 kbit/s up to 384); the FIC is over-the-air data and may announce anything
+    if (d.dab_plus < 0) d.dab_plus = (d.kbps > 0 && d.kbps <= 384 && d.kbps % 8 == 0) ? 1 : 0;
     int free_slot = -1;
     for (size_t j = 0; j < slots_.size(); j++) {
       if (slots_[j].kbps && slots_[j].subch_id == d.subch_id) return true;        // already running (msc_handler.cpp:100-108)

@@ -212,6 +212,7 @@ typedef struct {
 } ora_rx_capture;
 void ora_rx_enable_soft_capture(ora_receiver *r, int on);
 const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);
+int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 *nulls, const float *clock_err, int n_frames);   /* per-symbol class calls on given FFT outputs */
 int ora_rx_take_tii(ora_receiver *r, ora_cf32 *out2048);   /* TII null-symbol sum + count since the last call */
 ora_backend *ora_rx_backend(ora_receiver *r, int i);
 ora_fic *ora_rx_fic(ora_receiver *r);

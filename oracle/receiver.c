@@ -273,6 +273,38 @@ int ora_rx_run(ora_receiver *r, const ora_cf32 *iq, size_t n_samples, int max_fr
   return frames;
 }
 
+/* The per-symbol calls DabProcessor makes on OfdmDecoder, FicDecoder and MscHandler for one frame
+ * (dab_processor.cpp:199-202, :336-360, :267-286), driven with externally supplied FFT outputs instead of the sample
+ * reader: spectra = [n_frames][76][2048] (symbol 0 = phase reference), nulls = [n_frames][2048], clock_err[n_frames].
+ * Test driver for the class-level shims (tests/cxx/shim_symbols.cpp makes the same calls on the HIP classes). */
+int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 *nulls, const float *clock_err, int n_frames)
+{
+  for (int f = 0; f < n_frames; f++) {
+    const ora_cf32 *sp = spectra + (size_t)f * ORA_L * ORA_TU;
+    cap_reserve(r, f + 1);
+    ora_demap_store_ref(&r->dm, sp);
+    for (int sym = 1; sym < ORA_L; sym++) {
+      ora_demap_symbol(&r->dm, sp + (size_t)sym * ORA_TU, clock_err[f], r->bits);
+      if (r->want_soft) memcpy(&r->cap.soft[((size_t)f * 75 + (sym - 1)) * ORA_2K], r->bits, sizeof(r->bits));
+      if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);
+      if (sym > 3) msc_process_block(r, r->bits, sym);
+    }
+    if (!((r->fic.cif_count & 7) >= 4)) ora_demap_store_null(&r->dm, nulls + (size_t)f * ORA_TU);
+    for (int i = 0; i < 12; i++) {
+      uint8_t *dst = &r->cap.fibs[((size_t)f * 12 + i) * 32];
+      for (int b = 0; b < 32; b++) {
+        uint8_t t = 0;
+        for (int k = 0; k < 8; k++) t = (uint8_t)((t << 1) | (r->fic.fib_bits[i * 256 + b * 8 + k] & 1));
+        dst[b] = t;
+      }
+      r->cap.fib_crc[f * 12 + i] = r->fic.fib_crc[i];
+    }
+    r->cap.start_idx[f] = 0; r->cap.fbb[f] = 0; r->cap.sym0_pos[f] = 0;
+    r->cap.n_frames = f + 1;
+  }
+  return n_frames;
+}
+
 /* accumulated TII null-symbol spectrum (2048 cf32) and the number of null symbols in it; clears both */
 int ora_rx_take_tii(ora_receiver *r, ora_cf32 *out)
 {

@@ -76,6 +76,7 @@ def oracle():
     L.ora_rx_configure.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
     L.ora_rx_run.argtypes = [C.c_void_p, _c64p, C.c_size_t, C.c_int]
     L.ora_rx_enable_soft_capture.argtypes = [C.c_void_p, C.c_int]
+    L.ora_rx_run_spectra.argtypes = [C.c_void_p, _c64p, _c64p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int]
     L.ora_rx_get_capture.restype = C.POINTER(RxCapture)
     L.ora_rx_take_tii.argtypes = [C.c_void_p, _c64p]
     L.ora_rx_get_capture.argtypes = [C.c_void_p]

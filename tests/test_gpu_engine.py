@@ -877,3 +877,80 @@ def test_largest_and_smallest_subchannels():
         assert np.array_equal(eng.read_superframes(0, j, 3), sf_o[len(sf_o) - 3:]), j
         assert any(np.array_equal(sf_o[-1], ens.superframes[j][q]) for q in range(8)), j
     eng.close()
+
+
+def test_growing_the_largest_bit_rate_keeps_every_running_service_and_stream():
+    """Adding a sub-channel with a higher bit rate than any configured before widens the output-ring slots
+    (dabx_set_subchannels re-strides the rings with their contents).  The reference's MscHandler::set_channel only adds a
+    Backend (msc_handler.cpp:95-131): services already running -- on this and on every OTHER stream of the engine -- keep
+    decoding without a gap, their counters, logical frames, super frames and ETI frames unaffected."""
+    sub_a = [ds.SubCh(1, 0, 48, 64, 2, 0), ds.SubCh(2, 48, 48, 64, 2, 0)]
+    sub_b = [ds.SubCh(7, 100, 96, 128, 2, 0), ds.SubCh(8, 300, 48, 64, 2, 0)]
+    ens_a, ens_b = ds.build_ensemble(10, sub_a, seed=71), ds.build_ensemble(10, sub_b, seed=72)
+    xa = ds.channel(ens_a.iq, snr_db=19.0, cfo_hz=333.0, timing_offset=4321, seed=71, n_out=25 * ds.TF)
+    xb = ds.channel(ens_b.iq, snr_db=18.0, cfo_hz=-712.0, timing_offset=99999, seed=72, n_out=25 * ds.TF)
+    ora_a, ora_b = _oracle_run(xa, sub_a), _oracle_run(xb, sub_b)
+    mk = lambda c: dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0)   # noqa: E731
+    eng = dx.Engine(n_streams=2, ring_frames=26, max_subch=2, out_frames=8)
+    eng.set_subchannels([mk(c) for c in sub_a], stream=0)               # largest rate so far: 64 kbit/s
+    eng.push_iq(0, xa)
+    eng.push_iq(1, xb)
+    eng.process(9)
+    s0 = [eng.subch_stats(0, j) for j in range(2)]
+    assert all(q["cifs_decoded"] == 9 * 4 - 16 for q in s0)
+    eti_before, lost = eng.read_eti(0, 32)
+    assert lost == 0 and len(eti_before) == 9 * 4 - 16
+    eng.set_subchannels([mk(c) for c in sub_b], stream=1)               # 128 kbit/s on the OTHER stream: the rings grow
+    eng.process(12)
+    fr0, fr1 = eng.stats(0)["frames"], eng.stats(1)["frames"]
+    assert fr0 == 21 and fr1 == 21
+    eng.subch = list(sub_a)                                             # layout of the stream being read (wrapper: buffer sizes)
+    for j in range(2):                                                  # stream 0: no restart, no gap, bytes == oracle
+        q = eng.subch_stats(0, j)
+        assert q["start_cif"] == s0[j]["start_cif"] == 0 and q["cifs_decoded"] == fr0 * 4 - 16
+        o = ora_a["msc"][j].reshape(-1, 192)
+        assert np.array_equal(eng.read_msc(0, j, 32), o[fr0 * 4 - 16 - 32:fr0 * 4 - 16]), j
+        assert q["sf_ok"] == (fr0 * 4 - 20) // 5 and q["sf_fail"] == 0      # super frames start at CIFs that are multiples of 5: the first whole one begins at CIF 20
+        sf_o = ora_a["sf"][j].reshape(-1, 880)
+        assert np.array_equal(eng.read_superframes(0, j, 4), sf_o[q["sf_ok"] - 4:q["sf_ok"]]), j
+    eti_after, lost = eng.read_eti(0, 64)                               # the ETI stream of stream 0 continues seamlessly
+    assert lost == 0 and len(eti_after) == 12 * 4
+    both = np.concatenate([eti_before, eti_after])
+    import test_eti as te
+    descs = [mk(c) for c in sub_a]
+    for i in (0, len(eti_before) - 1, len(eti_before), len(eti_before) + 1, len(both) - 1):   # either side of the change == oracle assembly
+        r = 16 + i
+        F, k = divmod(r, 4)
+        fib = ora_a["fibs"][F].reshape(-1)
+        hi, lo = int(fib[4] & 0x1F), int(fib[5])
+        for g in range(4):
+            if ora_a["crc"][F][3 * g]:
+                hi, lo = int(ora_a["fibs"][F][3 * g][4] & 0x1F), int(ora_a["fibs"][F][3 * g][5])
+        msc = [ora_a["msc"][j].reshape(-1, 192)[r - 16] for j in range(2)]
+        want, _ = te._ora_frame(hi, lo, k, descs, fib[96 * k:96 * k + 96], msc)
+        assert np.array_equal(both[i], want), i
+    eng.subch = list(sub_b)
+    for j, c in enumerate(sub_b):                                       # stream 1: started at its own CIF, bytes == oracle
+        q = eng.subch_stats(1, j)
+        assert q["start_cif"] == 36 and q["cifs_decoded"] == fr1 * 4 - 36 - 16
+        o = ora_b["msc"][j].reshape(-1, 3 * c.kbps)
+        assert np.array_equal(eng.read_msc(1, j, 16), o[fr1 * 4 - 16 - 16:fr1 * 4 - 16]), j
+    eng.close()
+
+
+def test_dab_plus_is_refused_for_rates_the_super_frame_stage_cannot_hold():
+    """k_dabplus stages a super frame of at most 384 kbit/s (48 RS code words) in LDS and DAB+ rates are multiples of
+    8 kbit/s: anything else must be refused at configuration time (DABX_E_PROFILE), not decoded out of bounds."""
+    eng = dx.Engine(n_streams=1, ring_frames=3, max_subch=2, out_frames=2)
+    ok = dx.SubchDesc(1, 0, 6, 8, 2, 0, 1, 0)                            # 8 kbit/s EEP 3-A (n = 1): 6 CU
+    eng.set_subchannels([ok])
+    for kbps, cu, prot in ((392, 294, 2), (20, 15, 2)):                  # EEP 3-A: 6 n CU with n = kbps / 8 (20 is not a multiple of 8)
+        bad = dx.SubchDesc(2, 300, cu, kbps, prot, 0, 1, 0)
+        n_in = dx.load().dabx_profile_input_bits(kbps, prot, 0)
+        if n_in < 0:
+            continue                                                     # not a legal EEP profile at all: nothing to refuse
+        with pytest.raises(dx.DabxError):
+            eng.set_subchannels([ok, bad])
+        plain = dx.SubchDesc(2, 300, cu, kbps, prot, 0, 0, 0)            # the same sub-channel without the DAB+ stage is fine
+        eng.set_subchannels([ok, plain])
+    eng.close()
