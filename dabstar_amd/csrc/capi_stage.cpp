@@ -38,16 +38,18 @@ int dabx_set_device(int device)
   return 0;
 }
 
-int dabx_viterbi(const int16_t *soft, int nbits, int batch, uint8_t *bits)
+int dabx_viterbi(const int16_t *soft, int nbits, int batch, uint8_t *bits) { return dabx_viterbi_mode(soft, nbits, batch, 0, bits); }
+
+int dabx_viterbi_mode(const int16_t *soft, int nbits, int batch, int tie_mode, uint8_t *bits)
 {
-  if (!soft || !bits || nbits <= 0 || batch <= 0) { set_error("dabx_viterbi: bad argument"); return DABX_E_ARG; }
+  if (!soft || !bits || nbits <= 0 || batch <= 0 || tie_mode < 0 || tie_mode > 1) { set_error("dabx_viterbi: bad argument"); return DABX_E_ARG; }
   int rc = need_device();
   if (rc) return rc;
   DevBuf dsoft, dbits;
   const size_t nin = (size_t)batch * 4 * (nbits + 6);
   if ((rc = dsoft.from_host(soft, nin * 2))) return rc;
   if ((rc = dbits.alloc((size_t)batch * nbits))) return rc;
-  if ((rc = launch_viterbi_i16(dsoft.as<int16_t>(), nbits, batch, dbits.as<uint8_t>(), 0))) return rc;
+  if ((rc = launch_viterbi_i16(dsoft.as<int16_t>(), nbits, batch, dbits.as<uint8_t>(), 0, tie_mode))) return rc;
   return dbits.to_host(bits, (size_t)batch * nbits);
 }
 
@@ -215,6 +217,16 @@ static int demap_store(dabx_demap *d, const dabx_cf32 *fft, bool null_sym)
 }
 int dabx_demap_store_reference_symbol_0(dabx_demap *d, const dabx_cf32 *fft) { return demap_store(d, fft, false); }
 int dabx_demap_store_null_symbol_without_tii(dabx_demap *d, const dabx_cf32 *fft) { return demap_store(d, fft, true); }
+int dabx_demap_get_snr_db(dabx_demap *d, float *snr_db)
+{
+  if (!d || !snr_db) return DABX_E_ARG;
+  DevBuf dout;
+  int rc;
+  if ((rc = dout.alloc((size_t)d->d.batch * 4))) return rc;
+  if ((rc = launch_demap_snr(d->d, dout.as<float>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  return dout.to_host(snr_db, (size_t)d->d.batch * 4);
+}
 int dabx_demap_decode_symbols(dabx_demap *d, const dabx_cf32 *fft, int n_sym, const float *clock_err, int16_t *soft)
 {
   if (!d || !fft || !clock_err || !soft || n_sym <= 0) return DABX_E_ARG;

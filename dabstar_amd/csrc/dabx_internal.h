@@ -57,6 +57,7 @@ struct DemapDev {
   float *mean_sigma;    // [B][1536] mMeanSigmaSqVector
   float *null_power;    // [B][2048] mMeanNullPowerWithoutTII
   float *mean_value;    // [B]       mMeanValue
+  float *mean_power_all;// [B]       mMeanPowerOvrAll (display / SNR only, ofdm_decoder.cpp:214)
   int batch;
   int soft_type;        // 1..3
 };
@@ -65,7 +66,7 @@ void demap_free(DemapDev &d);
 
 // ---- kernel launchers (device pointers, asynchronous on `st`) -------------------------------------
 // viterbi.hip
-int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits_1perbyte, hipStream_t st);
+int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits_1perbyte, hipStream_t st, int tie_mode = 0);
 int launch_deconvolve_i16(const int16_t *in, int in_stride, const uint16_t *map, int nbits, int batch,
                           uint8_t *bits_1perbyte, hipStream_t st);
 int viterbi_scratch_bytes_per_trellis(int nbits);
@@ -82,5 +83,6 @@ int launch_demap_init(DemapDev &d, hipStream_t st);
 int launch_demap_store_ref(DemapDev &d, const float2 *fft, hipStream_t st);
 int launch_demap_store_null(DemapDev &d, const float2 *fft, hipStream_t st);
 int launch_demap_symbols(DemapDev &d, const float2 *fft, int n_sym, const float *clock_err, int16_t *soft, hipStream_t st);
+int launch_demap_snr(DemapDev &d, float *snr_db_dev, hipStream_t st);
 
 }  // namespace dabx

@@ -150,7 +150,7 @@ int dabx_engine::build_msc_classes()
   fast = sorted;
   fast.min_jobs = (int)std::min<size_t>(min_jobs, 0x7fffffff);
   fast.slots_active = active;
-  have_fast = fast.n_cls > 0 && (size_t)jobs_total >= min_jobs;
+  have_fast = fast.n_cls > 0 && (size_t)jobs_total >= min_jobs && !d.tie_mode;   // the lane-per-trellis kernel is the canonical arithmetic only
   DABX_HIP(hipMemcpy(d.subch, subch_host.data(), sizeof(SubchDev) * subch_host.size(), hipMemcpyHostToDevice));
   return 0;
 }
@@ -224,7 +224,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.n_streams = S; d.max_subch = cfg->max_subch; d.out_frames = cfg->out_frames;
   d.ring_len = cfg->ring_frames * TF;
   d.threshold = cfg->sync_threshold; d.strongest = cfg->sync_strongest;
-  d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft;
+  d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft; d.tie_mode = cfg->viterbi_tie_mode != 0;
   const DevTables *t;
   if ((rc = get_tables(&t))) { dabx_destroy(e); return rc; }
 #define A(x) if ((rc = (x))) { dabx_destroy(e); return rc; }

@@ -38,6 +38,21 @@ static int check_format(const dabx_iq_format *f, IqDecode *d)
     const int32_t sc = (int32_t)(1u << (bits - 1));
     d->int_scale = f->family == DABX_FAMILY_UFF ? 1.0f / (float)sc : ldexpf(1.0f, 1 - bits);
   }
+  d->quirk_block = 0; d->quirk_i24 = 0; d->quirk_sign7f = 0;
+  if (f->reference_quirks && f->family == DABX_FAMILY_UFF) {
+    // like the reference's reader, deliver whole 1-ms read blocks only (readSamples, xml_reader.cpp:224-227)
+    d->quirk_block = (int16_t)(f->sample_rate / 1000);
+    if (f->container == DABX_C_F32 && f->swap_iq) d->swap_iq = 0;                 // xml_reader.cpp:530,540: no swap
+    if (f->container == DABX_C_I24 && f->big_endian) {                            // :316 / :462, :465-469
+      d->quirk_i24 = 1;
+      d->quirk_sign7f = f->swap_iq ? 1 : 0;
+    }
+    if (f->container == DABX_C_U8 && f->swap_iq) {                                // :423
+      set_error("iq format: UFF QI/uint8 -- the reference indexes its 256-entry table with the loop counter "
+                "(xml_reader.cpp:423) and reads past it from the 128th sample of every block: undefined, not reproducible");
+      return DABX_E_ARG;
+    }
+  }
   return 0;
 }
 
@@ -376,7 +391,8 @@ static int feed_setup(dabx_feed *f, const dabx_iq_format *fmt)
 
 static long long bound_samples(const dabx_feed *f, size_t n_bytes)
 {
-  const size_t n = (n_bytes + f->odd.size()) / (size_t)(2 * f->dec.bytes);
+  size_t n = (n_bytes + f->odd.size()) / (size_t)(2 * f->dec.bytes);
+  if (f->dec.quirk_block) n -= n % (size_t)f->dec.quirk_block;
   if (!f->resample) return (long long)n;
   return (long long)(((size_t)f->carry_n + n) / (size_t)f->M) * 2048;
 }
@@ -394,7 +410,8 @@ static long long feed_push(dabx_feed *f, const uint8_t *bytes, size_t n_bytes)
     joined.insert(joined.end(), bytes, bytes + n_bytes);
     src = joined.data(); total = joined.size();
   }
-  const size_t n = total / sb;
+  size_t n = total / sb;
+  if (f->dec.quirk_block) n -= n % (size_t)f->dec.quirk_block;      // whole read blocks of the reference's reader only
   f->odd.assign(src + n * sb, src + total);
   if (n == 0) return 0;
 

@@ -53,7 +53,20 @@ __global__ __launch_bounds__(256) void k_decode_iq(const uint8_t *src, IqDecode 
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t *p = src + i * (size_t)(2 * d.bytes);
-  float a = decode_one(p, d), b = decode_one(p + d.bytes, d);
+  float a, b;
+  if (d.quirk_i24) {
+    // the reference's int24 / MSB loops, literally (xml_reader.cpp:312-325 IQ, :458-472 QI): `src` starts on a read block
+    const size_t c = i / (size_t)d.quirk_block, ii = i - c * (size_t)d.quirk_block;
+    const uint8_t *lbuf = src + c * (size_t)d.quirk_block * 6;
+    int32_t t1 = (int32_t)((lbuf[6 * ii] << 16) | (lbuf[6 * ii + 1] << 8) | lbuf[6 * ii + 2]);
+    int32_t t2 = (int32_t)((lbuf[6 * ii + 3] << 16) | (lbuf[4 * ii + 4] << 8) | lbuf[6 * ii + 5]);
+    const int32_t ext = d.quirk_sign7f ? (int32_t)0x7F000000 : (int32_t)0xFF000000;
+    if (t1 & 0x800000) t1 |= ext;
+    if (t2 & 0x800000) t2 |= ext;
+    a = __fmul_rn((float)t1, d.int_scale); b = __fmul_rn((float)t2, d.int_scale);
+  } else {
+    a = decode_one(p, d); b = decode_one(p + d.bytes, d);
+  }
   if (d.swap_iq) { const float t = a; a = b; b = t; }
   const size_t o = dst_len ? (size_t)((dst0 + i) % (unsigned long long)dst_len) : (size_t)(dst0 + i);
   dst[o] = make_float2(a, b);

@@ -57,13 +57,14 @@ int demap_alloc(DemapDev &d, int batch)
   DABX_HIP(hipMalloc((void **)&d.mean_sigma, sizeof(float) * K * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.null_power, sizeof(float) * TU * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.mean_value, sizeof(float) * (size_t)batch));
+  DABX_HIP(hipMalloc((void **)&d.mean_power_all, sizeof(float) * (size_t)batch));
   DABX_HIP(hipMemset(d.phase_ref, 0, sizeof(float2) * TU * (size_t)batch));
   return 0;
 }
 void demap_free(DemapDev &d)
 {
   (void)hipFree(d.phase_ref); (void)hipFree(d.integ); (void)hipFree(d.mean_power);
-  (void)hipFree(d.mean_sigma); (void)hipFree(d.null_power); (void)hipFree(d.mean_value);
+  (void)hipFree(d.mean_sigma); (void)hipFree(d.null_power); (void)hipFree(d.mean_value); (void)hipFree(d.mean_power_all);
   d = DemapDev{};
 }
 
@@ -76,6 +77,7 @@ __global__ void k_demap_reset(DemapDev d, int first)
   }
   for (int i = tid; i < TU; i += blockDim.x) d.null_power[(size_t)s * TU + i] = 0.f;
   if (first && tid == 0) d.mean_value[s] = 1.0f;
+  if (tid == 0) d.mean_power_all[s] = 1.0f;                  // :98
 }
 
 __global__ void k_demap_store_ref(DemapDev d, const float2 *fft)   // ofdm_decoder.cpp:132-136
@@ -119,8 +121,11 @@ __global__ __launch_bounds__(512) void k_demap_symbols(DemapDev d, const float2 
     c[q].mean_sigma_sq = d.mean_sigma[(size_t)s * K + k];
     c[q].null_power = d.null_power[(size_t)s * TU + bin[q]];
   }
-  float mean_value = d.mean_value[s];
+  float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
   const float ce = clock_err[s];
+  float wk[3], pacc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 3; q++) wk[q] = mpa_weight(tid + 512 * q);
   for (int l = 0; l < n_sym; l++) {
     const float2 *X = fft + ((size_t)s * n_sym + l) * TU;
     int16_t *o = soft + ((size_t)s * n_sym + l) * K2;
@@ -129,11 +134,20 @@ __global__ __launch_bounds__(512) void k_demap_symbols(DemapDev d, const float2 
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       int16_t sr, si;
-      part += demap_one(c[q], X[bin[q]], rel[q], ce, w2, d.soft_type, sr, si);
+      float pw;
+      part += demap_one(c[q], X[bin[q]], rel[q], ce, w2, d.soft_type, sr, si, pw);
+      pacc[q] = pacc[q] * mpa_decay() + pw;                        // sum_l d^(n-1-l) p_l per carrier, reduced once below
       o[tid + 512 * q] = sr;
       o[K + tid + 512 * q] = si;
     }
     mean_value = block_sum(part, red, tid) * (1.0f / (float)K);   // :294
+  }
+  {                                                                // :214 over the n_sym symbols in closed form
+    float wsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) wsum += wk[q] * pacc[q];
+    wsum = block_sum(wsum, red, tid);
+    mpa = mpa * mpa_decay_n(n_sym) + wsum;
   }
 #pragma unroll
   for (int q = 0; q < 3; q++) {
@@ -147,7 +161,21 @@ __global__ __launch_bounds__(512) void k_demap_symbols(DemapDev d, const float2 
     const float2 *X = fft + ((size_t)s * n_sym + (n_sym - 1)) * TU;
     for (int i = tid; i < TU; i += 512) d.phase_ref[(size_t)s * TU + i] = X[i];
   }
-  if (tid == 0) d.mean_value[s] = mean_value;
+  if (tid == 0) { d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa; }
+}
+
+// SNR estimate of the LCD statistics (ofdm_decoder.cpp:326-343) from the state as it stands
+__global__ __launch_bounds__(256) void k_demap_snr(DemapDev d, float *snr_db)
+{
+  __shared__ float red[8];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  float ns = 0.f;
+  for (int i = tid; i < K; i += 256) {
+    const int idx = i - K / 2;
+    ns += d.null_power[(size_t)s * TU + (idx < 0 ? idx + TU : idx + 1)];
+  }
+  ns = block_sum(ns, red, tid);
+  if (tid == 0) snr_db[s] = snr_db_from(d.mean_power_all[s], ns);
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------
@@ -183,6 +211,12 @@ int launch_demap_reset(DemapDev &d, hipStream_t st)
 int launch_demap_init(DemapDev &d, hipStream_t st)
 {
   hipLaunchKernelGGL(k_demap_reset, dim3(d.batch), dim3(256), 0, st, d, 1);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+int launch_demap_snr(DemapDev &d, float *snr_db_dev, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_demap_snr, dim3(d.batch), dim3(256), 0, st, d, snr_db_dev);
   DABX_HIP(hipGetLastError());
   return 0;
 }

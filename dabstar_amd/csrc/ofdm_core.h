@@ -41,6 +41,18 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float *red /* >= 
   for (int w = 0; w < nw; w++) { sa += red[w]; sb += red[4 + w]; }
   a = sa; b = sb;
 }
+// two sums in one pass for blocks of up to 16 waves (red[0..15] / red[16..31]); summation order of block_sum
+__device__ __forceinline__ void block_sum2w(float &a, float &b, float *red /* >= 32 floats of LDS */, int tid)
+{
+  a = wave_sum(a); b = wave_sum(b);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = a; red[16 + (tid >> 6)] = b; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float sa = 0.f, sb = 0.f;
+  for (int w = 0; w < nw; w++) { sa += red[w]; sb += red[16 + w]; }
+  a = sa; b = sb;
+}
 __device__ __forceinline__ int block_min_int(int v, int *red, int tid)
 {
 #pragma unroll
@@ -268,7 +280,7 @@ __device__ __forceinline__ float atan2_as(float y, float x)
 // hardware v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE expansions (the reference itself is built with
 // -ffast-math): 2x fewer VALU instructions, soft bits differ from the IEEE evaluation by at most 1 LSB.
 __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, float clock_err, float w2,
-                                           int soft_type, int16_t &soft_re, int16_t &soft_im)
+                                           int soft_type, int16_t &soft_re, int16_t &soft_im, float &power_out)
 {
   constexpr float ALPHA = 0.005f;
   const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
@@ -295,6 +307,7 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   const float lim = F_RAD_PER_DEG * 20.0f;
   if (c.integ > lim) c.integ = lim; else if (c.integ < -lim) c.integ = -lim;
   const float power = b.x * b.x + b.y * b.y;                    // :211-213
+  power_out = power;
   c.mean_power += ALPHA * (power - c.mean_power);
   const float mean_level = __builtin_amdgcn_sqrtf(c.mean_power);   // :217-223
   const float at_axis = mean_level * F_SQRT1_2;
@@ -359,7 +372,7 @@ __device__ __forceinline__ v2f atan2_as2(v2f y, v2f x)
 
 template <int SOFT_TYPE>
 __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f rel_f, float clock_err, float w2,
-                                          int16_t (&soft_re)[2], int16_t (&soft_im)[2])
+                                          int16_t (&soft_re)[2], int16_t (&soft_im)[2], v2f &power_out)
 {
   constexpr float ALPHA = 0.005f;
   const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
@@ -384,6 +397,7 @@ __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f 
   integ = (integ > lim) ? (v2f)(lim) : ((integ < -lim) ? (v2f)(-lim) : integ);
   c.integ = integ;
   const v2f power = b_re * b_re + b_im * b_im;                    // :211-213
+  power_out = power;
   c.mean_power += ALPHA * (power - c.mean_power);
   const v2f mean_level = v2_sqrt(c.mean_power);                   // :217-223
   const v2f at_axis = mean_level * F_SQRT1_2;
@@ -411,11 +425,42 @@ __device__ __forceinline__ float demap_w2(float mean_value, int soft_type)
   return (soft_type == 1 ? -100.0f : -140.0f) * __builtin_amdgcn_rcpf(mean_value);
 }
 
+// ---- mMeanPowerOvrAll and the SNR estimate (ofdm_decoder.cpp:214, 326-343, 358-371): display statistics only --------
+// The reference runs x += a (p_k - x), a = 0.005 / 1536, over the 1536 carriers of a symbol in de-interleaved order.  In
+// closed form one symbol is x <- x (1 - a)^K + sum_k a (1 - a)^(K-1-k) p_k: a weighted block sum, carriers in parallel.
+// (The serial float recurrence itself wanders by ~1e-6 relative; the estimate is compared with a 0.02 dB tolerance.)
+__device__ __forceinline__ float mpa_weight(int k)
+{
+  const float a = 0.005f / (float)K;
+  return a * __expf((float)(K - 1 - k) * -3.2552135e-6f);        // ln(1 - a) = -a - a^2 / 2
+}
+__device__ __forceinline__ float mpa_decay() { return 0.99501247f; }                     // (1 - a)^K
+__device__ __forceinline__ float mpa_decay_n(int n_sym) { return __expf((float)n_sym * (float)K * -3.2552135e-6f); }   // (1 - a)^(K n)
+// snr = (mMeanPowerOvrAll - noise) / noise, <= 0 -> 0.1; noise = mean null power over the used bins, all-zero -> floor
+__device__ __forceinline__ float snr_db_from(float mean_power_all, float null_sum)
+{
+  const float kMinNoisePower = (1.0f / 32767.0f) * (1.0f / 32767.0f);
+  if (null_sum == 0.0f) null_sum = kMinNoisePower * (float)K;
+  const float noise = null_sum / (float)K;
+  float snr = (mean_power_all - noise) / noise;
+  if (snr <= 0.0f) snr = 0.1f;
+  return 10.0f * log10f(snr);
+}
+
 __device__ __forceinline__ uint8_t soft_to_sym(int16_t s)       // viterbi_scalar.h:34-40
 {
   int v = (int16_t)(s + 127);
   v = v < 0 ? 0 : (v > 255 ? 255 : v);
   return (uint8_t)v;
 }
+
+// viterbi_16way.h:73-76 (the AVX2 build): _mm_adds_epi16(+127) SATURATES where the scalar body's i16 add wraps
+__device__ __forceinline__ uint8_t soft_to_sym_sat(int16_t s)
+{
+  int v = (int)s + 127;
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  return (uint8_t)v;
+}
+__device__ __forceinline__ uint8_t soft_to_sym_mode(int16_t s, int tie_mode) { return tie_mode ? soft_to_sym_sat(s) : soft_to_sym(s); }
 
 }  // namespace dabx

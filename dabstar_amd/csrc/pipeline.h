@@ -65,6 +65,7 @@ struct EngineDev {
   int32_t ring_len;               // IQ ring capacity per stream in samples
   float threshold;
   int32_t strongest, fic_only, capture_soft;
+  int32_t tie_mode;               // 1: Viterbi arithmetic of the reference's AVX2 / SSE2 builds (viterbi_core.h, vit_step_simd)
   int32_t msc_stride;             // bytes per logical-frame slot (3 * max kbps)
   int32_t sf_stride;              // bytes per super-frame slot (110 * max kbps / 8)
   int32_t vit_stride;             // decision-scratch words per trellis (max over FIC and all sub-channels)

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
     e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
   }
   for (int i = lane; i < TU; i += 64) e.demap.null_power[(size_t)s * TU + i] = 0.f;
+  if (lane == 0) e.demap.mean_power_all[s] = 1.0f;
   if (e.tii_acc) {                     // mTiiDetector.reset(); mTiiCounter = 0 (dab_processor.cpp:150-152)
     for (int i = lane; i < TU; i += 64) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
     if (lane == 0) { e.tii_cnt[2 * s] = 0; e.tii_cnt[2 * s + 1]++; }
@@ -272,10 +273,10 @@ constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers pe
 template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
 __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t)
 {
-  __shared__ float red[16];
+  __shared__ float red[32];
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
   const int s = blockIdx.x, tid = threadIdx.x;
-  const StreamCtl &c = e.ctl[s];
+  StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
   DemapDev &d = e.demap;
   DemapPair cr;                                            // the thread's two carriers, component-wise (demap_pair)
@@ -293,7 +294,9 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
     cr.null_power[q] = d.null_power[(size_t)s * TU + bin[q]];
   }
-  float mean_value = d.mean_value[s];
+  float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
+  const v2f wk = (v2f){mpa_weight(tid), mpa_weight(tid + DEMAP_THREADS)};
+  v2f pacc = (v2f)(0.0f);
   const float ce = c.clock_err;                           // mClockErrHz of the previous frame, dab_processor.cpp:342
   const long long cif0 = c.cif_no;
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
@@ -328,12 +331,14 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[tid + DEMAP_THREADS * q]; }
     int16_t sr[2], si[2];
-    const v2f mag = demap_pair<SOFT_TYPE>(cr, (v2f){xc[0].x, xc[1].x}, (v2f){xc[0].y, xc[1].y}, rel_f, ce, w2, sr, si);
+    v2f pw;
+    const v2f mag = demap_pair<SOFT_TYPE>(cr, (v2f){xc[0].x, xc[1].x}, (v2f){xc[0].y, xc[1].y}, rel_f, ce, w2, sr, si, pw);
     const float part = mag.x + mag.y;
+    pacc = pacc * mpa_decay() + pw;                         // per carrier: sum_l d^(74-l) p_l, reduced once per frame below
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) {
-      tl[tpos[2 * q]] = soft_to_sym(sr[q]);
-      tl[tpos[2 * q + 1]] = soft_to_sym(si[q]);
+      tl[tpos[2 * q]] = soft_to_sym_mode(sr[q], e.tie_mode);
+      tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[q], e.tie_mode);
       if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[q]; cap[(size_t)l * K2 + K + k] = si[q]; }
     }
     mean_value = block_sum(part, red, tid) * (1.0f / (float)K);   // two barriers: the tile is complete behind them
@@ -354,7 +359,14 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     d.mean_power[(size_t)s * K + k] = cr.mean_power[q];
     d.mean_sigma[(size_t)s * K + k] = cr.mean_sigma_sq[q];
   }
-  if (tid == 0) d.mean_value[s] = mean_value;
+  // SNR estimate as the LCD statistics compute it (ofdm_decoder.cpp:326-343) after the last symbol of the frame
+  // mMeanPowerOvrAll (ofdm_decoder.cpp:214) over the 75 symbols in closed form: x d^75 + sum_k w_k sum_l d^(74-l) p_(k,l)
+  float ns = cr.null_power.x + cr.null_power.y, wsum = wk.x * pacc.x + wk.y * pacc.y;
+  block_sum2w(ns, wsum, red, tid);
+  if (tid == 0) {
+    mpa = mpa * mpa_decay_n(75) + wsum;
+    d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa; c.snr_db = snr_db_from(mpa, ns);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- FIC
@@ -389,7 +401,8 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + fic * FIC_IN, t.fic_map};
     uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + fic) * (size_t)e.vit_stride;
     const VitLaneConst k = vit_lane_const(lane);
-    vit_forward(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
+    if (e.tie_mode) vit_forward<true>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
+    else vit_forward<false>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     vit_traceback(dec, FIC_OUT, lane, raw[wave]);
@@ -578,7 +591,8 @@ __global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, 
   SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64};
   uint32_t *dec = e.vit_scratch + ((size_t)e.n_streams * 4 + (size_t)job) * (size_t)e.vit_stride;
   const VitLaneConst k = vit_lane_const(lane);
-  vit_forward(src, sc.nbits + 6, wtab[wave], dec, lane, k);
+  if (e.tie_mode) vit_forward<true>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
+  else vit_forward<false>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t *out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)s * e.max_subch + j) * MSC_SLOTS + (size_t)(out_idx % MSC_SLOTS)) * e.msc_stride);
@@ -885,7 +899,7 @@ __global__ void k_stage_msc_block(EngineDev e, const int16_t *soft, int blk)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K2) return;
   uint8_t *tdi = e.tdi;                                     // stream 0
-  tdi[tdi_off(e.ctl[0].cif_no, blk * K2 + i)] = soft_to_sym(soft[i]);
+  tdi[tdi_off(e.ctl[0].cif_no, blk * K2 + i)] = soft_to_sym_mode(soft[i], e.tie_mode);
 }
 __global__ void k_stage_cif_done(EngineDev e) { e.ctl[0].cif_no += 1; }
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st)

@@ -6,9 +6,11 @@ namespace dabx {
 
 struct SrcI16 {                       // ViterbiSpiral::deconvolve input: 4*(n+6) int16, already depunctured
   const int16_t *soft;
+  int sat;                            // AVX2 body: saturating symbol conversion
   __device__ VitSyms operator()(int t) const
   {
     const short4 v = *reinterpret_cast<const short4 *>(soft + 4 * t);
+    if (sat) return {vit_sym_from_i16_sat(v.x), vit_sym_from_i16_sat(v.y), vit_sym_from_i16_sat(v.z), vit_sym_from_i16_sat(v.w)};
     return {vit_sym_from_i16(v.x), vit_sym_from_i16(v.y), vit_sym_from_i16(v.z), vit_sym_from_i16(v.w)};
   }
 };
@@ -26,10 +28,11 @@ struct SrcI16Map {                    // Protection::deconvolve input: punctured
 
 template <class Src>
 __device__ __forceinline__ void viterbi_wave_to_packed(const Src &src, int nbits, char *wtab, uint32_t *raw, uint32_t *dec,
-                                                       uint32_t *out_words, int lane)
+                                                       uint32_t *out_words, int lane, int tie_mode)
 {
   const VitLaneConst k = vit_lane_const(lane);
-  vit_forward(src, nbits + 6, wtab, dec, lane, k);
+  if (tie_mode) vit_forward<true>(src, nbits + 6, wtab, dec, lane, k);
+  else vit_forward<false>(src, nbits + 6, wtab, dec, lane, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);     // decision stores of this wave have left the CU before they are re-read
   vit_traceback(dec, nbits, lane, raw);
@@ -39,16 +42,16 @@ __device__ __forceinline__ void viterbi_wave_to_packed(const Src &src, int nbits
 }
 
 __global__ __launch_bounds__(256) void k_viterbi_i16(const int16_t *soft, int nbits, int batch, uint32_t *dec,
-                                                     uint32_t *packed, int words_per)
+                                                     uint32_t *packed, int words_per, int tie_mode)
 {
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t raw[4][VIT_RAW_WORDS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int job = blockIdx.x * 4 + wave;
   if (job >= batch) return;
-  SrcI16 src{soft + (size_t)job * 4 * (nbits + 6)};
+  SrcI16 src{soft + (size_t)job * 4 * (nbits + 6), tie_mode};
   viterbi_wave_to_packed(src, nbits, wtab[wave], raw[wave], dec + (size_t)job * vit_scratch_words(nbits),
-                         packed + (size_t)job * words_per, lane);
+                         packed + (size_t)job * words_per, lane, tie_mode);
 }
 
 __global__ __launch_bounds__(256) void k_deconvolve_i16(const int16_t *in, int in_stride, const uint16_t *map, int nbits,
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_deconvolve_i16(const int16_t *in, int i
   if (job >= batch) return;
   SrcI16Map src{in + (size_t)job * in_stride, map};
   viterbi_wave_to_packed(src, nbits, wtab[wave], raw[wave], dec + (size_t)job * vit_scratch_words(nbits),
-                         packed + (size_t)job * words_per, lane);
+                         packed + (size_t)job * words_per, lane, 0);
 }
 
 // packed (MSB-first bytes) -> one bit per byte, as the reference's output convention
@@ -94,13 +97,13 @@ static int run_packed_then_unpack(int nbits, int batch, uint8_t *bits, hipStream
   return 0;
 }
 
-int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits, hipStream_t st)
+int launch_viterbi_i16(const int16_t *soft, int nbits, int batch, uint8_t *bits, hipStream_t st, int tie_mode)
 {
-  struct Ctx { const int16_t *soft; int nbits, batch; hipStream_t st; } c{soft, nbits, batch, st};
+  struct Ctx { const int16_t *soft; int nbits, batch; hipStream_t st; int tie; } c{soft, nbits, batch, st, tie_mode};
   return run_packed_then_unpack(nbits, batch, bits, st, [](uint32_t *dec, uint32_t *packed, int wp, void *p) {
     auto *c = (Ctx *)p;
     hipLaunchKernelGGL(k_viterbi_i16, dim3((c->batch + 3) / 4), dim3(256), 0, c->st, c->soft, c->nbits, c->batch, dec,
-                       packed, wp);
+                       packed, wp, c->tie);
   }, &c);
 }
 

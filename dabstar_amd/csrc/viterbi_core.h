@@ -42,6 +42,12 @@ __device__ __forceinline__ int vit_sym_from_i16(int16_t s)
   return 2 * v - 255;
 }
 __device__ __forceinline__ int vit_sym_from_u8(uint8_t sym) { return 2 * (int)sym - 255; }
+__device__ __forceinline__ int vit_sym_from_i16_sat(int16_t s)      // viterbi_16way.h:73-76: saturating +127, then 0..255
+{
+  int v = (int)s + 127;
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  return 2 * v - 255;
+}
 
 __device__ __forceinline__ int rotl6(int x, int c) { return ((x << c) | (x >> (6 - c))) & 63; }
 
@@ -111,12 +117,48 @@ __device__ __forceinline__ void vit_step(int &m, unsigned &acc, const char *wrow
   asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
 }
 
+// ---- the reference's SIMD builds (VITERBI_AVX2 / VITERBI_SSE2: viterbi_16way.h, viterbi_8way.h) -------------------
+// Same trellis, different arithmetic: path metrics are uint16 with SATURATING adds (_mm256_adds_epu16, :36-39), the
+// survivor is min and the decision is `survivor == m1` (:44-45), i.e. a TIE goes to predecessor i + 32 (the scalar body
+// sends it to i), and after every second step the new metrics are reduced by their minimum when state 0's metric of the
+// step BEFORE exceeded 60000 (renormalize, :9-25: the test reads metrics2[0], the subtraction works on new_metrics).
+// Reproduced here in the reference's own metric domain (start 0 / 1000, branch metric 0..1020) so that saturation and
+// renormalisation fall on the same steps: bit-identical to the AVX2 object code (tests/test_oracle_ref.py builds it).
+template <int C>
+__device__ __forceinline__ void vit_step_simd(int &m, unsigned &acc, const char *wrow, const VitLaneConst &k)
+{
+  const int w = *reinterpret_cast<const int16_t *>(wrow + k.pat[C]);      // 2 * metric - 1020
+  const int bm = (w + 1020) >> 1;                                         // sum (Branch ^ sym), viterbi_16way.h:30-31
+  const int partner = vit_exchange<C>(m, k.lane);
+  int a = m + bm, b = partner + (1020 - bm);
+  a = a > 65535 ? 65535 : a; b = b > 65535 ? 65535 : b;                   // adds_epu16
+  // lower lane of the pair: decision0 = (min == m1) = (b <= a); upper lane: decision1 = (min == m3) = (a <= b)
+  const int dd = __mul24(a - b, k.sgn[C]);
+  m = a < b ? a : b;
+  asm("v_cmp_le_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
+}
+__device__ __forceinline__ int vit_wave_min(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
+  return v;
+}
+template <int C>
+__device__ __forceinline__ void vit_pair_simd(int &m, unsigned &acc, const char *row, const VitLaneConst &k)
+{
+  vit_step_simd<C>(m, acc, row, k);
+  const int m0_before = __builtin_amdgcn_readfirstlane(m);                // state 0 lives in lane 0 in every step class
+  vit_step_simd<C + 1>(m, acc, row + 16, k);
+  if (m0_before > 60000) m -= vit_wave_min(m);                            // renormalize: wave-uniform, rare
+}
+
 // Forward pass.  wtab: this wave's LDS area, VIT_BLK rows of 8 int16.  dec: u32[vit_blocks*2][64].
-template <class Src>
+// SIMD_RULE = true: arithmetic of the reference's AVX2 / SSE2 builds (see above) instead of the canonical scalar body.
+template <bool SIMD_RULE = false, class Src>
 __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wtab, uint32_t *dec, int lane,
                                             const VitLaneConst &k)
 {
-  int m = lane == 0 ? 0 : 2000;                 // viterbi_spiral.cpp:98-101 (0 / 1000), doubled
+  int m = SIMD_RULE ? (lane == 0 ? 0 : 1000) : (lane == 0 ? 0 : 2000);   // viterbi_spiral.cpp:98-101 (0 / 1000); doubled in the canonical form
   const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
   // The symbols of block b + 1 (two dependent global loads: depuncture map, then the soft symbols) are requested before
   // the 60 add-compare-select steps of block b run and only consumed afterwards: their latency is off the chain.
@@ -149,12 +191,18 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
 #pragma unroll
       for (int s6 = 0; s6 < VIT_DW; s6 += 6) {
         const char *row = wtab + (h * VIT_DW + s6) * 16;
-        vit_step<0>(m, acc, row + 0 * 16, k);
-        vit_step<1>(m, acc, row + 1 * 16, k);
-        vit_step<2>(m, acc, row + 2 * 16, k);
-        vit_step<3>(m, acc, row + 3 * 16, k);
-        vit_step<4>(m, acc, row + 4 * 16, k);
-        vit_step<5>(m, acc, row + 5 * 16, k);
+        if constexpr (SIMD_RULE) {
+          vit_pair_simd<0>(m, acc, row + 0 * 16, k);
+          vit_pair_simd<2>(m, acc, row + 2 * 16, k);
+          vit_pair_simd<4>(m, acc, row + 4 * 16, k);
+        } else {
+          vit_step<0>(m, acc, row + 0 * 16, k);
+          vit_step<1>(m, acc, row + 1 * 16, k);
+          vit_step<2>(m, acc, row + 2 * 16, k);
+          vit_step<3>(m, acc, row + 3 * 16, k);
+          vit_step<4>(m, acc, row + 4 * 16, k);
+          vit_step<5>(m, acc, row + 5 * 16, k);
+        }
       }
       dec[(size_t)(b * (VIT_BLK / VIT_DW) + h) * 64 + lane] = acc;
       acc = 0;

@@ -64,11 +64,12 @@ def _p(a):
 
 
 # ---------------------------------------------------------------------------------- stage level
-def viterbi(soft, nbits):
-    """soft: [batch, 4*(nbits+6)] int16 -> [batch, nbits] uint8 (ViterbiSpiral::deconvolve)."""
+def viterbi(soft, nbits, tie_mode=0):
+    """soft: [batch, 4*(nbits+6)] int16 -> [batch, nbits] uint8 (ViterbiSpiral::deconvolve); tie_mode 1 = the arithmetic of
+    the reference's AVX2 / SSE2 builds."""
     soft = np.ascontiguousarray(soft, np.int16).reshape(-1, 4 * (nbits + 6))
     out = np.zeros((soft.shape[0], nbits), np.uint8)
-    check(load().dabx_viterbi(_p(soft), nbits, soft.shape[0], _p(out)))
+    check(load().dabx_viterbi_mode(_p(soft), nbits, soft.shape[0], int(tie_mode), _p(out)))
     return out
 
 
@@ -179,6 +180,11 @@ class Demap:
         fft = np.ascontiguousarray(fft, np.complex64).reshape(self.batch, 2048)
         check(load().dabx_demap_store_null_symbol_without_tii(self._h, _p(fft)))
 
+    def snr_db(self):
+        out = np.zeros(self.batch, np.float32)
+        check(load().dabx_demap_get_snr_db(self._h, _p(out)))
+        return out
+
     def decode_symbols(self, fft, clock_err):
         fft = np.ascontiguousarray(fft, np.complex64).reshape(self.batch, -1, 2048)
         ce = np.ascontiguousarray(np.broadcast_to(np.asarray(clock_err, np.float32), (self.batch,)))
@@ -191,7 +197,7 @@ class Demap:
 class Config(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("ring_frames", C.c_int32), ("max_subch", C.c_int32), ("out_frames", C.c_int32),
                 ("sync_threshold", C.c_float), ("sync_strongest", C.c_int32), ("soft_bit_type", C.c_int32),
-                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("viterbi_tie_mode", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class SubchDesc(C.Structure):
@@ -250,13 +256,15 @@ class Tii:
 class IqFormat(C.Structure):
     """dabx_iq_format: family 0 raw / 1 wav / 2 uff; container 0 u8, 1 s8, 2 i16, 3 i24, 4 i32, 5 f32."""
     _fields_ = [("family", C.c_int32), ("container", C.c_int32), ("big_endian", C.c_int32), ("swap_iq", C.c_int32),
-                ("bits", C.c_int32), ("sample_rate", C.c_int32), ("data_offset", C.c_int64), ("data_bytes", C.c_int64)]
+                ("bits", C.c_int32), ("sample_rate", C.c_int32), ("data_offset", C.c_int64), ("data_bytes", C.c_int64),
+                ("reference_quirks", C.c_int32), ("reserved", C.c_int32)]
 
     def sample_bytes(self):
         return 2 * (1, 1, 2, 3, 4, 4)[self.container]
 
     def as_tuple(self):
-        return tuple(getattr(self, k) for k, _ in self._fields_)
+        """The probed description (family .. data_bytes); reference_quirks is a caller's switch, not part of it."""
+        return tuple(getattr(self, k) for k, _ in self._fields_[:8])
 
 
 class Stats(C.Structure):
@@ -277,13 +285,14 @@ class Engine:
     """Stream-batched receiver (device-side DabProcessor::run for n_streams ensembles)."""
 
     def __init__(self, n_streams=1, ring_frames=4, max_subch=18, out_frames=4, fic_only=False, capture_soft=False,
-                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False):
+                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False, viterbi_tie_mode=0):
         L = load()
         cfg = Config()
         L.dabx_default_config(C.byref(cfg))
         cfg.n_streams, cfg.ring_frames, cfg.max_subch, cfg.out_frames = n_streams, ring_frames, max_subch, out_frames
         cfg.fic_only, cfg.capture_soft, cfg.sync_threshold = int(fic_only), int(capture_soft), sync_threshold
         cfg.soft_bit_type, cfg.sync_strongest = soft_bit_type, int(sync_strongest)
+        cfg.viterbi_tie_mode = int(viterbi_tie_mode)
         self.cfg = cfg
         self._h = C.c_void_p()
         check(L.dabx_create(C.byref(cfg), C.byref(self._h)))

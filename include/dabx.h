@@ -54,6 +54,10 @@ int dabx_device_count(void);
  * soft  : batch x 4*(nbits+6) int16 mother-code soft bits (0 at punctured positions)
  * bits  : batch x nbits bytes, one decoded bit per byte.  Canonical scalar tie rule. */
 int dabx_viterbi(const int16_t *soft, int nbits, int batch, uint8_t *bits);
+/* The same with the decoder arithmetic selected: tie_mode 0 = the canonical scalar body (viterbi_scalar.h: int32 metrics, a
+ * tie keeps predecessor i); 1 = the reference's VITERBI_AVX2 / VITERBI_SSE2 builds (viterbi_16way.h:9-58: uint16 saturating
+ * metrics, renormalisation, a tie goes to predecessor i + 32).  Both are bit-identical to the respective object code. */
+int dabx_viterbi_mode(const int16_t *soft, int nbits, int batch, int tie_mode, uint8_t *bits);
 
 /* Protection::deconvolve for EEP/UEP (base/protection/protection.h:44; eep_protection.cpp:43-167,
  * uep_protection.cpp:52-212): in = batch x cu_size*64 punctured soft bits; out = batch x 24*kbps bits
@@ -148,6 +152,9 @@ int dabx_demap_store_null_symbol_without_tii(dabx_demap *d, const dabx_cf32 *fft
  * clock_err = batch floats, soft = batch x n_sym x 3072 int16. */
 int dabx_demap_decode_symbols(dabx_demap *d, const dabx_cf32 *fft, int n_sym, const float *clock_err, int16_t *soft);
 int dabx_demap_set_soft_bit_gen_type(dabx_demap *d, int type /*1..3*/);
+/* SLcdData::SNR as decode_symbol computes it for the LCD statistics (:326-343 with _compute_noise_Power :358-371) from the
+ * state as it stands: 10 log10((mMeanPowerOvrAll - noise) / noise); snr_db = batch floats. */
+int dabx_demap_get_snr_db(dabx_demap *d, float *snr_db);
 
 /* PhaseReference::correlate_with_phase_ref_and_find_max_peak (base/ofdm/phasereference.cpp:87-213):
  * v = batch x 2048 cf32, returns start index per problem (or -1). */
@@ -179,7 +186,9 @@ typedef struct {
   int32_t soft_bit_type;    /* glob_enums.h:49-56, default 1 (SOFTDEC1) */
   int32_t fic_only;         /* 1: BASELINE config 2 (FIC Viterbi only) */
   int32_t capture_soft;     /* 1: keep int16 soft bits of the last frame (debug / parity tests) */
-  int32_t reserved[7];
+  int32_t viterbi_tie_mode; /* 0: canonical scalar Viterbi (CMake default); 1: arithmetic of the VITERBI_AVX2 / _SSE2 builds, see
+                               dabx_viterbi_mode (FIC and MSC then run on the wave-per-trellis kernels) */
+  int32_t reserved[6];
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */
@@ -194,7 +203,8 @@ typedef struct {
   int64_t samples_consumed;
   int32_t state;             /* 0 wait-for-dip, 1 eval-sync, 2 in-frame */
   int32_t fic_ratio_percent; /* FicDecoder::get_fic_decode_ratio_percent */
-  float   freq_offs_bb_hz, clock_err_hz, snr_db_est;
+  float   freq_offs_bb_hz, clock_err_hz;
+  float   snr_db_est;        /* OfdmDecoder's LCD SNR (ofdm_decoder.cpp:326-343) after the newest frame's last symbol */
   int32_t last_start_index, cif_count;
   int64_t fib_ok, fib_total, sf_ok, sf_fail, rs_corrected, rs_failed, au_ok, au_bad, cifs_decoded;
 } dabx_stats;
@@ -269,9 +279,14 @@ int  dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t
  * Resampling follows the reference's non-liquid build: 1-ms blocks of rate/1000 input samples are linearly
  * interpolated to 2048 output samples (wav_reader.cpp:67-82,190-206; xml_reader.cpp:76-81,226-248; the two readers
  * differ in their table arithmetic and in how the first block is primed, selected by `family`).
- * Deliberate deviations, each a defect of the reference rather than a format rule: UFF QI/uint8 and
- * QI/float32 are decoded as the swapped IQ forms, UFF int24/MSB takes the Q middle byte from its own sample, and
- * single-channel (I-only / Q-only) UFF files are refused. */
+ * By default four defects of the reference's UFF reader are NOT reproduced (each evidently a typo, not a format rule;
+ * DESIGN.md 9): QI/float32 is decoded as swapped IQ (the reference does not swap, xml_reader.cpp:530,540), int24/MSB takes
+ * the middle byte of Q from its own sample (the reference reads lbuf[4*i+4] of its 1-ms read block, :316 and :462),
+ * QI/int24/MSB sign-extends with 0xFF000000 (the reference ORs 0x7F000000, :465,:469), QI/uint8 is decoded from the data
+ * (the reference indexes its 256-entry table with the loop counter, :423).  With dabx_iq_format.reference_quirks = 1 the
+ * first three are reproduced bit for bit -- the bytes a user of the reference gets from such a file -- and QI/uint8 is
+ * refused, because the reference's read runs past its table from the 128th sample of every block (undefined behaviour).
+ * Single-channel (I-only / Q-only) UFF files are refused in both modes. */
 enum { DABX_FAMILY_RAW = 0, DABX_FAMILY_WAV = 1, DABX_FAMILY_UFF = 2 };
 enum { DABX_C_U8 = 0, DABX_C_S8 = 1, DABX_C_I16 = 2, DABX_C_I24 = 3, DABX_C_I32 = 4, DABX_C_F32 = 5 };
 typedef struct dabx_iq_format_s {
@@ -283,6 +298,8 @@ typedef struct dabx_iq_format_s {
   int32_t sample_rate;   /* Hz; 2048000 = no resampling */
   int64_t data_offset;   /* first payload byte in the file */
   int64_t data_bytes;    /* payload length (clipped to the file) */
+  int32_t reference_quirks; /* 1: reproduce the reference's UFF reader defects bit for bit (see above); dabx_probe_iq_file sets 0 */
+  int32_t reserved;
 } dabx_iq_format;
 typedef struct dabx_feed dabx_feed;
 

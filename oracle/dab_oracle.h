@@ -66,6 +66,9 @@ void ora_prbs(uint8_t *out, int n);
  * input: 4*(nbits+6) soft bits (i16), output nbits bytes (1 bit/byte).
  * tie_mode 0 = scalar/SSE2 tie rule (decision 0), 1 = AVX2 tie rule (viterbi_16way.h). */
 void ora_viterbi(const int16_t *soft, int nbits, uint8_t *out_bits);
+void ora_viterbi_simd(const int16_t *soft, int nbits, uint8_t *out_bits);
+void ora_set_viterbi_mode(int mode);     /* 0 scalar body (default), 1 AVX2 body: what fic.c / protection.c decode with */
+void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits);   /* body of the VITERBI_AVX2 / _SSE2 builds, viterbi_16way.h */
 /* viterbi_spiral.cpp:128-164 */
 void ora_viterbi_ber(const int16_t *soft, const uint8_t *punct_table, const uint8_t *bits,
                      int nbits, int *io_bits, int *io_errors);
@@ -175,6 +178,7 @@ void ora_demap_reset(ora_demap *d);                                  /* ofdm_dec
 void ora_demap_store_ref(ora_demap *d, const ora_cf32 *fft);         /* ofdm_decoder.cpp:132-145 */
 void ora_demap_store_null(ora_demap *d, const ora_cf32 *fft);        /* ofdm_decoder.cpp:114-130 */
 void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_t out[ORA_2K]); /* :147-355 */
+float ora_demap_snr_db(const ora_demap *d);                       /* :326-343, :358-371 (SNR of the LCD statistics) */
 
 /* PRS correlator / coarse CFO: ofdm/phasereference.cpp */
 typedef struct {
@@ -209,6 +213,11 @@ typedef struct {
   int32_t *start_idx;  /* n_frames */
   float   *fbb;        /* n_frames : BB freq offset used for symbols 1..75 */
   int32_t *sym0_pos;   /* n_frames : absolute sample index of symbol-0 T_u start */
+  /* scalars as they stand when the frame is complete (after the null symbol): what the next frame's NCO / demapper use */
+  float   *fbb_end;    /* n_frames : mFreqOffsBBHz after the fine-CFO update, dab_processor.cpp:236-242 */
+  float   *clock_err;  /* n_frames : mClockErrHz, :246-251 */
+  int32_t *fic_ratio;  /* n_frames : FicDecoder::get_fic_decode_ratio_percent */
+  float   *snr_db;     /* n_frames : SNR of the LCD statistics after symbol 75, ofdm_decoder.cpp:326-343 */
 } ora_rx_capture;
 void ora_rx_enable_soft_capture(ora_receiver *r, int on);
 const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);

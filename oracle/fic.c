@@ -48,7 +48,7 @@ static void fic_process_input(ora_fic *f, int fic_idx)
   for (int i = 0; i < 3096; i++)
     if (f->map[i] >= 0) f->vit_in[i] = f->soft[f->map[i]];
   uint8_t *bits = &f->fib_bits[fic_idx * 768];
-  ora_viterbi(f->vit_in, 768, bits);                                         /* :197 */
+  ora_viterbi_build(f->vit_in, 768, bits);                                         /* :197 */
   ora_viterbi_ber(f->vit_in, f->punct, bits, 768, &f->fic_bits, &f->fic_errors); /* :199 */
   if (++f->fic_block == 40) { f->fic_block = 0; f->fic_errors /= 2; f->fic_bits /= 2; } /* :201-210 */
   for (int i = 0; i < 768; i++) bits[i] ^= f->prbs[i];                       /* :219-222 */

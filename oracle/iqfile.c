@@ -43,9 +43,62 @@ static float one_channel(const uint8_t *p, int family, int container, int be, in
   }
 }
 
+/* The reference's UFF loops that differ from the format's evident meaning, literally (test infrastructure for
+ * dabx_iq_format.reference_quirks): one read block of `amount` samples, lbuf = the block's bytes.
+ *   int24 / MSB, IQ  xml_reader.cpp:310-326 : Q's middle byte is lbuf[4 * i + 4]
+ *   int24 / MSB, QI  xml_reader.cpp:456-473 : the same index, sign extension ORs 0x7F000000, result swapped
+ *   float32,     QI  xml_reader.cpp:522-545 : stored order kept (no swap)                                              */
+static void uff_quirk_block(int container, int swap_iq, int be, int bits, const uint8_t *lbuf, int amount, float *out)
+{
+  const float scaler = (float)shift_bits(bits);
+  for (int i = 0; i < amount; i++) {
+    if (container == C_I24) {
+      int32_t t1 = (lbuf[6 * i] << 16) | (lbuf[6 * i + 1] << 8) | lbuf[6 * i + 2];
+      int32_t t2 = (lbuf[6 * i + 3] << 16) | (lbuf[4 * i + 4] << 8) | lbuf[6 * i + 5];
+      const int32_t ext = swap_iq ? 0x7F000000 : (int32_t)0xFF000000;
+      if (t1 & 0x800000) t1 |= ext;
+      if (t2 & 0x800000) t2 |= ext;
+      out[2 * i] = swap_iq ? (float)t2 / scaler : (float)t1 / scaler;
+      out[2 * i + 1] = swap_iq ? (float)t1 / scaler : (float)t2 / scaler;
+    } else {                                          /* float32 QI: c1, c2 in stored order */
+      uint32_t w[2];
+      for (int k = 0; k < 2; k++) {
+        const uint8_t *p = lbuf + 8 * i + 4 * k;
+        w[k] = be ? ((uint32_t)p[0] << 24 | p[1] << 16 | p[2] << 8 | p[3]) : ((uint32_t)p[3] << 24 | p[2] << 16 | p[1] << 8 | p[0]);
+      }
+      memcpy(&out[2 * i], &w[0], 4); memcpy(&out[2 * i + 1], &w[1], 4);
+    }
+  }
+}
+static int uff_quirk_applies(int family, int container, int big_endian, int swap_iq)
+{
+  return family == FAM_UFF && ((container == C_I24 && big_endian) || (container == C_F32 && swap_iq));
+}
+
+long long ora_iq_convert_q(int family, int container, int big_endian, int swap_iq, int bits, int rate, const uint8_t *bytes,
+                           long long n_bytes, float *out, long long max_out, int quirks);
 long long ora_iq_convert(int family, int container, int big_endian, int swap_iq, int bits, int rate, const uint8_t *bytes,
                          long long n_bytes, float *out, long long max_out)
 {
+  return ora_iq_convert_q(family, container, big_endian, swap_iq, bits, rate, bytes, n_bytes, out, max_out, 0);
+}
+
+long long ora_iq_convert_q(int family, int container, int big_endian, int swap_iq, int bits, int rate, const uint8_t *bytes,
+                           long long n_bytes, float *out, long long max_out, int quirks)
+{
+  if (quirks && uff_quirk_applies(family, container, big_endian, swap_iq)) {
+    /* decode read block by read block (readSamples, xml_reader.cpp:224-227: convBufferSize = rate / 1000 samples) into a
+     * cf32 stream in "as read" order, then let the normal path below resample it as already-decoded float32 IQ */
+    const int nb0 = container == C_I24 ? 3 : 4, M0 = (int16_t)(rate / 1000);
+    const long long blocks = n_bytes / (2LL * nb0 * M0);
+    float *tmp = (float *)malloc(sizeof(float) * 2 * (size_t)(blocks * M0 + 1));
+    for (long long c = 0; c < blocks; c++) uff_quirk_block(container, swap_iq, big_endian, bits, bytes + c * 2LL * nb0 * M0, M0, tmp + 2 * c * M0);
+    /* host-order float32, no swap: exactly the decoded values */
+    const union { uint32_t u; uint8_t b[4]; } probe = {1u};
+    const long long got = ora_iq_convert_q(FAM_UFF, C_F32, probe.b[0] ? 0 : 1, 0, 32, rate, (const uint8_t *)tmp, blocks * M0 * 8LL, out, max_out, 0);
+    free(tmp);
+    return got;
+  }
   const int nb = container == C_I16 ? 2 : container == C_I24 ? 3 : (container == C_I32 || container == C_F32) ? 4 : 1;
   const long long n = n_bytes / (2 * nb);
   long long produced = 0;

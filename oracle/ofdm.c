@@ -247,6 +247,18 @@ void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_
   memcpy(d->phase_ref, fft, sizeof(d->phase_ref));     /* :354 */
 }
 
+/* ofdm_decoder.cpp:326-343 (LCD statistics) with _compute_noise_Power, :358-371 */
+float ora_demap_snr_db(const ora_demap *d)
+{
+  float sum_noise = 0.0f;
+  for (int idx = -ORA_K / 2; idx < ORA_K / 2; ++idx) sum_noise += d->mean_null_power[idx < 0 ? idx + ORA_TU : idx + 1];
+  if (sum_noise == 0.0f) sum_noise = kMinNoisePower * ORA_K;
+  const float noise = sum_noise / (float)ORA_K;
+  float snr = (d->mean_power_ovr_all - noise) / noise;
+  if (snr <= 0.0f) snr = 0.1f;
+  return 10.0f * log10f(snr);
+}
+
 /* heap helpers for ctypes-based tests */
 ora_demap *ora_demap_new(void) { ora_demap *d = (ora_demap *)malloc(sizeof(ora_demap)); ora_demap_init(d); return d; }
 void ora_demap_free(ora_demap *d) { free(d); }

@@ -114,6 +114,6 @@ void ora_deconvolve(const int16_t *in, const int32_t *map, int kbps, uint8_t *ou
   int16_t *blk = (int16_t *)calloc((size_t)n, sizeof(int16_t));
   for (int i = 0; i < n; i++)
     if (map[i] >= 0) blk[i] = in[map[i]];
-  ora_viterbi(blk, 24 * kbps, out_bits);
+  ora_viterbi_build(blk, 24 * kbps, out_bits);
   free(blk);
 }

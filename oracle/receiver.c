@@ -121,6 +121,7 @@ void ora_rx_destroy(ora_receiver *r)
   for (int i = 0; i < r->n_back; i++) ora_backend_free(&r->back[i]);
   free(r->back);
   free(r->cap.fibs); free(r->cap.fib_crc); free(r->cap.soft); free(r->cap.start_idx); free(r->cap.fbb); free(r->cap.sym0_pos);
+  free(r->cap.fbb_end); free(r->cap.clock_err); free(r->cap.fic_ratio); free(r->cap.snr_db);
   free(r);
 }
 
@@ -139,6 +140,10 @@ static void cap_reserve(ora_receiver *r, int n)
   r->cap.start_idx = (int32_t *)realloc(r->cap.start_idx, sizeof(int32_t) * (size_t)na);
   r->cap.fbb = (float *)realloc(r->cap.fbb, sizeof(float) * (size_t)na);
   r->cap.sym0_pos = (int32_t *)realloc(r->cap.sym0_pos, sizeof(int32_t) * (size_t)na);
+  r->cap.fbb_end = (float *)realloc(r->cap.fbb_end, sizeof(float) * (size_t)na);
+  r->cap.clock_err = (float *)realloc(r->cap.clock_err, sizeof(float) * (size_t)na);
+  r->cap.fic_ratio = (int32_t *)realloc(r->cap.fic_ratio, sizeof(int32_t) * (size_t)na);
+  r->cap.snr_db = (float *)realloc(r->cap.snr_db, sizeof(float) * (size_t)na);
   if (r->want_soft) r->cap.soft = (int16_t *)realloc(r->cap.soft, sizeof(int16_t) * (size_t)na * 75 * ORA_2K);
   r->cap_alloc = na;
 }
@@ -191,6 +196,7 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
     if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);   /* :347-350 */
     if (sym > 3) msc_process_block(r, r->bits, sym);              /* :357-360 */
   }
+  r->cap.snr_db[frame_no] = ora_demap_snr_db(&r->dm);
   r->phase_offs_cp = atan2f(fc_im, fc_re);                        /* :366 */
 
   limit_sym(&r->phase_offs_cp, 20.0f * (float)(M_PI / 180.0));    /* :240-242 */
@@ -214,6 +220,9 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
     limit_sym(&ce, 307.2f);
     r->clock_err += 0.1f * (ce - r->clock_err);
   }
+  r->cap.fbb_end[frame_no] = r->freq_offs_bb;
+  r->cap.clock_err[frame_no] = r->clock_err;
+  r->cap.fic_ratio[frame_no] = r->fic.success_ratio * 10;
   return 1;
 }
 
@@ -289,6 +298,7 @@ int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 
       if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);
       if (sym > 3) msc_process_block(r, r->bits, sym);
     }
+    r->cap.snr_db[f] = ora_demap_snr_db(&r->dm);                  /* after symbol 75, before the null symbol (as process_rest_of_frame) */
     if (!((r->fic.cif_count & 7) >= 4)) ora_demap_store_null(&r->dm, nulls + (size_t)f * ORA_TU);
     for (int i = 0; i < 12; i++) {
       uint8_t *dst = &r->cap.fibs[((size_t)f * 12 + i) * 32];
@@ -300,6 +310,7 @@ int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 
       r->cap.fib_crc[f * 12 + i] = r->fic.fib_crc[i];
     }
     r->cap.start_idx[f] = 0; r->cap.fbb[f] = 0; r->cap.sym0_pos[f] = 0;
+    r->cap.fbb_end[f] = 0; r->cap.clock_err[f] = clock_err[f]; r->cap.fic_ratio[f] = r->fic.success_ratio * 10;
     r->cap.n_frames = f + 1;
   }
   return n_frames;

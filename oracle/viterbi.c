@@ -67,6 +67,75 @@ void ora_viterbi(const int16_t *soft, int nbits, uint8_t *out_bits)
   free(dec);
 }
 
+/* The body the reference's VITERBI_AVX2 / VITERBI_SSE2 builds use instead (viterbi_16way.h:9-110, viterbi_8way.h):
+ * uint16 path metrics with saturating adds, decision = (survivor == path through state i + 32), i.e. ties -> 1, and
+ * after every second step `renormalize`: if metrics2[0] -- state 0's metric of the step BEFORE the one just computed --
+ * exceeds 60000, the minimum of the new metrics is subtracted from all of them.  Pinned against the reference's AVX2
+ * object code (tests/test_oracle_ref.py). */
+void ora_viterbi_simd(const int16_t *soft, int nbits, uint8_t *out_bits)
+{
+  if (!g_branch_ready) build_branch();
+  const int nsteps = nbits + 6;
+  uint64_t *dec = (uint64_t *)calloc((size_t)nsteps, sizeof(uint64_t));
+  uint32_t m1[64], m2[64];                          /* metrics1 / metrics2, viterbi_spiral.cpp:41-42 */
+  uint32_t *old = m1, *nw = m2;
+  for (int i = 0; i < 64; i++) m1[i] = 1000, m2[i] = 0;
+  m1[0] = 0;
+  for (int t = 0; t < nsteps; t++) {
+    int sym[4];
+    for (int p = 0; p < 4; p++) {                   /* viterbi_16way.h:73-76: adds_epi16(+127), min 255, max 0 */
+      int v = (int)soft[4 * t + p] + 127;
+      if (v > 32767) v = 32767;                     /* saturating 16-bit add */
+      if (v > 255) v = 255;
+      if (v < 0) v = 0;
+      sym[p] = v;
+    }
+    uint64_t d = 0;
+    for (int i = 0; i < 32; i++) {                  /* BFLY, viterbi_16way.h:27-58 */
+      const int metric = (g_branch[0][i] ^ sym[0]) + (g_branch[1][i] ^ sym[1]) +
+                         (g_branch[2][i] ^ sym[2]) + (g_branch[3][i] ^ sym[3]);
+      const int m_metric = 1020 - metric;
+      uint32_t a0 = old[i] + metric, a1 = old[i + 32] + m_metric, a2 = old[i] + m_metric, a3 = old[i + 32] + metric;
+      if (a0 > 65535) a0 = 65535;                   /* adds_epu16 */
+      if (a1 > 65535) a1 = 65535;
+      if (a2 > 65535) a2 = 65535;
+      if (a3 > 65535) a3 = 65535;
+      const uint32_t s0 = a0 < a1 ? a0 : a1, s1 = a2 < a3 ? a2 : a3;
+      const int d0 = s0 == a1, d1 = s1 == a3;       /* cmpeq(survivor, m1 / m3): a tie selects the i + 32 path */
+      nw[2 * i] = s0; nw[2 * i + 1] = s1;
+      d |= (uint64_t)(d0 | (d1 << 1)) << (2 * i);
+    }
+    dec[t] = d;
+    if (t & 1) {                                    /* renormalize sits after the second butterfly pair of the loop body */
+      /* at this point new_metrics == metrics1 and metrics2 holds the metrics of step t - 1 (pointer swaps, :93-96,:110-113) */
+      const uint32_t *prev = old;                   /* `old` still points at the metrics of step t - 1 == metrics2 */
+      if (prev[0] > 60000) {
+        uint32_t mn = nw[0];
+        for (int i = 1; i < 64; i++) if (nw[i] < mn) mn = nw[i];
+        for (int i = 0; i < 64; i++) nw[i] -= mn;   /* subs_epu16: never below zero */
+      }
+    }
+    uint32_t *tmp = old; old = nw; nw = tmp;
+  }
+  unsigned endstate = 0;                            /* chain back: viterbi_spiral.cpp:114-125 */
+  for (int fb = nbits - 1; fb >= 0; fb--) {
+    const int k = (int)((dec[fb + 6] >> (endstate >> 2)) & 1);
+    endstate = (endstate >> 1) | ((unsigned)k << 7);
+    out_bits[fb] = (uint8_t)k;
+  }
+  free(dec);
+}
+
+/* Which body ViterbiSpiral::deconvolve was compiled with (viterbi_spiral.cpp:105-112 picks one by HAVE_VITERBI_*): the
+ * receiver-level oracle (fic.c, protection.c) decodes through this switch.  0 = scalar (CMake default), 1 = AVX2. */
+static int g_viterbi_mode = 0;
+void ora_set_viterbi_mode(int mode) { g_viterbi_mode = mode; }
+void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits)
+{
+  if (g_viterbi_mode == 1) ora_viterbi_simd(soft, nbits, out_bits);
+  else ora_viterbi(soft, nbits, out_bits);
+}
+
 /* viterbi_spiral.cpp:128-164 : re-encode and compare against hard decisions */
 void ora_viterbi_ber(const int16_t *soft, const uint8_t *punct, const uint8_t *bits,
                      int nbits, int *io_bits, int *io_errors)

@@ -10,15 +10,19 @@
 
 int main(int argc, char **argv)
 {
-  if (argc < 3) { std::fprintf(stderr, "usage: shim_replay <recording> <out.eti> [subChId ...]\n"); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: shim_replay <recording> <out.eti> [subChId ...] [--late subChId]\n"); return 2; }
+  int late_id = -1;                       // a service added 8 frames after the others (MscHandler::set_channel on a running receiver)
+  for (int i = 3; i + 1 < argc; i++)
+    if (std::string(argv[i]) == "--late") { late_id = std::atoi(argv[i + 1]); argc = i; break; }
   try {
     dabx::Processor::Params pp;
     pp.max_services = 24;
     dabx::Processor rx(pp);
     long long fibs_ok = 0, fibs = 0, lf = 0, sf = 0;
-    std::map<int, long long> lf_per_service;
+    std::map<int, long long> lf_per_service, lf_this_run, stalls;
+    long long late_added_at = -1;
     rx.on_fib = [&](const uint8_t *, bool ok, int) { fibs++; fibs_ok += ok; };
-    rx.on_logical_frame = [&](int id, const uint8_t *, int) { lf++; lf_per_service[id]++; };
+    rx.on_logical_frame = [&](int id, const uint8_t *, int) { lf++; lf_per_service[id]++; lf_this_run[id]++; };
     rx.on_super_frame = [&](int, const uint8_t *, int) { sf++; };
     const dabx_iq_format fmt = rx.open_recording(argv[1]);
     rx.start();
@@ -35,7 +39,16 @@ int main(int argc, char **argv)
       if (got == 0) break;
       left -= (long long)got;
       rx.put_file_bytes(block.data(), got);
-      frames += rx.run(4);
+      lf_this_run.clear();
+      const int ran = rx.run(4);
+      frames += ran;
+      // a service that has started delivering must deliver with every processed frame (4 logical frames each)
+      for (const auto &kv : lf_per_service)
+        if (ran > 0 && lf_this_run[kv.first] != 4 * ran && lf_per_service[kv.first] != lf_this_run[kv.first]) stalls[kv.first]++;
+      if (configured && late_id >= 0 && late_added_at < 0 && lf_per_service.size() > 0 && frames >= 14) {
+        if (!rx.set_audio_channel(late_id)) { std::fprintf(stderr, "late service %d not found\n", late_id); return 4; }
+        late_added_at = frames;
+      }
       if (!configured && rx.get_fic_decode_ratio_percent() >= 90) {
         if (argc > 3) { configured = true; for (int i = 3; i < argc; i++) configured = rx.set_audio_channel(std::atoi(argv[i])) && configured; }
         else configured = rx.set_all_channels() > 0;
@@ -44,8 +57,14 @@ int main(int argc, char **argv)
     std::fclose(fp);
     rx.stop_eti_generator();
     rx.stop();
+    long long n_stalls = 0;
+    for (const auto &kv : stalls) n_stalls += kv.second;
+    std::string per = "{";
+    for (const auto &kv : lf_per_service) per += (per.size() > 1 ? ", \"" : "\"") + std::to_string(kv.first) + "\": " + std::to_string(kv.second);
+    per += "}";
     std::printf("{\"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"services\": %zu, "
-                "\"eti_frames\": %lld}\n", frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written());
+                "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"lf_per_service\": %s}\n", frames, fibs, fibs_ok, lf, sf,
+                lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, per.c_str());
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "shim_replay: %s\n", e.what());

@@ -27,7 +27,9 @@ class SubchDesc(C.Structure):
 class RxCapture(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("fibs", C.POINTER(C.c_uint8)), ("fib_crc", C.POINTER(C.c_uint8)),
                 ("soft", C.POINTER(C.c_int16)), ("start_idx", C.POINTER(C.c_int32)),
-                ("fbb", C.POINTER(C.c_float)), ("sym0_pos", C.POINTER(C.c_int32))]
+                ("fbb", C.POINTER(C.c_float)), ("sym0_pos", C.POINTER(C.c_int32)),
+                ("fbb_end", C.POINTER(C.c_float)), ("clock_err", C.POINTER(C.c_float)), ("fic_ratio", C.POINTER(C.c_int32)),
+                ("snr_db", C.POINTER(C.c_float))]
 
 
 def build_oracle():
@@ -53,6 +55,8 @@ def oracle():
     L.ora_phase_table.argtypes = [_c64p]
     L.ora_prbs.argtypes = [_u8p, C.c_int]
     L.ora_viterbi.argtypes = [_i16p, C.c_int, _u8p]
+    L.ora_viterbi_simd.argtypes = [_i16p, C.c_int, _u8p]
+    L.ora_set_viterbi_mode.argtypes = [C.c_int]
     L.ora_viterbi_ber.argtypes = [_i16p, _u8p, _u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for f in (L.ora_eep_map, L.ora_uep_map):
         f.argtypes = [C.c_int, C.c_int, _i32p]
@@ -90,10 +94,14 @@ def oracle():
     L.ora_eti_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(SubchDesc), C.c_int, _u8p, C.POINTER(C.c_void_p), _u8p]
     L.ora_iq_convert.restype = C.c_longlong
     L.ora_iq_convert.argtypes = [C.c_int] * 6 + [_u8p, C.c_longlong, C.c_void_p, C.c_longlong]
+    L.ora_iq_convert_q.argtypes = [C.c_int] * 6 + [_u8p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int]
+    L.ora_iq_convert_q.restype = C.c_longlong
     L.ora_fic_init.argtypes = [C.c_void_p]
     L.ora_fic_process_block.argtypes = [C.c_void_p, _i16p, C.c_int]
     L.ora_demap_new.restype = C.c_void_p
     L.ora_demap_free.argtypes = [C.c_void_p]
+    L.ora_demap_snr_db.argtypes = [C.c_void_p]
+    L.ora_demap_snr_db.restype = C.c_float
     L.ora_demap_set_type.argtypes = [C.c_void_p, C.c_int]
     L.ora_demap_reset.argtypes = [C.c_void_p]
     L.ora_demap_store_ref.argtypes = [C.c_void_p, _c64p]
@@ -172,6 +180,12 @@ def ref():
 def ora_viterbi(soft, nbits):
     out = np.zeros(nbits, np.uint8)
     oracle().ora_viterbi(np.ascontiguousarray(soft, np.int16), nbits, out)
+    return out
+
+
+def ora_viterbi_simd(soft, nbits):
+    out = np.zeros(nbits, np.uint8)
+    oracle().ora_viterbi_simd(np.ascontiguousarray(soft, np.int16), nbits, out)
     return out
 
 

@@ -87,6 +87,28 @@ def test_adapter_replays_a_recording_to_eti(tmp_path, select):
         assert _crc(f[mst:pos]) == (f[pos] << 8 | f[pos + 1])
 
 
+@pytest.mark.gpu
+def test_adapter_adds_a_higher_rate_service_without_silencing_the_running_ones(tmp_path):
+    """Processor::set_channel on a running receiver with a service whose bit rate exceeds every configured one: the engine
+    widens its output rings in place, the services already running keep delivering 4 logical frames per frame (the
+    reference's MscHandler::set_channel only adds a Backend, msc_handler.cpp:123-135)."""
+    from tools import dab_synth as ds
+    from tools import iq_files as iqf
+    exe = _build()
+    subch = [ds.SubCh(1, 0, 48, 64, 2, 0), ds.SubCh(2, 48, 48, 64, 2, 0), ds.SubCh(5, 200, 96, 128, 2, 0)]
+    ens = ds.build_ensemble(10, subch, seed=43)
+    x = ds.channel(ens.iq, snr_db=22.0, cfo_hz=-300.0, timing_offset=9000, seed=9, n_out=40 * ds.TF)
+    rec = str(tmp_path / "rec.sdr")
+    iqf.write_sdr(rec, x, 2048000, 0.25 / np.sqrt(np.mean(np.abs(x) ** 2)))
+    p = subprocess.run([exe, rec, str(tmp_path / "o.eti"), "1", "2", "--late", "5"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["late_added_at"] >= 14 and res["stalls"] == 0 and res["services"] == 3
+    lf = {int(k): v for k, v in res["lf_per_service"].items()}
+    assert lf[1] == lf[2] and lf[1] >= 4 * (res["frames"] - 10) - 16          # ran from their configuration to the end, no gap
+    assert 0 < lf[5] == 4 * (res["frames"] - res["late_added_at"]) - 16        # the late one: 16-CIF fill from where it was added
+
+
 def test_host_parsers_are_clean_under_asan_and_ubsan():
     """tests/cxx/san_host.cpp: FIB walk, ETI assembly, container probing on mutated headers and the TII detector, built with
     g++ -fsanitize=address,undefined from the library's own host sources (GPU sanitizers are not available on the pool)."""

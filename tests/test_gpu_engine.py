@@ -30,6 +30,8 @@ def _oracle_run(x, subch, want_soft=False, config=None):
                crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy(),
                start=np.ctypeslib.as_array(cap.start_idx, (n,)).copy(),
                fbb=np.ctypeslib.as_array(cap.fbb, (n,)).copy(),
+               fbb_end=np.ctypeslib.as_array(cap.fbb_end, (n,)).copy(), clock_err=np.ctypeslib.as_array(cap.clock_err, (n,)).copy(),
+               fic_ratio=np.ctypeslib.as_array(cap.fic_ratio, (n,)).copy(), snr_db=np.ctypeslib.as_array(cap.snr_db, (n,)).copy(),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
                sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
                stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
@@ -45,6 +47,7 @@ def _engine_run(x, subch, n_frames, **kw):
         eng.set_subchannels(subch)
     eng.push_iq(0, x)
     fibs, crc, msc, sfs, starts, fbbs = [], [], [[] for _ in subch], [[] for _ in subch], [], []
+    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[])       # per frame, as they stand when the frame is complete
     last_sf = [0] * len(subch)
     for step in range(n_frames + 3):
         before = eng.stats(0)["frames"]
@@ -54,10 +57,26 @@ def _engine_run(x, subch, n_frames, **kw):
             continue
         f, c = eng.read_fibs(0, 1)
         fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
+        eng.scalars["clock_err"].append(st["clock_err_hz"]); eng.scalars["fic_ratio"].append(st["fic_ratio_percent"])
+        eng.scalars["snr_db"].append(st["snr_db_est"])
         for j in range(len(subch)):
             m = eng.read_msc(0, j, 4)
             msc[j].append((st["frames"], m))
     return eng, np.array(fibs), np.array(crc), msc, np.array(starts), np.array(fbbs)
+
+
+def _check_frame_scalars(eng, fbbs, ora, n):
+    """The per-frame receiver scalars that steer the NEXT frame (NCO frequency, clock-error phase ramp of the demapper,
+    coarse-CFO enable) and the SNR estimate, against the oracle's values at the same point of the same frame.
+    Tolerances: f_bb 0.05 Hz (float atan2 of a 37800-term correlation sum; one carrier is 1000 Hz, the NCO uses round(f_bb));
+    clock error: same integer sample count through the same float expression -> equal; FIC ratio: integer -> equal;
+    SNR: 0.02 dB (mMeanPowerOvrAll is a 115 200-step serial float recurrence in the reference, a weighted sum here)."""
+    assert np.abs(np.asarray(fbbs[:n], np.float64) - ora["fbb_end"][:n]).max() <= 0.05
+    assert np.array_equal(np.asarray(eng.scalars["clock_err"][:n], np.float32), ora["clock_err"][:n])
+    assert np.array_equal(np.asarray(eng.scalars["fic_ratio"][:n]), ora["fic_ratio"][:n])
+    a, b = np.asarray(eng.scalars["snr_db"][:n], np.float64), ora["snr_db"][:n].astype(np.float64)
+    ok = np.isfinite(a) & np.isfinite(b)                       # an all-zero stretch (drop-out) makes 0/0 on both sides alike
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and ok.sum() >= n - 3 and np.abs(a[ok] - b[ok]).max() <= 0.02
 
 
 @pytest.mark.parametrize("seed,snr,cfo,toff", [(1, 20.0, 1234.5, 50000), (2, 12.0, -1987.0, 170001), (3, 30.0, 0.0, 3),
@@ -75,6 +94,8 @@ def test_fic_and_msc_bit_exact_vs_oracle(seed, snr, cfo, toff):
     assert np.array_equal(crc[:n], ora["crc"][:n])
     assert np.array_equal(fibs[:n], ora["fibs"][:n])
     assert crc[6:n].all()                                      # locked and error free after the CFO has converged
+    _check_frame_scalars(eng, fbbs, ora, n)
+    assert snr - 1.0 < eng.scalars["snr_db"][n - 1] < snr + 9.0               # settling towards the channel's SNR (the noise IIR takes ~20 frames)
     # MSC logical frames: the engine ring keeps the newest 16 per sub-channel; the oracle kept the whole stream
     cnt = eng.counters()
     st = eng.stats(0)
@@ -663,6 +684,7 @@ def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind):
     eng.set_subchannels(subch)
     eng.push_iq(0, x)
     fibs, crc, starts, fbbs, idle, steps = [], [], [], [], 0, 0
+    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[])
     while idle < 4 and steps < 400:                         # a step without a frame is an acquisition pass: keep going
         before = eng.stats(0)
         eng.process(1)
@@ -672,6 +694,8 @@ def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind):
         if st["frames"] > before["frames"]:
             f, c = eng.read_fibs(0, 1)
             fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
+            eng.scalars["clock_err"].append(st["clock_err_hz"]); eng.scalars["fic_ratio"].append(st["fic_ratio_percent"])
+            eng.scalars["snr_db"].append(st["snr_db_est"])
     fibs, crc, starts, fbbs = np.array(fibs), np.array(crc), np.array(starts), np.array(fbbs)
     n = min(len(fibs), ora["n"])
     assert n >= ora["n"] - 1 and n >= 24, (len(fibs), ora["n"], steps)
@@ -685,6 +709,7 @@ def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind):
     assert np.array_equal(crc[:n], ora["crc"][:n])
     assert np.array_equal(fibs[:n], ora["fibs"][:n])
     assert abs(fbbs[n - 1] - ora["fbb"][n - 1]) < 1.0 and abs(fbbs[n - 1] + 1333.0) < 2.0     # same CFO estimate at the end
+    _check_frame_scalars(eng, fbbs, ora, n)                 # f_bb, clock error, FIC ratio, SNR: every frame, through the loss of lock
     assert crc[n - 6:n].all() and not crc[:n].all()         # locked again at the end
     if len(fibs) == ora["n"]:                               # the back ends ran straight through the drop-out on both sides
         k = 4 * ora["n"] - 16
@@ -792,6 +817,7 @@ def test_sample_clock_offset_is_tracked_like_the_oracle(ppm):
     assert len(set(starts[locked_from:n].tolist())) >= 2                    # the index does wander
     assert np.array_equal(crc[:n], ora["crc"][:n]) and np.array_equal(fibs[:n], ora["fibs"][:n])
     assert crc[locked_from:n].all() and n - locked_from >= 10
+    _check_frame_scalars(eng, fbbs, ora, n)                                  # incl. the clock error the demapper's phase ramp uses
     st = eng.stats(0)
     ce = -st["clock_err_hz"] / (2.048 * ppm)                                # 1 ppm = 2.048 Hz of sample clock; IIR still settling
     assert 0.5 < ce < 1.3, st["clock_err_hz"]
@@ -901,7 +927,9 @@ def test_growing_the_largest_bit_rate_keeps_every_running_service_and_stream():
     eti_before, lost = eng.read_eti(0, 32)
     assert lost == 0 and len(eti_before) == 9 * 4 - 16
     eng.set_subchannels([mk(c) for c in sub_b], stream=1)               # 128 kbit/s on the OTHER stream: the rings grow
-    eng.process(12)
+    eng.process(6)
+    eti_mid, lost_mid = eng.read_eti(0, 64)                             # (the FIB ring holds 8 frames: read at least that often)
+    eng.process(6)
     fr0, fr1 = eng.stats(0)["frames"], eng.stats(1)["frames"]
     assert fr0 == 21 and fr1 == 21
     eng.subch = list(sub_a)                                             # layout of the stream being read (wrapper: buffer sizes)
@@ -914,7 +942,9 @@ def test_growing_the_largest_bit_rate_keeps_every_running_service_and_stream():
         sf_o = ora_a["sf"][j].reshape(-1, 880)
         assert np.array_equal(eng.read_superframes(0, j, 4), sf_o[q["sf_ok"] - 4:q["sf_ok"]]), j
     eti_after, lost = eng.read_eti(0, 64)                               # the ETI stream of stream 0 continues seamlessly
-    assert lost == 0 and len(eti_after) == 12 * 4
+    assert lost == 0 and lost_mid == 0
+    eti_after = np.concatenate([eti_mid, eti_after])
+    assert len(eti_after) == 12 * 4
     both = np.concatenate([eti_before, eti_after])
     import test_eti as te
     descs = [mk(c) for c in sub_a]
@@ -953,4 +983,52 @@ def test_dab_plus_is_refused_for_rates_the_super_frame_stage_cannot_hold():
             eng.set_subchannels([ok, bad])
         plain = dx.SubchDesc(2, 300, cu, kbps, prot, 0, 0, 0)            # the same sub-channel without the DAB+ stage is fine
         eng.set_subchannels([ok, plain])
+    eng.close()
+
+
+def test_avx2_viterbi_build_of_the_reference_is_selectable_for_the_whole_receiver():
+    """cfg.viterbi_tie_mode = 1: FIC and MSC are decoded with the arithmetic of the reference's VITERBI_AVX2 build
+    (viterbi_16way.h; pinned against that object code in test_gpu_viterbi / test_oracle_ref).  At 4.3 dB -- where trellis
+    ties and near-ties decide bits -- the engine follows the oracle receiver switched to the same body, frame by frame,
+    including the FIBs that fail their CRC and the super frames RS cannot repair."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=77)
+    x = ds.channel(ens.iq, snr_db=4.3, cfo_hz=-150.0, timing_offset=31000, seed=77, n_out=24 * ds.TF)
+    L = ol.oracle()
+    canon = _oracle_run(x, subch)
+    L.ora_set_viterbi_mode(1)
+    try:
+        ora = _oracle_run(x, subch)
+    finally:
+        L.ora_set_viterbi_mode(0)
+    eng = dx.Engine(n_streams=1, ring_frames=25, max_subch=18, out_frames=4, viterbi_tie_mode=1)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    fibs, crc = [], []
+    for _ in range(ora["n"] + 3):
+        before = eng.stats(0)["frames"]
+        eng.process(1)
+        if eng.stats(0)["frames"] > before:
+            f, c = eng.read_fibs(0, 1)
+            fibs.append(f[0]); crc.append(c[0])
+    fibs, crc = np.array(fibs), np.array(crc)
+    n = min(len(fibs), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 18
+    assert np.array_equal(crc[:n], ora["crc"][:n])
+    ok = ora["crc"][:n].astype(bool)
+    assert np.array_equal(fibs[:n][ok], ora["fibs"][:n][ok])                # every FIB that passes its CRC (failed ones: float demapper tolerance)
+    k = eng.stats(0)["frames"] * 4 - 16
+    same = 0
+    for j in range(18):
+        st, o = eng.subch_stats(0, j), ora["stats"][j]
+        if st["cifs_decoded"] == o["cif_out"]:
+            assert (st["sf_ok"], st["sf_fail"], st["rs_corrected"], st["rs_failed"]) == (o["sf_ok"], o["sf_fail"], o["rs_corr"], o["rs_fail"]), j
+        got = eng.read_msc(0, j, 16)
+        want = ora["msc"][j].reshape(-1, 192)[k - 16:k]
+        same += int(np.array_equal(got, want))
+    assert same >= 16                                                      # byte-exact logical frames on (nearly) all sub-channels at 4.3 dB
+    # the two bodies do decode this signal differently somewhere
+    differs = not np.array_equal(canon["fibs"][:n], ora["fibs"][:n]) or any(
+        not np.array_equal(canon["msc"][j], ora["msc"][j]) for j in range(18))
+    assert differs
     eng.close()

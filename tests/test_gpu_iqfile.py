@@ -184,3 +184,49 @@ def test_long_replay_through_a_small_ring(tmp_path, rate):
     assert refused >= 1 or st["samples_consumed"] > 6 * ds.TF                       # the ring did wrap
     feed.close()
     eng.close()
+
+
+@pytest.mark.parametrize("container,be,swap,bits,rate", [(3, 1, 0, 24, 2048000), (3, 1, 1, 24, 2048000), (3, 1, 0, 20, 2500000),
+                                                         (3, 1, 1, 24, 1792000), (5, 1, 1, 32, 2048000), (5, 0, 1, 32, 2000000)])
+def test_reference_quirks_mode_reproduces_the_uff_reader_defects_bit_for_bit(container, be, swap, bits, rate):
+    """dabx_iq_format.reference_quirks = 1: what a user of the reference gets from such a file -- int24/MSB with Q's middle
+    byte taken from lbuf[4*i+4] of the 1-ms read block (xml_reader.cpp:316,462), QI/int24/MSB sign-extended with
+    0x7F000000 (:465,:469), QI/float32 not swapped (:530,:540) -- against the oracle's literal restatement of those loops;
+    the default mode decodes the format's evident meaning, and the two differ."""
+    rng = np.random.default_rng(container * 100 + be * 10 + swap + rate // 1000)
+    M = rate // 1000
+    n = M * 23 + 77                                             # whole read blocks + a tail the reference never delivers
+    if container == 5:
+        vals = rng.standard_normal(2 * n).astype(np.float32)
+        payload = vals.view(np.uint8).reshape(-1, 4)[:, ::-1].reshape(-1).copy() if be else vals.view(np.uint8).copy()
+    else:
+        payload = rng.integers(0, 256, n * 6).astype(np.uint8)
+    fq = dx.IqFormat(2, container, be, swap, bits, rate, 0, 0, 1, 0)
+    f0 = dx.IqFormat(2, container, be, swap, bits, rate, 0, 0, 0, 0)
+    cap = payload.size + 4096
+    want = np.zeros(cap, np.complex64)
+    nw = ol.oracle().ora_iq_convert_q(2, container, be, swap, bits, rate, payload, payload.size, want.ctypes.data, cap, 1)
+    want = want[:nw]
+    got = dx.convert_iq_bytes(fq, payload)
+    assert len(got) == len(want) == 23 * 2048 if rate != 2048000 else len(got) == len(want) == 23 * M
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    plain = dx.convert_iq_bytes(f0, payload)
+    assert not np.array_equal(plain[:len(got)].view(np.uint32), got.view(np.uint32))        # the defects are visible in the samples
+    # streaming feed: any split of the payload gives the same samples (read blocks are re-assembled inside the feed)
+    eng = dx.Engine(n_streams=1, ring_frames=2, max_subch=0, fic_only=1)
+    feed = dx.Feed(eng, 0, fq)
+    pos, total = 0, 0
+    for step in (5, 6143, 1, 40000, 1 << 22):
+        total += feed.push(payload[pos:pos + step])
+        pos += step
+    assert total == len(want)
+    assert np.array_equal(eng.read_iq(0, 0, total).view(np.uint32), want.view(np.uint32))
+    feed.close()
+    eng.close()
+
+
+def test_reference_quirks_mode_refuses_what_the_reference_leaves_undefined():
+    payload = np.zeros(4096, np.uint8)
+    with pytest.raises(dx.DabxError, match="423"):
+        dx.convert_iq_bytes(dx.IqFormat(2, 0, 0, 1, 8, 2048000, 0, 0, 1, 0), payload)       # UFF QI/uint8: out-of-bounds table walk
+    assert len(dx.convert_iq_bytes(dx.IqFormat(2, 0, 0, 1, 8, 2048000, 0, 0, 0, 0), payload)) == 2048   # default mode decodes it

@@ -177,6 +177,8 @@ def test_demapper_matches_oracle(soft_type):
         d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
         tot += d.size; off1 += int((d > 1).sum()); worst = max(worst, int(d.max()))
         assert np.array_equal(got > 0, exp > 0) or (d[(got > 0) != (exp > 0)] <= 2).all()
+        # SLcdData::SNR (ofdm_decoder.cpp:326-343) from mMeanPowerOvrAll and the null-symbol noise power: 0.02 dB
+        assert abs(float(dm.snr_db()[0]) - float(L.ora_demap_snr_db(od))) <= 0.02, f
         L.ora_demap_store_null(od, spec[f, 76])
         dm.store_null_symbol_without_tii(spec[f, 76])
     L.ora_demap_free(od)

@@ -73,3 +73,25 @@ def test_deconvolve_every_legal_profile_matches_oracle():
             L.ora_deconvolve(soft[i], m, kbps, want[i])
         got = dx.deconvolve(soft, kbps, prot, short)
         assert np.array_equal(got, want), (kbps, prot, short)
+
+
+@pytest.mark.parametrize("n", [768, 192, 1536, 9216])
+def test_avx2_tie_mode_matches_the_references_avx2_build(n):
+    """viterbi_tie_mode = 1 (dabx_viterbi_mode): the arithmetic of the reference's VITERBI_AVX2 build (viterbi_16way.h:
+    uint16 saturating metrics, renormalisation, ties to the i + 32 path, saturating symbol conversion).  Bit-identical to
+    the bits the reference's own AVX2 object code returned for the seeded rows of tests/golden/ref_viterbi_avx2.npz, and to
+    the oracle restatement that is pinned against that object on the CPU; the canonical mode differs on the same inputs."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_viterbi_avx2 as mk
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_viterbi_avx2.npz"))
+    soft = mk.rows_for(n)
+    want = np.unpackbits(G["bits_%d" % n], axis=1)[:, :n]
+    got = dx.viterbi(soft, n, tie_mode=1)
+    assert np.array_equal(got, want)
+    for i in range(len(soft)):
+        assert np.array_equal(got[i], ol.ora_viterbi_simd(soft[i], n)), i
+    canon = dx.viterbi(soft, n)
+    assert not np.array_equal(canon, want)
+    for i in range(len(soft)):
+        assert np.array_equal(canon[i], ol.ora_viterbi(soft[i], n)), i
