@@ -121,26 +121,81 @@ def fill_rings(eng, torch, dev, args, rank, subch):
     return n_frames
 
 
+def host_cpu():
+    """CPU model and physical core count of the host (for the cpu_baseline record)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, (len(cores) or logical), logical
+
+
 def cpu_baseline(args, subch):
-    """The oracle (CPU port of the reference algorithm) on one stream of the same workload, one core."""
+    """the CPU port of the reference algorithm (oracle/) on the same workload, on the host cores of this box.
+    Built -O3 -march=native here (`make -C oracle native`).  Two variants of the chain: reference-default (scalar
+    demapper + scalar int32 Viterbi: the reference's default CMake configuration) and reference-best (the Viterbi replaced by
+    the reference's OWN AVX2 object code, oracle/_ref/libdabref_vit_avx2.so, i.e. its VITERBI_AVX2 build; scalar demapper)."""
+    import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from tools import dab_synth as ds
+    model, phys_cores, logical = host_cpu()
+    build = "-O3 -march=native"
+    native = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
+    try:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, capture_output=True, timeout=300)
+        ol.ORA_SO = native
+        ol._ora = None                                        # (re)load the oracle from the native build
+    except Exception:
+        build = "-O2 (the native build failed on this host)"
     ens = ds.build_ensemble(10, subch, seed=0, cyclic=True)
     n = args.cpu_frames
     x10 = ds.channel(ens.iq, snr_db=args.snr, cfo_hz=417.0 / 0.96, timing_offset=12345, seed=0)   # cyclic, 10 frames
     x = np.ascontiguousarray(np.tile(x10, (n + 2 + 9) // 10))
     L = ol.oracle()
-    rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
-    t0 = time.perf_counter()
-    got = L.ora_rx_run(rx, x, len(x), n)
-    dt = time.perf_counter() - t0
-    L.ora_rx_destroy(rx)
-    out = {"value": round(got / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of 1 stream (18x64k EEP3-A, %g dB) through oracle/ (scalar C, -O2)" % (got, args.snr)}
+
+    def run_one(frames):
+        rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+        t0 = time.perf_counter()
+        got = L.ora_rx_run(rx, x, len(x), frames)
+        dt = time.perf_counter() - t0
+        L.ora_rx_destroy(rx)
+        return got, dt
+
+    got, dt = run_one(n)
+    sample = "%d frames of 1 stream (18x64k EEP3-A, %g dB) through oracle/ (plain C, %s)" % (got, args.snr, build)
+    out = {"value": round(got / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample,
+           "variant": "reference-default (scalar demapper, scalar int32 Viterbi)",
+           "cpu_model": model, "physical_cores": phys_cores, "logical_cpus": logical}
+    # reference-best: the reference's own AVX2 Viterbi object inside the same chain (single-threaded: its path metrics are
+    # file-scope arrays)
+    R = ol.ref_viterbi_variant("avx2")
+    if R is not None and hasattr(R, "ref_viterbi_cached"):
+        L.ora_set_viterbi_hook.argtypes = [C.c_void_p]
+        L.ora_set_viterbi_hook(C.cast(R.ref_viterbi_cached, C.c_void_p))
+        try:
+            got_b, dt_b = run_one(n)
+        finally:
+            L.ora_set_viterbi_hook(None)
+        out["reference_best"] = {"value": round(got_b / dt_b, 3), "unit": "frames/s", "cores": 1, "kind": "port+reference",
+                                 "variant": "reference-best (scalar demapper, the reference's VITERBI_AVX2 object code)",
+                                 "sample": "%d frames of the same stream" % got_b}
     # the same port on every host core (streams are independent: one receiver per thread, ctypes drops the GIL)
     import threading
-    ncpu = min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    ncpu = min(64, logical)
     if ncpu > 1:
         n2 = max(20, min(n, int(5.0 * got / dt)))          # about 5 s per thread (bounded even if the threads share cores)
         x2 = x[: (n2 + 3) * TF]
@@ -155,10 +210,10 @@ def cpu_baseline(args, subch):
             t.start()
         for t in th:
             t.join()
-        dt = time.perf_counter() - t0
+        dt2 = time.perf_counter() - t0
         for r in rxs:
             L.ora_rx_destroy(r)
-        out["all_cores"] = {"value": round(sum(done) / dt, 3), "unit": "frames/s", "cores": ncpu,
+        out["all_cores"] = {"value": round(sum(done) / dt2, 3), "unit": "frames/s", "cores": ncpu, "variant": "reference-default",
                             "sample": "%d threads x %d frames, one receiver each" % (ncpu, n2)}
     # the reference's OWN object code where it could be built (oracle/_ref, viterbi_spiral.cpp scalar): its Viterbi alone,
     # as a frame rate (72 MSC blocks of 1542 steps + 4 FIC blocks of 774 per frame)

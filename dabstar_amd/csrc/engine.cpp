@@ -39,7 +39,15 @@ struct dabx_engine {
   std::vector<void *> allocs;
   void *stage = nullptr;                       // host -> device staging of dabx_push_iq
   size_t stage_cap = 0;
+  // dabx_push_iq_async: a small pool of device staging slots, each guarded by the event of its last conversion kernel, so
+  // that consecutive pushes from pinned host memory queue back to back on the ingest stream (DMA at PCIe rate, no host wait)
+  static constexpr int ASYNC_SLOTS = 8;
+  void *aslot[ASYNC_SLOTS] = {nullptr};
+  size_t aslot_cap[ASYNC_SLOTS] = {0};
+  hipEvent_t aslot_done[ASYNC_SLOTS] = {nullptr};
+  unsigned long long async_pushes = 0;
   hipStream_t ingest = nullptr;                // dabx_push_iq: copy + format conversion, concurrent with the receiver streams
+  hipStream_t ingest2 = nullptr;               // dabx_push_iq_async alternates between the two: the DMA of push k + 1 runs under the conversion of push k
   hipEvent_t ingest_done = nullptr;
   std::vector<unsigned long long> rd_seen;     // [S] read index of every stream when last looked at (lower bound)
   std::vector<StreamCtl> ctl_peek;
@@ -217,6 +225,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
+  DABX_HIP(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
   DABX_HIP(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
   e->rd_seen.assign(cfg->n_streams, 0);
   const int S = cfg->n_streams;
@@ -283,8 +292,13 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
   if (e->ingest) { (void)hipStreamSynchronize(e->ingest); (void)hipStreamDestroy(e->ingest); }
+  if (e->ingest2) { (void)hipStreamSynchronize(e->ingest2); (void)hipStreamDestroy(e->ingest2); }
   if (e->ingest_done) (void)hipEventDestroy(e->ingest_done);
   if (e->stage) (void)hipFree(e->stage);
+  for (int i = 0; i < dabx_engine::ASYNC_SLOTS; i++) {
+    if (e->aslot[i]) (void)hipFree(e->aslot[i]);
+    if (e->aslot_done[i]) (void)hipEventDestroy(e->aslot_done[i]);
+  }
   for (void *p : e->allocs) (void)hipFree(p);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
@@ -393,19 +407,13 @@ int dabx_commit_iq(dabx_engine *e, int stream, size_t n)
   return launch_commit(e->dev, stream, n, e->stream);
 }
 
-int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
+// never overwrite samples the receiver has not read yet.  rd only grows, so the value seen at the last look is a safe
+// bound: the pipeline is drained (and rd read again) only when that bound says the ring is full
+static int push_room(dabx_engine *e, int stream, size_t n, const char *who)
 {
-  if (!e || stream < 0 || stream >= e->dev.n_streams || !iq || fmt < 0 || fmt > 2 || n > (size_t)e->dev.ring_len) {
-    set_error("dabx_push_iq: bad argument");
-    return DABX_E_ARG;
-  }
-  if (n == 0) return 0;
-  if (int rc = use_device(e)) return rc;
-  // never overwrite samples the receiver has not read yet.  rd only grows, so the value seen at the last look is a safe
-  // bound: the pipeline is drained (and rd read again) only when that bound says the ring is full
   for (int attempt = 0; e->wr_host[stream] - e->rd_seen[stream] + n > (unsigned long long)e->dev.ring_len; attempt++) {
     if (attempt == 2) {
-      set_error("dabx_push_iq: ring of stream %d has room for %llu samples, %zu offered (call dabx_process first)", stream,
+      set_error("%s: ring of stream %d has room for %llu samples, %zu offered (call dabx_process first)", who, stream,
                 (unsigned long long)e->dev.ring_len - (e->wr_host[stream] - e->rd_seen[stream]), n);
       return DABX_E_STATE;
     }
@@ -416,6 +424,18 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
     DABX_HIP(hipMemcpy(e->ctl_peek.data(), e->dev.ctl, sizeof(StreamCtl) * e->dev.n_streams, hipMemcpyDeviceToHost));
     for (int s = 0; s < e->dev.n_streams; s++) e->rd_seen[s] = std::max(e->rd_seen[s], e->ctl_peek[s].rd);
   }
+  return 0;
+}
+
+int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !iq || fmt < 0 || fmt > 2 || n > (size_t)e->dev.ring_len) {
+    set_error("dabx_push_iq: bad argument");
+    return DABX_E_ARG;
+  }
+  if (n == 0) return 0;
+  if (int rc = use_device(e)) return rc;
+  if (int rc = push_room(e, stream, n, "dabx_push_iq")) return rc;
   static const int bps[3] = {8, 4, 2};
   const size_t bytes = n * bps[fmt];
   if (bytes > e->stage_cap) {                   // one staging buffer per engine, grown on demand
@@ -434,6 +454,63 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
   rc = dabx_commit_iq(e, stream, n);
   DABX_HIP(hipStreamSynchronize(e->ingest));   // the caller's buffer and the staging buffer are free again
   return rc;
+}
+
+// The same without waiting for the copy: for producers that keep their buffers alive and unchanged until dabx_push_wait --
+// a file reader cycling through a few pinned buffers (hipHostMalloc / dabx_host_register).  From pinned memory the copies
+// of consecutive calls run back to back as DMA at PCIe rate while the host already issues the next ones; from pageable
+// memory the HIP runtime stages the copy itself and the call degrades gracefully to the synchronous behaviour.
+int dabx_push_iq_async(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !iq || fmt < 0 || fmt > 2 || n > (size_t)e->dev.ring_len) {
+    set_error("dabx_push_iq_async: bad argument");
+    return DABX_E_ARG;
+  }
+  if (n == 0) return 0;
+  if (int rc = use_device(e)) return rc;
+  if (int rc = push_room(e, stream, n, "dabx_push_iq_async")) return rc;
+  static const int bps[3] = {8, 4, 2};
+  const size_t bytes = n * bps[fmt];
+  const int k = (int)(e->async_pushes++ % dabx_engine::ASYNC_SLOTS);
+  if (!e->aslot_done[k]) DABX_HIP(hipEventCreateWithFlags(&e->aslot_done[k], hipEventDisableTiming));
+  else DABX_HIP(hipEventSynchronize(e->aslot_done[k]));              // the slot's previous conversion has read it
+  if (bytes > e->aslot_cap[k]) {
+    if (e->aslot[k]) DABX_HIP(hipFree(e->aslot[k]));
+    e->aslot[k] = nullptr; e->aslot_cap[k] = 0;
+    DABX_HIP(hipMalloc(&e->aslot[k], bytes));
+    e->aslot_cap[k] = bytes;
+  }
+  hipStream_t ing = (k & 1) ? e->ingest2 : e->ingest;
+  DABX_HIP(hipMemcpyAsync(e->aslot[k], iq, bytes, hipMemcpyHostToDevice, ing));
+  int rc = launch_convert_iq(e->aslot[k], fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, ing);
+  if (rc) return rc;
+  DABX_HIP(hipEventRecord(e->aslot_done[k], ing));
+  DABX_HIP(hipStreamWaitEvent(e->stream, e->aslot_done[k], 0));      // the commit (and every frame after it) sees the samples
+  return dabx_commit_iq(e, stream, n);
+}
+
+int dabx_push_wait(dabx_engine *e)
+{
+  if (!e) return DABX_E_ARG;
+  if (int rc = use_device(e)) return rc;
+  DABX_HIP(hipStreamSynchronize(e->ingest));
+  DABX_HIP(hipStreamSynchronize(e->ingest2));
+  return 0;
+}
+
+// hipHostRegister / hipHostUnregister for a producer's own buffers (page-locks them so that pushes are true DMA)
+int dabx_host_register(void *p, size_t bytes)
+{
+  if (!p || !bytes) return DABX_E_ARG;
+  if (int rc = need_device_e()) return rc;
+  DABX_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return 0;
+}
+int dabx_host_unregister(void *p)
+{
+  if (!p) return DABX_E_ARG;
+  DABX_HIP(hipHostUnregister(p));
+  return 0;
 }
 
 int dabx_read_iq(dabx_engine *e, int stream, uint64_t first, size_t n, float *iq_out)

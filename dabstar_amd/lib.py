@@ -323,6 +323,15 @@ class Engine:
         n = iq.size if fmt == 0 else iq.size // 2
         check(load().dabx_push_iq(self._h, stream, _p(iq), fmt, n))
 
+    def push_iq_async(self, stream, iq):
+        """iq must stay alive and unchanged until push_wait() (see dabx_push_iq_async)."""
+        fmt = {np.dtype(np.complex64): 0, np.dtype(np.int16): 1, np.dtype(np.uint8): 2}[iq.dtype]
+        n = iq.size if fmt == 0 else iq.size // 2
+        check(load().dabx_push_iq_async(self._h, stream, _p(iq), fmt, n))
+
+    def push_wait(self):
+        check(load().dabx_push_wait(self._h))
+
     def read_iq(self, stream, first, n):
         out = np.zeros(n, np.complex64)
         check(load().dabx_read_iq(self._h, stream, C.c_uint64(first), C.c_size_t(n), _p(out)))
@@ -412,6 +421,16 @@ def eti_frame(cif_hi, cif_lo, minor, subch, fic96, msc):
     out = np.zeros(6144, np.uint8)
     used = check(load().dabx_eti_frame(cif_hi, cif_lo, minor, arr, len(subch), _p(fic96), ptrs, _p(out)))
     return out, used
+
+
+def host_register(a):
+    """Page-locks a numpy array's memory (hipHostRegister) so that pushes from it are DMA; returns the array."""
+    check(load().dabx_host_register(_p(a), a.nbytes))
+    return a
+
+
+def host_unregister(a):
+    check(load().dabx_host_unregister(_p(a)))
 
 
 def probe_iq_file(path):

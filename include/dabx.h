@@ -223,6 +223,14 @@ int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, 
  * Returns when the caller's buffer is free again; copy and conversion run on their own HIP stream next to frames still
  * being decoded (the receiver is drained only if the ring looks full). */
 int  dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_samples);   /* DABX_E_STATE: would overwrite unread samples */
+/* The same without waiting for the copy: the caller keeps `iq` alive and unchanged until dabx_push_wait returns.  Meant
+ * for producers that cycle through a few page-locked buffers (hipHostMalloc, or their own memory passed once through
+ * dabx_host_register): consecutive pushes then run back to back as DMA at PCIe rate next to the decode.  With pageable
+ * memory the call behaves like dabx_push_iq. */
+int  dabx_push_iq_async(dabx_engine *e, int stream, const void *iq, int fmt, size_t n_samples);
+int  dabx_push_wait(dabx_engine *e);
+int  dabx_host_register(void *p, size_t bytes);     /* hipHostRegister: page-lock a producer's buffer */
+int  dabx_host_unregister(void *p);
 /* Device-resident producers: ring base (cf32, capacity ring_frames*T_F) and commit of n new samples. */
 int  dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *capacity_samples);
 int  dabx_commit_iq(dabx_engine *e, int stream /* <0: all */, size_t n_samples);

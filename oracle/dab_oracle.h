@@ -68,7 +68,8 @@ void ora_prbs(uint8_t *out, int n);
 void ora_viterbi(const int16_t *soft, int nbits, uint8_t *out_bits);
 void ora_viterbi_simd(const int16_t *soft, int nbits, uint8_t *out_bits);
 void ora_set_viterbi_mode(int mode);     /* 0 scalar body (default), 1 AVX2 body: what fic.c / protection.c decode with */
-void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits);   /* body of the VITERBI_AVX2 / _SSE2 builds, viterbi_16way.h */
+void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits);
+void ora_set_viterbi_hook(void (*fn)(const int16_t *, int, uint8_t *));   /* bench.py: the reference's AVX2 object as the decoder */   /* body of the VITERBI_AVX2 / _SSE2 builds, viterbi_16way.h */
 /* viterbi_spiral.cpp:128-164 */
 void ora_viterbi_ber(const int16_t *soft, const uint8_t *punct_table, const uint8_t *bits,
                      int nbits, int *io_bits, int *io_errors);

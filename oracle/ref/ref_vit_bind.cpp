@@ -4,6 +4,7 @@
 #include "viterbi_spiral.h"
 #include <chrono>
 #include <cstdint>
+#include <cstring>
 
 extern "C" {
 int ref_viterbi(const int16_t * soft, int nbits, uint8_t * out)   // viterbi_spiral.h:20
@@ -11,6 +12,21 @@ int ref_viterbi(const int16_t * soft, int nbits, uint8_t * out)   // viterbi_spi
   ViterbiSpiral v((short)nbits, true);
   v.deconvolve(soft, out);
   return 0;
+}
+// one decoder object per block length, kept (the receiver-level CPU baseline calls this for every FIC / MSC block);
+// single-threaded use only: ViterbiSpiral keeps its path metrics in file-scope arrays (viterbi_spiral.cpp:41-42)
+void ref_viterbi_cached(const int16_t * soft, int nbits, uint8_t * out)
+{
+  static ViterbiSpiral * cache[16] = {nullptr};
+  static int lens[16] = {0};
+  int i = 0;
+  while (i < 16 && lens[i] != 0 && lens[i] != nbits) i++;
+  if (i == 16) { ViterbiSpiral v((short)nbits, true); v.deconvolve(soft, out); return; }
+  if (lens[i] == 0) { lens[i] = nbits; cache[i] = new ViterbiSpiral((short)nbits, true); }
+  // the SIMD bodies read their input with aligned 128-bit loads (viterbi_16way.h:70): the caller's block may sit anywhere
+  alignas(64) static int16_t aligned[4 * (9216 + 6) + 64];
+  if (nbits <= 9216) { memcpy(aligned, soft, sizeof(int16_t) * 4 * (size_t)(nbits + 6)); soft = aligned; }
+  cache[i]->deconvolve(soft, out);
 }
 double ref_viterbi_seconds(const int16_t * soft, int nbits, uint8_t * out, int reps)
 {

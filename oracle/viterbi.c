@@ -129,10 +129,20 @@ void ora_viterbi_simd(const int16_t *soft, int nbits, uint8_t *out_bits)
 /* Which body ViterbiSpiral::deconvolve was compiled with (viterbi_spiral.cpp:105-112 picks one by HAVE_VITERBI_*): the
  * receiver-level oracle (fic.c, protection.c) decodes through this switch.  0 = scalar (CMake default), 1 = AVX2. */
 static int g_viterbi_mode = 0;
+static void (*g_viterbi_hook)(const int16_t *, int, uint8_t *) = 0;
 void ora_set_viterbi_mode(int mode) { g_viterbi_mode = mode; }
+/* CPU-baseline leg only (bench.py "reference-best"): decode through the reference's OWN AVX2 object code
+ * (oracle/_ref/libdabref_vit_avx2.so, ref_viterbi_cached) instead of the plain-C restatement above. */
+void ora_set_viterbi_hook(void (*fn)(const int16_t *, int, uint8_t *)) { g_viterbi_hook = fn; }
 void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits)
 {
-  if (g_viterbi_mode == 1) ora_viterbi_simd(soft, nbits, out_bits);
+  if (g_viterbi_hook) {
+#ifdef __AVX__
+    __builtin_ia32_vzeroupper();     /* native build: leave no dirty upper vector state for the callee's 128 / 256-bit code */
+#endif
+    g_viterbi_hook(soft, nbits, out_bits);
+  }
+  else if (g_viterbi_mode == 1) ora_viterbi_simd(soft, nbits, out_bits);
   else ora_viterbi(soft, nbits, out_bits);
 }
 

@@ -1032,3 +1032,44 @@ def test_avx2_viterbi_build_of_the_reference_is_selectable_for_the_whole_receive
         not np.array_equal(canon["msc"][j], ora["msc"][j]) for j in range(18))
     assert differs
     eng.close()
+
+
+@pytest.mark.parametrize("fmt", ["u8", "i16"])
+def test_async_pushes_from_page_locked_buffers_decode_like_synchronous_ones(fmt):
+    """dabx_push_iq_async + dabx_host_register: three streams fed in 2-frame pieces from one page-locked recording buffer,
+    many pushes queued before a single dabx_push_wait, decode exactly like the same samples pushed synchronously."""
+    subch = ds.default_subchannels(4, 64)
+    ens = ds.build_ensemble(10, subch, seed=81)
+    x = ds.channel(ens.iq, snr_db=18.0, cfo_hz=-640.0, timing_offset=7171, seed=81, n_out=20 * ds.TF)
+    pairs = (x * np.complex64(0.25 / np.sqrt(np.mean(np.abs(x) ** 2)))).view(np.float32)
+    host = (np.clip(np.round(pairs * 128.0 + 127.38), 0, 255).astype(np.uint8) if fmt == "u8"
+            else np.clip(np.round(pairs * 32768.0), -32768, 32767).astype(np.int16))
+    ref = dx.Engine(n_streams=1, ring_frames=21, max_subch=4, out_frames=8)
+    ref.set_subchannels(subch)
+    ref.push_iq(0, host)
+    ref.process(20)
+    eng = dx.Engine(n_streams=3, ring_frames=5, max_subch=4, out_frames=8)
+    eng.set_subchannels(subch)
+    dx.host_register(host)
+    try:
+        step = 2 * ds.TF * 2                                  # 2 frames of interleaved I/Q values
+        for pos in range(0, len(host), step):
+            for s in range(3):
+                eng.push_iq_async(s, host[pos:pos + step])   # 3 copies in flight, the caller does not wait
+            eng.process(2, sync=False)
+        eng.push_wait()
+        eng.synchronize()
+    finally:
+        dx.host_unregister(host)
+    a = ref.stats(0)
+    for s in range(3):
+        b = eng.stats(s)
+        for key in ("frames", "samples_consumed", "fib_ok", "fib_total", "sf_ok", "sf_fail", "cifs_decoded", "last_start_index"):
+            assert a[key] == b[key], (s, key, a[key], b[key])
+        fa, ca = ref.read_fibs(0, 8)
+        fb, cb = eng.read_fibs(s, 8)
+        assert np.array_equal(fa, fb) and np.array_equal(ca, cb)
+        for j in range(4):
+            assert np.array_equal(ref.read_msc(0, j, 16), eng.read_msc(s, j, 16)), (s, j)
+    assert a["frames"] >= 17 and a["sf_ok"] > 0
+    eng.close(); ref.close()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Hunting run of the differential fuzz tests (tests/test_gpu_fuzz.py) over a range of seeds and receiver options; one
+JSON line per run (seed, options, decoder path, verdict, seconds) -- the log kept under profiles/ is this output.
+
+    python tools/fuzz_hunt.py --seeds 1000:1040 > profiles/r02_fuzz_log.jsonl        (on the GPU box)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+CFGS = ["3.0,0,1", "3.0,0,1", "3.0,0,1", "4.0,1,2", "2.5,0,3", "3.0,1,1"]      # threshold, strongest-peak sync, soft-bit generator
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="1000:1030")
+    a = ap.parse_args()
+    lo, hi = [int(v) for v in a.seeds.split(":")]
+    n_pass = n_fail = 0
+    for seed in range(lo, hi):
+        cfg = CFGS[seed % len(CFGS)]
+        fast = seed % 4 == 3                     # every fourth run through the lane-per-trellis classes
+        which = "test_random_service_start_stop_schedules" if seed % 7 == 6 else "test_random_channels_and_layouts_follow_the_oracle"
+        env = dict(os.environ, DABX_FUZZ_SEED=str(seed), DABX_FUZZ_CFG=cfg)
+        if fast:
+            env.update(DABX_MSC_FAST_MIN_JOBS="64", DABX_MSC_CLASS_MIN_JOBS="1")
+        t0 = time.time()
+        p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_fuzz.py", "-k", which],
+                           cwd=ROOT, env=env, capture_output=True, text=True)
+        ok = p.returncode == 0
+        n_pass += ok; n_fail += (not ok)
+        rec = {"seed": seed, "test": which, "cfg_threshold_strongest_softtype": cfg, "lane_per_trellis_classes": bool(fast),
+               "passed": ok, "seconds": round(time.time() - t0, 1)}
+        if not ok:
+            rec["tail"] = p.stdout[-1500:]
+        print(json.dumps(rec), flush=True)
+    print(json.dumps({"summary": {"runs": n_pass + n_fail, "passed": n_pass, "failed": n_fail, "streams_per_run": 24}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

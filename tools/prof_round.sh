@@ -1,8 +1,11 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun): rocprofv3 kernel stats of the default bench command, PMC passes for
-# the hot kernels, and the HBM traffic per launch (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM").
+# the hot kernels, and the HBM traffic per launch (FETCH_SIZE / WRITE_SIZE in separate passes, MI355X_MICROARCH.md "HBM").
+# FETCH_SIZE correction per kernel from the calibration of tools/fetch_calib.hip (profiles/r02_fetch_calib.json): the counter
+# reads 0.5 of the bytes for coalesced 4 / 8 / 16-byte-per-lane streams and 256-B rows (x2) but 1.0 for k_msc_prep's
+# 64-byte runs, one HBM line each (x1); WRITE_SIZE is exact for the coalesced patterns.
 # Usage: tools/prof_round.sh <tag>      -> gpurun_out/<tag>/...
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -30,9 +33,14 @@ for k, v in acc.items():
     fs = sorted(v.get("FETCH_SIZE", [0])); ws = sorted(v.get("WRITE_SIZE", [0]))
     f = sum(fs[len(fs) // 2:]) / max(1, len(fs[len(fs) // 2:])); w = sum(ws[len(ws) // 2:]) / max(1, len(ws[len(ws) // 2:]))
     vs = sorted(v.get("SQ_INSTS_VALU", [0])); va = sum(vs[len(vs) // 2:]) / max(1, len(vs[len(vs) // 2:]))
-    res[k] = {"fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+    fx = 1.0 if k == "k_msc_prep" else 2.0
+    batched = k.startswith("k_msc") or k == "k_dabplus"
+    res[k] = {"fetch_size_raw_bytes": f * 1024, "fetch_correction": fx, "fetch_bytes": fx * f * 1024, "write_bytes": w * 1024,
+              "hbm_bytes_per_launch": fx * f * 1024 + w * 1024, "frames_per_launch": 512 * (7 if batched else 1),
               "valu_wave_insts_per_launch": va}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE doubled (gfx950), mean over full-size launches; SQ_INSTS_VALU = wave-level VALU instructions",
-           "streams": 512, "kernels": res}, open(out + "/traffic.json", "w"), indent=1)
+tot = sum(v["hbm_bytes_per_launch"] / (7 if (k.startswith("k_msc") or k == "k_dabplus") else 1) for k, v in res.items())
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, mean over full-size launches; FETCH_SIZE x fetch_correction "
+                   "(profiles/r02_fetch_calib.json: 0.5 counted for coalesced streams -> x2, exact for k_msc_prep's 64-B runs -> x1); SQ_INSTS_VALU = wave-level VALU instructions",
+           "streams": 512, "chain_hbm_bytes_per_step": tot, "kernels": res}, open(out + "/traffic.json", "w"), indent=1)
 PY
 cat $OUT/bench.json
