@@ -11,7 +11,7 @@
 #include <vector>
 
 namespace dabx {
-int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk);
+int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk);
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk);
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
 extern const char *const kStepKernelNames[10];
@@ -178,6 +178,7 @@ static int sync_all(dabx_engine *e)
   if (int rc = use_device(e)) return rc;
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
+  if (e->ss.c) DABX_HIP(hipStreamSynchronize(e->ss.c));
   return 0;
 }
 
@@ -224,6 +225,10 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   // release writes the caches back for host visibility on every record)
   DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  DABX_HIP(hipStreamCreateWithPriority(&e->ss.c, hipStreamNonBlocking, pa));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.fic_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
   DABX_HIP(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
   DABX_HIP(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -234,6 +239,14 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.ring_len = cfg->ring_frames * TF;
   d.threshold = cfg->sync_threshold; d.strongest = cfg->sync_strongest;
   d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft; d.tie_mode = cfg->viterbi_tie_mode != 0;
+  d.fused_front = 0;
+  d.front_prio = 1;
+  d.split_fic = 1;
+  d.prep_on_b = 1;
+  if (const char *ev = getenv("DABX_PREP_ON_B")) d.prep_on_b = atoi(ev) != 0;
+  if (const char *ev = getenv("DABX_SPLIT_FIC")) d.split_fic = atoi(ev) != 0;
+  if (const char *ev = getenv("DABX_FRONT_PRIO")) d.front_prio = atoi(ev) != 0;
+  if (const char *ev = getenv("DABX_FUSED_FRONT")) d.fused_front = atoi(ev);
   const DevTables *t;
   if ((rc = get_tables(&t))) { dabx_destroy(e); return rc; }
 #define A(x) if ((rc = (x))) { dabx_destroy(e); return rc; }
@@ -242,6 +255,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.ctl, S));
   A(e->alloc(&d.spectra, (size_t)S * 75 * K, false));
   A(e->alloc(&d.nco_tid, (size_t)S * 256));
+  A(e->alloc(&d.nco_sym, (size_t)S * 76));
   A(e->alloc(&e->snap_buf[0], S));
   A(e->alloc(&e->snap_buf[1], S));
   d.snap = e->snap_buf[0];
@@ -288,6 +302,10 @@ void dabx_destroy(dabx_engine *e)
   (void)use_device(e);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->ss.b) { (void)hipStreamSynchronize(e->ss.b); (void)hipStreamDestroy(e->ss.b); }
+  if (e->ss.c) { (void)hipStreamSynchronize(e->ss.c); (void)hipStreamDestroy(e->ss.c); }
+  if (e->ss.fic_go) (void)hipEventDestroy(e->ss.fic_go);
+  if (e->ss.fic_done) (void)hipEventDestroy(e->ss.fic_done);
+  if (e->ss.prep_b_done) (void)hipEventDestroy(e->ss.prep_b_done);
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
@@ -554,7 +572,12 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     e->classes_dirty = false;
   }
   for (int i = 0; i < max_frames; i++) {
-    int rc = launch_front_step(e->dev, e->stream, e->mk);
+    // the 5th frame after a batch starts rewriting time-de-interleaver slots the previous batch's k_msc_prep (stream b) reads
+    if (e->ss.prep_pending && e->pending_frames >= 4) {
+      DABX_HIP(hipStreamWaitEvent(e->stream, e->ss.prep_b_done, 0));
+      e->ss.prep_pending = false;
+    }
+    int rc = launch_front_step(e->dev, e->ss, e->mk);
     if (rc) return rc;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
       e->dev.snap = e->snap_buf[e->ss.batch_parity];

@@ -65,6 +65,10 @@ struct EngineDev {
   int32_t ring_len;               // IQ ring capacity per stream in samples
   float threshold;
   int32_t strongest, fic_only, capture_soft;
+  int32_t prep_on_b;              // 1: k_msc_prep on the decoder's HIP stream instead of the front end's
+  int32_t split_fic;              // 1: FIC decoder on its own HIP stream next to the demapping of the MSC symbols
+  int32_t front_prio;             // 1: front-end kernels raise their wave priority (s_setprio 3) over the batched MSC decoder
+  int32_t fused_front;            // 1: symbols + demap in one kernel (k_front_fused), spectra stay in LDS
   int32_t tie_mode;               // 1: Viterbi arithmetic of the reference's AVX2 / SSE2 builds (viterbi_core.h, vit_step_simd)
   int32_t msc_stride;             // bytes per logical-frame slot (3 * max kbps)
   int32_t sf_stride;              // bytes per super-frame slot (110 * max kbps / 8)
@@ -75,6 +79,7 @@ struct EngineDev {
   DemapDev demap;
   float2 *spectra;                // [S][75][1536]: symbols 1..75 in CARRIER order (frequency de-interleaved by k_symbols)
   double2 *nco_tid;               // [S][256] e^{-j 2 pi f tid / fs} of the current frame (k_frame_head -> k_symbols)
+  double2 *nco_sym;               // [S][76]  NCO phasor of the first FFT sample of symbols 1..75 ([75] = rotation per 256 samples)
   float2 *cp_part;                // [S][75] cyclic-prefix correlation partial sums
   float *abs_part;                // [S][76] sum |x| of the samples read per symbol (level tracking)
   uint8_t *fic_sym;               // [S][9216] Viterbi symbols of OFDM symbols 1..3
@@ -116,8 +121,9 @@ struct MscLaunch { int n, groups; MscLaunchCls c[MSC_MAX_CLASSES]; };
 // HIP streams/events of the engine: front end on `a`; the long lane-per-trellis decode of batch n runs on `b`
 // while `a` already demodulates the frames of batch n+1.
 struct EngineStreams {
-  hipStream_t a = nullptr, b = nullptr;
-  hipEvent_t prep_done = nullptr, msc_done = nullptr;
+  hipStream_t a = nullptr, b = nullptr, c = nullptr;       // c: the FIC decoder of the frame in flight
+  hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, fic_done = nullptr, prep_b_done = nullptr;
+  bool prep_pending = false;      // k_msc_prep of the previous batch may still be reading the TDI ring on stream b
   bool msc_in_flight = false;
   int batch_parity = 0;
 };

@@ -17,6 +17,13 @@
 
 namespace dabx {
 
+// Issue priority of the frame-serial front end.  Its kernels run with few waves per SIMD and long dependent chains (one
+// block per stream); the batched MSC decoder (k_msc_vitT, own HIP stream) keeps every SIMD's VALU busy with four waves of
+// independent work.  At equal priority the arbiter shares issue slots evenly and the front end -- the critical path of a
+// step -- runs at half speed whenever the decoder is resident.  s_setprio 3 lets front-end waves issue first; the decoder
+// fills the slots they leave.  DABX_FRONT_PRIO=0 switches it off (A/B in DESIGN.md 6).
+__device__ __forceinline__ void front_prio(const EngineDev &e) { if (e.front_prio) __builtin_amdgcn_s_setprio(3); }
+
 // IQ ring addressing: one 64-bit modulo per thread and kernel (for the window base), then 32-bit
 // add + conditional subtract per sample.
 struct RingView {
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
 // --------------------------------------------------------------------------------------------- frame head
 __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 {
+  front_prio(e);
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float peak[TU];
   __shared__ float red[8];
@@ -192,6 +200,14 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
     f_bb = f_sync;
   }
   e.nco_tid[(size_t)s * 256 + tid] = Nco::tid_factor((int)roundf(f_bb), tid);
+  // NCO phasor of the first FFT-window sample of every symbol 1..75 (two double sincospi each): 75 lanes in parallel here
+  // instead of one lane of every k_symbols block while its other 255 threads wait (12 % of that kernel's VALU issue)
+  if (tid < 75) {
+    double2 b, st;
+    Nco::block_consts(nco_advance(phase0, f, (long long)start + TU), (int)roundf(f_bb), (long long)tid * TS + TG, b, st);
+    e.nco_sym[(size_t)s * 76 + tid] = b;
+    if (tid == 0) e.nco_sym[(size_t)s * 76 + 75] = st;
+  }
   if (tid == 0) {
     c.start_index = start;
     c.head_abs_a = abs_a; c.head_abs_b = abs_b;
@@ -210,6 +226,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 // fine-CFO update that depends on all 75 cyclic-prefix correlations.)
 __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
 {
+  front_prio(e);
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red3[3][4];
   const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;   // l = symbol index - 1
@@ -217,8 +234,6 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   if (!c.frame_ok) return;
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
   const unsigned long long base = c.sym0_pos + TU + (unsigned long long)l * TS;   // first sample (CP) of this symbol
-  const int f = c.f_frame;
-  const long long n0 = (long long)l * TS;                                        // samples read since symbol 1 began
 
   // cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504 (dab_processor.cpp:330-333) on the RAW samples;
   // the NCO contributes the constant factor e^{-j 2 pi f Tu / fs} which k_frame_tail applies once.
@@ -232,10 +247,7 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   }
   float2 v[8];
   Nco nco;
-  __shared__ double2 s_nco[2];
-  if (tid == 0) Nco::block_consts(c.phase_sym1, f, n0 + TG, s_nco[0], s_nco[1]);
-  __syncthreads();
-  nco.init_from(s_nco[0], s_nco[1], e.nco_tid[(size_t)s * 256 + tid]);
+  nco.init_from(e.nco_sym[(size_t)s * 76 + l], e.nco_sym[(size_t)s * 76 + 75], e.nco_tid[(size_t)s * 256 + tid]);
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const float2 x = rv.at(TG + tid + 256 * u);
@@ -271,8 +283,12 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
 // -------------------------------------------------------------------------------------------------- demap
 constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
 template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
-__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t)
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t, int l0, int l1)
 {
+  // symbols [l0, l1) of the frame (0-based: l = symbol index - 1).  The engine runs [0, 3) -- the FIC symbols -- first so
+  // that k_fic_frame can start on its own HIP stream while [3, 75) is demapped; the per-carrier state passes through
+  // HBM between the two launches exactly as it does from frame to frame.
+  front_prio(e);
   __shared__ float red[32];
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -287,7 +303,8 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     const int k = tid + DEMAP_THREADS * q;
     bin[q] = t.perm_bin[k];
     rel_f[q] = (float)(K / 2 - t.perm_rel[k]);
-    const float2 pr = d.phase_ref[(size_t)s * TU + bin[q]];
+    // X_(l-1): the phase reference (symbol 0, FFT bin order) or the previous symbol's spectrum (carrier order)
+    const float2 pr = l0 == 0 ? d.phase_ref[(size_t)s * TU + bin[q]] : e.spectra[((size_t)s * 75 + (l0 - 1)) * K + k];
     cr.prev_re[q] = pr.x; cr.prev_im[q] = pr.y;
     cr.integ[q] = d.integ[(size_t)s * K + k];
     cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
   float2 xn[DEMAP_Q];                                           // spectrum values of the next symbol (gather latency off the chain)
   {
-    const float2 *X0 = e.spectra + (size_t)s * 75 * K;
+    const float2 *X0 = e.spectra + ((size_t)s * 75 + l0) * K;
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[tid + DEMAP_THREADS * q];
   }
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     tpos[2 * q + 1] = ((K + k) & 15) * 192 + ((K + k) >> 4);
   }
   const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
-  for (int l = 0; l < 75; l++) {                          // the demapper state advances on all 75 symbols in every mode
+  for (int l = l0; l < l1; l++) {                         // the demapper state advances on all 75 symbols in every mode
     const float2 *X = e.spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, SOFT_TYPE);
@@ -364,6 +381,149 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   float ns = cr.null_power.x + cr.null_power.y, wsum = wk.x * pacc.x + wk.y * pacc.y;
   block_sum2w(ns, wsum, red, tid);
   if (tid == 0) {
+    mpa = mpa * mpa_decay_n(l1 - l0) + wsum;
+    d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa;
+    if (l1 == 75) c.snr_db = snr_db_from(mpa, ns);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- symbols + demap, fused
+// k_symbols and k_demap_frame in one kernel (DABX_FUSED_FRONT, engine.cpp): the 75 spectra of a frame never travel to HBM
+// (0.92 MB written and read back per frame, 0.94 GB per step of 512 streams).  One block of 768 threads per stream; the 75
+// symbols are taken three at a time: (A) each 256-thread group g mixes and transforms symbol 3 i + g exactly as
+// k_symbols does and leaves the frequency-de-interleaved carriers in ITS FFT exchange buffer; (B) all 768 threads demap
+// the three symbols in order, two carriers per thread from LDS, exactly as k_demap_frame does.  Same operations in the
+// same order as the two-kernel path: identical soft bits, sums and state (tests compare the two paths bit for bit).
+template <int SOFT_TYPE, int WAVES_PER_SIMD>      // 6: two blocks per CU (80 VGPRs, some state spills across the FFT phase); 3: one block, no spills
+__global__ __launch_bounds__(DEMAP_THREADS, WAVES_PER_SIMD) void k_front_fused(EngineDev e, DevTables t)
+{
+  front_prio(e);
+  __shared__ float2 lds[3][FFT_LDS_FLOAT2];
+  __shared__ float red3[3][3][4];
+  __shared__ float red[32];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
+  const int s = blockIdx.x, tid = threadIdx.x, g = tid >> 8, gt = tid & 255;
+  StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  DemapDev &d = e.demap;
+  // ---- demapper state of this thread's two carriers (k_demap_frame)
+  DemapPair cr;
+  v2f rel_f;
+#pragma unroll
+  for (int q = 0; q < DEMAP_Q; q++) {
+    const int k = tid + DEMAP_THREADS * q;
+    const int bin = t.perm_bin[k];
+    rel_f[q] = (float)(K / 2 - t.perm_rel[k]);
+    const float2 pr = d.phase_ref[(size_t)s * TU + bin];
+    cr.prev_re[q] = pr.x; cr.prev_im[q] = pr.y;
+    cr.integ[q] = d.integ[(size_t)s * K + k];
+    cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
+    cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
+    cr.null_power[q] = d.null_power[(size_t)s * TU + bin];
+  }
+  float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
+  const v2f wk = (v2f){mpa_weight(tid), mpa_weight(tid + DEMAP_THREADS)};
+  v2f pacc = (v2f)(0.0f);
+  const float ce = c.clock_err;
+  const long long cif0 = c.cif_no;
+  uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
+  uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
+  int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
+  static_assert(DEMAP_THREADS == 768 && DEMAP_Q == 2, "tile <-> thread mapping below");
+  int tpos[2 * DEMAP_Q];
+#pragma unroll
+  for (int q = 0; q < DEMAP_Q; q++) {
+    const int k = tid + DEMAP_THREADS * q;
+    tpos[2 * q] = (k & 15) * 192 + (k >> 4);
+    tpos[2 * q + 1] = ((K + k) & 15) * 192 + ((K + k) >> 4);
+  }
+  const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
+  // ---- per-frame constants of the transform part (k_symbols)
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned long long sym1_pos = c.sym0_pos + TU;
+  const double2 nco_t = e.nco_tid[(size_t)s * 256 + gt];
+
+  for (int it = 0; it < 25; it++) {
+    // ================= (A) three symbols: NCO mix, cyclic-prefix correlation, FFT, frequency de-interleave (k_symbols)
+    {
+      const int l = 3 * it + g;
+      const unsigned long long base = sym1_pos + (unsigned long long)l * TS;
+      float cre = 0.f, cim = 0.f, asum = 0.f;
+      const RingView rv(ring, e.ring_len, base);
+      for (int i = gt; i < TG; i += 256) {
+        const float2 a = rv.at(TU + i), b = rv.at(i);
+        cre += a.x * b.x + a.y * b.y;
+        cim += a.y * b.x - a.x * b.y;
+        asum += cabsf_level(b);
+      }
+      float2 v[8];
+      Nco nco;
+      nco.init_from(e.nco_sym[(size_t)s * 76 + l], e.nco_sym[(size_t)s * 76 + 75], nco_t);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const float2 x = rv.at(TG + gt + 256 * u);
+        asum += cabsf_level(x);
+        v[u] = nco.mix(x);
+        nco.step();
+      }
+      cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
+      if ((gt & 63) == 0) { red3[g][0][gt >> 6] = cre; red3[g][1][gt >> 6] = cim; red3[g][2][gt >> 6] = asum; }
+      fft2048<false>(v, lds[g], t.twiddle, gt);
+      if (gt == 0) {
+        float r[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { float a = 0.f; for (int w = 0; w < 4; w++) a += red3[g][q][w]; r[q] = a; }
+        e.cp_part[(size_t)s * 75 + l] = make_float2(r[0], r[1]); e.abs_part[(size_t)s * 76 + l] = r[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int kk = t.bin_to_k[gt + 256 * u];
+        if (kk >= 0) lds[g][kk] = v[u];
+      }
+      __syncthreads();
+    }
+    // ================= (B) the three symbols through the demapper, in order (k_demap_frame)
+#pragma unroll 1
+    for (int q3 = 0; q3 < 3; q3++) {
+      const int l = 3 * it + q3;
+      const int m = l - 3, cif = m / 18, blk = m % 18;
+      const float w2 = demap_w2(mean_value, SOFT_TYPE);
+      uint8_t *tl = tile[l & 1];
+      const float2 x0 = lds[q3][tid], x1 = lds[q3][tid + DEMAP_THREADS];
+      int16_t sr[2], si[2];
+      v2f pw;
+      const v2f mag = demap_pair<SOFT_TYPE>(cr, (v2f){x0.x, x1.x}, (v2f){x0.y, x1.y}, rel_f, ce, w2, sr, si, pw);
+      const float part = mag.x + mag.y;
+      pacc = pacc * mpa_decay() + pw;
+#pragma unroll
+      for (int q = 0; q < DEMAP_Q; q++) {
+        tl[tpos[2 * q]] = soft_to_sym_mode(sr[q], e.tie_mode);
+        tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[q], e.tie_mode);
+        if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[q]; cap[(size_t)l * K2 + K + k] = si[q]; }
+      }
+      mean_value = block_sum(part, red, tid) * (1.0f / (float)K);
+      if (l < 3) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int i = 4 * tid + b; v |= (uint32_t)tl[(i & 15) * 192 + (i >> 4)] << (8 * b); }
+        reinterpret_cast<uint32_t *>(fic + l * K2)[tid] = v;
+      } else {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * 192 + 4 * out_dw);
+        *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
+      }
+    }
+    __syncthreads();                      // the exchange buffers are rewritten by the next triple
+  }
+#pragma unroll
+  for (int q = 0; q < DEMAP_Q; q++) {
+    const int k = tid + DEMAP_THREADS * q;
+    d.integ[(size_t)s * K + k] = cr.integ[q];
+    d.mean_power[(size_t)s * K + k] = cr.mean_power[q];
+    d.mean_sigma[(size_t)s * K + k] = cr.mean_sigma_sq[q];
+  }
+  float ns = cr.null_power.x + cr.null_power.y, wsum = wk.x * pacc.x + wk.y * pacc.y;
+  block_sum2w(ns, wsum, red, tid);
+  if (tid == 0) {
     mpa = mpa * mpa_decay_n(75) + wsum;
     d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa; c.snr_db = snr_db_from(mpa, ns);
   }
@@ -387,6 +547,7 @@ struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depun
 // and 3 with symbol 3.
 __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int first, int count)
 {
+  front_prio(e);
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
   __shared__ uint32_t raw[4][32];           // chain-back output, 30 bits per word (26 words + padding)
@@ -449,6 +610,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
 // --------------------------------------------------------------------------------------------- frame tail
 __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
 {
+  front_prio(e);
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red[8];
   __shared__ float s_fbb;
@@ -785,19 +947,55 @@ const char *const kStepKernelNames[10] = {"k_acquire", "k_frame_head", "k_symbol
 
 // Front end of one batch step (everything with frame-to-frame feedback).  mark(i) is called before kernel i
 // and once more after the last one (profiling hook, may be empty).
-int launch_front_step(const EngineDev &e, hipStream_t st, Marker &mk)
+int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
+  hipStream_t st = ss.a;
+  const bool split = e.split_fic && !e.fused_front && ss.c;
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
-  mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
-  mk.begin(3, st);
-  if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-  else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-  else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-  mk.end(3, st);
+  if (e.fused_front) {
+    // symbols + demap in one kernel (timed under "k_demap_frame"; "k_symbols" then has no launches)
+    mk.begin(3, st);
+    if (e.fused_front == 2) {
+      if (e.demap.soft_type == 3) hipLaunchKernelGGL((k_front_fused<3, 3>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+      else if (e.demap.soft_type == 2) hipLaunchKernelGGL((k_front_fused<2, 3>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+      else hipLaunchKernelGGL((k_front_fused<1, 3>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+    } else {
+      if (e.demap.soft_type == 3) hipLaunchKernelGGL((k_front_fused<3, 6>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+      else if (e.demap.soft_type == 2) hipLaunchKernelGGL((k_front_fused<2, 6>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+      else hipLaunchKernelGGL((k_front_fused<1, 6>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+    }
+    mk.end(3, st);
+  } else {
+    mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+    auto demap = [&](int l0, int l1) {
+      if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
+      else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
+      else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
+    };
+    if (split) {
+      // The FIC lives in symbols 1..3: demap those first, start the FIC decoder (four 774-step trellises per stream, a
+      // latency-bound kernel) on its own HIP stream and demap the 72 MSC symbols next to it; the frame tail needs both.
+      mk.begin(3, st);
+      demap(0, 3);
+      DABX_HIP(hipEventRecord(ss.fic_go, st));
+      DABX_HIP(hipStreamWaitEvent(ss.c, ss.fic_go, 0));
+      mk.begin(4, ss.c); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, ss.c, e, *t, 0, 4); mk.end(4, ss.c);
+      DABX_HIP(hipEventRecord(ss.fic_done, ss.c));
+      demap(3, 75);
+      mk.end(3, st);
+      DABX_HIP(hipStreamWaitEvent(st, ss.fic_done, 0));
+      mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
+      DABX_HIP(hipGetLastError());
+      return 0;
+    }
+    mk.begin(3, st);
+    demap(0, 75);
+    mk.end(3, st);
+  }
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
   DABX_HIP(hipGetLastError());
@@ -837,9 +1035,20 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
       }
   }
   if (L.n > 0) {
-    if ((rc = launch_msc_prep(e, cifs, L, ss.a, mk))) return rc;
-    DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
-    DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+    if (e.prep_on_b) {
+      // the time de-interleave of the batch runs on the decoder's stream too: the front end goes straight on to the next
+      // frames.  It reads ring slots the front end only rewrites 20 CIFs (5 frames) later; dabx_process makes the
+      // front-end stream wait for `prep_b_done` before it gets there.
+      DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
+      DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+      if ((rc = launch_msc_prep(e, cifs, L, ss.b, mk))) return rc;
+      DABX_HIP(hipEventRecord(ss.prep_b_done, ss.b));
+      ss.prep_pending = true;
+    } else {
+      if ((rc = launch_msc_prep(e, cifs, L, ss.a, mk))) return rc;
+      DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
+      DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+    }
     if ((rc = launch_msc_vitT(e, cifs, L, ss.b, mk))) return rc;
     if (fast_pairs < fast->slots_active) {
       // the remaining sub-channels: wave per trellis, on the front-end stream (it reads the TDI ring in place)

@@ -38,6 +38,7 @@ __device__ __forceinline__ int msc_class_of_group(const MscLaunch &L, int g)
 
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaunch L)
 {
+  if (e.front_prio) __builtin_amdgcn_s_setprio(3);      // runs on the front-end stream (pipeline.hip, front_prio)
   __shared__ __attribute__((aligned(16))) uint8_t tile[PJB * PJS];
   __shared__ const uint8_t *s_base[PJB];     // per job: stream ring + cu_start*4 (nullptr = invalid job)
   __shared__ long long s_r[PJB];

@@ -1073,3 +1073,39 @@ def test_async_pushes_from_page_locked_buffers_decode_like_synchronous_ones(fmt)
             assert np.array_equal(ref.read_msc(0, j, 16), eng.read_msc(s, j, 16)), (s, j)
     assert a["frames"] >= 17 and a["sf_ok"] > 0
     eng.close(); ref.close()
+
+
+@pytest.mark.parametrize("soft_type", [1, 2, 3])
+def test_fused_symbols_and_demap_kernel_is_bit_identical_to_the_two_kernel_path(monkeypatch, soft_type):
+    """k_front_fused (DABX_FUSED_FRONT=1: FFT + frequency de-interleave + demapper in one kernel, spectra never leave LDS)
+    performs the same operations in the same order as k_symbols + k_demap_frame: soft bits of every symbol, FIBs, MSC
+    bytes, the CFO / clock / SNR scalars and all counters are IDENTICAL, not merely within tolerance."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=91)
+    x = ds.channel(ens.iq, snr_db=9.0, cfo_hz=2210.0, timing_offset=140000, seed=91, n_out=20 * ds.TF)
+    runs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("DABX_FUSED_FRONT", fused)
+        eng = dx.Engine(n_streams=2, ring_frames=21, max_subch=18, out_frames=8, capture_soft=True, soft_bit_type=soft_type)
+        eng.set_subchannels(subch)
+        eng.push_iq(0, x)
+        eng.push_iq(1, x[3000:])
+        soft = []
+        for _ in range(18):
+            eng.process(1)
+            soft.append((eng.read_soft(0).copy(), eng.read_soft(1).copy()))
+        st = [eng.stats(s) for s in range(2)]
+        fibs = [eng.read_fibs(s, 8) for s in range(2)]
+        msc = [[eng.read_msc(s, j, 16) for j in range(18)] for s in range(2)]
+        runs.append((soft, st, fibs, msc, eng.counters()))
+        eng.close()
+    (sa, sta, fa, ma, ca), (sb, stb, fb, mb, cb) = runs
+    assert ca == cb and sta == stb                                   # every counter and scalar (f_bb, clock error, SNR ...) equal
+    assert sta[0]["frames"] >= 15
+    for i in range(18):
+        for s in range(2):
+            assert np.array_equal(sa[i][s], sb[i][s]), (i, s)
+    for s in range(2):
+        assert np.array_equal(fa[s][0], fb[s][0]) and np.array_equal(fa[s][1], fb[s][1])
+        for j in range(18):
+            assert np.array_equal(ma[s][j], mb[s][j]), (s, j)
