@@ -36,6 +36,7 @@ A_KERNEL = {
     "k_frame_head": 2 * 2048 * 8 + 2048 * 8,          # sync window + symbol 0 in, reference spectrum out
     "k_symbols": 75 * 2552 * 8 + 75 * 2048 * 8,       # IQ of symbols 1..75 in, spectra out
     "k_demap_frame": 75 * 2048 * 8 + 75 * 3072 + 86016,   # spectra in, Viterbi symbols out, carry state r+w
+    "k_demap_fic": 3 * 2048 * 8 + 3 * 3072 + 86016,       # the three FIC symbols (own launch since round 2)
     "k_fic_frame": 9216 + 384,
     "k_frame_tail": 2048 * 8 + 2 * 2048 * 4,
     "k_msc_frame": 4 * 55296 + 4 * 3456,              # time-deinterleaver read, packed logical frames out

@@ -56,6 +56,7 @@ struct DemapDev {
   float *mean_power;    // [B][1536] mMeanPowerVector
   float *mean_sigma;    // [B][1536] mMeanSigmaSqVector
   float *null_power;    // [B][2048] mMeanNullPowerWithoutTII
+  float *null_power2;   // [B][2048] second buffer: the engine's frame tail writes the one the demapper of the frame in flight does not read
   float *mean_value;    // [B]       mMeanValue
   float *mean_power_all;// [B]       mMeanPowerOvrAll (display / SNR only, ofdm_decoder.cpp:214)
   int batch;

@@ -13,8 +13,9 @@
 namespace dabx {
 int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk);
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk);
+int launch_dciq(const EngineDev &e, int mode, hipStream_t st);
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
-extern const char *const kStepKernelNames[10];
+extern const char *const kStepKernelNames[11];
 int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st);
 int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st);
 int launch_fic_only(const EngineDev &e, hipStream_t st, int first, int count);
@@ -179,6 +180,7 @@ static int sync_all(dabx_engine *e)
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
   if (e->ss.c) DABX_HIP(hipStreamSynchronize(e->ss.c));
+  if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
   return 0;
 }
 
@@ -204,7 +206,7 @@ void dabx_default_config(dabx_config *c)
 int dabx_create(const dabx_config *cfg, dabx_engine **out)
 {
   if (!cfg || !out || cfg->n_streams <= 0 || cfg->ring_frames < 2 || cfg->max_subch < 0 || cfg->max_subch > MAX_SUBCH ||
-      cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3) {
+      cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3 || cfg->dc_iq_correction < 0 || cfg->dc_iq_correction > 2) {
     set_error("dabx_create: bad configuration");
     return DABX_E_ARG;
   }
@@ -229,6 +231,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   DABX_HIP(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.fic_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  DABX_HIP(hipStreamCreateWithPriority(&e->ss.d, hipStreamNonBlocking, pa));
+  DABX_HIP(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
   DABX_HIP(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
   DABX_HIP(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
   DABX_HIP(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -243,6 +247,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.front_prio = 1;
   d.split_fic = 1;
   d.prep_on_b = 1;
+  d.async_demap = 1;
+  if (const char *ev = getenv("DABX_ASYNC_DEMAP")) d.async_demap = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_PREP_ON_B")) d.prep_on_b = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_SPLIT_FIC")) d.split_fic = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_FRONT_PRIO")) d.front_prio = atoi(ev) != 0;
@@ -253,7 +259,16 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.iq, (size_t)S * d.ring_len, false));
   A(e->alloc(&d.wr, S));
   A(e->alloc(&d.ctl, S));
-  A(e->alloc(&d.spectra, (size_t)S * 75 * K, false));
+  A(e->alloc(&d.spectra, (size_t)2 * S * 75 * K, false));
+  A(e->alloc(&d.fsnap, S));
+  A(e->alloc(&d.dciq_state, (size_t)S * 8));
+  A(e->alloc(&d.dciq_done, S));
+  {
+    std::vector<float> st8((size_t)S * 8, 0.0f);                  // sample_reader.h:102-106: meanII = meanQQ = 1
+    for (int s_ = 0; s_ < S; s_++) { st8[(size_t)s_ * 8 + 2] = 1.0f; st8[(size_t)s_ * 8 + 3] = 1.0f; }
+    DABX_HIP(hipMemcpyAsync(d.dciq_state, st8.data(), sizeof(float) * st8.size(), hipMemcpyHostToDevice, e->stream));
+    DABX_HIP(hipStreamSynchronize(e->stream));
+  }
   A(e->alloc(&d.nco_tid, (size_t)S * 256));
   A(e->alloc(&d.nco_sym, (size_t)S * 76));
   A(e->alloc(&e->snap_buf[0], S));
@@ -306,6 +321,8 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.fic_go) (void)hipEventDestroy(e->ss.fic_go);
   if (e->ss.fic_done) (void)hipEventDestroy(e->ss.fic_done);
   if (e->ss.prep_b_done) (void)hipEventDestroy(e->ss.prep_b_done);
+  if (e->ss.d) { (void)hipStreamSynchronize(e->ss.d); (void)hipStreamDestroy(e->ss.d); }
+  if (e->ss.demap_done) (void)hipEventDestroy(e->ss.demap_done);
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
@@ -422,7 +439,10 @@ int dabx_commit_iq(dabx_engine *e, int stream, size_t n)
   if (int rc = use_device(e)) return rc;
   for (int s = 0; s < e->dev.n_streams; s++)
     if (stream < 0 || s == stream) e->wr_host[s] += n;
-  return launch_commit(e->dev, stream, n, e->stream);
+  if (int rc = launch_commit(e->dev, stream, n, e->stream)) return rc;
+  // SampleReader's DC / IQ correction (off by default): the new samples are corrected in place before anything reads them
+  if (e->cfg.dc_iq_correction) return launch_dciq(e->dev, e->cfg.dc_iq_correction, e->stream);
+  return 0;
 }
 
 // never overwrite samples the receiver has not read yet.  rd only grows, so the value seen at the last look is a safe

@@ -56,6 +56,7 @@ int demap_alloc(DemapDev &d, int batch)
   DABX_HIP(hipMalloc((void **)&d.mean_power, sizeof(float) * K * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.mean_sigma, sizeof(float) * K * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.null_power, sizeof(float) * TU * (size_t)batch));
+  DABX_HIP(hipMalloc((void **)&d.null_power2, sizeof(float) * TU * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.mean_value, sizeof(float) * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.mean_power_all, sizeof(float) * (size_t)batch));
   DABX_HIP(hipMemset(d.phase_ref, 0, sizeof(float2) * TU * (size_t)batch));
@@ -64,7 +65,7 @@ int demap_alloc(DemapDev &d, int batch)
 void demap_free(DemapDev &d)
 {
   (void)hipFree(d.phase_ref); (void)hipFree(d.integ); (void)hipFree(d.mean_power);
-  (void)hipFree(d.mean_sigma); (void)hipFree(d.null_power); (void)hipFree(d.mean_value); (void)hipFree(d.mean_power_all);
+  (void)hipFree(d.mean_sigma); (void)hipFree(d.null_power); (void)hipFree(d.null_power2); (void)hipFree(d.mean_value); (void)hipFree(d.mean_power_all);
   d = DemapDev{};
 }
 
@@ -75,7 +76,7 @@ __global__ void k_demap_reset(DemapDev d, int first)
   for (int i = tid; i < K; i += blockDim.x) {
     d.integ[(size_t)s * K + i] = 0.f; d.mean_power[(size_t)s * K + i] = 0.f; d.mean_sigma[(size_t)s * K + i] = 0.f;
   }
-  for (int i = tid; i < TU; i += blockDim.x) d.null_power[(size_t)s * TU + i] = 0.f;
+  for (int i = tid; i < TU; i += blockDim.x) { d.null_power[(size_t)s * TU + i] = 0.f; d.null_power2[(size_t)s * TU + i] = 0.f; }
   if (first && tid == 0) d.mean_value[s] = 1.0f;
   if (tid == 0) d.mean_power_all[s] = 1.0f;                  // :98
 }

@@ -40,6 +40,7 @@ struct StreamCtl {
   // counters (summed across streams / GPUs by dabx_get_counters)
   long long fib_ok, fib_total, sync_lost;
   float head_abs_a, head_abs_b;   // sum |x| over the T_u correlation window / the start_index samples read after it (level tracker)
+  int32_t np_sel;                 // which noise-power buffer (DemapDev::null_power / null_power2) is current; k_frame_tail flips it
 };
 
 struct SubchDev {
@@ -59,12 +60,16 @@ struct SubchDev {
 // Per-batch snapshot of the CIF counters: the MSC kernels of a batch run on their own HIP stream while the front
 // end already advances cif_no for the next frames.
 struct BatchSnap { long long msc_done, cif_no; };
+// What the demapper of the MSC symbols (second k_demap_frame launch, own HIP stream) needs from StreamCtl: taken by the first
+// launch, because the frame tail and the next frame's head already rewrite those fields while it runs.
+struct FrameSnap { long long cif0; float clock_err; int32_t frame_ok, np_sel, pad_; };
 
 struct EngineDev {
   int32_t n_streams, max_subch, out_frames;
   int32_t ring_len;               // IQ ring capacity per stream in samples
   float threshold;
   int32_t strongest, fic_only, capture_soft;
+  int32_t async_demap;            // 1: MSC symbols demapped on their own HIP stream while the front end goes on to the next frame
   int32_t prep_on_b;              // 1: k_msc_prep on the decoder's HIP stream instead of the front end's
   int32_t split_fic;              // 1: FIC decoder on its own HIP stream next to the demapping of the MSC symbols
   int32_t front_prio;             // 1: front-end kernels raise their wave priority (s_setprio 3) over the batched MSC decoder
@@ -77,7 +82,12 @@ struct EngineDev {
   unsigned long long *wr;         // [S] absolute index one past the last committed sample
   StreamCtl *ctl;                 // [S]
   DemapDev demap;
-  float2 *spectra;                // [S][75][1536]: symbols 1..75 in CARRIER order (frequency de-interleaved by k_symbols)
+  float2 *spectra;                // [2][S][75][1536]: symbols 1..75 in CARRIER order (frequency de-interleaved by k_symbols); two
+                                  // buffers by step parity: k_symbols of step n + 1 runs while step n's MSC symbols are demapped
+  FrameSnap *fsnap;               // [S]
+  float *dciq_state;              // [S][8] meanI, meanQ, meanII, meanQQ, meanIQ of SampleReader's DC / IQ correction (sample_reader.h:102-106)
+  unsigned long long *dciq_done;  // [S] absolute index of the first sample not yet corrected
+  int32_t parity;                 // step parity (host sets it per launch)
   double2 *nco_tid;               // [S][256] e^{-j 2 pi f tid / fs} of the current frame (k_frame_head -> k_symbols)
   double2 *nco_sym;               // [S][76]  NCO phasor of the first FFT sample of symbols 1..75 ([75] = rotation per 256 samples)
   float2 *cp_part;                // [S][75] cyclic-prefix correlation partial sums
@@ -121,15 +131,17 @@ struct MscLaunch { int n, groups; MscLaunchCls c[MSC_MAX_CLASSES]; };
 // HIP streams/events of the engine: front end on `a`; the long lane-per-trellis decode of batch n runs on `b`
 // while `a` already demodulates the frames of batch n+1.
 struct EngineStreams {
-  hipStream_t a = nullptr, b = nullptr, c = nullptr;       // c: the FIC decoder of the frame in flight
-  hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, fic_done = nullptr, prep_b_done = nullptr;
+  hipStream_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;   // c: FIC decoder, d: demapper of the MSC symbols of the frame in flight
+  hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, fic_done = nullptr, prep_b_done = nullptr, demap_done = nullptr;
+  bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
+  unsigned step_count = 0;
   bool prep_pending = false;      // k_msc_prep of the previous batch may still be reading the TDI ring on stream b
   bool msc_in_flight = false;
   int batch_parity = 0;
 };
 
 // ---- profiling hook: HIP events around every kernel launch of a batch step ------------------------------------
-constexpr int N_STEP_KERNELS = 10;
+constexpr int N_STEP_KERNELS = 11;
 struct Marker {
   bool on = false;
   int only = -1;                  // >= 0: instrument just this kernel (2 events per launch instead of 2 per kernel)

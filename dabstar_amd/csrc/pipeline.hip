@@ -39,6 +39,129 @@ struct RingView {
   }
 };
 
+// ------------------------------------------------------------------------------------- DC / IQ correction
+// SampleReader::get_samples, scalar body (sample_reader.cpp:218-243; off by default, configuration.cpp:75-76): every
+// sample read passes five one-pole filters with alpha = 1 / 2 048 000 -- meanI, meanQ; meanII, meanIQ of the DC-free
+// sample; meanQQ of the phase-corrected Q -- and leaves as (x_i, x_q_corr * sqrt(meanII / meanQQ)) or, DC only, as
+// (v_i - meanI, v_q - meanQ).  Here the newly committed samples of a stream are corrected IN PLACE in the IQ ring before
+// any kernel reads them (everything the reference reads goes through get_samples exactly once, in order).  A filter
+// y <- y + alpha (x - y) is the affine map y -> (1 - alpha) y + alpha x: per tile of 4096 samples each thread composes the
+// maps of its 16 consecutive samples, a block scan gives every thread its start state, and the thread then runs the
+// reference's float recurrence over its 16 samples from there -- three dependent levels (means -> second moments -> QQ).
+// Not bit-identical to the 196 608-step serial recurrence (start states differ in the last ulps; each filter forgets rounding
+// noise with its own 1-s time constant), equal within 1e-5 of full scale (tests/test_gpu_engine.py).
+// The maps are kept as y -> y - e y + b with e = 1 - a: a itself (1 - 4.9e-7 per sample) has no exact float, its rounding
+// would change the filter's time constant by up to 6 %; e and b are small numbers and compose exactly enough.
+struct Affine { float a /* e = 1 - slope */, b; };
+__device__ __forceinline__ Affine aff_then(Affine f, Affine g) { return {f.a + g.a - g.a * f.a, f.b - g.a * f.b + g.b}; }   // g after f
+__device__ __forceinline__ float aff_apply(Affine f, float y) { return y + (f.b - f.a * y); }
+__device__ __forceinline__ Affine aff_block_exclusive(Affine v, Affine *sh /* [4] */, int tid, Affine &total)
+{
+  const int lane = tid & 63, w = tid >> 6;
+  Affine inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Affine t = {__shfl_up(inc.a, o), __shfl_up(inc.b, o)};
+    if (lane >= o) inc = aff_then(t, inc);
+  }
+  __syncthreads();
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  Affine pre = {0.0f, 0.0f};
+  for (int q = 0; q < w; q++) pre = aff_then(pre, sh[q]);
+  total = aff_then(aff_then(aff_then(sh[0], sh[1]), sh[2]), sh[3]);
+  Affine ex = {__shfl_up(inc.a, 1), __shfl_up(inc.b, 1)};
+  if (lane == 0) ex = {0.0f, 0.0f};
+  return aff_then(pre, ex);                                  // everything before this thread within the tile
+}
+
+__global__ __launch_bounds__(256) void k_dciq(EngineDev e, int mode /* 1 DC, 2 DC + IQ */)
+{
+  __shared__ Affine sh[4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long from = e.dciq_done[s], to = e.wr[s];
+  if (from >= to) return;
+  float2 *ring = e.iq + (size_t)s * e.ring_len;
+  float *st = e.dciq_state + (size_t)s * 8;
+  float meanI = st[0], meanQ = st[1], meanII = st[2], meanQQ = st[3], meanIQ = st[4];     // tile start states (all threads)
+  constexpr float ALPHA = 1.0f / (float)INPUT_RATE;
+  constexpr int PER = 16, TILE = 256 * PER;
+  for (unsigned long long t0 = from; t0 < to; t0 += TILE) {
+    const unsigned long long mine = t0 + (unsigned long long)tid * PER;
+    const int n = mine >= to ? 0 : (int)(to - mine < PER ? to - mine : PER);
+    float vi[PER], vq[PER];
+    unsigned o = (unsigned)(mine % (unsigned long long)e.ring_len);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      unsigned idx = o + k; if (idx >= (unsigned)e.ring_len) idx -= e.ring_len;
+      const float2 v = k < n ? ring[idx] : make_float2(0.f, 0.f);
+      vi[k] = v.x; vq[k] = v.y;
+    }
+    // ---- level 1: meanI, meanQ
+    Affine fI = {0.f, 0.f}, fQ = {0.f, 0.f}, tot;
+#pragma unroll
+    for (int k = 0; k < PER; k++) if (k < n) { fI = aff_then(fI, {ALPHA, ALPHA * vi[k]}); fQ = aff_then(fQ, {ALPHA, ALPHA * vq[k]}); }
+    Affine exI = aff_block_exclusive(fI, sh, tid, tot);
+    const float mI_end = aff_apply(tot, meanI);
+    float mI = aff_apply(exI, meanI);
+    Affine exQ = aff_block_exclusive(fQ, sh, tid, tot);
+    const float mQ_end = aff_apply(tot, meanQ);
+    float mQ = aff_apply(exQ, meanQ);
+#pragma unroll
+    for (int k = 0; k < PER; k++) if (k < n) {                // mean_filter + subtraction, sample_reader.cpp:222-225,246
+      mI += ALPHA * (vi[k] - mI); mQ += ALPHA * (vq[k] - mQ);
+      vi[k] -= mI; vq[k] -= mQ;
+    }
+    meanI = mI_end; meanQ = mQ_end;
+    if (mode == 2) {
+      // ---- level 2: meanII, meanIQ -> phi -> x_q_corr
+      Affine fII = {0.f, 0.f}, fIQ = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < PER; k++) if (k < n) { fII = aff_then(fII, {ALPHA, ALPHA * (vi[k] * vi[k])}); fIQ = aff_then(fIQ, {ALPHA, ALPHA * (vi[k] * vq[k])}); }
+      Affine ex2 = aff_block_exclusive(fII, sh, tid, tot);
+      const float mII_end = aff_apply(tot, meanII);
+      float mII = aff_apply(ex2, meanII);
+      Affine ex3 = aff_block_exclusive(fIQ, sh, tid, tot);
+      const float mIQ_end = aff_apply(tot, meanIQ);
+      float mIQ = aff_apply(ex3, meanIQ);
+      float mIIk[PER];
+#pragma unroll
+      for (int k = 0; k < PER; k++) if (k < n) {              // :229-233
+        mII += ALPHA * (vi[k] * vi[k] - mII); mIQ += ALPHA * (vi[k] * vq[k] - mIQ);
+        const float phi = mIQ / mII;
+        vq[k] = vq[k] - phi * vi[k];
+        mIIk[k] = mII;
+      }
+      meanII = mII_end; meanIQ = mIQ_end;
+      // ---- level 3: meanQQ -> gainQ
+      Affine fQQ = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < PER; k++) if (k < n) fQQ = aff_then(fQQ, {ALPHA, ALPHA * (vq[k] * vq[k])});
+      Affine ex4 = aff_block_exclusive(fQQ, sh, tid, tot);
+      const float mQQ_end = aff_apply(tot, meanQQ);
+      float mQQ = aff_apply(ex4, meanQQ);
+#pragma unroll
+      for (int k = 0; k < PER; k++) if (k < n) {              // :234-236
+        mQQ += ALPHA * (vq[k] * vq[k] - mQQ);
+        vq[k] *= sqrtf(mIIk[k] / mQQ);
+      }
+      meanQQ = mQQ_end;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) if (k < n) {
+      unsigned idx = o + k; if (idx >= (unsigned)e.ring_len) idx -= e.ring_len;
+      ring[idx] = make_float2(vi[k], vq[k]);
+    }
+  }
+  if (tid == 0) { st[0] = meanI; st[1] = meanQ; st[2] = meanII; st[3] = meanQQ; st[4] = meanIQ; e.dciq_done[s] = to; }
+}
+int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_dciq, dim3(e.n_streams), dim3(256), 0, st, e, mode);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ acquire
 // Sample-serial by nature (IIR level + 50-tap moving sum with data-dependent stop): lane 0 walks the
 // stream while the wave prefetches 256 samples at a time.  Only runs out of lock.
@@ -55,7 +178,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
   for (int i = lane; i < K; i += 64) {
     e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
   }
-  for (int i = lane; i < TU; i += 64) e.demap.null_power[(size_t)s * TU + i] = 0.f;
+  for (int i = lane; i < TU; i += 64) { e.demap.null_power[(size_t)s * TU + i] = 0.f; e.demap.null_power2[(size_t)s * TU + i] = 0.f; }
   if (lane == 0) e.demap.mean_power_all[s] = 1.0f;
   if (e.tii_acc) {                     // mTiiDetector.reset(); mTiiCounter = 0 (dab_processor.cpp:150-152)
     for (int i = lane; i < TU; i += 64) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
@@ -275,7 +398,7 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
     if (kk >= 0) lds[kk] = v[u];
   }
   __syncthreads();
-  float2 *dst = e.spectra + ((size_t)s * 75 + l) * K;
+  float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
 #pragma unroll
   for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
 }
@@ -293,8 +416,17 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
-  if (!c.frame_ok) return;
+  // the first launch of a frame (l0 == 0) reads the stream's scalars and leaves a snapshot; a later launch of the same frame
+  // uses the snapshot only (the frame tail / next head may already have moved the originals on)
+  FrameSnap fs;
+  if (l0 == 0) {
+    fs.cif0 = c.cif_no; fs.clock_err = c.clock_err; fs.frame_ok = c.frame_ok; fs.np_sel = c.np_sel; fs.pad_ = 0;
+    if (tid == 0) e.fsnap[s] = fs;
+  } else fs = e.fsnap[s];
+  if (!fs.frame_ok) return;
   DemapDev &d = e.demap;
+  const float *null_power = fs.np_sel ? d.null_power2 : d.null_power;
+  const float2 *spectra = e.spectra + (size_t)e.parity * e.n_streams * 75 * K;
   DemapPair cr;                                            // the thread's two carriers, component-wise (demap_pair)
   int bin[DEMAP_Q];
   v2f rel_f;
@@ -304,24 +436,24 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     bin[q] = t.perm_bin[k];
     rel_f[q] = (float)(K / 2 - t.perm_rel[k]);
     // X_(l-1): the phase reference (symbol 0, FFT bin order) or the previous symbol's spectrum (carrier order)
-    const float2 pr = l0 == 0 ? d.phase_ref[(size_t)s * TU + bin[q]] : e.spectra[((size_t)s * 75 + (l0 - 1)) * K + k];
+    const float2 pr = l0 == 0 ? d.phase_ref[(size_t)s * TU + bin[q]] : spectra[((size_t)s * 75 + (l0 - 1)) * K + k];
     cr.prev_re[q] = pr.x; cr.prev_im[q] = pr.y;
     cr.integ[q] = d.integ[(size_t)s * K + k];
     cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
     cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
-    cr.null_power[q] = d.null_power[(size_t)s * TU + bin[q]];
+    cr.null_power[q] = null_power[(size_t)s * TU + bin[q]];
   }
   float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
   const v2f wk = (v2f){mpa_weight(tid), mpa_weight(tid + DEMAP_THREADS)};
   v2f pacc = (v2f)(0.0f);
-  const float ce = c.clock_err;                           // mClockErrHz of the previous frame, dab_processor.cpp:342
-  const long long cif0 = c.cif_no;
+  const float ce = fs.clock_err;                          // mClockErrHz of the previous frame, dab_processor.cpp:342
+  const long long cif0 = fs.cif0;
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
   uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
   float2 xn[DEMAP_Q];                                           // spectrum values of the next symbol (gather latency off the chain)
   {
-    const float2 *X0 = e.spectra + ((size_t)s * 75 + l0) * K;
+    const float2 *X0 = spectra + ((size_t)s * 75 + l0) * K;
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[tid + DEMAP_THREADS * q];
   }
@@ -340,7 +472,7 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
   }
   const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
   for (int l = l0; l < l1; l++) {                         // the demapper state advances on all 75 symbols in every mode
-    const float2 *X = e.spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
+    const float2 *X = spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, SOFT_TYPE);
     uint8_t *tl = tile[l & 1];
@@ -419,7 +551,7 @@ __global__ __launch_bounds__(DEMAP_THREADS, WAVES_PER_SIMD) void k_front_fused(E
     cr.integ[q] = d.integ[(size_t)s * K + k];
     cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
     cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
-    cr.null_power[q] = d.null_power[(size_t)s * TU + bin];
+    cr.null_power[q] = (c.np_sel ? d.null_power2 : d.null_power)[(size_t)s * TU + bin];
   }
   float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
   const v2f wk = (v2f){mpa_weight(tid), mpa_weight(tid + DEMAP_THREADS)};
@@ -671,15 +803,23 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     }
     if (tid == 0) e.tii_cnt[2 * s]++;
   }
-  if (!is_tii) {                                           // store_null_symbol_without_tii
+  // store_null_symbol_without_tii (ofdm_decoder.cpp:114-130).  The updated noise power goes into the buffer the demapper of
+  // THIS frame does not read (its MSC symbols may still be in flight on another HIP stream); a TII frame carries the values
+  // over unchanged.  np_sel is flipped below.
+  {
     const float kMinNoisePower = (1.0f / 32767.0f) * (1.0f / 32767.0f);
+    const float *np_cur = c.np_sel ? e.demap.null_power2 : e.demap.null_power;
+    float *np_new = c.np_sel ? e.demap.null_power : e.demap.null_power2;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int bin = tid + 256 * u;
       if ((bin >= 1 && bin <= K / 2) || bin >= TU - K / 2) {
-        float *np = &e.demap.null_power[(size_t)s * TU + bin];
-        const float power = v[u].x * v[u].x + v[u].y * v[u].y + kMinNoisePower;
-        *np += 0.05f * (power - *np);
+        float np = np_cur[(size_t)s * TU + bin];
+        if (!is_tii) {
+          const float power = v[u].x * v[u].x + v[u].y * v[u].y + kMinNoisePower;
+          np += 0.05f * (power - np);
+        }
+        np_new[(size_t)s * TU + bin] = np;
       }
     }
   }
@@ -710,6 +850,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     c.nco_phase = nco_advance(phase_null, f2, TN);
     c.cif_no += 4;
     c.frames += 1;
+    c.np_sel ^= 1;
     c.sync_thr = 2.0f * e.threshold;                       // :178
     c.state = ST_EVAL_SYNC;
   }
@@ -941,17 +1082,20 @@ __global__ void k_msc_done(EngineDev e)
   if (s < e.n_streams) e.ctl[s].msc_done_cif = e.snap[s].cif_no;
 }
 
-extern const char *const kStepKernelNames[10];
-const char *const kStepKernelNames[10] = {"k_acquire", "k_frame_head", "k_symbols", "k_demap_frame", "k_fic_frame",
-                                          "k_frame_tail", "k_msc_prep", "k_msc_vitT", "k_msc_frame", "k_dabplus"};
+extern const char *const kStepKernelNames[11];
+// "k_demap_fic": the first k_demap_frame launch of a frame (symbols 1..3) when the FIC is decoded on its own stream
+const char *const kStepKernelNames[11] = {"k_acquire", "k_frame_head", "k_symbols", "k_demap_frame", "k_fic_frame",
+                                          "k_frame_tail", "k_msc_prep", "k_msc_vitT", "k_msc_frame", "k_dabplus", "k_demap_fic"};
 
 // Front end of one batch step (everything with frame-to-frame feedback).  mark(i) is called before kernel i
 // and once more after the last one (profiling hook, may be empty).
-int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk)
+int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
+  EngineDev e = e_in;
+  e.parity = (int)(ss.step_count++ & 1u);               // spectra buffer of this step
   hipStream_t st = ss.a;
   const bool split = e.split_fic && !e.fused_front && ss.c;
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
@@ -977,16 +1121,29 @@ int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk)
       else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
     };
     if (split) {
-      // The FIC lives in symbols 1..3: demap those first, start the FIC decoder (four 774-step trellises per stream, a
-      // latency-bound kernel) on its own HIP stream and demap the 72 MSC symbols next to it; the frame tail needs both.
-      mk.begin(3, st);
+      // The FIC lives in symbols 1..3: demap those first, then start the FIC decoder (four 774-step trellises per stream, a
+      // latency-bound kernel) on its own HIP stream c and the demapping of the 72 MSC symbols on stream d.  The frame tail
+      // needs the FIC only, so with async_demap the front end goes on to the next frame while stream d is still busy; the
+      // next frame's first demapper launch (and the MSC batch) wait for it.
+      if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
+      mk.begin(10, st);
       demap(0, 3);
+      mk.end(10, st);
       DABX_HIP(hipEventRecord(ss.fic_go, st));
       DABX_HIP(hipStreamWaitEvent(ss.c, ss.fic_go, 0));
       mk.begin(4, ss.c); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, ss.c, e, *t, 0, 4); mk.end(4, ss.c);
       DABX_HIP(hipEventRecord(ss.fic_done, ss.c));
-      demap(3, 75);
-      mk.end(3, st);
+      if (e.async_demap && ss.d) {
+        DABX_HIP(hipStreamWaitEvent(ss.d, ss.fic_go, 0));
+        hipStream_t keep = st;
+        st = ss.d;
+        mk.begin(3, st); demap(3, 75); mk.end(3, st);
+        st = keep;
+        DABX_HIP(hipEventRecord(ss.demap_done, ss.d));
+        ss.demap_in_flight = true;
+      } else {
+        mk.begin(3, st); demap(3, 75); mk.end(3, st);
+      }
       DABX_HIP(hipStreamWaitEvent(st, ss.fic_done, 0));
       mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
       DABX_HIP(hipGetLastError());
@@ -1014,6 +1171,8 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
   if (rc) return rc;
   if (e.fic_only || e.max_subch <= 0 || !e.msc_out) return 0;
   const int jobs = e.n_streams * cifs * e.max_subch;
+  // the MSC symbols of the newest frame may still be on their way into the time-de-interleaver ring (stream d)
+  if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.demap_done, 0)); ss.demap_in_flight = false; }
   // the previous batch (stream b) owns SubchDev / msc_done_cif until it has finished
   if (ss.msc_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0)); ss.msc_in_flight = false; }
   hipLaunchKernelGGL(k_msc_snap, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e, cifs);

@@ -197,7 +197,7 @@ class Demap:
 class Config(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("ring_frames", C.c_int32), ("max_subch", C.c_int32), ("out_frames", C.c_int32),
                 ("sync_threshold", C.c_float), ("sync_strongest", C.c_int32), ("soft_bit_type", C.c_int32),
-                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("viterbi_tie_mode", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("viterbi_tie_mode", C.c_int32), ("dc_iq_correction", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class SubchDesc(C.Structure):
@@ -285,7 +285,7 @@ class Engine:
     """Stream-batched receiver (device-side DabProcessor::run for n_streams ensembles)."""
 
     def __init__(self, n_streams=1, ring_frames=4, max_subch=18, out_frames=4, fic_only=False, capture_soft=False,
-                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False, viterbi_tie_mode=0):
+                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False, viterbi_tie_mode=0, dc_iq_correction=0):
         L = load()
         cfg = Config()
         L.dabx_default_config(C.byref(cfg))
@@ -293,6 +293,7 @@ class Engine:
         cfg.fic_only, cfg.capture_soft, cfg.sync_threshold = int(fic_only), int(capture_soft), sync_threshold
         cfg.soft_bit_type, cfg.sync_strongest = soft_bit_type, int(sync_strongest)
         cfg.viterbi_tie_mode = int(viterbi_tie_mode)
+        cfg.dc_iq_correction = int(dc_iq_correction)
         self.cfg = cfg
         self._h = C.c_void_p()
         check(L.dabx_create(C.byref(cfg), C.byref(self._h)))

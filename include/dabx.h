@@ -188,7 +188,10 @@ typedef struct {
   int32_t capture_soft;     /* 1: keep int16 soft bits of the last frame (debug / parity tests) */
   int32_t viterbi_tie_mode; /* 0: canonical scalar Viterbi (CMake default); 1: arithmetic of the VITERBI_AVX2 / _SSE2 builds, see
                                dabx_viterbi_mode (FIC and MSC then run on the wave-per-trellis kernels) */
-  int32_t reserved[6];
+  int32_t dc_iq_correction; /* SampleReader::set_dc_and_iq_correction (sample_reader.cpp:218-243, 334-346; configuration.cpp:75-76
+                               default off): 0 off, 1 DC removal, 2 DC removal + IQ-imbalance correction, applied to every
+                               committed sample in place in the ring (dabx_read_iq then returns corrected samples) */
+  int32_t reserved[5];
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */

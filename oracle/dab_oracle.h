@@ -202,6 +202,10 @@ void ora_phaseref_set_strongest(ora_phaseref *p, int on);
 typedef struct ora_receiver ora_receiver;
 ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch);
 void ora_rx_destroy(ora_receiver *r);
+void ora_rx_set_dc_iq(ora_receiver *r, int mode);   /* SampleReader::set_dc_and_iq_correction: 0 off, 1 DC, 2 DC + IQ */
+void ora_dciq_sample(ora_cf32 *v, int mode, float *st5);
+void ora_dciq_buffer(ora_cf32 *iq, size_t n, int mode, float *st5);
+void ora_dciq_buffer_f64(ora_cf32 *iq, size_t n, int mode, double *st5);
 void ora_rx_configure(ora_receiver *r, float threshold, int sync_strongest, int soft_bit_type);   /* defaults 3.0, 0, 1 */
 /* Feed a finite cf32 buffer (file-player mode, no pacing); returns #frames processed. */
 int ora_rx_run(ora_receiver *r, const ora_cf32 *iq, size_t n_samples, int max_frames);

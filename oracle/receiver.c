@@ -11,8 +11,10 @@
 struct ora_receiver {
   /* input */
   const ora_cf32 *iq; size_t n_iq, pos; int eof;
-  /* SampleReader state (sample_reader.h:91-101) */
+  /* SampleReader state (sample_reader.h:91-108) */
   int32_t cur_phase; float s_level, peak_level;
+  int dc_iq_mode;                    /* 0 off, 1 mDoDcOrIqCorr, 2 + mDoIqCorr (set_dc_and_iq_correction, sample_reader.cpp:334-346) */
+  float mean_i, mean_q, mean_ii, mean_qq, mean_iq;
   /* DabProcessor state (dab_processor.h:129-138) */
   float phase_offs_cp, freq_offs_sync, freq_offs_bb, clock_err;
   float threshold; int sync_strongest;
@@ -37,14 +39,61 @@ static void build_osc(void)
   }
 }
 
-/* sample_reader.cpp:102-297, scalar branch :212-283 (DC/IQ correction off: configuration.cpp:75-76) */
+/* sample_reader.cpp:218-243: DC removal and IQ-imbalance correction of one sample; st = {meanI, meanQ, meanII, meanQQ, meanIQ} */
+void ora_dciq_sample(ora_cf32 *v, int mode, float *st)
+{
+  const float ALPHA = 1.0f / (float)ORA_INPUT_RATE / 1.00f;
+  const float v_i = v->re, v_q = v->im;
+  st[0] += ALPHA * (v_i - st[0]);
+  st[1] += ALPHA * (v_q - st[1]);
+  if (mode == 2) {
+    const float x_i = v_i - st[0], x_q = v_q - st[1];
+    st[2] += ALPHA * (x_i * x_i - st[2]);
+    st[4] += ALPHA * (x_i * x_q - st[4]);
+    const float phi = st[4] / st[2];
+    const float x_q_corr = x_q - phi * x_i;
+    st[3] += ALPHA * (x_q_corr * x_q_corr - st[3]);
+    const float gain_q = sqrtf(st[2] / st[3]);
+    v->re = x_i; v->im = x_q_corr * gain_q;
+  } else {
+    v->re = v_i - st[0]; v->im = v_q - st[1];
+  }
+}
+/* the same over a buffer (test helper): state in / out as above */
+void ora_dciq_buffer(ora_cf32 *iq, size_t n, int mode, float *st)
+{
+  for (size_t i = 0; i < n; i++) ora_dciq_sample(&iq[i], mode, st);
+}
+
+/* the same filters with double-precision states (test helper: what the recurrence converges to without float rounding
+ * noise -- with ALPHA = 4.9e-7 every float update of a mean near 1 rounds away up to 6 % of its increment) */
+void ora_dciq_buffer_f64(ora_cf32 *iq, size_t n, int mode, double *st)
+{
+  const double ALPHA = (double)(1.0f / (float)ORA_INPUT_RATE);
+  for (size_t i = 0; i < n; i++) {
+    const double v_i = iq[i].re, v_q = iq[i].im;
+    st[0] += ALPHA * (v_i - st[0]);
+    st[1] += ALPHA * (v_q - st[1]);
+    const double x_i = v_i - st[0], x_q = v_q - st[1];
+    if (mode == 2) {
+      st[2] += ALPHA * (x_i * x_i - st[2]);
+      st[4] += ALPHA * (x_i * x_q - st[4]);
+      const double x_q_corr = x_q - st[4] / st[2] * x_i;
+      st[3] += ALPHA * (x_q_corr * x_q_corr - st[3]);
+      iq[i].re = (float)x_i; iq[i].im = (float)(x_q_corr * sqrt(st[2] / st[3]));
+    } else { iq[i].re = (float)x_i; iq[i].im = (float)x_q; }
+  }
+}
+
+/* sample_reader.cpp:102-297, scalar branch :212-283 (DC/IQ correction off by default: configuration.cpp:75-76) */
 static int get_samples(ora_receiver *r, ora_cf32 *dst, int n, float freq_bb)
 {
   if (r->pos + (size_t)n > r->n_iq) { r->eof = 1; return 0; }   /* :108-113 -> throw 20 */
   const int32_t f = (int32_t)roundf(freq_bb);                  /* :211 std::round */
   const ora_cf32 *src = r->iq + r->pos;
   for (int i = 0; i < n; i++) {
-    const ora_cf32 v = src[i];
+    ora_cf32 v = src[i];
+    if (r->dc_iq_mode) ora_dciq_sample(&v, r->dc_iq_mode, &r->mean_i);   /* :218-243 */
     const float a = sqrtf(v.re * v.re + v.im * v.im);          /* :245-248 */
     if (a > r->peak_level) r->peak_level = a;
     r->s_level += 0.00001f * (a - r->s_level);
@@ -95,6 +144,7 @@ ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch)
   if (!g_osc) build_osc();
   ora_receiver *r = (ora_receiver *)calloc(1, sizeof(*r));
   r->s_level = 0.1f; r->peak_level = -1.0e6f;
+  r->mean_ii = 1.0f; r->mean_qq = 1.0f;        /* sample_reader.h:102-106 */
   r->threshold = 3.0f;                         /* main/dabradio.cpp:92 */
   ora_phaseref_init(&r->pr);
   ora_demap_init(&r->dm);
@@ -114,6 +164,8 @@ void ora_rx_configure(ora_receiver *r, float threshold, int sync_strongest, int 
   ora_phaseref_set_strongest(&r->pr, sync_strongest);
   ora_demap_set_type(&r->dm, soft_bit_type);
 }
+
+void ora_rx_set_dc_iq(ora_receiver *r, int mode) { r->dc_iq_mode = mode; }
 
 void ora_rx_destroy(ora_receiver *r)
 {

@@ -80,6 +80,9 @@ def oracle():
     L.ora_rx_configure.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
     L.ora_rx_run.argtypes = [C.c_void_p, _c64p, C.c_size_t, C.c_int]
     L.ora_rx_enable_soft_capture.argtypes = [C.c_void_p, C.c_int]
+    L.ora_rx_set_dc_iq.argtypes = [C.c_void_p, C.c_int]
+    L.ora_dciq_buffer.argtypes = [_c64p, C.c_size_t, C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]
+    L.ora_dciq_buffer_f64.argtypes = [_c64p, C.c_size_t, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
     L.ora_rx_run_spectra.argtypes = [C.c_void_p, _c64p, _c64p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int]
     L.ora_rx_get_capture.restype = C.POINTER(RxCapture)
     L.ora_rx_take_tii.argtypes = [C.c_void_p, _c64p]

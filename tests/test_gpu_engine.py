@@ -1109,3 +1109,65 @@ def test_fused_symbols_and_demap_kernel_is_bit_identical_to_the_two_kernel_path(
         assert np.array_equal(fa[s][0], fb[s][0]) and np.array_equal(fa[s][1], fb[s][1])
         for j in range(18):
             assert np.array_equal(ma[s][j], mb[s][j]), (s, j)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_dc_and_iq_imbalance_correction_follows_the_oracle(mode):
+    """cfg.dc_iq_correction (SampleReader::set_dc_and_iq_correction, sample_reader.cpp:218-243; off by default): a receiver
+    front end with a DC offset and a Q channel that is 6 % too strong and 3 degrees skewed.  The GPU corrects the committed
+    samples in place with a block scan of the five one-pole filters: floating point, so parity is a tolerance -- 4e-6 of full scale
+    against the same filters with exact (double) states, and no further from the oracle's float recurrence than that recurrence's
+    own rounding noise.  The receiver behind it decodes the same FIBs and MSC bytes as the oracle receiver with the correction on."""
+    subch = ds.default_subchannels(6, 64)
+    ens = ds.build_ensemble(10, subch, seed=95)
+    x = ds.channel(ens.iq, snr_db=17.0, cfo_hz=380.0, timing_offset=52000, seed=95, n_out=22 * ds.TF)
+    g, ph = 1.06, np.deg2rad(3.0)
+    y = (x.real + 1j * g * (x.imag * np.cos(ph) + x.real * np.sin(ph)) + (0.03 - 0.02j)).astype(np.complex64)
+    L = ol.oracle()
+    rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    L.ora_rx_set_dc_iq(rx, mode)
+    n = L.ora_rx_run(rx, y, len(y), 10000)
+    cap = L.ora_rx_get_capture(rx).contents
+    o_fibs = np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy()
+    o_crc = np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy()
+    o_start = np.ctypeslib.as_array(cap.start_idx, (n,)).copy()
+    o_msc = [ol.backend_bytes(rx, i, "msc").reshape(-1, 192) for i in range(len(subch))]
+    L.ora_rx_destroy(rx)
+    eng = dx.Engine(n_streams=1, ring_frames=23, max_subch=len(subch), out_frames=4, dc_iq_correction=mode)
+    eng.set_subchannels(subch)
+    pos, fibs, crc, starts = 0, [], [], []
+    rng = np.random.default_rng(3)
+    while pos < len(y):                                      # pushed in uneven pieces: the filters carry their state across calls
+        m = int(min(len(y) - pos, rng.choice([4096, 100000, 3 * ds.TF + 17])))
+        eng.push_iq(0, y[pos:pos + m])
+        pos += m
+        while True:
+            before = eng.stats(0)["frames"]
+            eng.process(1)
+            st = eng.stats(0)
+            if st["frames"] == before:
+                break
+            f, c = eng.read_fibs(0, 1)
+            fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"])
+    # corrected samples in the ring: against the filters run with double-precision states (what the block scan computes up to
+    # float rounding of its outputs), and against the oracle's float recurrence, whose own rounding noise is the larger part:
+    # with ALPHA = 4.9e-7 a float update of a mean near 1 loses up to 6 % of its increment (measured here, not assumed)
+    want32, want64 = y.copy(), y.copy()
+    st5, st5d = np.array([0, 0, 1, 1, 0], np.float32), np.array([0, 0, 1, 1, 0], np.float64)
+    L.ora_dciq_buffer(want32, len(y), mode, st5)
+    L.ora_dciq_buffer_f64(want64, len(y), mode, st5d)
+    got = eng.read_iq(0, 0, len(y))
+    ref_noise = np.abs(want32 - want64).max()
+    assert np.abs(got - want64).max() <= 4e-6                               # full scale 1, signal rms 0.26
+    assert np.abs(got - want32).max() <= ref_noise + 4e-6
+    assert ref_noise < (5e-6 if mode == 1 else 1e-3)
+    assert abs(st5[0] - 0.03) < 0.01 and abs(st5[1] + 0.02) < 0.01        # the DC estimate has settled on the offset (1-s time constant, 2.1 s of signal)
+    k = min(len(fibs), n)
+    assert k >= n - 1 and k >= 18
+    assert np.array_equal(np.array(starts)[:k], o_start[:k])
+    assert np.array_equal(np.array(crc)[:k], o_crc[:k]) and np.array_equal(np.array(fibs)[:k], o_fibs[:k])
+    assert np.array(crc)[8:k].all()
+    kk = eng.stats(0)["frames"] * 4 - 16
+    for j in range(len(subch)):
+        assert np.array_equal(eng.read_msc(0, j, 16), o_msc[j][kk - 16:kk]), j
+    eng.close()
