@@ -249,6 +249,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.prep_on_b = 1;
   d.async_demap = 1;
   if (const char *ev = getenv("DABX_ASYNC_DEMAP")) d.async_demap = atoi(ev) != 0;
+  d.demap_occ6 = 1; d.vit_prio = 0;
+  if (const char *ev = getenv("DABX_DEMAP_OCC6")) d.demap_occ6 = atoi(ev) != 0;
+  if (const char *ev = getenv("DABX_VIT_PRIO")) d.vit_prio = atoi(ev);
   if (const char *ev = getenv("DABX_PREP_ON_B")) d.prep_on_b = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_SPLIT_FIC")) d.split_fic = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_FRONT_PRIO")) d.front_prio = atoi(ev) != 0;
@@ -271,6 +274,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   }
   A(e->alloc(&d.nco_tid, (size_t)S * 256));
   A(e->alloc(&d.nco_sym, (size_t)S * 76));
+  A(e->alloc(&d.sym_off, (size_t)S * 76));
   A(e->alloc(&e->snap_buf[0], S));
   A(e->alloc(&e->snap_buf[1], S));
   d.snap = e->snap_buf[0];
@@ -847,6 +851,7 @@ int dabx_set_profiling(dabx_engine *e, int on)
   if (!e) return DABX_E_ARG;
   if (int rc = sync_all(e)) return rc;
   e->mk.on = on != 0;
+  e->mk.serial = on < 0;
   e->mk.only = on >= 2 ? on - 2 : -1;
   e->mk.used = 0;
   e->mk.recs.clear();

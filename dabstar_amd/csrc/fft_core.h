@@ -73,43 +73,68 @@ template <bool INV> __device__ __forceinline__ void dft8(float2 v[8])
 
 __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 4); }
 
-// One radix-8 Stockham pass: v[t] = x[j + 256 t] in; results are scattered to LDS.
-template <bool INV, int NS> __device__ __forceinline__ void fft_pass8(float2 v[8], int j, float2 *lds, const float2 *tw)
+// One radix-8 Stockham pass: v[t] = x[j + 256 t] in; results are scattered to LDS.  w = the pass's seven twiddles
+// (tw[section + (t - 1) * NS + (j & (NS - 1))], fft_twiddles8), fetched by the caller one pass AHEAD.
+template <bool INV, int NS> __device__ __forceinline__ void fft_pass8(float2 v[8], int j, float2 *lds, const float2 (&w)[7])
 {
   const int k = j & (NS - 1);
   if (NS > 1) {
 #pragma unroll
-    for (int t = 1; t < 8; t++) v[t] = cmul(v[t], tw_dir<INV>(tw[(NS == 8 ? FFT_TW_P2 : FFT_TW_P3) + (t - 1) * NS + k]));
+    for (int t = 1; t < 8; t++) v[t] = cmul(v[t], tw_dir<INV>(w[t - 1]));
   }
   dft8<INV>(v);
   const int base = (j - k) * 8 + k;
 #pragma unroll
   for (int t = 0; t < 8; t++) lds[fft_pad(base + t * NS)] = v[t];
 }
+template <int NS> __device__ __forceinline__ void fft_twiddles8(float2 (&w)[7], int j, const float2 *tw)
+{
+#pragma unroll
+  for (int t = 1; t < 8; t++) w[t - 1] = tw[(NS == 8 ? FFT_TW_P2 : FFT_TW_P3) + (t - 1) * NS + (j & (NS - 1))];
+}
+
+struct FftNoHook { __device__ void operator()() const {} };
 
 // Whole transform.  All 256 threads of the block must call it; `lds` holds FFT_LDS_FLOAT2 float2.
-template <bool INV> __device__ __forceinline__ void fft2048(float2 v[8], float2 *lds, const float2 *tw, int tid)
+// The twiddles of a pass are requested before the PREVIOUS pass computes -- their addresses depend on the thread index only --
+// so the table look-ups (L1 / L2 hits, but a full memory round trip each) no longer sit between a barrier and the pass's
+// first multiply.  before_last() runs where the last pass's twiddles are requested: callers put loads there whose results
+// they need right after the transform.
+template <bool INV, class Hook = FftNoHook>
+__device__ __forceinline__ void fft2048(float2 v[8], float2 *lds, const float2 *tw, int tid, Hook before_last = Hook())
 {
-  fft_pass8<INV, 1>(v, tid, lds, tw);
+  float2 w2[7], w3[7], none[7] = {};
+  fft_twiddles8<8>(w2, tid, tw);
+  asm volatile("" ::: "memory");
+  fft_pass8<INV, 1>(v, tid, lds, none);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < 8; t++) v[t] = lds[fft_pad(tid + 256 * t)];
   __syncthreads();
-  fft_pass8<INV, 8>(v, tid, lds, tw);
+  fft_twiddles8<64>(w3, tid, tw);
+  asm volatile("" ::: "memory");
+  fft_pass8<INV, 8>(v, tid, lds, w2);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < 8; t++) v[t] = lds[fft_pad(tid + 256 * t)];
   __syncthreads();
-  fft_pass8<INV, 64>(v, tid, lds, tw);
+  float2 w4[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) w4[h][q] = tw[FFT_TW_P4 + 512 * q + tid + 256 * h];
+  before_last();
+  asm volatile("" ::: "memory");
+  fft_pass8<INV, 64>(v, tid, lds, w3);
   __syncthreads();
   // last pass: radix 4, NS = 512, two butterflies per thread (j = tid and tid + 256); output index j + 512 t
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int j = tid + 256 * h;
     float2 a = lds[fft_pad(j)], b = lds[fft_pad(j + 512)], c = lds[fft_pad(j + 1024)], d = lds[fft_pad(j + 1536)];
-    b = cmul(b, tw_dir<INV>(tw[FFT_TW_P4 + j]));
-    c = cmul(c, tw_dir<INV>(tw[FFT_TW_P4 + 512 + j]));
-    d = cmul(d, tw_dir<INV>(tw[FFT_TW_P4 + 1024 + j]));
+    b = cmul(b, tw_dir<INV>(w4[h][0]));
+    c = cmul(c, tw_dir<INV>(w4[h][1]));
+    d = cmul(d, tw_dir<INV>(w4[h][2]));
     dft4<INV>(a, b, c, d);
     v[h] = a; v[h + 2] = b; v[h + 4] = c; v[h + 6] = d;     // X[j + 512 t] -> register u = 2 t + h
   }

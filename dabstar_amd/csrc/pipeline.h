@@ -70,6 +70,8 @@ struct EngineDev {
   float threshold;
   int32_t strongest, fic_only, capture_soft;
   int32_t async_demap;            // 1: MSC symbols demapped on their own HIP stream while the front end goes on to the next frame
+  int32_t demap_occ6;             // 1 (default): the demapper build for six waves per SIMD -- two 12-wave blocks share a CU (DABX_DEMAP_OCC6)
+  int32_t vit_prio;               // 1: lane-per-trellis decoder waves lower their priority as they progress (measured: kernel -6 %, chain -2 %; off)
   int32_t prep_on_b;              // 1: k_msc_prep on the decoder's HIP stream instead of the front end's
   int32_t split_fic;              // 1: FIC decoder on its own HIP stream next to the demapping of the MSC symbols
   int32_t front_prio;             // 1: front-end kernels raise their wave priority (s_setprio 3) over the batched MSC decoder
@@ -90,6 +92,8 @@ struct EngineDev {
   int32_t parity;                 // step parity (host sets it per launch)
   double2 *nco_tid;               // [S][256] e^{-j 2 pi f tid / fs} of the current frame (k_frame_head -> k_symbols)
   double2 *nco_sym;               // [S][76]  NCO phasor of the first FFT sample of symbols 1..75 ([75] = rotation per 256 samples)
+  int32_t *sym_off;               // [S][76]  ring offset of the first (cyclic-prefix) sample of symbols 1..75 of this step's frame,
+                                  //          -1 = the stream has no frame in this step (k_acquire / k_frame_head -> k_symbols)
   float2 *cp_part;                // [S][75] cyclic-prefix correlation partial sums
   float *abs_part;                // [S][76] sum |x| of the samples read per symbol (level tracking)
   uint8_t *fic_sym;               // [S][9216] Viterbi symbols of OFDM symbols 1..3
@@ -144,6 +148,7 @@ struct EngineStreams {
 constexpr int N_STEP_KERNELS = 11;
 struct Marker {
   bool on = false;
+  bool serial = false;            // the host waits for every instrumented kernel: one kernel on the chip at a time = stand-alone durations
   int only = -1;                  // >= 0: instrument just this kernel (2 events per launch instead of 2 per kernel)
   std::vector<hipEvent_t> pool;
   size_t used = 0;
@@ -158,7 +163,13 @@ struct Marker {
     return used++;
   }
   void begin(int k, hipStream_t st) { if (on && (only < 0 || only == k)) open_ev[k] = take(st); }
-  void end(int k, hipStream_t st) { if (on && (only < 0 || only == k)) recs.push_back(Rec{k, open_ev[k], take(st)}); }
+  void end(int k, hipStream_t st)
+  {
+    if (!on || !(only < 0 || only == k)) return;
+    const size_t b = take(st);
+    recs.push_back(Rec{k, open_ev[k], b});
+    if (serial) (void)hipEventSynchronize(pool[b]);
+  }
 };
 
 // ---- MSC job decoding shared by the decoder kernels: job J = (stream, pending CIF k, sub-channel j) -------------

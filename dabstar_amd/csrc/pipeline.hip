@@ -26,6 +26,15 @@ __device__ __forceinline__ void front_prio(const EngineDev &e) { if (e.front_pri
 
 // IQ ring addressing: one 64-bit modulo per thread and kernel (for the window base), then 32-bit
 // add + conditional subtract per sample.
+// Block-uniform word that no thread of the running kernel writes: read through the CONSTANT address space, i.e. one
+// s_load over the scalar cache instead of a vector load of the same address in every lane.
+template <class T> __device__ __forceinline__ T uniform_load(const T *p)
+{
+  typedef unsigned Raw __attribute__((ext_vector_type(sizeof(T) / 4)));
+  const Raw raw = *(const __attribute__((address_space(4))) Raw *)(const void *)p;
+  return __builtin_bit_cast(T, raw);
+}
+
 struct RingView {
   const float2 *p;
   unsigned len, base;
@@ -171,6 +180,8 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
   StreamCtl &c = e.ctl[s];
   const int st = c.state;
   if (lane == 0) c.frame_ok = 0;
+  e.sym_off[(size_t)s * 76 + lane] = -1;
+  if (lane < 12) e.sym_off[(size_t)s * 76 + 64 + lane] = -1;
   if (st == ST_EVAL_SYNC) return;
   const unsigned long long avail = e.wr[s] - c.rd;
   if (avail < (unsigned long long)ACQ_NEED) return;
@@ -330,6 +341,8 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
     Nco::block_consts(nco_advance(phase0, f, (long long)start + TU), (int)roundf(f_bb), (long long)tid * TS + TG, b, st);
     e.nco_sym[(size_t)s * 76 + tid] = b;
     if (tid == 0) e.nco_sym[(size_t)s * 76 + 75] = st;
+    // where the symbol starts in the IQ ring (the 64-bit modulo once per symbol here, not once per k_symbols block)
+    e.sym_off[(size_t)s * 76 + tid] = (int32_t)((rd + (unsigned long long)start + TU + (unsigned long long)tid * TS) % (unsigned long long)e.ring_len);
   }
   if (tid == 0) {
     c.start_index = start;
@@ -353,27 +366,40 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red3[3][4];
   const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;   // l = symbol index - 1
-  const StreamCtl &c = e.ctl[s];
-  if (!c.frame_ok) return;
+  // Everything this block needs from memory is requested up front, in one go: the block-uniform words over the scalar cache
+  // (the kernel does not write them), then the 12 samples of this thread and its NCO factor.  (As first written the block
+  // made five dependent round trips before its first butterfly -- frame_ok, sym0_pos, two cyclic-prefix iterations, the
+  // FFT samples -- and spent 70 % of its wave cycles waiting.)
+  const int off = uniform_load(e.sym_off + (size_t)s * 76 + l);
+  const double2 nco_base = uniform_load(e.nco_sym + (size_t)s * 76 + l), nco_step = uniform_load(e.nco_sym + (size_t)s * 76 + 75);
+  if (off < 0) return;                                           // no frame for this stream in this step
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  const unsigned long long base = c.sym0_pos + TU + (unsigned long long)l * TS;   // first sample (CP) of this symbol
-
+  const unsigned len = (unsigned)e.ring_len;
+  auto at = [&](unsigned i) { unsigned o = (unsigned)off + i; if (o >= len) o -= len; return ring[o]; };
   // cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504 (dab_processor.cpp:330-333) on the RAW samples;
   // the NCO contributes the constant factor e^{-j 2 pi f Tu / fs} which k_frame_tail applies once.
-  float cre = 0.f, cim = 0.f, asum = 0.f;
-  const RingView rv(ring, e.ring_len, base);
-  for (int i = tid; i < TG; i += 256) {
-    const float2 a = rv.at(TU + i), b = rv.at(i);
-    cre += a.x * b.x + a.y * b.y;
-    cim += a.y * b.x - a.x * b.y;
-    asum += cabsf_level(b);
-  }
+  const bool two = tid + 256 < TG;                               // i = tid and, for tid < 248, i = tid + 256
+  const float2 cb0 = at(tid), ca0 = at(TU + tid);
+  const float2 cb1 = at(two ? tid + 256 : tid), ca1 = at(two ? TU + tid + 256 : TU + tid);
   float2 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) v[u] = at(TG + tid + 256 * u);
+  const double2 nco_t = e.nco_tid[(size_t)s * 256 + tid];
+  asm volatile("" ::: "memory");                                  // the loads stay above this line
+  float cre = 0.f, cim = 0.f, asum = 0.f;
+  cre += ca0.x * cb0.x + ca0.y * cb0.y;
+  cim += ca0.y * cb0.x - ca0.x * cb0.y;
+  asum += cabsf_level(cb0);
+  if (two) {
+    cre += ca1.x * cb1.x + ca1.y * cb1.y;
+    cim += ca1.y * cb1.x - ca1.x * cb1.y;
+    asum += cabsf_level(cb1);
+  }
   Nco nco;
-  nco.init_from(e.nco_sym[(size_t)s * 76 + l], e.nco_sym[(size_t)s * 76 + 75], e.nco_tid[(size_t)s * 256 + tid]);
+  nco.init_from(nco_base, nco_step, nco_t);
 #pragma unroll
   for (int u = 0; u < 8; u++) {
-    const float2 x = rv.at(TG + tid + 256 * u);
+    const float2 x = v[u];
     asum += cabsf_level(x);
     v[u] = nco.mix(x);
     nco.step();
@@ -382,7 +408,11 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   // as block_sum does) once the transform has synchronised the block
   cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
   if ((tid & 63) == 0) { red3[0][tid >> 6] = cre; red3[1][tid >> 6] = cim; red3[2][tid >> 6] = asum; }
-  fft2048<false>(v, lds, t.twiddle, tid);                 // :337-338
+  int kk[8];
+  fft2048<false>(v, lds, t.twiddle, tid, [&]() {          // :337-338; the hook runs before the last pass: de-interleaver indices on their way
+#pragma unroll
+    for (int u = 0; u < 8; u++) kk[u] = t.bin_to_k[tid + 256 * u];
+  });
   if (tid == 0) {
     float r[3];
 #pragma unroll
@@ -393,10 +423,8 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   // (the transform's exchange buffer is free again), the 1536 used carriers are then stored contiguously.  The demapper
   // reads carrier k of every symbol with coalesced loads; the 512 unused bins are never written.
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const int kk = t.bin_to_k[tid + 256 * u];
-    if (kk >= 0) lds[kk] = v[u];
-  }
+  for (int u = 0; u < 8; u++)
+    if (kk[u] >= 0) lds[kk[u]] = v[u];
   __syncthreads();
   float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
 #pragma unroll
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
 // -------------------------------------------------------------------------------------------------- demap
 constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
 template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
-__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t, int l0, int l1)
+__device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &t, const int l0, const int l1)
 {
   // symbols [l0, l1) of the frame (0-based: l = symbol index - 1).  The engine runs [0, 3) -- the FIC symbols -- first so
   // that k_fic_frame can start on its own HIP stream while [3, 75) is demapped; the per-carrier state passes through
@@ -518,6 +546,16 @@ __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevT
     if (l1 == 75) c.snr_db = snr_db_from(mpa, ns);
   }
 }
+
+template <int SOFT_TYPE>
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
+// the same, compiled for six waves per SIMD (<= 80 VGPRs): two 12-wave blocks share a CU instead of taking turns
+template <int SOFT_TYPE>
+__global__ __launch_bounds__(DEMAP_THREADS, 6) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
+// the FIC symbols alone (first launch of a frame when the FIC decoder has its own stream): its own kernel symbol so that
+// rocprofv3's per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
+template <int SOFT_TYPE>
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE>(e, t, 0, 3); }
 
 // ------------------------------------------------------------------------------------------- symbols + demap, fused
 // k_symbols and k_demap_frame in one kernel (DABX_FUSED_FRONT, engine.cpp): the 75 spectra of a frame never travel to HBM
@@ -1116,6 +1154,12 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
   } else {
     mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
     auto demap = [&](int l0, int l1) {
+      if (e.demap_occ6) {
+        if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame6<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
+        else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame6<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
+        else hipLaunchKernelGGL(k_demap_frame6<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
+        return;
+      }
       if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
       else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
       else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
@@ -1127,7 +1171,9 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
       // next frame's first demapper launch (and the MSC batch) wait for it.
       if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
       mk.begin(10, st);
-      demap(0, 3);
+      if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_fic<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+      else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_fic<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+      else hipLaunchKernelGGL(k_demap_fic<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
       mk.end(10, st);
       DABX_HIP(hipEventRecord(ss.fic_go, st));
       DABX_HIP(hipStreamWaitEvent(ss.c, ss.fic_go, 0));

@@ -244,7 +244,13 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
     for (int r = 0; r < 32; r++) R[r] = R[r] - ref;
   };
   int t = 0;
+  // vit_prio: the SIMD's arbiter favours its oldest wave, so the four waves of a SIMD drift apart (one runs ahead at the
+  // single-wave rate, the last one finishes alone).  Lowering a wave's priority as it progresses lets the others catch up.
+  const int q1 = e.vit_prio ? nsteps / 3 : 0x7fffffff, q2 = e.vit_prio ? 2 * nsteps / 3 : 0x7fffffff;
+  if (e.vit_prio) __builtin_amdgcn_s_setprio(2);
   for (; t + 12 <= nsteps; t += 12) {
+    if (t >= q1 && t < q1 + 12) __builtin_amdgcn_s_setprio(1);
+    if (t >= q2 && t < q2 + 12) __builtin_amdgcn_s_setprio(0);
     recentre();
     vt_cycle(R, ca, t, dec_lane);
     vt_fetch(ca, in_grp, lane, cmap, t + 12 < last ? t + 12 : last);

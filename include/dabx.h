@@ -270,8 +270,10 @@ int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
 /* Per-kernel timing with HIP events recorded on the engine's stream around every launch of a batch step
  * (bench.py's roofline leg).  dabx_get_profile drains the events recorded since the last call: for each of
  * the n kernels of a step it returns the accumulated milliseconds and the number of launches; names[i]
- * points to a static string.  Returns n.  dabx_set_profiling: 0 = off, 1 = every kernel, 2 + i = only kernel i (the
- * event pairs of mode 1 serialise neighbouring kernels a little: ~4 % on the 512-stream bench). */
+ * points to a static string.  Returns n.  dabx_set_profiling: 0 = off, 1 = every kernel as scheduled (kernels of the engine's
+ * HIP streams overlap, so a duration includes what the kernel waited for the chip's other tenants; the event pairs
+ * serialise neighbouring kernels a little: ~4 % on the 512-stream bench), -1 = every kernel with the host waiting for each
+ * one (one kernel on the chip at a time: stand-alone durations; slow), 2 + i = only kernel i, as scheduled. */
 #define DABX_MAX_KERNELS 16
 int  dabx_set_profiling(dabx_engine *e, int on);
 int  dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t launches[DABX_MAX_KERNELS],

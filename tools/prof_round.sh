@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/stats_bench.log 2>&1
-FILT="k_msc_vitT|k_msc_prep|k_demap_frame|k_symbols|k_dabplus|k_fic_frame|k_frame_head|k_frame_tail"
+FILT="k_msc_vitT|k_msc_prep|k_demap_frame|k_demap_fic|k_symbols|k_dabplus|k_fic_frame|k_frame_head|k_frame_tail"
 ARGS="--steps 14 --warmup 7 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
   --kernel-include-regex "$FILT" -d $OUT/p1 --output-format csv -- python3 bench.py $ARGS > $OUT/p1.log 2>&1
