@@ -408,11 +408,11 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   // as block_sum does) once the transform has synchronised the block
   cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
   if ((tid & 63) == 0) { red3[0][tid >> 6] = cre; red3[1][tid >> 6] = cim; red3[2][tid >> 6] = asum; }
-  int kk[8];
+  uint4 kk4;                                               // eight int16 carrier indices
   fft2048<false>(v, lds, t.twiddle, tid, [&]() {          // :337-338; the hook runs before the last pass: de-interleaver indices on their way
-#pragma unroll
-    for (int u = 0; u < 8; u++) kk[u] = t.bin_to_k[tid + 256 * u];
+    kk4 = reinterpret_cast<const uint4 *>(t.bin_to_k8)[tid];
   });
+  const unsigned kkw[4] = {kk4.x, kk4.y, kk4.z, kk4.w};
   if (tid == 0) {
     float r[3];
 #pragma unroll
@@ -423,8 +423,10 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   // (the transform's exchange buffer is free again), the 1536 used carriers are then stored contiguously.  The demapper
   // reads carrier k of every symbol with coalesced loads; the 512 unused bins are never written.
 #pragma unroll
-  for (int u = 0; u < 8; u++)
-    if (kk[u] >= 0) lds[kk[u]] = v[u];
+  for (int u = 0; u < 8; u++) {
+    const int kk = (int)(int16_t)(kkw[u >> 1] >> (16 * (u & 1)));
+    if (kk >= 0) lds[kk] = v[u];
+  }
   __syncthreads();
   float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
 #pragma unroll

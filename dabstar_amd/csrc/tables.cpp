@@ -302,6 +302,10 @@ static int build_tables(DevTables &t)
     std::vector<int16_t> inv(TU, (int16_t)-1);
     for (int k = 0; k < K; k++) inv[bin[k]] = (int16_t)k;
     if ((rc = upload(&t.bin_to_k, inv))) return rc;
+    std::vector<int16_t> inv8((size_t)TU);                       // [256][8]: thread tid of a 256-thread transform holds bins tid + 256 u
+    for (int tid = 0; tid < 256; tid++)
+      for (int u = 0; u < 8; u++) inv8[(size_t)tid * 8 + u] = inv[tid + 256 * u];
+    if ((rc = upload(&t.bin_to_k8, inv8))) return rc;
   }
   if ((rc = upload(&t.perm_rel, rel))) return rc;
   if ((rc = upload(&t.prs_ref, prs))) return rc;

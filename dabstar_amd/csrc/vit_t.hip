@@ -129,36 +129,35 @@ __device__ __forceinline__ void vt_fetch(VtCycle &c, vt_rsrc in_grp, int lane, v
 }
 
 template <int C>
-__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, uint2 *dec_lane)
+__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, uint2 *dec_lane, vt::s2 v2n)
 {
-  int x[4];
+  // the step's four symbols: dword + byte lane each (the lanes are wave-uniform and end up in SGPR selectors); the packed
+  // branch metrics come straight from those (vit_t_gen.h, bm<C>): no scalar extraction, no 32-bit sums
+  unsigned w[4], b[4];
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    const unsigned sh = (unsigned)((cy.sh >> (2 * (4 * C + p))) & 3) * 8;
-    x[p] = 2 * (int)((cy.w[4 * C + p] >> sh) & 0xFFu) - 255;
+    w[p] = cy.w[4 * C + p];
+    b[p] = (unsigned)((cy.sh >> (2 * (4 * C + p))) & 3);
   }
-  const int y0 = x[0] + x[3], a1 = y0 + x[1], a2 = y0 - x[1];
-  int W[8];
-  W[0] = a1 + x[2]; W[1] = a1 - x[2]; W[2] = a2 + x[2]; W[3] = a2 - x[2];
-  W[4] = -W[3]; W[5] = -W[2]; W[6] = -W[1]; W[7] = -W[0];
+  vt::s2 M[4];
   unsigned acc0, acc1;
-  if constexpr (C == 0) vt::step0(R, W, acc0, acc1);
-  else if constexpr (C == 1) vt::step1(R, W, acc0, acc1);
-  else if constexpr (C == 2) vt::step2(R, W, acc0, acc1);
-  else if constexpr (C == 3) vt::step3(R, W, acc0, acc1);
-  else if constexpr (C == 4) vt::step4(R, W, acc0, acc1);
-  else vt::step5(R, W, acc0, acc1);
+  if constexpr (C == 0) { vt::bm0(w, b, v2n, M); vt::step0(R, M, acc0, acc1); }
+  else if constexpr (C == 1) { vt::bm1(w, b, v2n, M); vt::step1(R, M, acc0, acc1); }
+  else if constexpr (C == 2) { vt::bm2(w, b, v2n, M); vt::step2(R, M, acc0, acc1); }
+  else if constexpr (C == 3) { vt::bm3(w, b, v2n, M); vt::step3(R, M, acc0, acc1); }
+  else if constexpr (C == 4) { vt::bm4(w, b, v2n, M); vt::step4(R, M, acc0, acc1); }
+  else { vt::bm5(w, b, v2n, M); vt::step5(R, M, acc0, acc1); }
   dec_lane[(size_t)t * 64] = make_uint2(acc0, acc1);
 }
 
-__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane)
+__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane, vt::s2 v2n)
 {
-  vt_one<0>(R, cy, t0 + 0, dec_lane);
-  vt_one<1>(R, cy, t0 + 1, dec_lane);
-  vt_one<2>(R, cy, t0 + 2, dec_lane);
-  vt_one<3>(R, cy, t0 + 3, dec_lane);
-  vt_one<4>(R, cy, t0 + 4, dec_lane);
-  vt_one<5>(R, cy, t0 + 5, dec_lane);
+  vt_one<0>(R, cy, t0 + 0, dec_lane, v2n);
+  vt_one<1>(R, cy, t0 + 1, dec_lane, v2n);
+  vt_one<2>(R, cy, t0 + 2, dec_lane, v2n);
+  vt_one<3>(R, cy, t0 + 3, dec_lane, v2n);
+  vt_one<4>(R, cy, t0 + 4, dec_lane, v2n);
+  vt_one<5>(R, cy, t0 + 5, dec_lane, v2n);
 }
 
 // ---- chain-back helpers: one 6-step cycle of decision words in named registers
@@ -243,6 +242,8 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
 #pragma unroll
     for (int r = 0; r < 32; r++) R[r] = R[r] - ref;
   };
+  vt::s2 v2n;                                                      // (2, -2), pinned in a VGPR (VOP3P takes no literal on gfx9)
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v2n) : "s"(0xFFFE0002u));
   int t = 0;
   // vit_prio: the SIMD's arbiter favours its oldest wave, so the four waves of a SIMD drift apart (one runs ahead at the
   // single-wave rate, the last one finishes alone).  Lowering a wave's priority as it progresses lets the others catch up.
@@ -252,14 +253,14 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
     if (t >= q1 && t < q1 + 12) __builtin_amdgcn_s_setprio(1);
     if (t >= q2 && t < q2 + 12) __builtin_amdgcn_s_setprio(0);
     recentre();
-    vt_cycle(R, ca, t, dec_lane);
+    vt_cycle(R, ca, t, dec_lane, v2n);
     vt_fetch(ca, in_grp, lane, cmap, t + 12 < last ? t + 12 : last);
-    vt_cycle(R, cb, t + 6, dec_lane);
+    vt_cycle(R, cb, t + 6, dec_lane, v2n);
     vt_fetch(cb, in_grp, lane, cmap, t + 18 < last ? t + 18 : last);
   }
   if (t < nsteps) {                                                // odd number of cycles
     recentre();
-    vt_cycle(R, ca, t, dec_lane);
+    vt_cycle(R, ca, t, dec_lane, v2n);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);

@@ -143,12 +143,64 @@ def selftest():
                     rng.choice([-32768, 32767, 32640, -200, 200, 0], m), np.zeros(m)][case].astype(np.int16)
             assert np.array_equal(model_decode(soft, n), ol.ora_viterbi(soft, n)), (n, case)
     print("lane-per-trellis model == oracle")
+    assert bm_check()
+    print("packed branch-metric formulas == W[q]")
 
 
-if __name__ == "__main__":
-    if "--selftest" in sys.argv:
-        selftest()
 
+# ------------------------------------------------------------------------------------------- packed branch metrics
+# The four packed branch-metric registers of a step, M[i] = (W[ql], W[qh]), are formed from the step's four symbol bytes
+# with packed 16-bit arithmetic only (W[q] = (1-2c0) y + (1-2c1) x1 + (1-2c2) x2, y = x0 + x3, x = 2 sym - 255).  Atoms:
+#   A = (s0, s3), B = (s1, s2), U1 = (s1, s1), U2 = (s2, s2)                 one v_perm_b32 each (wave-uniform selector)
+#   TS = A + A.swap = (s0 + s3) twice;  Y2 = 2 TS - 510 = (y, y);  YN = (y, -y)             v_pk_add / v_pk_mad_i16
+#   X1 = (x1, x1), X1N = (x1, -x1), X2, X2N likewise, XB = (x1, x2)                          v_pk_mad_i16
+# and per class two sums of those plus the four final adds / subs -- 11 to 13 instructions per step where the scalar
+# formulation (four byte extractions, eight 32-bit sums, four packs) took 27.  BM_PLAN[c] = (atoms, intermediates, {(ql, qh): expr}).
+BM_PLAN = {
+    0: (["A", "B", "TS", "Y2", "XB"], [("S", "swap_add(XB)"), ("D", "swap_sub(XB)")],
+        {(0, 0): "Y2 + S", (3, 3): "Y2 - S", (1, 1): "add_lolo(Y2, D)", (2, 2): "add_hihi(Y2, D)"}),
+    1: (["A", "U1", "U2", "TS", "Y2", "X1N", "X2N"], [("SN", "X1N + X2N"), ("DN", "X1N - X2N")],
+        {(0, 3): "Y2 + SN", (3, 0): "Y2 - SN", (1, 2): "Y2 + DN", (2, 1): "Y2 - DN"}),
+    2: (["A", "U1", "U2", "TS", "YN", "X1N", "X2"], [("PN", "YN + X1N"), ("QN", "YN - X1N")],
+        {(0, 6): "PN + X2", (1, 7): "PN - X2", (3, 5): "QN - X2", (2, 4): "QN + X2"}),
+    4: (["A", "U1", "U2", "TS", "Y2", "X1", "X2N"], [("PP", "Y2 + X1"), ("QQ", "Y2 - X1")],
+        {(0, 1): "PP + X2N", (1, 0): "PP - X2N", (3, 2): "QQ - X2N", (2, 3): "QQ + X2N"}),
+    5: (["A", "U1", "U2", "TS", "YN", "X1", "X2"], [("SS", "X1 + X2"), ("DD", "X1 - X2")],
+        {(0, 4): "YN + SS", (3, 7): "YN - SS", (1, 5): "YN + DD", (2, 6): "YN - DD"}),
+}
+BM_PLAN[3] = BM_PLAN[2]
+
+
+def bm_check():
+    """Evaluates every formula of BM_PLAN on random symbols with int16 wrap-around and compares with W[q]."""
+    import random
+
+    class P:                                                     # a packed pair of wrapped int16
+        def __init__(self, lo, hi):
+            w = lambda v: ((v + 32768) & 0xFFFF) - 32768
+            self.lo, self.hi = w(lo), w(hi)
+        def __add__(self, o): return P(self.lo + o.lo, self.hi + o.hi)
+        def __sub__(self, o): return P(self.lo - o.lo, self.hi - o.hi)
+    env_fn = {"swap_add": lambda a: P(a.lo + a.hi, a.hi + a.lo), "swap_sub": lambda a: P(a.lo - a.hi, a.hi - a.lo),
+              "add_lolo": lambda a, b: P(a.lo + b.lo, a.hi + b.lo), "add_hihi": lambda a, b: P(a.lo + b.hi, a.hi + b.hi)}
+    rnd = random.Random(1)
+    for _ in range(200):
+        s0, s1, s2, s3 = (rnd.choice([0, 255, 127, rnd.randrange(256)]) for _ in range(4))
+        x = [2 * v - 255 for v in (s0, s1, s2, s3)]
+        y = x[0] + x[3]
+        W = [(1 - 2 * ((q >> 2) & 1)) * y + (1 - 2 * ((q >> 1) & 1)) * x[1] + (1 - 2 * (q & 1)) * x[2] for q in range(8)]
+        ts = s0 + s3
+        env = dict(env_fn, A=P(s0, s3), B=P(s1, s2), U1=P(s1, s1), U2=P(s2, s2), TS=P(ts, ts), Y2=P(2 * ts - 510, 2 * ts - 510),
+                   YN=P(2 * ts - 510, 510 - 2 * ts), X1=P(x[1], x[1]), X1N=P(x[1], -x[1]), X2=P(x[2], x[2]), X2N=P(x[2], -x[2]),
+                   XB=P(x[1], x[2]))
+        for c, (atoms, inter, finals) in BM_PLAN.items():
+            e = dict(env)
+            for name, expr in inter:
+                e[name] = eval(expr, {}, e)
+            for (ql, qh), expr in finals.items():
+                r = eval(expr, {}, e)
+                assert (r.lo, r.hi) == (W[ql], W[qh]), (c, ql, qh, expr)
+    return True
 
 # ------------------------------------------------------------------------------------------- code emitter
 def emit():
@@ -179,6 +231,22 @@ def emit():
     A("{ constexpr unsigned M = 0x01010101u << K;   // one v_and_or_b32 per gather (hipcc splits the and/or otherwise)")
     A("  if (K == 0) acc = p & M;")
     A("  else asm(\"v_and_or_b32 %0, %1, %2, %0\" : \"+v\"(acc) : \"v\"(p), \"s\"(M)); }")
+    A("// ---- packed branch metrics (tools/gen_vit_t.py, BM_PLAN): VOP3P forms the compiler does not pick by itself")
+    A("__device__ __forceinline__ s2 swap_add(s2 a)        // (a.lo + a.hi) in both halves")
+    A("{ s2 r; asm(\"v_pk_add_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]\" : \"=v\"(r) : \"v\"(a)); return r; }")
+    A("__device__ __forceinline__ s2 swap_sub(s2 a) { return sub_lh(a, a); }          // (a.lo - a.hi, a.hi - a.lo)")
+    A("__device__ __forceinline__ s2 add_lolo(s2 a, s2 b)  // (a.lo + b.lo, a.hi + b.lo)")
+    A("{ s2 r; asm(\"v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\" : \"=v\"(r) : \"v\"(a), \"v\"(b)); return r; }")
+    A("__device__ __forceinline__ s2 add_hihi(s2 a, s2 b)  // (a.lo + b.hi, a.hi + b.hi)")
+    A("{ s2 r; asm(\"v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]\" : \"=v\"(r) : \"v\"(a), \"v\"(b)); return r; }")
+    A("__device__ __forceinline__ s2 mad2(s2 a, unsigned k)             // 2 a + k (k: packed constant in an SGPR)")
+    A("{ s2 r; asm(\"v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]\" : \"=v\"(r) : \"v\"(a), \"s\"(k)); return r; }")
+    A("__device__ __forceinline__ s2 madv(s2 a, s2 m, unsigned k)       // a * m + k per half (m = (2, -2) kept in a VGPR)")
+    A("{ s2 r; asm(\"v_pk_mad_i16 %0, %1, %2, %3\" : \"=v\"(r) : \"v\"(a), \"v\"(m), \"s\"(k)); return r; }")
+    A("// symbol bytes b_lo of dword w_lo and b_hi of dword w_hi as a zero-extended pair (wave-uniform byte lanes -> SGPR selector)")
+    A("__device__ __forceinline__ s2 pick(unsigned w_lo, unsigned b_lo, unsigned w_hi, unsigned b_hi)")
+    A("{ return s(__builtin_amdgcn_perm(w_hi, w_lo, 0x0C000C00u | b_lo | ((4u + b_hi) << 16))); }")
+    A("constexpr unsigned K_M255 = 0xFF01FF01u, K_M255_P255 = 0x00FFFF01u, K_M510 = 0xFE02FE02u, K_M510_P510 = 0x01FEFE02u;")
     A("")
     A("// exchange bit of each step class and decision bit position of every label (chain-back tables)")
     A("__device__ constexpr unsigned char VT_P[6] = {%s};" % ", ".join(str(pl["p"]) for pl in PLANS))
@@ -187,15 +255,42 @@ def emit():
         A("  {%s}," % ", ".join(str(x) for x in pl["pos"]))
     A("};")
     A("")
-    A("// W[q], q = c0*4 + c1*2 + c2: branch metric (1-2c0) y0 + (1-2c1) x1 + (1-2c2) x2 of pattern q")
+    A("// M[i]: packed branch metrics (W[ql], W[qh]) of the step's four register-pair groups; W[q], q = c0*4 + c1*2 + c2, is")
+    A("// (1-2c0) y0 + (1-2c1) x1 + (1-2c2) x2 with x = 2 sym - 255, y0 = x0 + x3.  w[p] / b[p]: the dword holding symbol p and")
+    A("// its byte lane; v2n = (2, -2).")
+    atom_code = {
+        "A": "const s2 A = pick(w[0], b[0], w[3], b[3]);", "B": "const s2 B = pick(w[1], b[1], w[2], b[2]);",
+        "U1": "const s2 U1 = pick(w[1], b[1], w[1], b[1]);", "U2": "const s2 U2 = pick(w[2], b[2], w[2], b[2]);",
+        "TS": "const s2 TS = swap_add(A);", "Y2": "const s2 Y2 = mad2(TS, K_M510);", "YN": "const s2 YN = madv(TS, v2n, K_M510_P510);",
+        "X1": "const s2 X1 = mad2(U1, K_M255);", "X1N": "const s2 X1N = madv(U1, v2n, K_M255_P255);",
+        "X2": "const s2 X2 = mad2(U2, K_M255);", "X2N": "const s2 X2N = madv(U2, v2n, K_M255_P255);",
+        "XB": "const s2 XB = mad2(B, K_M255);"}
     for pl in PLANS:
         c = pl["c"]
-        A("__device__ __forceinline__ void step%d(s2 (&R)[32], const int (&W)[8], unsigned &acc0, unsigned &acc1)" % c)
+        atoms, inter, finals = BM_PLAN[c]
+        if c == 0:
+            order = [(q, q) for q in sorted(set(min(q, 7 - q) for _, q in pl["regs"]))]
+        else:
+            combos = {}
+            for ra, rb, ql, qh in pl["pairs"]:
+                key = (ql, qh) if ql < 4 else (7 - ql, 7 - qh)
+                combos.setdefault(key, len(combos))
+            order = [k for k, _ in sorted(combos.items(), key=lambda kv: kv[1])]
+        A("__device__ __forceinline__ void bm%d(const unsigned (&w)[4], const unsigned (&b)[4], s2 v2n, s2 (&M)[4])" % c)
+        A("{")
+        for a in atoms:
+            A("  " + atom_code[a])
+        for name, expr in inter:
+            A("  const s2 %s = %s;" % (name, expr))
+        for i, key in enumerate(order):
+            A("  M[%d] = %s;   // (W[%d], W[%d])" % (i, finals[key], key[0], key[1]))
+        A("}")
+        A("__device__ __forceinline__ void step%d(s2 (&R)[32], const s2 (&M)[4], unsigned &acc0, unsigned &acc1)" % c)
         A("{")
         if c == 0:
-            qs = sorted(set(min(q, 7 - q) for _, q in pl["regs"]))
-            for q in qs:
-                A("  const s2 M%d = pk(W[%d], W[%d]);" % (q, q, q))
+            qs = [q for q, _ in order]
+            for i, q in enumerate(qs):
+                A("  const s2 M%d = M[%d];" % (q, i))
             for j in range(16):
                 names = []
                 for r in (2 * j, 2 * j + 1):
@@ -207,12 +302,8 @@ def emit():
                     names.append((r, "sub_hl(t2_%d, t1_%d)" % (r, r), "sub_lh(t1_%d, t2_%d)" % (r, r)))
                 A("  fold<%d>(acc%d, sg_even(%s, %s) | sg_odd(%s, %s));" % (j % 8, j // 8, names[0][1], names[0][2], names[1][1], names[1][2]))
         else:
-            combos = {}
-            for ra, rb, ql, qh in pl["pairs"]:
-                key = (ql, qh) if ql < 4 else (7 - ql, 7 - qh)
-                combos.setdefault(key, len(combos))
             for (ql, qh), idx in combos.items():
-                A("  const s2 M%d = pk(W[%d], W[%d]);" % (idx, ql, qh))
+                A("  const s2 M%d = M[%d];" % (idx, idx))
             for k, (ra, rb, ql, qh) in enumerate(pl["pairs"]):
                 flip = ql >= 4
                 key = (ql, qh) if not flip else (7 - ql, 7 - qh)
@@ -235,3 +326,6 @@ if __name__ == "__main__" and "--emit" in sys.argv:
     for pl in PLANS[1:]:
         combos = set((ql, qh) if ql < 4 else (7 - ql, 7 - qh) for _, _, ql, qh in pl["pairs"])
         print("class", pl["c"], "p", pl["p"], "distinct packed M:", len(combos))
+
+if __name__ == "__main__" and "--selftest" in sys.argv:
+    selftest()
