@@ -42,7 +42,7 @@ int dabx_viterbi(const int16_t *soft, int nbits, int batch, uint8_t *bits) { ret
 
 int dabx_viterbi_mode(const int16_t *soft, int nbits, int batch, int tie_mode, uint8_t *bits)
 {
-  if (!soft || !bits || nbits <= 0 || batch <= 0 || tie_mode < 0 || tie_mode > 1) { set_error("dabx_viterbi: bad argument"); return DABX_E_ARG; }
+  if (!soft || !bits || nbits <= 0 || batch <= 0 || tie_mode < 0 || tie_mode > 2) { set_error("dabx_viterbi: bad argument"); return DABX_E_ARG; }
   int rc = need_device();
   if (rc) return rc;
   DevBuf dsoft, dbits;

@@ -242,7 +242,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.n_streams = S; d.max_subch = cfg->max_subch; d.out_frames = cfg->out_frames;
   d.ring_len = cfg->ring_frames * TF;
   d.threshold = cfg->sync_threshold; d.strongest = cfg->sync_strongest;
-  d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft; d.tie_mode = cfg->viterbi_tie_mode != 0;
+  d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft; d.tie_mode = cfg->viterbi_tie_mode;
   d.fused_front = 0;
   d.front_prio = 1;
   d.split_fic = 1;

@@ -734,8 +734,9 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + fic * FIC_IN, t.fic_map};
     uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + fic) * (size_t)e.vit_stride;
     const VitLaneConst k = vit_lane_const(lane);
-    if (e.tie_mode) vit_forward<true>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
-    else vit_forward<false>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
+    if (e.tie_mode == 2) vit_forward<2>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
+    else if (e.tie_mode) vit_forward<1>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
+    else vit_forward<0>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     vit_traceback(dec, FIC_OUT, lane, raw[wave]);
@@ -934,8 +935,9 @@ __global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, 
   SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64};
   uint32_t *dec = e.vit_scratch + ((size_t)e.n_streams * 4 + (size_t)job) * (size_t)e.vit_stride;
   const VitLaneConst k = vit_lane_const(lane);
-  if (e.tie_mode) vit_forward<true>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
-  else vit_forward<false>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
+  if (e.tie_mode == 2) vit_forward<2>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
+  else if (e.tie_mode) vit_forward<1>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
+  else vit_forward<0>(src, sc.nbits + 6, wtab[wave], dec, lane, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t *out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)s * e.max_subch + j) * MSC_SLOTS + (size_t)(out_idx % MSC_SLOTS)) * e.msc_stride);

@@ -247,8 +247,8 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   int t = 0;
   // vit_prio: the SIMD's arbiter favours its oldest wave, so the four waves of a SIMD drift apart (one runs ahead at the
   // single-wave rate, the last one finishes alone).  Lowering a wave's priority as it progresses lets the others catch up.
-  const int q1 = e.vit_prio ? nsteps / 3 : 0x7fffffff, q2 = e.vit_prio ? 2 * nsteps / 3 : 0x7fffffff;
-  if (e.vit_prio) __builtin_amdgcn_s_setprio(2);
+  const int q1 = (e.vit_prio & 1) ? nsteps / 3 : 0x7fffffff, q2 = (e.vit_prio & 1) ? 2 * nsteps / 3 : 0x7fffffff;
+  if (e.vit_prio & 1) __builtin_amdgcn_s_setprio(2);
   for (; t + 12 <= nsteps; t += 12) {
     if (t >= q1 && t < q1 + 12) __builtin_amdgcn_s_setprio(1);
     if (t >= q2 && t < q2 + 12) __builtin_amdgcn_s_setprio(0);
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   // registers: as arrays indexed through a lambda the compiler had put one set in scratch and one in LDS, and the chain
   // then ran at ~1150 cycles per step, a third of the kernel.)
   unsigned L = 0, outw = 0;
+  if (e.vit_prio & 2) __builtin_amdgcn_s_setprio(3);            // experiment: the latency-bound chain ahead of the other waves' forward passes
   VtDec6 cur = vt_load_dec(dec_lane, nsteps - 6);
   VtDec6 nx1 = vt_load_dec(dec_lane, nsteps - 12);                // nsteps >= 18 for every legal profile (24 * 8 + 6 = 198 at least)
   for (int tc = nsteps - 6; tc >= 6; tc -= 6) {

@@ -31,8 +31,9 @@ __device__ __forceinline__ void viterbi_wave_to_packed(const Src &src, int nbits
                                                        uint32_t *out_words, int lane, int tie_mode)
 {
   const VitLaneConst k = vit_lane_const(lane);
-  if (tie_mode) vit_forward<true>(src, nbits + 6, wtab, dec, lane, k);
-  else vit_forward<false>(src, nbits + 6, wtab, dec, lane, k);
+  if (tie_mode == 2) vit_forward<2>(src, nbits + 6, wtab, dec, lane, k);
+  else if (tie_mode) vit_forward<1>(src, nbits + 6, wtab, dec, lane, k);
+  else vit_forward<0>(src, nbits + 6, wtab, dec, lane, k);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);     // decision stores of this wave have left the CU before they are re-read
   vit_traceback(dec, nbits, lane, raw);

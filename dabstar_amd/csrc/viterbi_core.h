@@ -117,25 +117,30 @@ __device__ __forceinline__ void vit_step(int &m, unsigned &acc, const char *wrow
   asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
 }
 
-// ---- the reference's SIMD builds (VITERBI_AVX2 / VITERBI_SSE2: viterbi_16way.h, viterbi_8way.h) -------------------
-// Same trellis, different arithmetic: path metrics are uint16 with SATURATING adds (_mm256_adds_epu16, :36-39), the
-// survivor is min and the decision is `survivor == m1` (:44-45), i.e. a TIE goes to predecessor i + 32 (the scalar body
-// sends it to i), and after every second step the new metrics are reduced by their minimum when state 0's metric of the
-// step BEFORE exceeded 60000 (renormalize, :9-25: the test reads metrics2[0], the subtraction works on new_metrics).
+// ---- the reference's SIMD builds (VITERBI_AVX2: viterbi_16way.h; VITERBI_SSE2 / NEON: viterbi_8way.h) -------------
+// Same trellis, different arithmetic.  RULE 1 (AVX2): path metrics are uint16 with SATURATING adds (_mm256_adds_epu16,
+// :36-39), the survivor is min and the decision is `survivor == m1` (:44-45), i.e. a TIE goes to predecessor i + 32 (the
+// scalar body sends it to i), and after every second step the new metrics are reduced by their minimum when state 0's metric
+// of the step BEFORE exceeded 60000 (renormalize, :9-25: the test reads metrics2[0], the subtraction works on new_metrics).
+// RULE 2 (SSE2 / NEON, viterbi_8way.h:9-53): SIGNED int16 metrics, adds saturating at 32767, decision = m0 > m1 (a tie keeps
+// predecessor i, as in the scalar body), the same renormalisation with threshold 30000.
 // Reproduced here in the reference's own metric domain (start 0 / 1000, branch metric 0..1020) so that saturation and
-// renormalisation fall on the same steps: bit-identical to the AVX2 object code (tests/test_oracle_ref.py builds it).
-template <int C>
+// renormalisation fall on the same steps: bit-identical to the respective object code (tests/test_oracle_ref.py builds both).
+template <int C, int RULE>
 __device__ __forceinline__ void vit_step_simd(int &m, unsigned &acc, const char *wrow, const VitLaneConst &k)
 {
+  constexpr int CEIL = RULE == 1 ? 65535 : 32767;
   const int w = *reinterpret_cast<const int16_t *>(wrow + k.pat[C]);      // 2 * metric - 1020
   const int bm = (w + 1020) >> 1;                                         // sum (Branch ^ sym), viterbi_16way.h:30-31
   const int partner = vit_exchange<C>(m, k.lane);
   int a = m + bm, b = partner + (1020 - bm);
-  a = a > 65535 ? 65535 : a; b = b > 65535 ? 65535 : b;                   // adds_epu16
-  // lower lane of the pair: decision0 = (min == m1) = (b <= a); upper lane: decision1 = (min == m3) = (a <= b)
+  a = a > CEIL ? CEIL : a; b = b > CEIL ? CEIL : b;                       // adds_epu16 / adds_epi16
+  // AVX2: lower lane of the pair: decision0 = (min == m1) = (b <= a); upper lane: decision1 = (min == m3) = (a <= b)
+  // SSE2: decision0 = m0 > m1 = (a > b) in the lower lane, decision1 = m2 > m3 = (b > a) in the upper lane
   const int dd = __mul24(a - b, k.sgn[C]);
   m = a < b ? a : b;
-  asm("v_cmp_le_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
+  if constexpr (RULE == 1) asm("v_cmp_le_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
+  else asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
 }
 __device__ __forceinline__ int vit_wave_min(int v)
 {
@@ -143,22 +148,22 @@ __device__ __forceinline__ int vit_wave_min(int v)
   for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
   return v;
 }
-template <int C>
+template <int C, int RULE>
 __device__ __forceinline__ void vit_pair_simd(int &m, unsigned &acc, const char *row, const VitLaneConst &k)
 {
-  vit_step_simd<C>(m, acc, row, k);
+  vit_step_simd<C, RULE>(m, acc, row, k);
   const int m0_before = __builtin_amdgcn_readfirstlane(m);                // state 0 lives in lane 0 in every step class
-  vit_step_simd<C + 1>(m, acc, row + 16, k);
-  if (m0_before > 60000) m -= vit_wave_min(m);                            // renormalize: wave-uniform, rare
+  vit_step_simd<C + 1, RULE>(m, acc, row + 16, k);
+  if (m0_before > (RULE == 1 ? 60000 : 30000)) m -= vit_wave_min(m);      // renormalize: wave-uniform, rare
 }
 
 // Forward pass.  wtab: this wave's LDS area, VIT_BLK rows of 8 int16.  dec: u32[vit_blocks*2][64].
-// SIMD_RULE = true: arithmetic of the reference's AVX2 / SSE2 builds (see above) instead of the canonical scalar body.
-template <bool SIMD_RULE = false, class Src>
+// RULE 1 / 2: arithmetic of the reference's AVX2 / SSE2 builds (see above) instead of the canonical scalar body (0).
+template <int RULE = 0, class Src>
 __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wtab, uint32_t *dec, int lane,
                                             const VitLaneConst &k)
 {
-  int m = SIMD_RULE ? (lane == 0 ? 0 : 1000) : (lane == 0 ? 0 : 2000);   // viterbi_spiral.cpp:98-101 (0 / 1000); doubled in the canonical form
+  int m = RULE ? (lane == 0 ? 0 : 1000) : (lane == 0 ? 0 : 2000);   // viterbi_spiral.cpp:98-101 (0 / 1000); doubled in the canonical form
   const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
   // The symbols of block b + 1 (two dependent global loads: depuncture map, then the soft symbols) are requested before
   // the 60 add-compare-select steps of block b run and only consumed afterwards: their latency is off the chain.
@@ -191,10 +196,10 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
 #pragma unroll
       for (int s6 = 0; s6 < VIT_DW; s6 += 6) {
         const char *row = wtab + (h * VIT_DW + s6) * 16;
-        if constexpr (SIMD_RULE) {
-          vit_pair_simd<0>(m, acc, row + 0 * 16, k);
-          vit_pair_simd<2>(m, acc, row + 2 * 16, k);
-          vit_pair_simd<4>(m, acc, row + 4 * 16, k);
+        if constexpr (RULE != 0) {
+          vit_pair_simd<0, RULE>(m, acc, row + 0 * 16, k);
+          vit_pair_simd<2, RULE>(m, acc, row + 2 * 16, k);
+          vit_pair_simd<4, RULE>(m, acc, row + 4 * 16, k);
         } else {
           vit_step<0>(m, acc, row + 0 * 16, k);
           vit_step<1>(m, acc, row + 1 * 16, k);

@@ -55,8 +55,10 @@ int dabx_device_count(void);
  * bits  : batch x nbits bytes, one decoded bit per byte.  Canonical scalar tie rule. */
 int dabx_viterbi(const int16_t *soft, int nbits, int batch, uint8_t *bits);
 /* The same with the decoder arithmetic selected: tie_mode 0 = the canonical scalar body (viterbi_scalar.h: int32 metrics, a
- * tie keeps predecessor i); 1 = the reference's VITERBI_AVX2 / VITERBI_SSE2 builds (viterbi_16way.h:9-58: uint16 saturating
- * metrics, renormalisation, a tie goes to predecessor i + 32).  Both are bit-identical to the respective object code. */
+ * tie keeps predecessor i); 1 = the reference's VITERBI_AVX2 build (viterbi_16way.h:9-58: uint16 saturating metrics,
+ * renormalisation above 60000, a tie goes to predecessor i + 32); 2 = its VITERBI_SSE2 / NEON builds (viterbi_8way.h:9-53:
+ * signed int16 metrics saturating at 32767, renormalisation above 30000, ties as in the scalar body).  Each is bit-identical
+ * to the respective object code of the reference. */
 int dabx_viterbi_mode(const int16_t *soft, int nbits, int batch, int tie_mode, uint8_t *bits);
 
 /* Protection::deconvolve for EEP/UEP (base/protection/protection.h:44; eep_protection.cpp:43-167,
@@ -186,8 +188,8 @@ typedef struct {
   int32_t soft_bit_type;    /* glob_enums.h:49-56, default 1 (SOFTDEC1) */
   int32_t fic_only;         /* 1: BASELINE config 2 (FIC Viterbi only) */
   int32_t capture_soft;     /* 1: keep int16 soft bits of the last frame (debug / parity tests) */
-  int32_t viterbi_tie_mode; /* 0: canonical scalar Viterbi (CMake default); 1: arithmetic of the VITERBI_AVX2 / _SSE2 builds, see
-                               dabx_viterbi_mode (FIC and MSC then run on the wave-per-trellis kernels) */
+  int32_t viterbi_tie_mode; /* 0: canonical scalar Viterbi (CMake default); 1 / 2: arithmetic of the VITERBI_AVX2 / VITERBI_SSE2 builds,
+                               see dabx_viterbi_mode (FIC and MSC then run on the wave-per-trellis kernels) */
   int32_t dc_iq_correction; /* SampleReader::set_dc_and_iq_correction (sample_reader.cpp:218-243, 334-346; configuration.cpp:75-76
                                default off): 0 off, 1 DC removal, 2 DC removal + IQ-imbalance correction, applied to every
                                committed sample in place in the ring (dabx_read_iq then returns corrected samples) */

@@ -126,8 +126,64 @@ void ora_viterbi_simd(const int16_t *soft, int nbits, uint8_t *out_bits)
   free(dec);
 }
 
+/* The body of the VITERBI_SSE2 (and NEON) build (viterbi_8way.h:9-120): SIGNED int16 path metrics with saturating adds
+ * (_mm_adds_epi16: ceiling 32767), decision = m0 > m1 (:39,:41: a tie keeps predecessor i, like the scalar body), and after
+ * every second step `renormalize` with threshold 30000 on metrics2[0] -- state 0's metric of the step BEFORE -- subtracting the
+ * minimum of the new metrics (_mm_subs_epi16).  Differs from the scalar body only where a metric saturates.  Pinned against
+ * the reference's SSE2 object code (tests/test_oracle_ref.py). */
+void ora_viterbi_sse2(const int16_t *soft, int nbits, uint8_t *out_bits)
+{
+  if (!g_branch_ready) build_branch();
+  const int nsteps = nbits + 6;
+  uint64_t *dec = (uint64_t *)calloc((size_t)nsteps, sizeof(uint64_t));
+  int32_t m1[64], m2[64];
+  int32_t *old = m1, *nw = m2;
+  for (int i = 0; i < 64; i++) m1[i] = 1000, m2[i] = 0;
+  m1[0] = 0;
+  for (int t = 0; t < nsteps; t++) {
+    int sym[4];
+    for (int p = 0; p < 4; p++) {                   /* viterbi_8way.h:72-75 */
+      int v = (int)soft[4 * t + p] + 127;
+      if (v > 32767) v = 32767;
+      if (v > 255) v = 255;
+      if (v < 0) v = 0;
+      sym[p] = v;
+    }
+    uint64_t d = 0;
+    for (int i = 0; i < 32; i++) {                  /* BFLY, viterbi_8way.h:27-53 */
+      const int metric = (g_branch[0][i] ^ sym[0]) + (g_branch[1][i] ^ sym[1]) +
+                         (g_branch[2][i] ^ sym[2]) + (g_branch[3][i] ^ sym[3]);
+      const int m_metric = 1020 - metric;
+      int32_t a0 = old[i] + metric, a1 = old[i + 32] + m_metric, a2 = old[i] + m_metric, a3 = old[i + 32] + metric;
+      if (a0 > 32767) a0 = 32767;                   /* adds_epi16 (the operands are never negative) */
+      if (a1 > 32767) a1 = 32767;
+      if (a2 > 32767) a2 = 32767;
+      if (a3 > 32767) a3 = 32767;
+      const int d0 = a0 > a1, d1 = a2 > a3;
+      nw[2 * i] = d0 ? a1 : a0; nw[2 * i + 1] = d1 ? a3 : a2;
+      d |= (uint64_t)(d0 | (d1 << 1)) << (2 * i);
+    }
+    dec[t] = d;
+    if (t & 1) {
+      if (old[0] > 30000) {                         /* `old` = the metrics of step t - 1 = metrics2 */
+        int32_t mn = nw[0];
+        for (int i = 1; i < 64; i++) if (nw[i] < mn) mn = nw[i];
+        for (int i = 0; i < 64; i++) nw[i] -= mn;
+      }
+    }
+    int32_t *tmp = old; old = nw; nw = tmp;
+  }
+  unsigned endstate = 0;                            /* chain back: viterbi_spiral.cpp:114-125 */
+  for (int fb = nbits - 1; fb >= 0; fb--) {
+    const int k = (int)((dec[fb + 6] >> (endstate >> 2)) & 1);
+    endstate = (endstate >> 1) | ((unsigned)k << 7);
+    out_bits[fb] = (uint8_t)k;
+  }
+  free(dec);
+}
+
 /* Which body ViterbiSpiral::deconvolve was compiled with (viterbi_spiral.cpp:105-112 picks one by HAVE_VITERBI_*): the
- * receiver-level oracle (fic.c, protection.c) decodes through this switch.  0 = scalar (CMake default), 1 = AVX2. */
+ * receiver-level oracle (fic.c, protection.c) decodes through this switch.  0 = scalar (CMake default), 1 = AVX2, 2 = SSE2. */
 static int g_viterbi_mode = 0;
 static void (*g_viterbi_hook)(const int16_t *, int, uint8_t *) = 0;
 void ora_set_viterbi_mode(int mode) { g_viterbi_mode = mode; }
@@ -143,6 +199,7 @@ void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits)
     g_viterbi_hook(soft, nbits, out_bits);
   }
   else if (g_viterbi_mode == 1) ora_viterbi_simd(soft, nbits, out_bits);
+  else if (g_viterbi_mode == 2) ora_viterbi_sse2(soft, nbits, out_bits);
   else ora_viterbi(soft, nbits, out_bits);
 }
 

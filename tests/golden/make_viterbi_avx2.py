@@ -1,6 +1,7 @@
-"""Generates tests/golden/ref_viterbi_avx2.npz from the GENUINE reference object oracle/_ref/libdabref_vit_avx2.so
-(the unmodified viterbi_spiral.cpp compiled with -DHAVE_VITERBI_AVX2 -mavx2 by oracle/ref/Makefile): seeded soft-bit rows
-and the bits ViterbiSpiral::deconvolve returns for them.  Build container only; the fixture is data.
+"""Generates tests/golden/ref_viterbi_avx2.npz and ref_viterbi_sse2.npz from the GENUINE reference objects
+oracle/_ref/libdabref_vit_{avx2,sse2}.so (the unmodified viterbi_spiral.cpp compiled with -DHAVE_VITERBI_AVX2 -mavx2 /
+-DHAVE_VITERBI_SSE2 by oracle/ref/Makefile): seeded soft-bit rows and the bits ViterbiSpiral::deconvolve returns for them.
+Build container only; the fixtures are data.
 
     python tests/golden/make_viterbi_avx2.py
 """
@@ -25,17 +26,18 @@ def rows_for(n):
 
 
 def main():
-    R = ol.ref_viterbi_variant("avx2")
-    assert R is not None, "needs oracle/_ref/libdabref_vit_avx2.so and an AVX2 CPU"
-    out = {}
-    for n in (768, 192, 1536, 9216):
-        soft = rows_for(n)
-        bits = np.zeros((len(soft), n), np.uint8)
-        for i in range(len(soft)):
-            R.ref_viterbi(np.ascontiguousarray(soft[i]), n, bits[i])
-        out["bits_%d" % n] = np.packbits(bits, axis=1)
-    np.savez_compressed(os.path.join(HERE, "ref_viterbi_avx2.npz"), **out)
-    print("wrote ref_viterbi_avx2.npz:", {k: v.shape for k, v in out.items()})
+    for variant in ("avx2", "sse2"):
+        R = ol.ref_viterbi_variant(variant)
+        assert R is not None, "needs oracle/_ref/libdabref_vit_%s.so and a CPU with that instruction set" % variant
+        out = {}
+        for n in (768, 192, 1536, 9216):
+            soft = rows_for(n)
+            bits = np.zeros((len(soft), n), np.uint8)
+            for i in range(len(soft)):
+                R.ref_viterbi(np.ascontiguousarray(soft[i]), n, bits[i])
+            out["bits_%d" % n] = np.packbits(bits, axis=1)
+        np.savez_compressed(os.path.join(HERE, "ref_viterbi_%s.npz" % variant), **out)
+        print("wrote ref_viterbi_%s.npz:" % variant, {k: v.shape for k, v in out.items()})
 
 
 if __name__ == "__main__":

@@ -56,6 +56,7 @@ def oracle():
     L.ora_prbs.argtypes = [_u8p, C.c_int]
     L.ora_viterbi.argtypes = [_i16p, C.c_int, _u8p]
     L.ora_viterbi_simd.argtypes = [_i16p, C.c_int, _u8p]
+    L.ora_viterbi_sse2.argtypes = [_i16p, C.c_int, _u8p]
     L.ora_set_viterbi_mode.argtypes = [C.c_int]
     L.ora_viterbi_ber.argtypes = [_i16p, _u8p, _u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for f in (L.ora_eep_map, L.ora_uep_map):
@@ -183,6 +184,12 @@ def ref():
 def ora_viterbi(soft, nbits):
     out = np.zeros(nbits, np.uint8)
     oracle().ora_viterbi(np.ascontiguousarray(soft, np.int16), nbits, out)
+    return out
+
+
+def ora_viterbi_sse2(soft, nbits):
+    out = np.zeros(nbits, np.uint8)
+    oracle().ora_viterbi_sse2(np.ascontiguousarray(soft, np.int16), nbits, out)
     return out
 
 

@@ -76,22 +76,28 @@ def test_deconvolve_every_legal_profile_matches_oracle():
 
 
 @pytest.mark.parametrize("n", [768, 192, 1536, 9216])
-def test_avx2_tie_mode_matches_the_references_avx2_build(n):
-    """viterbi_tie_mode = 1 (dabx_viterbi_mode): the arithmetic of the reference's VITERBI_AVX2 build (viterbi_16way.h:
-    uint16 saturating metrics, renormalisation, ties to the i + 32 path, saturating symbol conversion).  Bit-identical to
-    the bits the reference's own AVX2 object code returned for the seeded rows of tests/golden/ref_viterbi_avx2.npz, and to
-    the oracle restatement that is pinned against that object on the CPU; the canonical mode differs on the same inputs."""
+@pytest.mark.parametrize("variant,mode", [("avx2", 1), ("sse2", 2)])
+def test_avx2_tie_mode_matches_the_references_avx2_build(n, variant, mode):
+    """viterbi_tie_mode = 1 / 2 (dabx_viterbi_mode): the arithmetic of the reference's VITERBI_AVX2 build (viterbi_16way.h:
+    uint16 saturating metrics, renormalisation above 60000, ties to the i + 32 path) and of its VITERBI_SSE2 / NEON builds
+    (viterbi_8way.h: signed int16 metrics saturating at 32767, renormalisation above 30000, scalar tie rule); both with the
+    saturating symbol conversion.  Bit-identical to the bits the reference's own object code returned for the seeded rows of
+    tests/golden/ref_viterbi_{avx2,sse2}.npz, and to the oracle restatements that are pinned against those objects on the
+    CPU; the canonical mode differs on the same inputs, and so do the two SIMD builds from each other."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import make_viterbi_avx2 as mk
-    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_viterbi_avx2.npz"))
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_viterbi_%s.npz" % variant))
     soft = mk.rows_for(n)
     want = np.unpackbits(G["bits_%d" % n], axis=1)[:, :n]
-    got = dx.viterbi(soft, n, tie_mode=1)
+    got = dx.viterbi(soft, n, tie_mode=mode)
     assert np.array_equal(got, want)
+    restate = ol.ora_viterbi_simd if mode == 1 else ol.ora_viterbi_sse2
     for i in range(len(soft)):
-        assert np.array_equal(got[i], ol.ora_viterbi_simd(soft[i], n)), i
+        assert np.array_equal(got[i], restate(soft[i], n)), i
     canon = dx.viterbi(soft, n)
     assert not np.array_equal(canon, want)
     for i in range(len(soft)):
         assert np.array_equal(canon[i], ol.ora_viterbi(soft[i], n)), i
+    other = np.unpackbits(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_viterbi_%s.npz" % ("sse2" if mode == 1 else "avx2")))["bits_%d" % n], axis=1)[:, :n]
+    assert not np.array_equal(other, want)
