@@ -36,6 +36,36 @@ __device__ __forceinline__ int msc_class_of_group(const MscLaunch &L, int g)
   return c;
 }
 
+constexpr int PREP_STG = PJB * 16 * (PCH / 4) / 256;             // (job, plane, dword) items per thread and chunk (32)
+__device__ __forceinline__ void prep_item(int it, int cw, bool full, int &d, int &pl, int &job)
+{
+  int jp;
+  if (full) { d = it & (PCH / 4 - 1); jp = it / (PCH / 4); }       // shifts/masks for whole chunks
+  else { d = it % cw; jp = it / cw; }
+  pl = jp & 15; job = jp >> 4;
+}
+// requests this thread's items of the chunk at ring position p0 (cw dwords per run) into registers
+__device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int tid, int p0, int cw, const uint8_t *const *s_base, const long long *s_r)
+{
+  const bool full = cw == PCH / 4;
+#pragma unroll
+  for (int r = 0; r < PREP_STG; r++) {
+    const int it = tid + 256 * r;
+    uint32_t v = 0x7F7F7F7Fu;
+    if (it < PJB * 16 * cw) {
+      int d, pl, job;
+      prep_item(it, cw, full, d, pl, job);
+      const uint8_t *base = s_base[job];
+      if (base) {
+        // out_r[idx] = in_{r-16+map[idx&15]}[idx], map = 4-bit reversal (backend.cpp:129); planar ring: plane = idx & 15
+        const long long cif = s_r[job] - 16 + bitrev4(pl);
+        v = *reinterpret_cast<const uint32_t *>(base + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d);
+      }
+    }
+    stage[r] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaunch L)
 {
   if (e.front_prio) __builtin_amdgcn_s_setprio(3);      // runs on the front-end stream (pipeline.hip, front_prio)
@@ -58,25 +88,27 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
   if (pg == 0 && qd == 0) dst[(size_t)(rows - 1) * 64] = 0x7F7F7F7Fu;      // punctured soft bit = 0 -> symbol 127
   __syncthreads();
   const int npos = n_in / 16;                                      // ring positions per plane of one job
+  // Software pipeline over the chunks: the (job, plane, dword) items of chunk c + 1 are requested into registers before
+  // chunk c is transposed and stored, so the ring reads (64-byte runs, one HBM line each: long latency, little to
+  // coalesce) are in flight behind the LDS reads, permutes and stores of the chunk before instead of in front of a barrier.
+  uint32_t stage[PREP_STG];
+  auto chunk_dwords = [&](int p0) { return (npos - p0 < PCH ? npos - p0 : PCH) / 4; };     // npos % 4 == 0
+  if (npos > 0) prep_request(stage, tid, 0, chunk_dwords(0), s_base, s_r);
   for (int p0 = 0; p0 < npos; p0 += PCH) {
-    const int cw = (npos - p0 < PCH ? npos - p0 : PCH) / 4;       // dwords per run in this chunk (npos % 4 == 0)
-    // (1) coalesced load: item = (job, plane, dword)
+    const int cw = chunk_dwords(p0);                               // dwords per run in this chunk
     const bool full = cw == PCH / 4;
-    for (int it = tid; it < PJB * 16 * cw; it += 256) {
-      int d, jp;
-      if (full) { d = it & (PCH / 4 - 1); jp = it / (PCH / 4); }   // shifts/masks for whole chunks
-      else { d = it % cw; jp = it / cw; }
-      const int pl = jp & 15, job = jp >> 4;
-      const uint8_t *base = s_base[job];
-      uint32_t v = 0x7F7F7F7Fu;
-      if (base) {
-        // out_r[idx] = in_{r-16+map[idx&15]}[idx], map = 4-bit reversal (backend.cpp:129); planar ring: plane = idx & 15
-        const long long cif = s_r[job] - 16 + bitrev4(pl);
-        v = *reinterpret_cast<const uint32_t *>(base + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d);
+    // (1) this chunk's items into the LDS tile
+#pragma unroll
+    for (int r = 0; r < PREP_STG; r++) {
+      const int it = tid + 256 * r;
+      if (it < PJB * 16 * cw) {
+        int d, pl, job;
+        prep_item(it, cw, full, d, pl, job);
+        *reinterpret_cast<uint32_t *>(tile + job * PJS + pl * PCH + 4 * d) = stage[r];
       }
-      *reinterpret_cast<uint32_t *>(tile + job * PJS + pl * PCH + 4 * d) = v;
     }
     __syncthreads();
+    if (p0 + PCH < npos) prep_request(stage, tid, p0 + PCH, chunk_dwords(p0 + PCH), s_base, s_r);
     // (2) transpose 4 planes x 4 positions, write idx-ordered dwords
     const uint8_t *mine = tile + jl * PJS + (4 * pg) * PCH;
     for (int d = qd; d < cw; d += 2) {
