@@ -520,7 +520,19 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[q], e.tie_mode);
       if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[q]; cap[(size_t)l * K2 + K + k] = si[q]; }
     }
-    mean_value = block_sum(part, red, tid) * (1.0f / (float)K);   // two barriers: the tile is complete behind them
+    // mMeanValue (ofdm_decoder.cpp:256,294): block sum in block_sum()'s order -- per-wave butterflies, then the wave partials
+    // added in wave order by every thread.  ONE barrier per symbol: the partials (and the tile) are double-buffered by
+    // symbol parity, so what a thread still reads of symbol l cannot be overwritten before the barrier of symbol l + 1.
+    {
+      float *rp = red + 16 * (l & 1);
+      const float pw_sum = wave_sum(part);
+      if ((tid & 63) == 0) rp[tid >> 6] = pw_sum;
+      __syncthreads();                                      // the tile is complete behind it, too
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < DEMAP_THREADS / 64; w++) sum += rp[w];
+      mean_value = sum * (1.0f / (float)K);
+    }
     if (l < 3) {                                            // symbols 1..3 -> FIC, linear: bytes 4 tid .. 4 tid + 3
       uint32_t v = 0;
 #pragma unroll
@@ -954,7 +966,7 @@ __global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, 
 // positions of mOutVec (:225-228), so the super frame is simply window[0 .. 110 R) corrected in place.
 // Syndromes of all R code words x 10 roots are evaluated lane-parallel (Horner over LDS); the full
 // Berlekamp-Massey / Chien / Forney decoder runs only for code words whose syndromes are not all zero.
-__global__ __launch_bounds__(64) void k_dabplus(EngineDev e, DevTables t)
+__global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   // <= 128 VGPRs: four waves per SIMD (it took 129)
 {
   const int job = blockIdx.x, lane = threadIdx.x;
   const int s = job / e.max_subch, j = job % e.max_subch;

@@ -174,6 +174,8 @@ typedef struct {
   float mean_value;
   int16_t perm[ORA_K];
   int soft_bit_type;   /* 1,2,3 = SOFTDEC1..3 (glob_enums.h:49-56), default 1 */
+  long long overflow_count;   /* test bookkeeping: soft values that left the int16 range before the (i16) cast -- undefined
+                                 behaviour in the reference (ofdm_decoder.cpp:254-255), wrapped here as x86-64 does it */
 } ora_demap;
 void ora_demap_init(ora_demap *d);                                   /* ofdm_decoder.cpp:43-66 */
 void ora_demap_reset(ora_demap *d);                                  /* ofdm_decoder.cpp:90-101 */
@@ -224,6 +226,8 @@ typedef struct {
   float   *clock_err;  /* n_frames : mClockErrHz, :246-251 */
   int32_t *fic_ratio;  /* n_frames : FicDecoder::get_fic_decode_ratio_percent */
   float   *snr_db;     /* n_frames : SNR of the LCD statistics after symbol 75, ofdm_decoder.cpp:326-343 */
+  int32_t *fic_overflow;  /* n_frames : soft values of symbols 1..3 that left the int16 range (see ora_demap.overflow_count) */
+  int32_t *msc_overflow;  /* n_frames : the same for symbols 4..75 */
 } ora_rx_capture;
 void ora_rx_enable_soft_capture(ora_receiver *r, int on);
 const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);

@@ -241,6 +241,8 @@ void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_
     /* :254-255 */
     out[k] = cvt_i16(r1.re * w2);
     out[ORA_K + k] = cvt_i16(r1.im * w2);
+    if (!(fabsf(r1.re * w2) < 32768.0f)) d->overflow_count++;
+    if (!(fabsf(r1.im * w2) < 32768.0f)) d->overflow_count++;
     sum += cabs_f(r1);                                 /* :256 */
   }
   d->mean_value = sum / (float)ORA_K;                  /* :294 */

@@ -173,7 +173,7 @@ void ora_rx_destroy(ora_receiver *r)
   for (int i = 0; i < r->n_back; i++) ora_backend_free(&r->back[i]);
   free(r->back);
   free(r->cap.fibs); free(r->cap.fib_crc); free(r->cap.soft); free(r->cap.start_idx); free(r->cap.fbb); free(r->cap.sym0_pos);
-  free(r->cap.fbb_end); free(r->cap.clock_err); free(r->cap.fic_ratio); free(r->cap.snr_db);
+  free(r->cap.fbb_end); free(r->cap.clock_err); free(r->cap.fic_ratio); free(r->cap.snr_db); free(r->cap.fic_overflow); free(r->cap.msc_overflow);
   free(r);
 }
 
@@ -196,6 +196,8 @@ static void cap_reserve(ora_receiver *r, int n)
   r->cap.clock_err = (float *)realloc(r->cap.clock_err, sizeof(float) * (size_t)na);
   r->cap.fic_ratio = (int32_t *)realloc(r->cap.fic_ratio, sizeof(int32_t) * (size_t)na);
   r->cap.snr_db = (float *)realloc(r->cap.snr_db, sizeof(float) * (size_t)na);
+  r->cap.fic_overflow = (int32_t *)realloc(r->cap.fic_overflow, sizeof(int32_t) * (size_t)na);
+  r->cap.msc_overflow = (int32_t *)realloc(r->cap.msc_overflow, sizeof(int32_t) * (size_t)na);
   if (r->want_soft) r->cap.soft = (int16_t *)realloc(r->cap.soft, sizeof(int16_t) * (size_t)na * 75 * ORA_2K);
   r->cap_alloc = na;
 }
@@ -233,6 +235,7 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
 
   /* _process_ofdm_symbols_1_to_L, :304-367 */
   float fc_re = 0, fc_im = 0;
+  r->cap.fic_overflow[frame_no] = r->cap.msc_overflow[frame_no] = 0;
   for (int sym = 1; sym < ORA_L; sym++) {
     if (!get_samples(r, r->buf, ORA_TS, r->freq_offs_bb)) return 0;
     *sample_count += ORA_TS;
@@ -243,7 +246,10 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
     }
     memcpy(fin, &r->buf[ORA_TG], sizeof(fin));
     ora_fft2048(fin, fout, 0);
+    const long long ovf0 = r->dm.overflow_count;
     ora_demap_symbol(&r->dm, fout, r->clock_err, r->bits);        /* :342 */
+    if (sym <= 3) r->cap.fic_overflow[frame_no] += (int32_t)(r->dm.overflow_count - ovf0);
+    else r->cap.msc_overflow[frame_no] += (int32_t)(r->dm.overflow_count - ovf0);
     if (r->want_soft) memcpy(&r->cap.soft[((size_t)frame_no * 75 + (sym - 1)) * ORA_2K], r->bits, sizeof(r->bits));
     if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);   /* :347-350 */
     if (sym > 3) msc_process_block(r, r->bits, sym);              /* :357-360 */
@@ -344,8 +350,12 @@ int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 
     const ora_cf32 *sp = spectra + (size_t)f * ORA_L * ORA_TU;
     cap_reserve(r, f + 1);
     ora_demap_store_ref(&r->dm, sp);
+    r->cap.fic_overflow[f] = r->cap.msc_overflow[f] = 0;
     for (int sym = 1; sym < ORA_L; sym++) {
+      const long long ovf0 = r->dm.overflow_count;
       ora_demap_symbol(&r->dm, sp + (size_t)sym * ORA_TU, clock_err[f], r->bits);
+      if (sym <= 3) r->cap.fic_overflow[f] += (int32_t)(r->dm.overflow_count - ovf0);
+      else r->cap.msc_overflow[f] += (int32_t)(r->dm.overflow_count - ovf0);
       if (r->want_soft) memcpy(&r->cap.soft[((size_t)f * 75 + (sym - 1)) * ORA_2K], r->bits, sizeof(r->bits));
       if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);
       if (sym > 3) msc_process_block(r, r->bits, sym);

@@ -40,6 +40,8 @@ def _oracle(x, subch, cfg):
     cap = L.ora_rx_get_capture(rx).contents
     res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy() if n else np.zeros((0, 12, 32), np.uint8),
                crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy() if n else np.zeros((0, 12), np.uint8),
+               fic_ovf=np.ctypeslib.as_array(cap.fic_overflow, (n,)).copy() if n else np.zeros(0, np.int32),
+               msc_ovf=np.ctypeslib.as_array(cap.msc_overflow, (n,)).copy() if n else np.zeros(0, np.int32),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
                sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
                stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
@@ -98,7 +100,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
                 assert len(a) == new
                 fibs[s].extend(a); crcs[s].extend(b)
 
-    locked = n_bad = n_bad_diff = compared = eti_checked = 0
+    locked = n_bad = n_bad_diff = compared = eti_checked = n_ovf_frames = 0
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
         tag = (s, li, round(snr, 1), round(cfo), toff, gain)
         subch = layouts[li]
@@ -108,20 +110,27 @@ def test_random_channels_and_layouts_follow_the_oracle():
         n = min(n, ora["n"])
         if n == 0:
             continue
-        assert np.array_equal(np.array(crcs[s])[:n], ora["crc"][:n]), tag
+        # Frames in which soft values of the FIC symbols left the int16 range (the level returning after a drop-out before the
+        # demapper's means have followed) are outside the comparison: the reference's `(i16)` cast is undefined behaviour
+        # there, the x86 wrap-around both sides reproduce turns a last-ulp float difference into a full-scale one, and the
+        # decoder's answer to such symbols is arbitrary (fuzz seed 3003: one FIB of one frame).
+        clean = ora["fic_ovf"][:n] == 0
+        n_ovf_frames += int((~clean).sum())
+        assert np.array_equal(np.array(crcs[s])[:n][clean], ora["crc"][:n][clean]), tag
         ef, of, okm = np.array(fibs[s])[:n], ora["fibs"][:n], ora["crc"][:n].astype(bool)
+        okm &= clean[:, None]
         assert np.array_equal(ef[okm], of[okm]), tag                  # every FIB that passes its CRC: identical bytes
         # FIBs that fail the CRC are the decoder's answer to noise; with the float demapper equal only within tolerance
         #  a few of them may differ -- they must stay rare and confined to frames without a good FIB
-        bad_diff = (ef != of).any(axis=2) & ~okm
-        n_bad_diff += int(bad_diff.sum()); n_bad += int((~okm).sum())
+        bad_diff = (ef != of).any(axis=2) & ~okm & clean[:, None]
+        n_bad_diff += int(bad_diff.sum()); n_bad += int((~okm & clean[:, None]).sum())
         if os.environ.get("DABX_FUZZ_VERBOSE") and bad_diff.any():
             print("garbage FIBs differ:", tag, "frames", np.nonzero(bad_diff.any(axis=1))[0].tolist(), "of", n, "crc ok per frame", okm.sum(axis=1).tolist())
         locked += int(ora["crc"][:n].sum() > 12 * n // 2)
         # MSC bytes are compared where the signal is decodable.  Below ~6 dB the EEP 3-A sub-channels decode with residual
         # errors, and a soft bit that differs by one LSB (float demapper) can tip a survivor path: seen once in
         # 2 600 streams, at 3.7 dB, identically on both MSC decoder kernels.
-        if n < 7 or not okm[n - 7:].all() or snr < 6.0:
+        if n < 7 or not okm[n - 7:].all() or snr < 6.0 or ora["msc_ovf"][max(0, n - 9):n].any():
             continue                                       # the newest 16 logical
         eng.subch = list(subch)                            # frames reach back 32 CIFs = 8 frames, of which the last 7 are clean here
         compared += 1
@@ -160,6 +169,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
     assert eti_checked >= N_CASES // 4
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
     assert n_bad_diff <= (2 if soft_type != 3 else 6), (n_bad_diff, n_bad)   # generator 3 (no normalisation) is the touchiest
+    assert n_ovf_frames <= 2 * N_CASES, n_ovf_frames                          # overflow frames (excluded above) stay the exception: 528 frames in all
     eng.close()
 
 
