@@ -416,6 +416,7 @@ def main():
     if not dry:
         nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
         share = {names[i].decode(): ms[i] / max(1, args.warmup) for i in range(nk) if cnt[i]}      # stand-alone ms per step (warm-up)
+        sa_launch = {names[i].decode(): (ms[i] / cnt[i], int(cnt[i])) for i in range(nk) if cnt[i]}  # stand-alone ms per launch, launches
         dom = max(share, key=share.get) if share else "k_symbols"
         dom_idx = [names[i].decode() for i in range(nk)].index(dom)
         dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
@@ -459,10 +460,20 @@ def main():
                     vi = tj["valu_per_frame"] * units
                     valu = {"wave_insts_per_launch": int(vi), "issue_peak_per_s": peak, "issue_peak_source": peak_src,
                             "util": round(vi / (kern[dom] * 1e-3) / peak, 4)}
+            standalone = None
+            if dom in sa_launch and args.warmup > 0:
+                # the same kernel with the chip to itself (warm-up, dabx_set_profiling -1): how far the kernel itself is from its
+                # bounds, apart from what the co-running front end takes away from it in the timed region
+                sa_ms, sa_n = sa_launch[dom]
+                sa_units = args.streams * args.warmup / sa_n
+                standalone = {"avg_launch_ms": round(sa_ms, 4), "frames_per_launch": round(sa_units, 2),
+                              "achieved_GBps": round(A_KERNEL[dom] * sa_units / (sa_ms * 1e-3) / 1e9, 2)}
+                if valu is not None:
+                    standalone["valu_util"] = round(tj["valu_per_frame"] * sa_units / (sa_ms * 1e-3) / valu["issue_peak_per_s"], 4)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": round(units, 2),
-                        "avg_launch_ms": round(kern[dom], 4), "valu": valu}
+                        "avg_launch_ms": round(kern[dom], 4), "valu": valu, "standalone": standalone}
         a_frame = A_FRAME_FIC if args.fic_only else A_FRAME
         out = {
             "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
