@@ -403,22 +403,27 @@ def main():
     eng.commit(ring_frames * TF - TF)
     step(40)
     eng.synchronize()
-    # warm-up with every kernel instrumented and the host waiting for each one (dabx_set_profiling -1: one kernel on the chip
-    # at a time): the per-kernel STAND-ALONE breakdown, whose largest entry is the dominant kernel.  (As scheduled, the
-    # kernels of the engine's four HIP streams overlap and a kernel's duration includes its waiting for the others.)  The
-    # timed region then runs as scheduled and instruments only that kernel (one HIP event pair per launch on its stream).
+    # Still priming: one whole MSC batch (7 steps) with every kernel instrumented and the host waiting for each one
+    # (dabx_set_profiling -1: one kernel on the chip at a time) -- the per-kernel STAND-ALONE breakdown, whose largest entry is
+    # the dominant kernel.  (As scheduled, the kernels of the engine's four HIP streams overlap and a kernel's duration
+    # includes its waiting for the others.)  The warm-up and the timed region then run as scheduled; the timed region
+    # instruments only the dominant kernel (one HIP event pair per launch on its stream).
+    PROF_STEPS = 7
     ms = (C.c_double * 16)(); cnt = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
+    share, sa_launch, dom, nk = {}, {}, None, 0
     if not dry:
         dx.check(dx.load().dabx_set_profiling(eng._h, -1))
-    step(args.warmup)
-    eng.synchronize()
-    share, dom, nk = {}, None, 0
-    if not dry:
+        step(PROF_STEPS)
+        eng.synchronize()
         nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
-        share = {names[i].decode(): ms[i] / max(1, args.warmup) for i in range(nk) if cnt[i]}      # stand-alone ms per step (warm-up)
+        share = {names[i].decode(): ms[i] / PROF_STEPS for i in range(nk) if cnt[i]}               # stand-alone ms per step
         sa_launch = {names[i].decode(): (ms[i] / cnt[i], int(cnt[i])) for i in range(nk) if cnt[i]}  # stand-alone ms per launch, launches
         dom = max(share, key=share.get) if share else "k_symbols"
         dom_idx = [names[i].decode() for i in range(nk)].index(dom)
+        dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+    step(args.warmup)
+    eng.synchronize()
+    if not dry:
         dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
     c1 = eng.counters()
 
@@ -461,11 +466,11 @@ def main():
                     valu = {"wave_insts_per_launch": int(vi), "issue_peak_per_s": peak, "issue_peak_source": peak_src,
                             "util": round(vi / (kern[dom] * 1e-3) / peak, 4)}
             standalone = None
-            if dom in sa_launch and args.warmup > 0:
-                # the same kernel with the chip to itself (warm-up, dabx_set_profiling -1): how far the kernel itself is from its
+            if dom in sa_launch:
+                # the same kernel with the chip to itself (priming pass, dabx_set_profiling -1): how far the kernel itself is from its
                 # bounds, apart from what the co-running front end takes away from it in the timed region
                 sa_ms, sa_n = sa_launch[dom]
-                sa_units = args.streams * args.warmup / sa_n
+                sa_units = args.streams * PROF_STEPS / sa_n
                 standalone = {"avg_launch_ms": round(sa_ms, 4), "frames_per_launch": round(sa_units, 2),
                               "achieved_GBps": round(A_KERNEL[dom] * sa_units / (sa_ms * 1e-3) / 1e9, 2)}
                 if valu is not None:
