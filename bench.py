@@ -234,16 +234,21 @@ def cpu_baseline(args, subch):
     return out
 
 
-def launch_ranks(args):
-    """`--gpus N` without a launcher: start N ranks of this script -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* in the environment as torch.distributed.run would set them -- BEFORE anything in this process touches the GPU
-    (the parent never initialises HIP), relay rank 0's JSON line, and fail if any rank fails."""
+def free_port():
     import socket
-    import subprocess
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
+    return port
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start N ranks of this script -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment as torch.distributed.run would set them -- BEFORE anything in this process touches the GPU
+    (the parent never initialises HIP), relay rank 0's JSON line, and fail if any rank fails."""
+    import subprocess
+    port = free_port()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
@@ -358,6 +363,9 @@ def main():
     if world > 1 or os.environ.get("DABX_BENCH_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist_
         dist = dist_
+        if "RANK" not in os.environ:                  # DABX_BENCH_FORCE_DIST without a launcher: a one-rank group on this host
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if dry:
             dist.init_process_group("gloo")
         else:
