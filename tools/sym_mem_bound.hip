@@ -1,0 +1,76 @@
+// sym_mem_bound.hip -- how fast can the MEMORY side of k_symbols go?  The same grid (75 x 512 blocks of 256 threads), the same
+// per-block traffic (a contiguous 2552-sample slice of a stream's ring read once, 12 of the samples per thread in one go; 1536
+// float2 written contiguously), the same residency (17.4 KB of LDS per block: 8 blocks per CU) -- and no transform: a few
+// FLOPs, one barrier.  Variants: (a) as above, (b) with four more barriers and an LDS round trip each (the transform's
+// synchronisation skeleton without its arithmetic).  k_symbols itself takes 0.29 ms per 512-stream step.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o build/sym_mem_bound tools/sym_mem_bound.hip && build/sym_mem_bound
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+constexpr int TU = 2048, TG = 504, TS = 2552, K = 1536, TF = 196608, S = 512, RING = 10 * TF;
+
+template <int SKEL>
+__global__ __launch_bounds__(256, 8) void k_stub(const float2 *iq, float2 *spectra, int frame)
+{
+  __shared__ float2 lds[2048 + 128];
+  const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
+  const float2 *ring = iq + (size_t)s * RING;
+  unsigned off = (unsigned)(((size_t)frame * TF + 2656 + (size_t)l * TS) % RING);
+  auto at = [&](unsigned i) { unsigned o = off + i; if (o >= RING) o -= RING; return ring[o]; };
+  const bool two = tid + 256 < TG;
+  const float2 cb0 = at(tid), ca0 = at(TU + tid), cb1 = at(two ? tid + 256 : tid), ca1 = at(two ? TU + tid + 256 : TU + tid);
+  float2 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) v[u] = at(TG + tid + 256 * u);
+  float acc = ca0.x * cb0.x + ca0.y * cb0.y + ca1.x * cb1.y;
+#pragma unroll
+  for (int u = 0; u < 8; u++) { v[u].x = v[u].x * 0.5f + acc; v[u].y = v[u].y * 0.25f - acc; }
+  if (SKEL) {
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) lds[(tid * 8 + u) + ((tid * 8 + u) >> 4)] = v[u];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; v[u] = lds[i + (i >> 4)]; }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; if (i < K + 256) lds[i] = v[u]; }
+  __syncthreads();
+  float2 *dst = spectra + ((size_t)s * 75 + l) * K;
+#pragma unroll
+  for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
+}
+
+int main()
+{
+  float2 *iq, *sp;
+  CK(hipMalloc(&iq, (size_t)S * RING * sizeof(float2)));
+  CK(hipMalloc(&sp, (size_t)S * 75 * K * sizeof(float2)));
+  CK(hipMemset(iq, 0, (size_t)S * RING * sizeof(float2)));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int skel = 0; skel < 2; skel++) {
+    std::vector<float> ms;
+    for (int it = 0; it < 24; it++) {
+      CK(hipEventRecord(a));
+      if (skel) hipLaunchKernelGGL(k_stub<1>, dim3(75, S), dim3(256), 0, 0, iq, sp, it % 10);
+      else hipLaunchKernelGGL(k_stub<0>, dim3(75, S), dim3(256), 0, 0, iq, sp, it % 10);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float t; CK(hipEventElapsedTime(&t, a, b));
+      if (it >= 4) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double med = ms[ms.size() / 2], bytes = (double)S * 75 * (TS + K) * 8;
+    printf("{\"variant\": \"%s\", \"median_ms\": %.4f, \"min_ms\": %.4f, \"GBps\": %.0f, \"bytes\": %.0f}\n",
+           skel ? "loads + 3 LDS exchanges with barriers + store" : "loads + store", med, ms[0], bytes / med / 1e6, bytes);
+  }
+  return 0;
+}
