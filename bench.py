@@ -122,6 +122,19 @@ def fill_rings(eng, torch, dev, args, rank, subch):
     return n_frames
 
 
+def load_pcie_inclusive():
+    """The PCIe-inclusive rate (every sample handed over as a host buffer) is measured by tools/bench_ingest.py, not in this
+    run -- value keeps the IQ resident in HBM -- and quoted from the kept profile so that it travels with the line."""
+    path = os.path.join(ROOT, "profiles", "r02_ingest_pcie.json")
+    try:
+        j = json.load(open(path))
+        best = max(j["formats"].items(), key=lambda kv: kv[1]["frames_per_s"])
+        return {"frames_per_s": best[1]["frames_per_s"], "host_GBps": best[1]["host_GBps"], "format_and_mode": best[0],
+                "streams": j["streams"], "measured_by": "tools/bench_ingest.py (separate run)", "source": "profiles/r02_ingest_pcie.json"}
+    except Exception:
+        return None
+
+
 def host_cpu():
     """CPU model and physical core count of the host (for the cpu_baseline record)."""
     model, cores = "unknown", set()
@@ -506,6 +519,8 @@ def main():
                       "frac_of_hbm_peak": round(value / n_joined * a_frame / HBM_PEAK, 6),
                       "kernel_ms_per_step_standalone": {k: round(v, 4) for k, v in share.items()}},
         }
+        if not dry and not args.fic_only and args.layout == "uniform" and args.streams == 512:
+            out["config"]["pcie_inclusive"] = load_pcie_inclusive()
         if dry:
             out["dry"] = True
             out["data"] = "none (dry launch: control flow only)"
