@@ -328,9 +328,12 @@ def load_traffic(dom):
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
-        if dom not in tj.get("kernels", {}):
+        # the profiler sees the kernel symbols, the engine's profile the step names: k_symbols runs as k_symbols_persistent, the
+        # MSC symbols' demapper as k_demap_frame6
+        sym = next((n for n in (dom, dom + "_persistent", dom + "6") if n in tj.get("kernels", {})), None)
+        if sym is None:
             continue
-        k = tj["kernels"][dom]
+        k = tj["kernels"][sym]
         fpl = k.get("frames_per_launch") or tj["streams"] * (7 if dom.startswith("k_msc") or dom == "k_dabplus" else 1)
         return {"file": "profiles/" + name, "streams": tj["streams"], "hbm_bytes_per_frame": k["hbm_bytes_per_launch"] / fpl,
                 "valu_per_frame": (k.get("valu_wave_insts_per_launch") or 0) / fpl}

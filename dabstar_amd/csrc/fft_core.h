@@ -141,4 +141,45 @@ __device__ __forceinline__ void fft2048(float2 v[8], float2 *lds, const float2 *
   __syncthreads();
 }
 
+// The same transform with all twenty twiddles of the thread already in registers (they depend on the thread index only): for
+// kernels that run many transforms per thread (persistent k_symbols) and must keep their vector-memory queue free of table
+// look-ups -- vmcnt is in order, a twiddle fetched behind a prefetch would make the wait for it a wait for the prefetch.
+struct FftTwiddles { float2 w2[7], w3[7], w4[2][3]; };
+__device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const float2 *tw, int tid)
+{
+  fft_twiddles8<8>(t.w2, tid, tw);
+  fft_twiddles8<64>(t.w3, tid, tw);
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) t.w4[h][q] = tw[FFT_TW_P4 + 512 * q + tid + 256 * h];
+}
+template <bool INV> __device__ __forceinline__ void fft2048_regs(float2 v[8], float2 *lds, const FftTwiddles &t, int tid)
+{
+  const float2 none[7] = {};
+  fft_pass8<INV, 1>(v, tid, lds, none);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; u++) v[u] = lds[fft_pad(tid + 256 * u)];
+  __syncthreads();
+  fft_pass8<INV, 8>(v, tid, lds, t.w2);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; u++) v[u] = lds[fft_pad(tid + 256 * u)];
+  __syncthreads();
+  fft_pass8<INV, 64>(v, tid, lds, t.w3);
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int j = tid + 256 * h;
+    float2 a = lds[fft_pad(j)], b = lds[fft_pad(j + 512)], c = lds[fft_pad(j + 1024)], d = lds[fft_pad(j + 1536)];
+    b = cmul(b, tw_dir<INV>(t.w4[h][0]));
+    c = cmul(c, tw_dir<INV>(t.w4[h][1]));
+    d = cmul(d, tw_dir<INV>(t.w4[h][2]));
+    dft4<INV>(a, b, c, d);
+    v[h] = a; v[h + 2] = b; v[h + 4] = c; v[h + 6] = d;
+  }
+  __syncthreads();
+}
+
 }  // namespace dabx

@@ -433,6 +433,97 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
   for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
 }
 
+// The same work with PERSISTENT blocks (DABX_SYM_PERSIST, grid (SYM_G, S)): a block walks symbols l = g, g + SYM_G, ... of its
+// stream, requests the NEXT symbol's twelve samples per thread before it transforms the current one, and keeps everything
+// that depends on the thread index only -- twenty twiddles, the de-interleaver indices, the NCO factor -- in registers
+// across symbols, so the only vector loads in the loop are the prefetch (tools/sym_mem_bound.hip: the memory side of this
+// kernel runs at 0.23-0.25 ms per step in that shape, with or without the transform's arithmetic next to it).  Same
+// operations on the same operands in the same order as k_symbols: identical results.
+constexpr int SYM_G = 15;                                    // blocks per stream: 5 symbols each
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_symbols_persistent(EngineDev e, DevTables t)
+{
+  front_prio(e);
+  __shared__ float2 lds[FFT_LDS_FLOAT2];
+  __shared__ float red3[3][4];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  int l = blockIdx.x;
+  int off = uniform_load(e.sym_off + (size_t)s * 76 + l);
+  double2 nco_base = uniform_load(e.nco_sym + (size_t)s * 76 + l);
+  const double2 nco_step = uniform_load(e.nco_sym + (size_t)s * 76 + 75);
+  if (off < 0) return;                                       // no frame for this stream in this step (all 75 entries are -1 then)
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned len = (unsigned)e.ring_len;
+  const bool two = tid + 256 < TG;
+  float2 nx[12];
+  auto request = [&](int o) {
+    auto at = [&](unsigned i) { unsigned a = (unsigned)o + i; if (a >= len) a -= len; return ring[a]; };
+    nx[0] = at(tid); nx[1] = at(TU + tid);
+    nx[2] = at(two ? tid + 256 : tid); nx[3] = at(two ? TU + tid + 256 : TU + tid);
+#pragma unroll
+    for (int u = 0; u < 8; u++) nx[4 + u] = at(TG + tid + 256 * u);
+  };
+  request(off);
+  const double2 nco_t = e.nco_tid[(size_t)s * 256 + tid];
+  FftTwiddles tw;
+  fft_load_twiddles(tw, t.twiddle, tid);
+  const uint4 kk4 = reinterpret_cast<const uint4 *>(t.bin_to_k8)[tid];
+  const unsigned kkw[4] = {kk4.x, kk4.y, kk4.z, kk4.w};
+  for (;;) {
+    const float2 cb0 = nx[0], ca0 = nx[1], cb1 = nx[2], ca1 = nx[3];
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = nx[4 + u];
+    const double2 base_now = nco_base;
+    const int l_next = l + SYM_G;
+    if (l_next < 75) {                                       // block-uniform
+      off = uniform_load(e.sym_off + (size_t)s * 76 + l_next);
+      nco_base = uniform_load(e.nco_sym + (size_t)s * 76 + l_next);
+      request(off);
+    }
+    asm volatile("" ::: "memory");
+    float cre = 0.f, cim = 0.f, asum = 0.f;
+    cre += ca0.x * cb0.x + ca0.y * cb0.y;
+    cim += ca0.y * cb0.x - ca0.x * cb0.y;
+    asum += cabsf_level(cb0);
+    if (two) {
+      cre += ca1.x * cb1.x + ca1.y * cb1.y;
+      cim += ca1.y * cb1.x - ca1.x * cb1.y;
+      asum += cabsf_level(cb1);
+    }
+    Nco nco;
+    nco.init_from(base_now, nco_step, nco_t);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const float2 x = v[u];
+      asum += cabsf_level(x);
+      v[u] = nco.mix(x);
+      nco.step();
+    }
+    cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
+    if ((tid & 63) == 0) { red3[0][tid >> 6] = cre; red3[1][tid >> 6] = cim; red3[2][tid >> 6] = asum; }
+    fft2048_regs<false>(v, lds, tw, tid);
+    if (tid == 0) {
+      float r[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { float a = 0.f; for (int w = 0; w < 4; w++) a += red3[q][w]; r[q] = a; }
+      e.cp_part[(size_t)s * 75 + l] = make_float2(r[0], r[1]); e.abs_part[(size_t)s * 76 + l] = r[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int kk = (int)(int16_t)(kkw[u >> 1] >> (16 * (u & 1)));
+      if (kk >= 0) lds[kk] = v[u];
+    }
+    __syncthreads();
+    float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
+#pragma unroll
+    for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
+    if (l_next >= 75) break;
+    l = l_next;
+    __syncthreads();                                          // the exchange buffer and red3 are free again
+  }
+}
+
 // -------------------------------------------------------------------------------------------------- demap
 constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
 template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
@@ -1168,7 +1259,11 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
     }
     mk.end(3, st);
   } else {
-    mk.begin(2, st); hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+    mk.begin(2, st);
+    if (e.sym_persist == 2) hipLaunchKernelGGL(k_symbols_persistent<3>, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t);
+    else if (e.sym_persist) hipLaunchKernelGGL(k_symbols_persistent<4>, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t);
+    else hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t);
+    mk.end(2, st);
     auto demap = [&](int l0, int l1) {
       if (e.demap_occ6) {
         if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame6<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);

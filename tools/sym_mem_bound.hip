@@ -49,6 +49,74 @@ __global__ __launch_bounds__(256, 8) void k_stub(const float2 *iq, float2 *spect
   for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
 }
 
+// (c) persistent blocks: grid (G, S), a block walks symbols l = g, g + G, ... with the NEXT symbol's 12 samples per thread
+// requested before the current one is "transformed" (WORK dependent FMAs per register stand in for the arithmetic) and stored;
+// BLOCKS_PER_CU residency via the launch bound (registers) -- does the memory side still reach its floor with 4 or 5 blocks per
+// CU when every block always has a symbol's loads in flight?
+template <int WAVES_PER_EU, int WORK>
+__global__ __launch_bounds__(256, WAVES_PER_EU) void k_stub_persistent(const float2 *iq, float2 *spectra, int frame, int G)
+{
+  __shared__ float2 lds[2048 + 128];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const float2 *ring = iq + (size_t)s * RING;
+  float2 nx[12];
+  auto request = [&](int l) {
+    const unsigned off = (unsigned)(((size_t)frame * TF + 2656 + (size_t)l * TS) % RING);
+    auto at = [&](unsigned i) { unsigned o = off + i; if (o >= RING) o -= RING; return ring[o]; };
+    const bool two = tid + 256 < TG;
+    nx[0] = at(tid); nx[1] = at(TU + tid); nx[2] = at(two ? tid + 256 : tid); nx[3] = at(two ? TU + tid + 256 : TU + tid);
+#pragma unroll
+    for (int u = 0; u < 8; u++) nx[4 + u] = at(TG + tid + 256 * u);
+  };
+  request(blockIdx.x);
+  for (int l = blockIdx.x; l < 75; l += G) {
+    float2 v[8];
+    float acc = nx[1].x * nx[0].x + nx[1].y * nx[0].y + nx[3].x * nx[2].y;
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = nx[4 + u];
+    if (l + G < 75) request(l + G);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 8; u++) { v[u].x = v[u].x * 0.5f + acc; v[u].y = v[u].y * 0.25f - acc; }
+#pragma unroll 1
+    for (int w = 0; w < WORK; w++)
+#pragma unroll
+      for (int u = 0; u < 8; u++) { v[u].x = __builtin_fmaf(v[u].x, 0.999f, v[u].y); v[u].y = __builtin_fmaf(v[u].y, 1.001f, -v[u].x); }
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) lds[(tid * 8 + u) + ((tid * 8 + u) >> 4)] = v[u];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; v[u] = lds[i + (i >> 4)]; }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = tid + 256 * u; if (i < K + 256) lds[i] = v[u]; }
+    __syncthreads();
+    float2 *dst = spectra + ((size_t)s * 75 + l) * K;
+#pragma unroll
+    for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
+    __syncthreads();
+  }
+}
+
+template <int WPE, int WORK> static void run_persistent(const float2 *iq, float2 *sp, int G, hipEvent_t a, hipEvent_t b)
+{
+  std::vector<float> ms;
+  for (int it = 0; it < 24; it++) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_stub_persistent<WPE, WORK>), dim3(G, S), dim3(256), 0, 0, iq, sp, it % 10, G);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float t; CK(hipEventElapsedTime(&t, a, b));
+    if (it >= 4) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double med = ms[ms.size() / 2], bytes = (double)S * 75 * (TS + K) * 8;
+  printf("{\"variant\": \"persistent, next symbol prefetched, %d waves/SIMD bound, G = %d, work = %d x 16 dependent FMAs\", \"median_ms\": %.4f, \"min_ms\": %.4f, \"GBps\": %.0f}\n",
+         WPE, G, WORK, med, ms[0], bytes / med / 1e6);
+}
+
 int main()
 {
   float2 *iq, *sp;
@@ -72,5 +140,12 @@ int main()
     printf("{\"variant\": \"%s\", \"median_ms\": %.4f, \"min_ms\": %.4f, \"GBps\": %.0f, \"bytes\": %.0f}\n",
            skel ? "loads + 3 LDS exchanges with barriers + store" : "loads + store", med, ms[0], bytes / med / 1e6, bytes);
   }
+  run_persistent<8, 0>(iq, sp, 15, a, b);
+  run_persistent<4, 0>(iq, sp, 15, a, b);
+  run_persistent<4, 0>(iq, sp, 25, a, b);
+  run_persistent<4, 24>(iq, sp, 15, a, b);      // ~ the transform's 400 non-load VALU instructions per thread
+  run_persistent<4, 24>(iq, sp, 25, a, b);
+  run_persistent<5, 24>(iq, sp, 15, a, b);
+  run_persistent<8, 24>(iq, sp, 15, a, b);
   return 0;
 }
