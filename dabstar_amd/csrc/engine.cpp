@@ -252,8 +252,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.demap_occ6 = 1; d.vit_prio = 0;
   if (const char *ev = getenv("DABX_DEMAP_OCC6")) d.demap_occ6 = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_VIT_PRIO")) d.vit_prio = atoi(ev);
-  d.sym_persist = 2;
-  if (const char *ev = getenv("DABX_SYM_PERSIST")) d.sym_persist = atoi(ev);
+  d.sym_persist = 1;
+  if (const char *ev = getenv("DABX_SYM_PERSIST")) d.sym_persist = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_PREP_ON_B")) d.prep_on_b = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_SPLIT_FIC")) d.split_fic = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_FRONT_PRIO")) d.front_prio = atoi(ev) != 0;

@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
 // kernel runs at 0.23-0.25 ms per step in that shape, with or without the transform's arithmetic next to it).  Same
 // operations on the same operands in the same order as k_symbols: identical results.
 constexpr int SYM_G = 15;                                    // blocks per stream: 5 symbols each
-template <int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_symbols_persistent(EngineDev e, DevTables t)
+// 3 waves per SIMD: 170 VGPRs without spills (bounded to 4 it spills 8 registers and runs 25 % slower)
+__global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevTables t)
 {
   front_prio(e);
   __shared__ float2 lds[FFT_LDS_FLOAT2];
@@ -1260,8 +1260,7 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
     mk.end(3, st);
   } else {
     mk.begin(2, st);
-    if (e.sym_persist == 2) hipLaunchKernelGGL(k_symbols_persistent<3>, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t);
-    else if (e.sym_persist) hipLaunchKernelGGL(k_symbols_persistent<4>, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t);
+    if (e.sym_persist) hipLaunchKernelGGL(k_symbols_persistent, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t);
     else hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t);
     mk.end(2, st);
     auto demap = [&](int l0, int l1) {
