@@ -1,0 +1,36 @@
+"""GPU: the one JSON line bench.py prints keeps its contract (the driver parses it): metric / value / unit, the run's own
+parameters, the `roofline` object of the dominant kernel with measured traffic and VALU figures, the `chain` view, and a
+receiver that actually decoded everything it was timed on."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_keeps_its_contract():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "14", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["metric"].startswith("DAB Mode-I ensembles/s") and j["unit"] == "frames/s" and j["higher_is_better"] is True
+    assert (j["n_gpus"], j["steps"], j["warmup"]) == (1, 14, 2) and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["data"] == "synthetic" and j["dtype"] == "f32+i32" and "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 50000 and abs(j["value"] * j["ms_per_step"] * 1e-3 - 512) < 2            # frames per step = 512 streams
+    # the timed work was really done: every stream in lock, every FIB good, 4 CIFs x 18 sub-channels x 192 bytes per frame
+    assert j["streams_locked"] == 512 and j["fib_crc_match_pct"] == 100.0 and j["superframes_failed"] == 0
+    assert j["msc_bytes"] == 512 * 14 * 4 * 18 * 192 and j["superframes_ok"] > 0
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_msc_vitT"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
+    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes_per_launch"] > 0          # measured bytes incl. the decision round trip
+    assert 0.2 < r["valu"]["util"] < 1.0 and 0.5 < r["standalone"]["valu_util"] < 1.0 and r["standalone"]["avg_launch_ms"] < r["avg_launch_ms"]
+    c = j["chain"]
+    assert c["algorithmic_bytes_per_frame"] == 2115456 and abs(c["frac_of_hbm_peak"] - j["value"] * 2115456 / 8e12) < 1e-4
+    assert set(c["kernel_ms_per_step_standalone"]) >= {"k_symbols", "k_demap_frame", "k_fic_frame", "k_msc_prep", "k_msc_vitT", "k_dabplus"}
