@@ -219,9 +219,12 @@ int  dabx_create(const dabx_config *cfg, dabx_engine **out);
 void dabx_destroy(dabx_engine *e);
 /* MscHandler::set_channel / stop_service equivalent for stream (or all streams when stream < 0): d[j] describes slot j
  * (kbps == 0: empty slot).  A slot whose description is unchanged keeps decoding without interruption; new or changed
- * slots start their 16-CIF de-interleaver fill at the current CIF (growing the largest bit rate restarts all).
+ * slots start their 16-CIF de-interleaver fill at the current CIF; a new largest bit rate re-strides the output rings in
+ * place, running services are not disturbed.
  * Streams may carry different layouts: the decoder groups the slots of all streams by protection profile (rebuilt by the
- * next dabx_process after a series of calls). */
+ * next dabx_process after a series of calls).  The 16 most populated profiles run on the lane-per-trellis kernels; further
+ * profiles and classes too small to fill a few wavefronts are decoded by the wave-per-trellis kernel in the same batch -- a
+ * throughput distinction only, no limit on the number of different profiles. */
 int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
 /* Host IQ -> device ring (IDeviceHandler::getSamples contract, common/device_handler_if.h:47-48).
  * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70).
