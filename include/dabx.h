@@ -222,7 +222,8 @@ void dabx_destroy(dabx_engine *e);
  * slots start their 16-CIF de-interleaver fill at the current CIF; a new largest bit rate re-strides the output rings in
  * place, running services are not disturbed.
  * Streams may carry different layouts: the decoder groups the slots of all streams by protection profile (rebuilt by the
- * next dabx_process after a series of calls).  The 16 most populated profiles run on the lane-per-trellis kernels; further
+ * next dabx_process after a series of calls).  The 16 profiles with the most decoder work (sub-channels x bit rate) run on the
+ * lane-per-trellis kernels; further
  * profiles and classes too small to fill a few wavefronts are decoded by the wave-per-trellis kernel in the same batch -- a
  * throughput distinction only, no limit on the number of different profiles. */
 int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
