@@ -532,7 +532,13 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   // symbols [l0, l1) of the frame (0-based: l = symbol index - 1).  The engine runs [0, 3) -- the FIC symbols -- first so
   // that k_fic_frame can start on its own HIP stream while [3, 75) is demapped; the per-carrier state passes through
   // HBM between the two launches exactly as it does from frame to frame.
-  front_prio(e);
+  // Wave priority: the FIC symbols are on the frame's feedback chain (FIC decoder -> frame tail -> next head); the MSC symbols
+  // are not once they are demapped asynchronously, and then they yield to the FIC decoder running next to them.
+  if (e.front_prio) {
+    if (l0 == 0 || e.demap_prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (e.demap_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (e.demap_prio == 1) __builtin_amdgcn_s_setprio(1);
+  }
   __shared__ float red[32];
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
   const int s = blockIdx.x, tid = threadIdx.x;

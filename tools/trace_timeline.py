@@ -5,7 +5,7 @@ root = sys.argv[1]
 rows = []
 for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].split("(")[0].replace("dabx::", "")
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dabx::", "").split("<")[0]
         if not n.startswith("k_"):
             continue
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
