@@ -1292,9 +1292,14 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
       else hipLaunchKernelGGL(k_demap_fic<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
       mk.end(10, st);
       DABX_HIP(hipEventRecord(ss.fic_go, st));
-      DABX_HIP(hipStreamWaitEvent(ss.c, ss.fic_go, 0));
-      mk.begin(4, ss.c); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, ss.c, e, *t, 0, 4); mk.end(4, ss.c);
-      DABX_HIP(hipEventRecord(ss.fic_done, ss.c));
+      // fic_on_a (needs async_demap): the FIC decoder stays on the front-end stream -- it is the next link of the frame's
+      // feedback chain anyway -- and only the MSC symbols' demapper leaves it: one cross-queue event pair per frame less
+      const bool fic_on_a = e.fic_on_a && e.async_demap && ss.d;
+      if (!fic_on_a) {
+        DABX_HIP(hipStreamWaitEvent(ss.c, ss.fic_go, 0));
+        mk.begin(4, ss.c); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, ss.c, e, *t, 0, 4); mk.end(4, ss.c);
+        DABX_HIP(hipEventRecord(ss.fic_done, ss.c));
+      }
       if (e.async_demap && ss.d) {
         DABX_HIP(hipStreamWaitEvent(ss.d, ss.fic_go, 0));
         hipStream_t keep = st;
@@ -1306,7 +1311,8 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
       } else {
         mk.begin(3, st); demap(3, 75); mk.end(3, st);
       }
-      DABX_HIP(hipStreamWaitEvent(st, ss.fic_done, 0));
+      if (fic_on_a) { mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st); }
+      else DABX_HIP(hipStreamWaitEvent(st, ss.fic_done, 0));
       mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
       DABX_HIP(hipGetLastError());
       return 0;
