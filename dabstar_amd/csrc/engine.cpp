@@ -254,7 +254,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   if (const char *ev = getenv("DABX_VIT_PRIO")) d.vit_prio = atoi(ev);
   d.sym_persist = 1;
   d.demap_prio = 1;
-  d.fic_on_a = 0;
+  d.fic_on_a = 1;
   if (const char *ev = getenv("DABX_FIC_ON_A")) d.fic_on_a = atoi(ev) != 0;
   if (const char *ev = getenv("DABX_DEMAP_PRIO")) d.demap_prio = atoi(ev) & 3;
   if (const char *ev = getenv("DABX_SYM_PERSIST")) d.sym_persist = atoi(ev) != 0;

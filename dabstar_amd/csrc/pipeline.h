@@ -71,7 +71,7 @@ struct EngineDev {
   int32_t strongest, fic_only, capture_soft;
   int32_t async_demap;            // 1: MSC symbols demapped on their own HIP stream while the front end goes on to the next frame
   int32_t demap_occ6;             // 1 (default): the demapper build for six waves per SIMD -- two 12-wave blocks share a CU (DABX_DEMAP_OCC6)
-  int32_t fic_on_a;               // 1: FIC decoder on the front-end stream, only the MSC demapper on its own (DABX_FIC_ON_A)
+  int32_t fic_on_a;               // 1 (default): FIC decoder on the front-end stream, only the MSC demapper on its own (DABX_FIC_ON_A)
   int32_t demap_prio;             // wave priority of the MSC symbols' demapper (0..3, default 1: below the FIC decoder that runs next to it; DABX_DEMAP_PRIO)
   int32_t sym_persist;            // 1 (default): persistent, prefetching k_symbols; 0: one block per symbol (DABX_SYM_PERSIST)
   int32_t vit_prio;               // 1: lane-per-trellis decoder waves lower their priority as they progress (measured: kernel -6 %, chain -2 %; off)
