@@ -1174,3 +1174,55 @@ def test_dc_and_iq_imbalance_correction_follows_the_oracle(mode):
     for j in range(len(subch)):
         assert np.array_equal(eng.read_msc(0, j, 16), o_msc[j][kk - 16:kk]), j
     eng.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"DABX_FIC_ON_A": "0"},                                                        # FIC decoder on its own (third) stream
+    {"DABX_ASYNC_DEMAP": "0"},                                                     # MSC symbols demapped on the front-end stream
+    {"DABX_SPLIT_FIC": "0"},                                                       # one demapper launch per frame, FIC behind it
+    {"DABX_SYM_PERSIST": "0", "DABX_DEMAP_OCC6": "0", "DABX_DEMAP_PRIO": "3"},     # one block per symbol, round-1 demapper build
+    {"DABX_FRONT_PRIO": "0", "DABX_PREP_ON_B": "0", "DABX_STREAM_PRIO": "0,0"},     # no priorities, k_msc_prep on the front-end stream
+    {"DABX_VIT_PRIO": "3", "DABX_MSC_FAST_MIN_JOBS": "64", "DABX_MSC_CLASS_MIN_JOBS": "1"},   # lane-per-trellis decoder with its priority experiments on
+], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+def test_scheduling_switches_do_not_change_a_byte(monkeypatch, env):
+    """The run-time switches of INTEGRATION.md section 7 only move kernels between HIP streams, change wave / stream
+    priorities or select another build of the same arithmetic: soft bits of every symbol, FIBs and CRC flags, MSC bytes, super
+    frames, the per-frame scalars and every counter are identical to the default configuration's (which the rest of this
+    file compares with the oracle)."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=92)
+    x = ds.channel(ens.iq, snr_db=8.0, cfo_hz=-1730.0, timing_offset=99000, seed=92, n_out=21 * ds.TF)
+
+    def run():
+        eng = dx.Engine(n_streams=3, ring_frames=22, max_subch=18, out_frames=8, capture_soft=True)
+        eng.set_subchannels(subch)
+        for s in range(3):
+            eng.push_iq(s, x[2111 * s:])
+        soft = []
+        for m in (1, 1, 3, 7, 2, 5):                                   # 19 frames in calls of different sizes (MSC batches of 1..7 frames)
+            eng.process(m)
+            soft.append([eng.read_soft(s).copy() for s in range(3)])
+        out = dict(soft=soft, stats=[eng.stats(s) for s in range(3)], fibs=[eng.read_fibs(s, 8) for s in range(3)],
+                   msc=[[eng.read_msc(s, j, 16) for j in range(18)] for s in range(3)],
+                   sf=[[eng.read_superframes(s, j, 2) for j in range(18)] for s in range(3)],
+                   sub=[[eng.subch_stats(s, j) for j in range(18)] for s in range(3)], counters=eng.counters())
+        eng.close()
+        return out
+
+    for k in ("DABX_FIC_ON_A", "DABX_ASYNC_DEMAP", "DABX_SPLIT_FIC", "DABX_SYM_PERSIST", "DABX_DEMAP_OCC6", "DABX_DEMAP_PRIO", "DABX_FRONT_PRIO",
+              "DABX_PREP_ON_B", "DABX_STREAM_PRIO", "DABX_VIT_PRIO", "DABX_MSC_FAST_MIN_JOBS", "DABX_MSC_CLASS_MIN_JOBS", "DABX_FUSED_FRONT"):
+        monkeypatch.delenv(k, raising=False)
+    ref = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    assert ref["stats"][0]["frames"] >= 17 and ref["counters"]["sf_ok"] > 0
+    assert got["counters"] == ref["counters"] and got["stats"] == ref["stats"] and got["sub"] == ref["sub"]
+    for a, b in zip(got["soft"], ref["soft"]):
+        for s in range(3):
+            assert np.array_equal(a[s], b[s]), s
+    for s in range(3):
+        assert np.array_equal(got["fibs"][s][0], ref["fibs"][s][0]) and np.array_equal(got["fibs"][s][1], ref["fibs"][s][1])
+        for j in range(18):
+            assert np.array_equal(got["msc"][s][j], ref["msc"][s][j]), (s, j)
+            assert np.array_equal(got["sf"][s][j], ref["sf"][s][j]), (s, j)
