@@ -429,7 +429,7 @@ def main():
     eng.synchronize()
     # Still priming: one whole MSC batch (7 steps) with every kernel instrumented and the host waiting for each one
     # (dabx_set_profiling -1: one kernel on the chip at a time) -- the per-kernel STAND-ALONE breakdown, whose largest entry is
-    # the dominant kernel.  (As scheduled, the kernels of the engine's four HIP streams overlap and a kernel's duration
+    # the dominant kernel.  (As scheduled, the kernels of the engine's HIP streams overlap and a kernel's duration
     # includes its waiting for the others.)  The warm-up and the timed region then run as scheduled; the timed region
     # instruments only the dominant kernel (one HIP event pair per launch on its stream).
     PROF_STEPS = 7
