@@ -181,19 +181,29 @@ def cpu_baseline(args, subch):
     x = np.ascontiguousarray(np.tile(x10, (n + 2 + 9) // 10))
     L = ol.oracle()
 
-    def run_one(frames):
+    L.ora_viterbi_seconds.restype = C.c_double
+    L.ora_viterbi_seconds.argtypes = [C.POINTER(C.c_longlong)]
+    vit = {}
+
+    def run_one(frames, tag=None):
         rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+        L.ora_viterbi_seconds_reset()
         t0 = time.perf_counter()
         got = L.ora_rx_run(rx, x, len(x), frames)
         dt = time.perf_counter() - t0
+        if tag:                                       # where the chain's time goes: the decoder's share (single-threaded legs only)
+            calls = C.c_longlong()
+            sec = L.ora_viterbi_seconds(C.byref(calls))
+            vit[tag] = {"viterbi_share_of_time": round(sec / dt, 3), "viterbi_us_per_block": round(1e6 * sec / max(1, calls.value), 1)}
         L.ora_rx_destroy(rx)
         return got, dt
 
-    got, dt = run_one(n)
+    got, dt = run_one(n, "default")
     sample = "%d frames of 1 stream (18x64k EEP3-A, %g dB) through oracle/ (plain C, %s)" % (got, args.snr, build)
     out = {"value": round(got / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample,
            "variant": "reference-default (scalar demapper, scalar int32 Viterbi)",
            "cpu_model": model, "physical_cores": phys_cores, "logical_cpus": logical}
+    out.update(vit.get("default", {}))
     # reference-best: the reference's own AVX2 Viterbi object inside the same chain (single-threaded: its path metrics are
     # file-scope arrays)
     R = ol.ref_viterbi_variant("avx2")
@@ -201,12 +211,13 @@ def cpu_baseline(args, subch):
         L.ora_set_viterbi_hook.argtypes = [C.c_void_p]
         L.ora_set_viterbi_hook(C.cast(R.ref_viterbi_cached, C.c_void_p))
         try:
-            got_b, dt_b = run_one(n)
+            got_b, dt_b = run_one(n, "best")
         finally:
             L.ora_set_viterbi_hook(None)
         out["reference_best"] = {"value": round(got_b / dt_b, 3), "unit": "frames/s", "cores": 1, "kind": "port+reference",
                                  "variant": "reference-best (scalar demapper, the reference's VITERBI_AVX2 object code)",
                                  "sample": "%d frames of the same stream" % got_b}
+        out["reference_best"].update(vit.get("best", {}))
     # the same port on every host core (streams are independent: one receiver per thread, ctypes drops the GIL)
     import threading
     ncpu = min(64, logical)

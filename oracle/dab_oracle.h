@@ -67,7 +67,9 @@ void ora_prbs(uint8_t *out, int n);
  * tie_mode 0 = scalar/SSE2 tie rule (decision 0), 1 = AVX2 tie rule (viterbi_16way.h). */
 void ora_viterbi(const int16_t *soft, int nbits, uint8_t *out_bits);
 void ora_viterbi_simd(const int16_t *soft, int nbits, uint8_t *out_bits);
-void ora_viterbi_sse2(const int16_t *soft, int nbits, uint8_t *out_bits);   /* viterbi_8way.h body (VITERBI_SSE2 / NEON builds) */
+void ora_viterbi_sse2(const int16_t *soft, int nbits, uint8_t *out_bits);
+double ora_viterbi_seconds(long long *calls);   /* wall time spent in ora_viterbi_build since the last reset (single-threaded use) */
+void ora_viterbi_seconds_reset(void);   /* viterbi_8way.h body (VITERBI_SSE2 / NEON builds) */
 void ora_set_viterbi_mode(int mode);     /* 0 scalar body (default), 1 AVX2 body: what fic.c / protection.c decode with */
 void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits);
 void ora_set_viterbi_hook(void (*fn)(const int16_t *, int, uint8_t *));   /* bench.py: the reference's AVX2 object as the decoder */   /* body of the VITERBI_AVX2 / _SSE2 builds, viterbi_16way.h */

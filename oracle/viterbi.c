@@ -190,13 +190,32 @@ void ora_set_viterbi_mode(int mode) { g_viterbi_mode = mode; }
 /* CPU-baseline leg only (bench.py "reference-best"): decode through the reference's OWN AVX2 object code
  * (oracle/_ref/libdabref_vit_avx2.so, ref_viterbi_cached) instead of the plain-C restatement above. */
 void ora_set_viterbi_hook(void (*fn)(const int16_t *, int, uint8_t *)) { g_viterbi_hook = fn; }
+/* time spent inside the decoder (all bodies), for the CPU-baseline breakdown of bench.py */
+#include <time.h>
+static double g_viterbi_seconds = 0.0;
+static long long g_viterbi_calls = 0;
+double ora_viterbi_seconds(long long *calls) { if (calls) *calls = g_viterbi_calls; return g_viterbi_seconds; }
+void ora_viterbi_seconds_reset(void) { g_viterbi_seconds = 0.0; g_viterbi_calls = 0; }
+static void viterbi_build_inner(const int16_t *soft, int nbits, uint8_t *out_bits);
 void ora_viterbi_build(const int16_t *soft, int nbits, uint8_t *out_bits)
+{
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  viterbi_build_inner(soft, nbits, out_bits);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  g_viterbi_seconds += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+  g_viterbi_calls++;
+}
+static void viterbi_build_inner(const int16_t *soft, int nbits, uint8_t *out_bits)
 {
   if (g_viterbi_hook) {
 #ifdef __AVX__
     __builtin_ia32_vzeroupper();     /* native build: leave no dirty upper vector state for the callee's 128 / 256-bit code */
 #endif
     g_viterbi_hook(soft, nbits, out_bits);
+#ifdef __AVX__
+    __builtin_ia32_vzeroupper();     /* ... and none for the non-VEX library code that runs after it (the callee returns with its own) */
+#endif
   }
   else if (g_viterbi_mode == 1) ora_viterbi_simd(soft, nbits, out_bits);
   else if (g_viterbi_mode == 2) ora_viterbi_sse2(soft, nbits, out_bits);
