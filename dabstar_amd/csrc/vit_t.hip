@@ -48,6 +48,24 @@ __device__ __forceinline__ void prep_item(int it, int cw, bool full, int &d, int
 __device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int tid, int p0, int cw, const uint8_t *const *s_base, const long long *s_r)
 {
   const bool full = cw == PCH / 4;
+  if (full) {
+    // whole chunk: item r of thread tid is (job r, plane (tid >> 4) & 15, dword tid & 15) -- tid + 256 r split by 16 and 16 --
+    // so the plane's part of the address is per-thread constant and only the job's base changes with r
+    const int pl = (tid >> 4) & 15, d = tid & 15;
+    const int brev = bitrev4(pl);
+    const unsigned in_plane = (unsigned)pl * (CIF_BITS / 16) + (unsigned)p0 + 4u * (unsigned)d;
+#pragma unroll
+    for (int r = 0; r < PREP_STG; r++) {
+      const uint8_t *base = s_base[r];
+      uint32_t v = 0x7F7F7F7Fu;
+      if (base) {
+        const unsigned slot = (unsigned)(s_r[r] - 16 + brev) & (TDI_SLOTS - 1);      // out_r[idx] = in_{r-16+map[idx&15]}[idx], backend.cpp:129
+        v = *reinterpret_cast<const uint32_t *>(base + (size_t)slot * CIF_BITS + in_plane);
+      }
+      stage[r] = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < PREP_STG; r++) {
     const int it = tid + 256 * r;
@@ -98,13 +116,19 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
     const int cw = chunk_dwords(p0);                               // dwords per run in this chunk
     const bool full = cw == PCH / 4;
     // (1) this chunk's items into the LDS tile
+    if (full) {                                                     // item r = (job r, this thread's plane and dword): see prep_request
+      uint8_t *mine_w = tile + ((tid >> 4) & 15) * PCH + 4 * (tid & 15);
 #pragma unroll
-    for (int r = 0; r < PREP_STG; r++) {
-      const int it = tid + 256 * r;
-      if (it < PJB * 16 * cw) {
-        int d, pl, job;
-        prep_item(it, cw, full, d, pl, job);
-        *reinterpret_cast<uint32_t *>(tile + job * PJS + pl * PCH + 4 * d) = stage[r];
+      for (int r = 0; r < PREP_STG; r++) *reinterpret_cast<uint32_t *>(mine_w + r * PJS) = stage[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < PREP_STG; r++) {
+        const int it = tid + 256 * r;
+        if (it < PJB * 16 * cw) {
+          int d, pl, job;
+          prep_item(it, cw, full, d, pl, job);
+          *reinterpret_cast<uint32_t *>(tile + job * PJS + pl * PCH + 4 * d) = stage[r];
+        }
       }
     }
     __syncthreads();

@@ -2,6 +2,7 @@
 # Builds libdabx of the committed HEAD into ab/libdabx_head.so (git worktree in /tmp), for same-box A/B runs against the
 # working tree's build with tools/ab.sh.  ab/ is not tracked (*.so is git-ignored) but travels to the GPU box.
 set -e
+mkdir -p "$(cd "$(dirname "$0")/.." && pwd)/ab"
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=$(mktemp -d /tmp/dabx_head.XXXXXX)
 git -C "$ROOT" worktree add -f "$W" HEAD -q
