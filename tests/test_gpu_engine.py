@@ -905,6 +905,36 @@ def test_largest_and_smallest_subchannels():
     eng.close()
 
 
+def test_maximum_dab_plus_rate_384_kbit_with_rs_corrections():
+    """The largest sub-channel the DAB+ stage holds: 384 kbit/s (EEP 3-A, 288 CU; 48 RS code words per super frame fill the
+    5-frame window in LDS to its last byte, 1152-byte logical frames, a 9216-step trellis) next to a 64 kbit/s one, at
+    9.5 dB where Reed-Solomon has byte errors to correct -- bit-exact vs the oracle including every RS / AU counter (the
+    synthetic super frame's sixth AU is longer than 960 bytes at this rate: counted as bad on both sides, mp4processor.cpp:300-304)."""
+    subch = [ds.SubCh(1, 0, 288, 384, 2, 0), ds.SubCh(2, 400, 48, 64, 2, 0)]
+    ens = ds.build_ensemble(10, subch, seed=133)
+    x = ds.channel(ens.iq, snr_db=9.5, cfo_hz=-377.0, timing_offset=7777, seed=23, n_out=23 * ds.TF + 50000)
+    ora = _oracle_run(x, subch)
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"])
+    n = min(len(fibs), ora["n"])
+    assert len(fibs) == ora["n"] and n >= 20
+    assert np.array_equal(crc[:n], ora["crc"][:n])
+    ok = ora["crc"][:n].astype(bool)
+    assert np.array_equal(fibs[:n][ok], ora["fibs"][:n][ok])
+    for j, c in enumerate(subch):
+        st, o = eng.subch_stats(0, j), ora["stats"][j]
+        assert st["cifs_decoded"] == o["cif_out"] and st["cifs_decoded"] >= 60
+        for a, b in (("sf_ok", "sf_ok"), ("sf_fail", "sf_fail"), ("rs_corrected", "rs_corr"), ("rs_failed", "rs_fail"),
+                     ("au_ok", "au_ok"), ("au_bad", "au_bad")):
+            assert st[a] == o[b], (j, a, st[a], o[b])
+        assert st["sf_ok"] >= 8
+        k, nb = st["cifs_decoded"], 3 * c.kbps
+        assert np.array_equal(eng.read_msc(0, j, 16), ora["msc"][j].reshape(-1, nb)[k - 16:k]), j
+        sf_o = ora["sf"][j].reshape(-1, 110 * c.kbps // 8)
+        assert np.array_equal(eng.read_superframes(0, j, 3), sf_o[len(sf_o) - 3:]), j
+    assert eng.subch_stats(0, 0)["rs_corrected"] > 0                      # the decoder really had errors to correct at this SNR
+    eng.close()
+
+
 def test_growing_the_largest_bit_rate_keeps_every_running_service_and_stream():
     """Adding a sub-channel with a higher bit rate than any configured before widens the output-ring slots
     (dabx_set_subchannels re-strides the rings with their contents).  The reference's MscHandler::set_channel only adds a

@@ -199,7 +199,7 @@ def build_superframe(kbps: int, rng: np.random.Generator) -> np.ndarray:
     else:
         # high bit rates: dac_rate=1, sbr=0 -> 6 AUs (each must stay <= 960 bytes), first starts at 11
         sf[2] = (1 << 6) | (1 << 4)
-        step = (n - 11) // 6
+        step = min((n - 11) // 6, (4095 - 11) // 5)        # AU starts are 12-bit fields (beyond 352 kbit/s the last AU takes the rest)
         a = [11 + i * step for i in range(6)]
         sf[3], sf[4], sf[5] = a[1] >> 4, ((a[1] & 0xF) << 4) | (a[2] >> 8), a[2] & 0xFF
         sf[6], sf[7], sf[8] = a[3] >> 4, ((a[3] & 0xF) << 4) | (a[4] >> 8), a[4] & 0xFF
