@@ -68,3 +68,16 @@ def test_stream_params_are_deterministic_and_rank_independent():
     b = [shard.stream_params(g) for g in range(16)]
     assert a == b and len(set(a)) == 16
     assert shard.streams_for_rank(3, 8, 512)[0] == 1536
+
+
+def test_eight_rank_partition_covers_4096_streams_once():
+    """BASELINE configs[4]: 4096 ensembles over 8 GPUs = 512 per rank, contiguous blocks, every stream on exactly one rank,
+    channel parameters a function of the global stream id only (a stream decodes the same wherever it runs)."""
+    from dabstar_amd import shard
+    owned = [shard.streams_for_rank(r, 8, 512) for r in range(8)]
+    flat = [s for o in owned for s in o]
+    assert len(flat) == 4096 and sorted(flat) == list(range(4096)) and all(len(o) == 512 for o in owned)
+    assert all(o == list(range(o[0], o[0] + 512)) for o in owned)
+    p = [shard.stream_params(s) for s in (0, 511, 512, 4095)]
+    assert p == [shard.stream_params(s) for s in (0, 511, 512, 4095)] and len(set(p)) == 4
+    assert all(0 <= t < 196608 and abs(c) <= 1900 / 0.96 + 1e-9 for t, c in p)
