@@ -27,7 +27,9 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 struct DevTables {
   uint16_t *perm_bin;       // [1536] carrier k -> FFT bin (0..2047)                 freq_interleaver.cpp:40-76
   int16_t *bin_to_k;        // [2048] inverse of perm_bin: FFT bin -> carrier index k, -1 for the unused bins
-  int16_t *bin_to_k8;       // [256][8] the same in the register layout of fft_core.h: [tid][u] = bin_to_k[tid + 256 u] (one 16-byte load)
+  int16_t *bin_to_slot8;    // [256][8] register layout of fft_core.h: [tid][u] = LDS slot of the carrier of bin tid + 256 u (-1 unused):
+                            //          slot(k) = (k & ~15) | sigma(k), sigma a permutation within each run of 16 carriers (tables.cpp)
+  uint32_t *carrier_slot_rd;// [256] sigma(tid + 256 u), u = 0..5, four bits each: what thread tid of k_symbols reads back
   int16_t *perm_rel;        // [1536] realCarrRelIdx                                   ofdm_decoder.cpp:171-179
   float2 *prs_ref;          // [2048] phase reference symbol                           phasetable.cpp:87-101
   float2 *prs_arg_conj;     // [2048] conj(IFFT(relative phase of PRS))                phasereference.cpp:58-66

@@ -105,12 +105,11 @@ int dabx_engine::build_msc_classes()
   std::vector<std::pair<Key, std::vector<uint32_t>>> order(groups.begin(), groups.end());
   std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) {
     return (long long)a.second.size() * a.first.kbps > (long long)b.second.size() * b.first.kbps; });
-  // 64 trellises per wave, decoded on the second HIP stream: measured break-even against the wave-per-trellis kernel at
-  // ~320 waves per batch (40-48 streams of 18 sub-channels); DABX_MSC_FAST_MIN_JOBS overrides (tests)
-  size_t min_jobs = 64 * 320;
-  if (const char *ev = getenv("DABX_MSC_FAST_MIN_JOBS")) min_jobs = (size_t)atoll(ev);
-  size_t class_min_jobs = 256;                                     // fewer than 4 decoder waves per full batch: not worth a class
-  if (const char *ev = getenv("DABX_MSC_CLASS_MIN_JOBS")) class_min_jobs = (size_t)atoll(ev);
+  // 64 trellises per wave: measured break-even against the wave-per-trellis kernel at ~320 waves per batch (40-48 streams
+  // of 18 sub-channels); a class with fewer than 4 decoder waves per full batch is not worth its own launch slice.
+  // dabx_config.msc_fast_min_jobs / msc_class_min_jobs override both (include/dabx.h).
+  const size_t min_jobs = cfg.msc_fast_min_jobs > 0 ? (size_t)cfg.msc_fast_min_jobs : (size_t)64 * 320;
+  const size_t class_min_jobs = cfg.msc_class_min_jobs > 0 ? (size_t)cfg.msc_class_min_jobs : 256;
   const int max_cifs = 4 * MSC_BATCH_FRAMES;
   long long jobs_total = 0;
   std::vector<std::vector<uint32_t>> host_pairs;
@@ -179,7 +178,6 @@ static int sync_all(dabx_engine *e)
   if (int rc = use_device(e)) return rc;
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
-  if (e->ss.c) DABX_HIP(hipStreamSynchronize(e->ss.c));
   if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
   return 0;
 }
@@ -206,7 +204,9 @@ void dabx_default_config(dabx_config *c)
 int dabx_create(const dabx_config *cfg, dabx_engine **out)
 {
   if (!cfg || !out || cfg->n_streams <= 0 || cfg->ring_frames < 2 || cfg->max_subch < 0 || cfg->max_subch > MAX_SUBCH ||
-      cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3 || cfg->dc_iq_correction < 0 || cfg->dc_iq_correction > 2) {
+      cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3 || cfg->dc_iq_correction < 0 || cfg->dc_iq_correction > 2 ||
+      cfg->viterbi_tie_mode < 0 || cfg->viterbi_tie_mode > 2 || cfg->schedule < 0 || cfg->schedule > 1 ||
+      cfg->msc_fast_min_jobs < 0 || cfg->msc_class_min_jobs < 0 || cfg->exact_level_tracker < 0 || cfg->exact_level_tracker > 1) {
     set_error("dabx_create: bad configuration");
     return DABX_E_ARG;
   }
@@ -214,28 +214,29 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   if (rc) return rc;
   auto *e = new dabx_engine();
   e->cfg = *cfg;
-  DABX_HIP(hipGetDevice(&e->device));
-  // front end (frame-to-frame feedback = critical path) above the batched MSC decode; DABX_STREAM_PRIO=a,b overrides
-  int prio_lo = 0, prio_hi = 0, pa, pb;
+  // from here on every failure goes through dabx_destroy (streams, events and buffers created so far are released)
+#define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); dabx_destroy(e); return DABX_E_HIP; } } while (0)
+  H(hipGetDevice(&e->device));
+  // front end (frame-to-frame feedback = critical path) above the batched MSC decode
+  int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // lo = least urgent (numerically greatest)
-  pa = prio_hi; pb = prio_lo;
-  if (const char *ev = getenv("DABX_STREAM_PRIO")) { if (sscanf(ev, "%d,%d", &pa, &pb) != 2) { pa = prio_hi; pb = prio_lo; } }
-  DABX_HIP(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, pa));
+  H(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi));
   e->ss.a = e->stream;
-  DABX_HIP(hipStreamCreateWithPriority(&e->ss.b, hipStreamNonBlocking, pb));
-  // both HIP streams live on this device: a device-scope release is all the dependency needs (the default system-scope
-  // release writes the caches back for host visibility on every record)
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
-  DABX_HIP(hipStreamCreateWithPriority(&e->ss.c, hipStreamNonBlocking, pa));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.fic_done, hipEventDisableTiming | hipEventReleaseToDevice));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
-  DABX_HIP(hipStreamCreateWithPriority(&e->ss.d, hipStreamNonBlocking, pa));
-  DABX_HIP(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
-  DABX_HIP(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
-  DABX_HIP(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
-  DABX_HIP(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  if (cfg->schedule == 0) {
+    // overlapped schedule (default): MSC batches on b, the MSC symbols' demapper on d (pipeline.hip, launch_front_step /
+    // launch_msc_batch).  All streams live on this device: a device-scope release is all a dependency needs (the default
+    // system-scope release writes the caches back for host visibility on every record)
+    H(hipStreamCreateWithPriority(&e->ss.b, hipStreamNonBlocking, prio_lo));
+    H(hipStreamCreateWithPriority(&e->ss.d, hipStreamNonBlocking, prio_hi));
+    H(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
+  }
+  H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
+  H(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
+  H(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
   e->rd_seen.assign(cfg->n_streams, 0);
   const int S = cfg->n_streams;
   EngineDev &d = e->dev;
@@ -243,25 +244,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.ring_len = cfg->ring_frames * TF;
   d.threshold = cfg->sync_threshold; d.strongest = cfg->sync_strongest;
   d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft; d.tie_mode = cfg->viterbi_tie_mode;
-  d.fused_front = 0;
-  d.front_prio = 1;
-  d.split_fic = 1;
-  d.prep_on_b = 1;
-  d.async_demap = 1;
-  if (const char *ev = getenv("DABX_ASYNC_DEMAP")) d.async_demap = atoi(ev) != 0;
-  d.demap_occ6 = 1; d.vit_prio = 0;
-  if (const char *ev = getenv("DABX_DEMAP_OCC6")) d.demap_occ6 = atoi(ev) != 0;
-  if (const char *ev = getenv("DABX_VIT_PRIO")) d.vit_prio = atoi(ev);
-  d.sym_persist = 1;
-  d.demap_prio = 1;
-  d.fic_on_a = 1;
-  if (const char *ev = getenv("DABX_FIC_ON_A")) d.fic_on_a = atoi(ev) != 0;
-  if (const char *ev = getenv("DABX_DEMAP_PRIO")) d.demap_prio = atoi(ev) & 3;
-  if (const char *ev = getenv("DABX_SYM_PERSIST")) d.sym_persist = atoi(ev) != 0;
-  if (const char *ev = getenv("DABX_PREP_ON_B")) d.prep_on_b = atoi(ev) != 0;
-  if (const char *ev = getenv("DABX_SPLIT_FIC")) d.split_fic = atoi(ev) != 0;
-  if (const char *ev = getenv("DABX_FRONT_PRIO")) d.front_prio = atoi(ev) != 0;
-  if (const char *ev = getenv("DABX_FUSED_FRONT")) d.fused_front = atoi(ev);
+  d.exact_level = cfg->exact_level_tracker;
   const DevTables *t;
   if ((rc = get_tables(&t))) { dabx_destroy(e); return rc; }
 #define A(x) if ((rc = (x))) { dabx_destroy(e); return rc; }
@@ -275,8 +258,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   {
     std::vector<float> st8((size_t)S * 8, 0.0f);                  // sample_reader.h:102-106: meanII = meanQQ = 1
     for (int s_ = 0; s_ < S; s_++) { st8[(size_t)s_ * 8 + 2] = 1.0f; st8[(size_t)s_ * 8 + 3] = 1.0f; }
-    DABX_HIP(hipMemcpyAsync(d.dciq_state, st8.data(), sizeof(float) * st8.size(), hipMemcpyHostToDevice, e->stream));
-    DABX_HIP(hipStreamSynchronize(e->stream));
+    H(hipMemcpyAsync(d.dciq_state, st8.data(), sizeof(float) * st8.size(), hipMemcpyHostToDevice, e->stream));
+    H(hipStreamSynchronize(e->stream));
   }
   A(e->alloc(&d.nco_tid, (size_t)S * 256));
   A(e->alloc(&d.nco_sym, (size_t)S * 76));
@@ -306,8 +289,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     memset(&c, 0, sizeof(c));
     c.state = ST_INIT; c.s_level = 0.1f; c.peak_level = -1.0e6f; c.sync_thr = cfg->sync_threshold;
   }
-  DABX_HIP(hipMemcpyAsync(d.ctl, ctl.data(), sizeof(StreamCtl) * S, hipMemcpyHostToDevice, e->stream));
-  DABX_HIP(hipStreamSynchronize(e->stream));
+  H(hipMemcpyAsync(d.ctl, ctl.data(), sizeof(StreamCtl) * S, hipMemcpyHostToDevice, e->stream));
+  H(hipStreamSynchronize(e->stream));
   e->wr_host.assign(S, 0);
   e->subch_host.assign((size_t)S * std::max(1, d.max_subch), SubchDev{});
   e->subch_id_host.assign((size_t)S * std::max(1, d.max_subch), -1);
@@ -317,6 +300,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.vit_scratch, (size_t)S * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * d.vit_stride, false));
   d.msc_stride = 0; d.sf_stride = 0;
 #undef A
+#undef H
   *out = e;
   return 0;
 }
@@ -327,9 +311,7 @@ void dabx_destroy(dabx_engine *e)
   (void)use_device(e);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->ss.b) { (void)hipStreamSynchronize(e->ss.b); (void)hipStreamDestroy(e->ss.b); }
-  if (e->ss.c) { (void)hipStreamSynchronize(e->ss.c); (void)hipStreamDestroy(e->ss.c); }
   if (e->ss.fic_go) (void)hipEventDestroy(e->ss.fic_go);
-  if (e->ss.fic_done) (void)hipEventDestroy(e->ss.fic_done);
   if (e->ss.prep_b_done) (void)hipEventDestroy(e->ss.prep_b_done);
   if (e->ss.d) { (void)hipStreamSynchronize(e->ss.d); (void)hipStreamDestroy(e->ss.d); }
   if (e->ss.demap_done) (void)hipEventDestroy(e->ss.demap_done);
@@ -393,24 +375,34 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
   // (MscHandler::set_channel only adds a Backend, msc_handler.cpp:95-131): the rings are re-strided with their contents,
   // every counter and ring index stays valid, the superseded buffers are freed.
   if (max_kbps > e->max_kbps) {
-    const int old_msc = d.msc_stride, old_sf = d.sf_stride;
-    uint8_t *old_msc_out = d.msc_out, *old_sf_out = d.sf_out;
-    uint32_t *old_scratch = d.vit_scratch;
-    e->max_kbps = max_kbps;
-    d.msc_stride = 3 * max_kbps;
-    d.sf_stride = ((110 * max_kbps / 8) + 15) & ~15;
-    d.vit_stride = (int)std::max(vit_scratch_words(FIC_OUT), vit_scratch_words(24 * max_kbps));
+    // new buffers first; pointers, strides and max_kbps change only after all three exist and the contents are moved, so a
+    // failed allocation leaves the engine exactly as it was
+    const int new_msc = 3 * max_kbps, new_sf = ((110 * max_kbps / 8) + 15) & ~15;
+    const int new_vit = (int)std::max(vit_scratch_words(FIC_OUT), vit_scratch_words(24 * max_kbps));
     const size_t msc_rows = (size_t)d.n_streams * d.max_subch * MSC_SLOTS, sf_rows = (size_t)d.n_streams * d.max_subch * SF_SLOTS;
-    if ((rc = e->alloc(&d.msc_out, msc_rows * d.msc_stride))) return rc;
-    if ((rc = e->alloc(&d.sf_out, sf_rows * d.sf_stride))) return rc;
-    if ((rc = e->alloc(&d.vit_scratch, (size_t)d.n_streams * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * d.vit_stride, false))) return rc;
-    if (old_msc_out && old_msc > 0)
-      DABX_HIP(hipMemcpy2DAsync(d.msc_out, d.msc_stride, old_msc_out, old_msc, old_msc, msc_rows, hipMemcpyDeviceToDevice, e->stream));
-    if (old_sf_out && old_sf > 0)
-      DABX_HIP(hipMemcpy2DAsync(d.sf_out, d.sf_stride, old_sf_out, old_sf, old_sf, sf_rows, hipMemcpyDeviceToDevice, e->stream));
-    DABX_HIP(hipStreamSynchronize(e->stream));
-    for (void *q : {(void *)old_msc_out, (void *)old_sf_out, (void *)old_scratch})
-      if (q) { (void)hipFree(q); e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), q), e->allocs.end()); }
+    uint8_t *n_msc = nullptr, *n_sf = nullptr;
+    uint32_t *n_scratch = nullptr;
+    auto drop = [&](void *q) { if (q) { (void)hipFree(q); e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), q), e->allocs.end()); } };
+    if ((rc = e->alloc(&n_msc, msc_rows * new_msc)) || (rc = e->alloc(&n_sf, sf_rows * new_sf)) ||
+        (rc = e->alloc(&n_scratch, (size_t)d.n_streams * (4 + 4 * MSC_BATCH_FRAMES * d.max_subch) * new_vit, false))) {
+      drop(n_msc); drop(n_sf); drop(n_scratch);
+      return rc;
+    }
+    hipError_t herr = hipSuccess;
+    if (d.msc_out && d.msc_stride > 0)
+      herr = hipMemcpy2DAsync(n_msc, new_msc, d.msc_out, d.msc_stride, d.msc_stride, msc_rows, hipMemcpyDeviceToDevice, e->stream);
+    if (herr == hipSuccess && d.sf_out && d.sf_stride > 0)
+      herr = hipMemcpy2DAsync(n_sf, new_sf, d.sf_out, d.sf_stride, d.sf_stride, sf_rows, hipMemcpyDeviceToDevice, e->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
+    if (herr != hipSuccess) {
+      drop(n_msc); drop(n_sf); drop(n_scratch);
+      set_error("dabx_set_subchannels: HIP error %d (%s) while re-striding the output rings", (int)herr, hipGetErrorString(herr));
+      return DABX_E_HIP;
+    }
+    drop(d.msc_out); drop(d.sf_out); drop(d.vit_scratch);
+    d.msc_out = n_msc; d.sf_out = n_sf; d.vit_scratch = n_scratch;
+    d.msc_stride = new_msc; d.sf_stride = new_sf; d.vit_stride = new_vit;
+    e->max_kbps = max_kbps;
   }
   for (int s = 0; s < d.n_streams; s++) {
     if (stream >= 0 && s != stream) continue;
@@ -557,6 +549,7 @@ int dabx_host_register(void *p, size_t bytes)
 int dabx_host_unregister(void *p)
 {
   if (!p) return DABX_E_ARG;
+  if (int rc = need_device_e()) return rc;
   DABX_HIP(hipHostUnregister(p));
   return 0;
 }
@@ -810,6 +803,7 @@ int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)
   out->fic_ratio_percent = c.fic_ratio * 10; out->freq_offs_bb_hz = c.f_bb; out->clock_err_hz = c.clock_err;
   out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;
   out->fib_ok = c.fib_ok; out->fib_total = c.fib_total;
+  out->signal_level = c.s_level; out->peak_level = c.peak_level;
   std::vector<SubchDev> sc(std::max(1, e->dev.max_subch));
   DABX_HIP(hipMemcpy(sc.data(), e->dev.subch + (size_t)stream * e->dev.max_subch, sizeof(SubchDev) * e->dev.max_subch, hipMemcpyDeviceToHost));
   for (int j = 0; j < e->dev.max_subch; j++) {

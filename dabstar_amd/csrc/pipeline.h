@@ -69,16 +69,7 @@ struct EngineDev {
   int32_t ring_len;               // IQ ring capacity per stream in samples
   float threshold;
   int32_t strongest, fic_only, capture_soft;
-  int32_t async_demap;            // 1: MSC symbols demapped on their own HIP stream while the front end goes on to the next frame
-  int32_t demap_occ6;             // 1 (default): the demapper build for six waves per SIMD -- two 12-wave blocks share a CU (DABX_DEMAP_OCC6)
-  int32_t fic_on_a;               // 1 (default): FIC decoder on the front-end stream, only the MSC demapper on its own (DABX_FIC_ON_A)
-  int32_t demap_prio;             // wave priority of the MSC symbols' demapper (0..3, default 1: below the FIC decoder that runs next to it; DABX_DEMAP_PRIO)
-  int32_t sym_persist;            // 1 (default): persistent, prefetching k_symbols; 0: one block per symbol (DABX_SYM_PERSIST)
-  int32_t vit_prio;               // 1: lane-per-trellis decoder waves lower their priority as they progress (measured: kernel -6 %, chain -2 %; off)
-  int32_t prep_on_b;              // 1: k_msc_prep on the decoder's HIP stream instead of the front end's
-  int32_t split_fic;              // 1: FIC decoder on its own HIP stream next to the demapping of the MSC symbols
-  int32_t front_prio;             // 1: front-end kernels raise their wave priority (s_setprio 3) over the batched MSC decoder
-  int32_t fused_front;            // 1: symbols + demap in one kernel (k_front_fused), spectra stay in LDS
+  int32_t exact_level;            // 1: in lock, SampleReader's level IIR is run sample by sample too (cfg.exact_level_tracker)
   int32_t tie_mode;               // 1: Viterbi arithmetic of the reference's AVX2 / SSE2 builds (viterbi_core.h, vit_step_simd)
   int32_t msc_stride;             // bytes per logical-frame slot (3 * max kbps)
   int32_t sf_stride;              // bytes per super-frame slot (110 * max kbps / 8)
@@ -116,7 +107,7 @@ struct EngineDev {
 // ---- lane-per-trellis path of the MSC decoder (vit_t.hip) ------------------------------------------------------
 // The sub-channels of ALL streams are grouped into classes of equal protection profile (same depuncture map and
 // trellis length): the 64 lanes of a decoder wave then share the map and step count whatever ensemble they come from.
-constexpr int MSC_MAX_CLASSES = 16;
+constexpr int MSC_MAX_CLASSES = DABX_MSC_FAST_CLASSES;   // include/dabx.h
 struct MscClass {
   int n_in, nbits;          // soft bits per job (cu_size*64), decoded bits (24*kbps)
   int n_pairs;              // (stream, slot) pairs in the class
@@ -138,8 +129,8 @@ struct MscLaunch { int n, groups; MscLaunchCls c[MSC_MAX_CLASSES]; };
 // HIP streams/events of the engine: front end on `a`; the long lane-per-trellis decode of batch n runs on `b`
 // while `a` already demodulates the frames of batch n+1.
 struct EngineStreams {
-  hipStream_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;   // c: FIC decoder, d: demapper of the MSC symbols of the frame in flight
-  hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, fic_done = nullptr, prep_b_done = nullptr, demap_done = nullptr;
+  hipStream_t a = nullptr, b = nullptr, d = nullptr;   // d: demapper of the MSC symbols of the frame in flight; b, d null = serial schedule
+  hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
   unsigned step_count = 0;
   bool prep_pending = false;      // k_msc_prep of the previous batch may still be reading the TDI ring on stream b

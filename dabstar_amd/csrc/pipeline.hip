@@ -21,8 +21,8 @@ namespace dabx {
 // block per stream); the batched MSC decoder (k_msc_vitT, own HIP stream) keeps every SIMD's VALU busy with four waves of
 // independent work.  At equal priority the arbiter shares issue slots evenly and the front end -- the critical path of a
 // step -- runs at half speed whenever the decoder is resident.  s_setprio 3 lets front-end waves issue first; the decoder
-// fills the slots they leave.  DABX_FRONT_PRIO=0 switches it off (A/B in DESIGN.md 6).
-__device__ __forceinline__ void front_prio(const EngineDev &e) { if (e.front_prio) __builtin_amdgcn_s_setprio(3); }
+// fills the slots they leave (+2.5 % same-box).
+__device__ __forceinline__ void front_prio() { __builtin_amdgcn_s_setprio(3); }
 
 // IQ ring addressing: one 64-bit modulo per thread and kernel (for the window base), then 32-bit
 // add + conditional subtract per sample.
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
 // --------------------------------------------------------------------------------------------- frame head
 __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 {
-  front_prio(e);
+  front_prio();
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float peak[TU];
   __shared__ float red[8];
@@ -358,92 +358,25 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 }
 
 // ------------------------------------------------------------------------------------------------ symbols
-// grid (76, S): x = 0..74 -> OFDM symbols 1..75.  (The null symbol is handled by k_frame_tail: it needs the
-// fine-CFO update that depends on all 75 cyclic-prefix correlations.)
-__global__ __launch_bounds__(256, 8) void k_symbols(EngineDev e, DevTables t)
-{
-  front_prio(e);
-  __shared__ float2 lds[FFT_LDS_FLOAT2];
-  __shared__ float red3[3][4];
-  const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;   // l = symbol index - 1
-  // Everything this block needs from memory is requested up front, in one go: the block-uniform words over the scalar cache
-  // (the kernel does not write them), then the 12 samples of this thread and its NCO factor.  (As first written the block
-  // made five dependent round trips before its first butterfly -- frame_ok, sym0_pos, two cyclic-prefix iterations, the
-  // FFT samples -- and spent 70 % of its wave cycles waiting.)
-  const int off = uniform_load(e.sym_off + (size_t)s * 76 + l);
-  const double2 nco_base = uniform_load(e.nco_sym + (size_t)s * 76 + l), nco_step = uniform_load(e.nco_sym + (size_t)s * 76 + 75);
-  if (off < 0) return;                                           // no frame for this stream in this step
-  const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  const unsigned len = (unsigned)e.ring_len;
-  auto at = [&](unsigned i) { unsigned o = (unsigned)off + i; if (o >= len) o -= len; return ring[o]; };
-  // cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504 (dab_processor.cpp:330-333) on the RAW samples;
-  // the NCO contributes the constant factor e^{-j 2 pi f Tu / fs} which k_frame_tail applies once.
-  const bool two = tid + 256 < TG;                               // i = tid and, for tid < 248, i = tid + 256
-  const float2 cb0 = at(tid), ca0 = at(TU + tid);
-  const float2 cb1 = at(two ? tid + 256 : tid), ca1 = at(two ? TU + tid + 256 : TU + tid);
-  float2 v[8];
-#pragma unroll
-  for (int u = 0; u < 8; u++) v[u] = at(TG + tid + 256 * u);
-  const double2 nco_t = e.nco_tid[(size_t)s * 256 + tid];
-  asm volatile("" ::: "memory");                                  // the loads stay above this line
-  float cre = 0.f, cim = 0.f, asum = 0.f;
-  cre += ca0.x * cb0.x + ca0.y * cb0.y;
-  cim += ca0.y * cb0.x - ca0.x * cb0.y;
-  asum += cabsf_level(cb0);
-  if (two) {
-    cre += ca1.x * cb1.x + ca1.y * cb1.y;
-    cim += ca1.y * cb1.x - ca1.x * cb1.y;
-    asum += cabsf_level(cb1);
-  }
-  Nco nco;
-  nco.init_from(nco_base, nco_step, nco_t);
-#pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const float2 x = v[u];
-    asum += cabsf_level(x);
-    v[u] = nco.mix(x);
-    nco.step();
-  }
-  // the three block sums ride on the FFT's barriers: per-wave partials go to LDS now, thread 0 adds them (in wave order,
-  // as block_sum does) once the transform has synchronised the block
-  cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
-  if ((tid & 63) == 0) { red3[0][tid >> 6] = cre; red3[1][tid >> 6] = cim; red3[2][tid >> 6] = asum; }
-  uint4 kk4;                                               // eight int16 carrier indices
-  fft2048<false>(v, lds, t.twiddle, tid, [&]() {          // :337-338; the hook runs before the last pass: de-interleaver indices on their way
-    kk4 = reinterpret_cast<const uint4 *>(t.bin_to_k8)[tid];
-  });
-  const unsigned kkw[4] = {kk4.x, kk4.y, kk4.z, kk4.w};
-  if (tid == 0) {
-    float r[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) { float a = 0.f; for (int w = 0; w < 4; w++) a += red3[q][w]; r[q] = a; }
-    e.cp_part[(size_t)s * 75 + l] = make_float2(r[0], r[1]); e.abs_part[(size_t)s * 76 + l] = r[2];
-  }
-  // Frequency de-interleaving rides on the way out (freq_interleaver.cpp:40-76): each bin goes to its carrier index in LDS
-  // (the transform's exchange buffer is free again), the 1536 used carriers are then stored contiguously.  The demapper
-  // reads carrier k of every symbol with coalesced loads; the 512 unused bins are never written.
-#pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const int kk = (int)(int16_t)(kkw[u >> 1] >> (16 * (u & 1)));
-    if (kk >= 0) lds[kk] = v[u];
-  }
-  __syncthreads();
-  float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
-#pragma unroll
-  for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
-}
-
-// The same work with PERSISTENT blocks (DABX_SYM_PERSIST, grid (SYM_G, S)): a block walks symbols l = g, g + SYM_G, ... of its
-// stream, requests the NEXT symbol's twelve samples per thread before it transforms the current one, and keeps everything
-// that depends on the thread index only -- twenty twiddles, the de-interleaver indices, the NCO factor -- in registers
-// across symbols, so the only vector loads in the loop are the prefetch (tools/sym_mem_bound.hip: the memory side of this
-// kernel runs at 0.23-0.25 ms per step in that shape, with or without the transform's arithmetic next to it).  Same
-// operations on the same operands in the same order as k_symbols: identical results.
+// Symbols 1..75 of a frame: NCO mix, cyclic-prefix correlation, FFT, frequency de-interleave (dab_processor.cpp:304-341).
+// (The null symbol is handled by k_frame_tail: it needs the fine-CFO update that depends on all 75 correlations.)
+// PERSISTENT blocks, grid (SYM_G, S): a block walks symbols l = g, g + SYM_G, ... of its stream, requests the NEXT symbol's
+// twelve samples per thread (4 for the cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504, taken on the RAW samples --
+// the NCO contributes the constant factor e^{-j 2 pi f Tu / fs}, which k_frame_tail applies once -- and 8 for the transform;
+// coalesced 8-byte loads) before it transforms the current one, and keeps everything that depends on the thread index only --
+// twenty twiddles, the de-interleaver slots, the NCO factor -- in registers across symbols.  The block-uniform words (ring
+// offset of the symbol, written per symbol by k_frame_head; NCO base) come over the scalar cache, so the only vector loads in
+// the loop are the prefetch (vmcnt is in order: a table look-up behind it would wait for it).  tools/sym_mem_bound.hip: the
+// memory side of this kernel runs at 0.23-0.25 ms per step in that shape, with or without the transform next to it.
+// The three block sums ride on the FFT's barriers: per-wave partials go to LDS, thread 0 adds them in wave order.
+// Frequency de-interleaving rides on the way out (freq_interleaver.cpp:40-76): each bin goes to its carrier's slot in LDS
+// (the transform's exchange buffer is free again), the 1536 used carriers are then stored contiguously; the demapper reads
+// carrier k of every symbol with coalesced loads, the 512 unused bins are never written.
 constexpr int SYM_G = 15;                                    // blocks per stream: 5 symbols each
 // 3 waves per SIMD: 170 VGPRs without spills (bounded to 4 it spills 8 registers and runs 25 % slower)
 __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevTables t)
 {
-  front_prio(e);
+  front_prio();
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red3[3][4];
   const int s = blockIdx.y, tid = threadIdx.x;
@@ -467,8 +400,12 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
   const double2 nco_t = e.nco_tid[(size_t)s * 256 + tid];
   FftTwiddles tw;
   fft_load_twiddles(tw, t.twiddle, tid);
-  const uint4 kk4 = reinterpret_cast<const uint4 *>(t.bin_to_k8)[tid];
+  // LDS slot of the carrier each of this thread's eight bins goes to (-1: unused bin), and the low four slot bits of the six
+  // carriers it stores afterwards (tables.cpp, carrier_slots: a permutation within each run of 16 carriers, chosen so that
+  // neither the scatter nor the read-back has a bank conflict)
+  const uint4 kk4 = reinterpret_cast<const uint4 *>(t.bin_to_slot8)[tid];
   const unsigned kkw[4] = {kk4.x, kk4.y, kk4.z, kk4.w};
+  const unsigned rd_lo = t.carrier_slot_rd[tid];
   for (;;) {
     const float2 cb0 = nx[0], ca0 = nx[1], cb1 = nx[2], ca1 = nx[3];
     float2 v[8];
@@ -517,7 +454,7 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
     __syncthreads();
     float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
 #pragma unroll
-    for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[tid + 256 * u];
+    for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[((tid + 256 * u) & ~15) | ((rd_lo >> (4 * u)) & 15u)];
     if (l_next >= 75) break;
     l = l_next;
     __syncthreads();                                          // the exchange buffer and red3 are free again
@@ -526,6 +463,7 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
 
 // -------------------------------------------------------------------------------------------------- demap
 constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
+constexpr int TILE_PLANE = 196;                                   // LDS bytes per plane of the output tile (192 used)
 template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
 __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &t, const int l0, const int l1)
 {
@@ -533,14 +471,11 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   // that k_fic_frame can start on its own HIP stream while [3, 75) is demapped; the per-carrier state passes through
   // HBM between the two launches exactly as it does from frame to frame.
   // Wave priority: the FIC symbols are on the frame's feedback chain (FIC decoder -> frame tail -> next head); the MSC symbols
-  // are not once they are demapped asynchronously, and then they yield to the FIC decoder running next to them.
-  if (e.front_prio) {
-    if (l0 == 0 || e.demap_prio == 3) __builtin_amdgcn_s_setprio(3);
-    else if (e.demap_prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (e.demap_prio == 1) __builtin_amdgcn_s_setprio(1);
-  }
+  // are not once they are demapped on their own HIP stream, and then they yield to the FIC decoder running next to them but
+  // stay above the batched MSC decoder (+1.7 % same-box against priority 3, profiles/r02_ab/ab11.json).
+  if (l0 == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
   __shared__ float red[32];
-  __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[2][16 * TILE_PLANE];
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
   // the first launch of a frame (l0 == 0) reads the stream's scalars and leaves a snapshot; a later launch of the same frame
@@ -588,14 +523,16 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barriers of
   // the mean-value reduction each of the 768 threads stores ONE aligned dword -- 48 consecutive dwords per plane --
   // instead of four scattered byte stores with their address arithmetic.  Two tiles: a fast thread may already fill the
-  // next symbol's tile while a slow one still drains this one.
+  // next symbol's tile while a slow one still drains this one.  A plane takes TILE_PLANE = 196 bytes of LDS (49 dwords,
+  // odd): the 16 planes a wave's byte stores touch then fall on 16 different banks (with 192 B = 48 dwords they fell on two,
+  // an 8-way conflict on each of the four stores per thread and symbol; tools/lds_conflicts.py).
   static_assert(DEMAP_THREADS == 768 && DEMAP_Q == 2, "tile <-> thread mapping below");
   int tpos[2 * DEMAP_Q];                                   // tile byte offsets of (re, im) of this thread's carriers
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
     const int k = tid + DEMAP_THREADS * q;
-    tpos[2 * q] = (k & 15) * 192 + (k >> 4);
-    tpos[2 * q + 1] = ((K + k) & 15) * 192 + ((K + k) >> 4);
+    tpos[2 * q] = (k & 15) * TILE_PLANE + (k >> 4);
+    tpos[2 * q + 1] = ((K + k) & 15) * TILE_PLANE + ((K + k) >> 4);
   }
   const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
   for (int l = l0; l < l1; l++) {                         // the demapper state advances on all 75 symbols in every mode
@@ -633,10 +570,10 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     if (l < 3) {                                            // symbols 1..3 -> FIC, linear: bytes 4 tid .. 4 tid + 3
       uint32_t v = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) { const int i = 4 * tid + b; v |= (uint32_t)tl[(i & 15) * 192 + (i >> 4)] << (8 * b); }
+      for (int b = 0; b < 4; b++) { const int i = 4 * tid + b; v |= (uint32_t)tl[(i & 15) * TILE_PLANE + (i >> 4)] << (8 * b); }
       reinterpret_cast<uint32_t *>(fic + l * K2)[tid] = v;
     } else {                                                // MSC -> planar time-de-interleaver ring
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * 192 + 4 * out_dw);
+      const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * TILE_PLANE + 4 * out_dw);
       *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
     }
   }
@@ -658,157 +595,14 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   }
 }
 
-template <int SOFT_TYPE>
-__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_frame(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
-// the same, compiled for six waves per SIMD (<= 80 VGPRs): two 12-wave blocks share a CU instead of taking turns
+// Built for six waves per SIMD (<= 80 VGPRs, 7 values spilled outside the loop): two 12-wave blocks share a CU instead of
+// taking turns (at 94 VGPRs only one fitted: 0.32 -> 0.24 ms per step).
 template <int SOFT_TYPE>
 __global__ __launch_bounds__(DEMAP_THREADS, 6) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
-// the FIC symbols alone (first launch of a frame when the FIC decoder has its own stream): its own kernel symbol so that
-// rocprofv3's per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
+// the FIC symbols alone (first launch of a frame in the overlapped schedule): its own kernel symbol so that rocprofv3's
+// per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
 template <int SOFT_TYPE>
 __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE>(e, t, 0, 3); }
-
-// ------------------------------------------------------------------------------------------- symbols + demap, fused
-// k_symbols and k_demap_frame in one kernel (DABX_FUSED_FRONT, engine.cpp): the 75 spectra of a frame never travel to HBM
-// (0.92 MB written and read back per frame, 0.94 GB per step of 512 streams).  One block of 768 threads per stream; the 75
-// symbols are taken three at a time: (A) each 256-thread group g mixes and transforms symbol 3 i + g exactly as
-// k_symbols does and leaves the frequency-de-interleaved carriers in ITS FFT exchange buffer; (B) all 768 threads demap
-// the three symbols in order, two carriers per thread from LDS, exactly as k_demap_frame does.  Same operations in the
-// same order as the two-kernel path: identical soft bits, sums and state (tests compare the two paths bit for bit).
-template <int SOFT_TYPE, int WAVES_PER_SIMD>      // 6: two blocks per CU (80 VGPRs, some state spills across the FFT phase); 3: one block, no spills
-__global__ __launch_bounds__(DEMAP_THREADS, WAVES_PER_SIMD) void k_front_fused(EngineDev e, DevTables t)
-{
-  front_prio(e);
-  __shared__ float2 lds[3][FFT_LDS_FLOAT2];
-  __shared__ float red3[3][3][4];
-  __shared__ float red[32];
-  __shared__ __attribute__((aligned(16))) uint8_t tile[2][K2];
-  const int s = blockIdx.x, tid = threadIdx.x, g = tid >> 8, gt = tid & 255;
-  StreamCtl &c = e.ctl[s];
-  if (!c.frame_ok) return;
-  DemapDev &d = e.demap;
-  // ---- demapper state of this thread's two carriers (k_demap_frame)
-  DemapPair cr;
-  v2f rel_f;
-#pragma unroll
-  for (int q = 0; q < DEMAP_Q; q++) {
-    const int k = tid + DEMAP_THREADS * q;
-    const int bin = t.perm_bin[k];
-    rel_f[q] = (float)(K / 2 - t.perm_rel[k]);
-    const float2 pr = d.phase_ref[(size_t)s * TU + bin];
-    cr.prev_re[q] = pr.x; cr.prev_im[q] = pr.y;
-    cr.integ[q] = d.integ[(size_t)s * K + k];
-    cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
-    cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
-    cr.null_power[q] = (c.np_sel ? d.null_power2 : d.null_power)[(size_t)s * TU + bin];
-  }
-  float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
-  const v2f wk = (v2f){mpa_weight(tid), mpa_weight(tid + DEMAP_THREADS)};
-  v2f pacc = (v2f)(0.0f);
-  const float ce = c.clock_err;
-  const long long cif0 = c.cif_no;
-  uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
-  uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
-  int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
-  static_assert(DEMAP_THREADS == 768 && DEMAP_Q == 2, "tile <-> thread mapping below");
-  int tpos[2 * DEMAP_Q];
-#pragma unroll
-  for (int q = 0; q < DEMAP_Q; q++) {
-    const int k = tid + DEMAP_THREADS * q;
-    tpos[2 * q] = (k & 15) * 192 + (k >> 4);
-    tpos[2 * q + 1] = ((K + k) & 15) * 192 + ((K + k) >> 4);
-  }
-  const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
-  // ---- per-frame constants of the transform part (k_symbols)
-  const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  const unsigned long long sym1_pos = c.sym0_pos + TU;
-  const double2 nco_t = e.nco_tid[(size_t)s * 256 + gt];
-
-  for (int it = 0; it < 25; it++) {
-    // ================= (A) three symbols: NCO mix, cyclic-prefix correlation, FFT, frequency de-interleave (k_symbols)
-    {
-      const int l = 3 * it + g;
-      const unsigned long long base = sym1_pos + (unsigned long long)l * TS;
-      float cre = 0.f, cim = 0.f, asum = 0.f;
-      const RingView rv(ring, e.ring_len, base);
-      for (int i = gt; i < TG; i += 256) {
-        const float2 a = rv.at(TU + i), b = rv.at(i);
-        cre += a.x * b.x + a.y * b.y;
-        cim += a.y * b.x - a.x * b.y;
-        asum += cabsf_level(b);
-      }
-      float2 v[8];
-      Nco nco;
-      nco.init_from(e.nco_sym[(size_t)s * 76 + l], e.nco_sym[(size_t)s * 76 + 75], nco_t);
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const float2 x = rv.at(TG + gt + 256 * u);
-        asum += cabsf_level(x);
-        v[u] = nco.mix(x);
-        nco.step();
-      }
-      cre = wave_sum(cre); cim = wave_sum(cim); asum = wave_sum(asum);
-      if ((gt & 63) == 0) { red3[g][0][gt >> 6] = cre; red3[g][1][gt >> 6] = cim; red3[g][2][gt >> 6] = asum; }
-      fft2048<false>(v, lds[g], t.twiddle, gt);
-      if (gt == 0) {
-        float r[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) { float a = 0.f; for (int w = 0; w < 4; w++) a += red3[g][q][w]; r[q] = a; }
-        e.cp_part[(size_t)s * 75 + l] = make_float2(r[0], r[1]); e.abs_part[(size_t)s * 76 + l] = r[2];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int kk = t.bin_to_k[gt + 256 * u];
-        if (kk >= 0) lds[g][kk] = v[u];
-      }
-      __syncthreads();
-    }
-    // ================= (B) the three symbols through the demapper, in order (k_demap_frame)
-#pragma unroll 1
-    for (int q3 = 0; q3 < 3; q3++) {
-      const int l = 3 * it + q3;
-      const int m = l - 3, cif = m / 18, blk = m % 18;
-      const float w2 = demap_w2(mean_value, SOFT_TYPE);
-      uint8_t *tl = tile[l & 1];
-      const float2 x0 = lds[q3][tid], x1 = lds[q3][tid + DEMAP_THREADS];
-      int16_t sr[2], si[2];
-      v2f pw;
-      const v2f mag = demap_pair<SOFT_TYPE>(cr, (v2f){x0.x, x1.x}, (v2f){x0.y, x1.y}, rel_f, ce, w2, sr, si, pw);
-      const float part = mag.x + mag.y;
-      pacc = pacc * mpa_decay() + pw;
-#pragma unroll
-      for (int q = 0; q < DEMAP_Q; q++) {
-        tl[tpos[2 * q]] = soft_to_sym_mode(sr[q], e.tie_mode);
-        tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[q], e.tie_mode);
-        if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[q]; cap[(size_t)l * K2 + K + k] = si[q]; }
-      }
-      mean_value = block_sum(part, red, tid) * (1.0f / (float)K);
-      if (l < 3) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) { const int i = 4 * tid + b; v |= (uint32_t)tl[(i & 15) * 192 + (i >> 4)] << (8 * b); }
-        reinterpret_cast<uint32_t *>(fic + l * K2)[tid] = v;
-      } else {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * 192 + 4 * out_dw);
-        *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
-      }
-    }
-    __syncthreads();                      // the exchange buffers are rewritten by the next triple
-  }
-#pragma unroll
-  for (int q = 0; q < DEMAP_Q; q++) {
-    const int k = tid + DEMAP_THREADS * q;
-    d.integ[(size_t)s * K + k] = cr.integ[q];
-    d.mean_power[(size_t)s * K + k] = cr.mean_power[q];
-    d.mean_sigma[(size_t)s * K + k] = cr.mean_sigma_sq[q];
-  }
-  float ns = cr.null_power.x + cr.null_power.y, wsum = wk.x * pacc.x + wk.y * pacc.y;
-  block_sum2w(ns, wsum, red, tid);
-  if (tid == 0) {
-    mpa = mpa * mpa_decay_n(75) + wsum;
-    d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa; c.snr_db = snr_db_from(mpa, ns);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------- FIC
 struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map
@@ -828,7 +622,7 @@ struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depun
 // and 3 with symbol 3.
 __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int first, int count)
 {
-  front_prio(e);
+  front_prio();
   __shared__ __attribute__((aligned(16))) char wtab[4][VIT_BLK * 16];
   __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
   __shared__ uint32_t raw[4][32];           // chain-back output, 30 bits per word (26 words + padding)
@@ -892,7 +686,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
 // --------------------------------------------------------------------------------------------- frame tail
 __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
 {
-  front_prio(e);
+  front_prio();
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red[8];
   __shared__ float s_fbb;
@@ -993,7 +787,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
       // symbols 1..75: lv <- lv q^75 + (1 - q) sum_l q^(74-l) mean_l, the weighted sum taken in parallel above
       lv = lv * __expf((float)(75 * TS) * LNQ) + (1.0f - __expf((float)TS * LNQ)) * sym_w;
       upd(an * (1.0f / (float)TN), __expf((float)TN * LNQ));
-      c.s_level = lv;
+      if (!e.exact_level) c.s_level = lv;                  // cfg.exact_level_tracker: k_level_exact walks the frame's samples instead
     }
     c.sample_count = sample_count;
     c.rd = base + TN;
@@ -1004,6 +798,67 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     c.sync_thr = 2.0f * e.threshold;                       // :178
     c.state = ST_EVAL_SYNC;
   }
+}
+
+// ------------------------------------------------------------------------------------- exact level tracker
+// cfg.exact_level_tracker = 1: SampleReader's level IIR (sample_reader.cpp:245-248: a = |x|; peak = max(peak, a);
+// sLevel += 0.00001f * (a - sLevel) for EVERY sample get_samples hands out) over the samples of the frame just demodulated,
+// one by one in the order they were read -- the correlation window, the start_index samples behind it, symbols 1..75 and the
+// null symbol are one contiguous run [sym0_pos - start_index, rd) of the ring.  A dependent chain of three float operations
+// per sample, 196 104 + start_index samples per frame: one wave per stream computes |x| for 1024 samples at a time into LDS
+// (all lanes) and then walks them (every lane redundantly: LDS broadcast reads, no divergence).  About 1.5 ms per frame,
+// more than the rest of the receiver together -- which is why the default advances the tracker chunk-wise (k_frame_tail).
+__global__ __launch_bounds__(64) void k_level_exact(EngineDev e)
+{
+  const int s = blockIdx.x, lane = threadIdx.x;
+  StreamCtl &c = e.ctl[s];
+  if (!c.frame_ok) return;
+  constexpr int CH = 1024;
+  __shared__ __attribute__((aligned(16))) float chunk[2][CH];
+  const unsigned long long rd0 = c.sym0_pos - (unsigned long long)c.start_index;   // k_frame_tail has moved c.rd to the frame's end
+  const unsigned n = (unsigned)(c.rd - rd0);
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned len = (unsigned)e.ring_len, base = (unsigned)(rd0 % (unsigned long long)e.ring_len);
+  auto mags = [&](unsigned p0, float *dst) {               // |x| of samples [p0, p0 + CH) (0 beyond n)
+#pragma unroll
+    for (int q = 0; q < CH / 64; q++) {
+      const unsigned i = p0 + lane + 64 * q;
+      float a = 0.f;
+      if (i < n) {
+        unsigned o = base + i; if (o >= len) o -= len;
+        const float2 v = ring[o];
+        a = sqrtf(v.x * v.x + v.y * v.y);
+      }
+      dst[lane + 64 * q] = a;
+    }
+  };
+  float lv = c.s_level, pk = c.peak_level;
+  mags(0, chunk[0]);
+  __syncthreads();
+  for (unsigned p0 = 0, b = 0; p0 < n; p0 += CH, b ^= 1) {
+    if (p0 + CH < n) mags(p0 + CH, chunk[b ^ 1]);          // the next chunk's loads and square roots are issued ahead of the walk
+    const unsigned m = n - p0 < CH ? n - p0 : CH;
+    const float4 *src = reinterpret_cast<const float4 *>(chunk[b]);
+    unsigned i = 0;
+    for (; i + 4 <= m; i += 4) {
+      const float4 a = src[i >> 2];
+      if (a.x > pk) pk = a.x;
+      lv += 0.00001f * (a.x - lv);
+      if (a.y > pk) pk = a.y;
+      lv += 0.00001f * (a.y - lv);
+      if (a.z > pk) pk = a.z;
+      lv += 0.00001f * (a.z - lv);
+      if (a.w > pk) pk = a.w;
+      lv += 0.00001f * (a.w - lv);
+    }
+    for (; i < m; i++) {
+      const float a = chunk[b][i];
+      if (a > pk) pk = a;
+      lv += 0.00001f * (a - lv);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) { c.s_level = lv; c.peak_level = pk; }
 }
 
 // ---------------------------------------------------------------------------------------------------- MSC
@@ -1238,8 +1093,12 @@ extern const char *const kStepKernelNames[11];
 const char *const kStepKernelNames[11] = {"k_acquire", "k_frame_head", "k_symbols", "k_demap_frame", "k_fic_frame",
                                           "k_frame_tail", "k_msc_prep", "k_msc_vitT", "k_msc_frame", "k_dabplus", "k_demap_fic"};
 
-// Front end of one batch step (everything with frame-to-frame feedback).  mark(i) is called before kernel i
-// and once more after the last one (profiling hook, may be empty).
+// Front end of one batch step (everything with frame-to-frame feedback).
+// Overlapped schedule (ss.d set): the FIC lives in symbols 1..3 -- those are demapped first on the front-end stream a, then
+// the FIC decoder (four 774-step trellises per stream, a latency-bound kernel and the next link of the frame's feedback
+// chain) and the frame tail follow on a, while the 72 MSC symbols are demapped on stream d: nothing on the chain of the NEXT
+// frame needs them, so a goes on to frame n + 1 while d is busy; the next frame's first demapper launch (and the MSC batch)
+// wait for d.  Serial schedule (cfg.schedule = 1, ss.d null): every kernel on a in program order.
 int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
 {
   const DevTables *t;
@@ -1248,81 +1107,32 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
   EngineDev e = e_in;
   e.parity = (int)(ss.step_count++ & 1u);               // spectra buffer of this step
   hipStream_t st = ss.a;
-  const bool split = e.split_fic && !e.fused_front && ss.c;
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
-  if (e.fused_front) {
-    // symbols + demap in one kernel (timed under "k_demap_frame"; "k_symbols" then has no launches)
-    mk.begin(3, st);
-    if (e.fused_front == 2) {
-      if (e.demap.soft_type == 3) hipLaunchKernelGGL((k_front_fused<3, 3>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      else if (e.demap.soft_type == 2) hipLaunchKernelGGL((k_front_fused<2, 3>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      else hipLaunchKernelGGL((k_front_fused<1, 3>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-    } else {
-      if (e.demap.soft_type == 3) hipLaunchKernelGGL((k_front_fused<3, 6>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      else if (e.demap.soft_type == 2) hipLaunchKernelGGL((k_front_fused<2, 6>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      else hipLaunchKernelGGL((k_front_fused<1, 6>), dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-    }
-    mk.end(3, st);
+  mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+  auto demap = [&](hipStream_t q, int l0, int l1) {
+    if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame6<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
+    else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame6<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
+    else hipLaunchKernelGGL(k_demap_frame6<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
+  };
+  if (ss.d) {
+    if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
+    mk.begin(10, st);
+    if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_fic<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+    else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_fic<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+    else hipLaunchKernelGGL(k_demap_fic<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+    mk.end(10, st);
+    DABX_HIP(hipEventRecord(ss.fic_go, st));
+    DABX_HIP(hipStreamWaitEvent(ss.d, ss.fic_go, 0));
+    mk.begin(3, ss.d); demap(ss.d, 3, 75); mk.end(3, ss.d);
+    DABX_HIP(hipEventRecord(ss.demap_done, ss.d));
+    ss.demap_in_flight = true;
   } else {
-    mk.begin(2, st);
-    if (e.sym_persist) hipLaunchKernelGGL(k_symbols_persistent, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t);
-    else hipLaunchKernelGGL(k_symbols, dim3(75, e.n_streams), dim3(256), 0, st, e, *t);
-    mk.end(2, st);
-    auto demap = [&](int l0, int l1) {
-      if (e.demap_occ6) {
-        if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame6<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
-        else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame6<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
-        else hipLaunchKernelGGL(k_demap_frame6<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
-        return;
-      }
-      if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
-      else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
-      else hipLaunchKernelGGL(k_demap_frame<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t, l0, l1);
-    };
-    if (split) {
-      // The FIC lives in symbols 1..3: demap those first, then start the FIC decoder (four 774-step trellises per stream, a
-      // latency-bound kernel) on its own HIP stream c and the demapping of the 72 MSC symbols on stream d.  The frame tail
-      // needs the FIC only, so with async_demap the front end goes on to the next frame while stream d is still busy; the
-      // next frame's first demapper launch (and the MSC batch) wait for it.
-      if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
-      mk.begin(10, st);
-      if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_fic<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_fic<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      else hipLaunchKernelGGL(k_demap_fic<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-      mk.end(10, st);
-      DABX_HIP(hipEventRecord(ss.fic_go, st));
-      // fic_on_a (needs async_demap): the FIC decoder stays on the front-end stream -- it is the next link of the frame's
-      // feedback chain anyway -- and only the MSC symbols' demapper leaves it: one cross-queue event pair per frame less
-      const bool fic_on_a = e.fic_on_a && e.async_demap && ss.d;
-      if (!fic_on_a) {
-        DABX_HIP(hipStreamWaitEvent(ss.c, ss.fic_go, 0));
-        mk.begin(4, ss.c); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, ss.c, e, *t, 0, 4); mk.end(4, ss.c);
-        DABX_HIP(hipEventRecord(ss.fic_done, ss.c));
-      }
-      if (e.async_demap && ss.d) {
-        DABX_HIP(hipStreamWaitEvent(ss.d, ss.fic_go, 0));
-        hipStream_t keep = st;
-        st = ss.d;
-        mk.begin(3, st); demap(3, 75); mk.end(3, st);
-        st = keep;
-        DABX_HIP(hipEventRecord(ss.demap_done, ss.d));
-        ss.demap_in_flight = true;
-      } else {
-        mk.begin(3, st); demap(3, 75); mk.end(3, st);
-      }
-      if (fic_on_a) { mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st); }
-      else DABX_HIP(hipStreamWaitEvent(st, ss.fic_done, 0));
-      mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
-      DABX_HIP(hipGetLastError());
-      return 0;
-    }
-    mk.begin(3, st);
-    demap(0, 75);
-    mk.end(3, st);
+    mk.begin(3, st); demap(st, 0, 75); mk.end(3, st);
   }
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
+  if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, st, e);
   DABX_HIP(hipGetLastError());
   return 0;
 }
@@ -1348,7 +1158,7 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
   MscLaunch L{};
   unsigned fast_mask = 0;
   long long fast_jobs = 0, fast_pairs = 0;
-  if (fast && ss.b) {
+  if (fast) {
     for (int c = 0; c < fast->n_cls; c++) fast_jobs += (long long)fast->cls[c].n_pairs * cifs;
     if (fast_jobs >= fast->min_jobs)
       for (int c = 0; c < fast->n_cls; c++) {
@@ -1362,35 +1172,39 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
       }
   }
   if (L.n > 0) {
-    if (e.prep_on_b) {
-      // the time de-interleave of the batch runs on the decoder's stream too: the front end goes straight on to the next
-      // frames.  It reads ring slots the front end only rewrites 20 CIFs (5 frames) later; dabx_process makes the
-      // front-end stream wait for `prep_b_done` before it gets there.
-      DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
-      DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
-      if ((rc = launch_msc_prep(e, cifs, L, ss.b, mk))) return rc;
-      DABX_HIP(hipEventRecord(ss.prep_b_done, ss.b));
-      ss.prep_pending = true;
-    } else {
-      if ((rc = launch_msc_prep(e, cifs, L, ss.a, mk))) return rc;
+    // Overlapped schedule: time de-interleave, lane-per-trellis decode and DAB+ stage of the batch run on stream b while the
+    // front end (a) goes straight on to the next frames.  k_msc_prep reads ring slots the front end only rewrites 20 CIFs
+    // (5 frames) later; dabx_process makes the front-end stream wait for `prep_b_done` before it gets there.  Serial
+    // schedule (ss.b null): the same kernels on a.
+    hipStream_t sb = ss.b ? ss.b : ss.a;
+    if (ss.b) {
       DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
       DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
     }
-    if ((rc = launch_msc_vitT(e, cifs, L, ss.b, mk))) return rc;
+    if ((rc = launch_msc_prep(e, cifs, L, sb, mk))) return rc;
+    if (ss.b) {
+      DABX_HIP(hipEventRecord(ss.prep_b_done, ss.b));
+      ss.prep_pending = true;
+    }
+    if ((rc = launch_msc_vitT(e, cifs, L, sb, mk))) return rc;
     if (fast_pairs < fast->slots_active) {
       // the remaining sub-channels: wave per trellis, on the front-end stream (it reads the TDI ring in place)
       mk.begin(8, ss.a);
       hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs, fast_mask);
       mk.end(8, ss.a);
-      DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
-      DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+      if (ss.b) {
+        DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
+        DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+      }
     }
-    mk.begin(9, ss.b);
-    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.b, e, *t);
-    hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.b, e);
-    mk.end(9, ss.b);
-    DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
-    ss.msc_in_flight = true;
+    mk.begin(9, sb);
+    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, sb, e, *t);
+    hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, sb, e);
+    mk.end(9, sb);
+    if (ss.b) {
+      DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
+      ss.msc_in_flight = true;
+    }
   } else {
     mk.begin(8, ss.a);
     hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs, 0u);

@@ -302,10 +302,56 @@ static int build_tables(DevTables &t)
     std::vector<int16_t> inv(TU, (int16_t)-1);
     for (int k = 0; k < K; k++) inv[bin[k]] = (int16_t)k;
     if ((rc = upload(&t.bin_to_k, inv))) return rc;
-    std::vector<int16_t> inv8((size_t)TU);                       // [256][8]: thread tid of a 256-thread transform holds bins tid + 256 u
+    // k_symbols de-interleaves through LDS: thread tid of the 256-thread transform holds bins tid + 256 u and scatters them
+    // (ds_write_b64: groups of 16 contiguous lanes, bank = slot mod 16), then reads carriers tid + 256 u back in order
+    // (ds_read_b64: groups of 32 lanes, bank = slot mod 32).  slot(k) = (k & ~15) | sigma(k) keeps every aligned run of 16
+    // carriers in place, so the read-back is conflict-free for ANY set of permutations sigma; the scatter is conflict-free
+    // iff the carriers written by one 16-lane group get 16 different sigma.  That is an edge colouring of the bipartite
+    // multigraph (write group) -- carrier k -- (run k >> 4) with 16 colours, which exists because no vertex has more
+    // than 16 edges (Koenig); built with alternating-path recolouring.
+    std::vector<int> sigma(K, -1);
+    {
+      const int NG = 8 * 16, NB = K / 16, NC = 16;
+      std::vector<int> at_g((size_t)NG * NC, -1), at_b((size_t)NB * NC, -1);      // edge (carrier) using colour c at the vertex
+      auto group_of = [&](int k) { const int b = bin[k]; return (b >> 8) * 16 + ((b & 255) >> 4); };   // (u, tid >> 4)
+      for (int k = 0; k < K; k++) {
+        const int g = group_of(k), b = k >> 4;
+        int cg = 0, cb = 0;
+        while (at_g[(size_t)g * NC + cg] >= 0) cg++;
+        while (at_b[(size_t)b * NC + cb] >= 0) cb++;
+        if (at_b[(size_t)b * NC + cg] >= 0) {
+          // cg is taken at b: swap cg <-> cb along the alternating path that starts at b with colour cg (it cannot reach g)
+          std::vector<int> path;
+          int v_is_b = 1, v = b, want = cg;
+          for (;;) {
+            const int e = v_is_b ? at_b[(size_t)v * NC + want] : at_g[(size_t)v * NC + want];
+            if (e < 0) break;
+            path.push_back(e);
+            v = v_is_b ? group_of(e) : (e >> 4);
+            v_is_b ^= 1;
+            want = want == cg ? cb : cg;
+          }
+          for (int e : path) { at_g[(size_t)group_of(e) * NC + sigma[e]] = -1; at_b[(size_t)(e >> 4) * NC + sigma[e]] = -1; }
+          for (int e : path) {
+            sigma[e] = sigma[e] == cg ? cb : cg;
+            at_g[(size_t)group_of(e) * NC + sigma[e]] = e; at_b[(size_t)(e >> 4) * NC + sigma[e]] = e;
+          }
+        }
+        sigma[k] = cg;
+        at_g[(size_t)g * NC + cg] = k; at_b[(size_t)b * NC + cg] = k;
+      }
+    }
+    std::vector<int16_t> slot8((size_t)TU);
     for (int tid = 0; tid < 256; tid++)
-      for (int u = 0; u < 8; u++) inv8[(size_t)tid * 8 + u] = inv[tid + 256 * u];
-    if ((rc = upload(&t.bin_to_k8, inv8))) return rc;
+      for (int u = 0; u < 8; u++) {
+        const int k = inv[tid + 256 * u];
+        slot8[(size_t)tid * 8 + u] = (int16_t)(k < 0 ? -1 : ((k & ~15) | sigma[k]));
+      }
+    if ((rc = upload(&t.bin_to_slot8, slot8))) return rc;
+    std::vector<uint32_t> rd(256, 0);
+    for (int tid = 0; tid < 256; tid++)
+      for (int u = 0; u < K / 256; u++) rd[tid] |= (uint32_t)sigma[tid + 256 * u] << (4 * u);
+    if ((rc = upload(&t.carrier_slot_rd, rd))) return rc;
   }
   if ((rc = upload(&t.perm_rel, rel))) return rc;
   if ((rc = upload(&t.prs_ref, prs))) return rc;

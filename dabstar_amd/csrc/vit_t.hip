@@ -86,7 +86,7 @@ __device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int ti
 
 __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaunch L)
 {
-  if (e.front_prio) __builtin_amdgcn_s_setprio(3);      // runs on the front-end stream (pipeline.hip, front_prio)
+  __builtin_amdgcn_s_setprio(3);      // above the decoder whose input it prepares (pipeline.hip, front_prio)
   __shared__ __attribute__((aligned(16))) uint8_t tile[PJB * PJS];
   __shared__ const uint8_t *s_base[PJB];     // per job: stream ring + cu_start*4 (nullptr = invalid job)
   __shared__ long long s_r[PJB];
@@ -301,13 +301,7 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   vt::s2 v2n;                                                      // (2, -2), pinned in a VGPR (VOP3P takes no literal on gfx9)
   asm volatile("v_mov_b32 %0, %1" : "=v"(v2n) : "s"(0xFFFE0002u));
   int t = 0;
-  // vit_prio: the SIMD's arbiter favours its oldest wave, so the four waves of a SIMD drift apart (one runs ahead at the
-  // single-wave rate, the last one finishes alone).  Lowering a wave's priority as it progresses lets the others catch up.
-  const int q1 = (e.vit_prio & 1) ? nsteps / 3 : 0x7fffffff, q2 = (e.vit_prio & 1) ? 2 * nsteps / 3 : 0x7fffffff;
-  if (e.vit_prio & 1) __builtin_amdgcn_s_setprio(2);
   for (; t + 12 <= nsteps; t += 12) {
-    if (t >= q1 && t < q1 + 12) __builtin_amdgcn_s_setprio(1);
-    if (t >= q2 && t < q2 + 12) __builtin_amdgcn_s_setprio(0);
     recentre();
     vt_cycle(R, ca, t, dec_lane, v2n);
     vt_fetch(ca, in_grp, lane, cmap, t + 12 < last ? t + 12 : last);
@@ -333,7 +327,6 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   // registers: as arrays indexed through a lambda the compiler had put one set in scratch and one in LDS, and the chain
   // then ran at ~1150 cycles per step, a third of the kernel.)
   unsigned L = 0, outw = 0;
-  if (e.vit_prio & 2) __builtin_amdgcn_s_setprio(3);            // experiment: the latency-bound chain ahead of the other waves' forward passes
   VtDec6 cur = vt_load_dec(dec_lane, nsteps - 6);
   VtDec6 nx1 = vt_load_dec(dec_lane, nsteps - 12);                // nsteps >= 18 for every legal profile (24 * 8 + 6 = 198 at least)
   for (int tc = nsteps - 6; tc >= 6; tc -= 6) {

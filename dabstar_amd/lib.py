@@ -42,6 +42,13 @@ def load(build_if_missing=True):
     L.dabx_feed_bound.argtypes = [C.c_void_p, C.c_size_t]
     L.dabx_feed_close.argtypes = [C.c_void_p]
     L.dabx_convert_iq_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    # size_t arguments must not travel as C int (buffers of 2 GiB and more)
+    L.dabx_push_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t]
+    L.dabx_push_iq_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t]
+    L.dabx_push_wait.argtypes = [C.c_void_p]
+    L.dabx_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.dabx_host_unregister.argtypes = [C.c_void_p]
+    L.dabx_commit_iq.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     _LIB = L
     return L
 
@@ -197,7 +204,9 @@ class Demap:
 class Config(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("ring_frames", C.c_int32), ("max_subch", C.c_int32), ("out_frames", C.c_int32),
                 ("sync_threshold", C.c_float), ("sync_strongest", C.c_int32), ("soft_bit_type", C.c_int32),
-                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("viterbi_tie_mode", C.c_int32), ("dc_iq_correction", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("viterbi_tie_mode", C.c_int32), ("dc_iq_correction", C.c_int32),
+                ("schedule", C.c_int32), ("msc_fast_min_jobs", C.c_int32), ("msc_class_min_jobs", C.c_int32),
+                ("exact_level_tracker", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class SubchDesc(C.Structure):
@@ -273,7 +282,7 @@ class Stats(C.Structure):
                 ("last_start_index", C.c_int32), ("cif_count", C.c_int32),
                 ("fib_ok", C.c_int64), ("fib_total", C.c_int64), ("sf_ok", C.c_int64), ("sf_fail", C.c_int64),
                 ("rs_corrected", C.c_int64), ("rs_failed", C.c_int64), ("au_ok", C.c_int64), ("au_bad", C.c_int64),
-                ("cifs_decoded", C.c_int64)]
+                ("cifs_decoded", C.c_int64), ("signal_level", C.c_float), ("peak_level", C.c_float)]
 
 
 COUNTER_NAMES = ["frames", "samples", "fib_ok", "fib_total", "sync_lost", "streams_locked", "cifs_decoded", "sf_ok", "sf_fail",
@@ -285,7 +294,8 @@ class Engine:
     """Stream-batched receiver (device-side DabProcessor::run for n_streams ensembles)."""
 
     def __init__(self, n_streams=1, ring_frames=4, max_subch=18, out_frames=4, fic_only=False, capture_soft=False,
-                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False, viterbi_tie_mode=0, dc_iq_correction=0):
+                 sync_threshold=3.0, soft_bit_type=1, sync_strongest=False, viterbi_tie_mode=0, dc_iq_correction=0,
+                 schedule=0, msc_fast_min_jobs=0, msc_class_min_jobs=0, exact_level_tracker=False):
         L = load()
         cfg = Config()
         L.dabx_default_config(C.byref(cfg))
@@ -294,6 +304,8 @@ class Engine:
         cfg.soft_bit_type, cfg.sync_strongest = soft_bit_type, int(sync_strongest)
         cfg.viterbi_tie_mode = int(viterbi_tie_mode)
         cfg.dc_iq_correction = int(dc_iq_correction)
+        cfg.schedule, cfg.msc_fast_min_jobs, cfg.msc_class_min_jobs = int(schedule), int(msc_fast_min_jobs), int(msc_class_min_jobs)
+        cfg.exact_level_tracker = int(exact_level_tracker)
         self.cfg = cfg
         self._h = C.c_void_p()
         check(L.dabx_create(C.byref(cfg), C.byref(self._h)))
@@ -325,7 +337,10 @@ class Engine:
         check(load().dabx_push_iq(self._h, stream, _p(iq), fmt, n))
 
     def push_iq_async(self, stream, iq):
-        """iq must stay alive and unchanged until push_wait() (see dabx_push_iq_async)."""
+        """iq must stay alive and unchanged until push_wait() (see dabx_push_iq_async); it is pushed in place, so it has to be
+        C-contiguous (a strided view cannot be copied here: the copy would not outlive the call)."""
+        if not iq.flags.c_contiguous:
+            raise ValueError("push_iq_async needs a C-contiguous array")
         fmt = {np.dtype(np.complex64): 0, np.dtype(np.int16): 1, np.dtype(np.uint8): 2}[iq.dtype]
         n = iq.size if fmt == 0 else iq.size // 2
         check(load().dabx_push_iq_async(self._h, stream, _p(iq), fmt, n))

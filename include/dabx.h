@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DABX_ABI_VERSION 2
+#define DABX_ABI_VERSION 3
 
 typedef enum {
   DABX_OK = 0,
@@ -189,11 +189,23 @@ typedef struct {
   int32_t fic_only;         /* 1: BASELINE config 2 (FIC Viterbi only) */
   int32_t capture_soft;     /* 1: keep int16 soft bits of the last frame (debug / parity tests) */
   int32_t viterbi_tie_mode; /* 0: canonical scalar Viterbi (CMake default); 1 / 2: arithmetic of the VITERBI_AVX2 / VITERBI_SSE2 builds,
-                               see dabx_viterbi_mode (FIC and MSC then run on the wave-per-trellis kernels) */
+                               see dabx_viterbi_mode */
   int32_t dc_iq_correction; /* SampleReader::set_dc_and_iq_correction (sample_reader.cpp:218-243, 334-346; configuration.cpp:75-76
                                default off): 0 off, 1 DC removal, 2 DC removal + IQ-imbalance correction, applied to every
                                committed sample in place in the ring (dabx_read_iq then returns corrected samples) */
-  int32_t reserved[5];
+  int32_t schedule;         /* 0 (default): overlapped -- the batched MSC decode and the demapping of a frame's MSC symbols run on
+                               their own HIP streams next to the front end of the following frames; 1: serial -- every kernel on
+                               ONE HIP stream in program order (debugging aid, deterministic per-kernel profiles; same bytes) */
+  int32_t msc_fast_min_jobs;  /* trellises per 7-frame MSC batch (all streams together) from which the MSC runs on the
+                                 lane-per-trellis kernels; below it the wave-per-trellis kernel decodes everything.  0 = default
+                                 20480 (measured break-even, about 41 streams x 18 sub-channels) */
+  int32_t msc_class_min_jobs; /* smallest protection-profile class (trellises per batch, all streams together) that gets its own
+                                 lane-per-trellis class; smaller ones stay on the wave-per-trellis kernel.  0 = default 256 */
+  int32_t exact_level_tracker;/* SampleReader's signal-level IIR (sample_reader.cpp:246-248) in lock: 0 (default) advanced chunk by
+                                 chunk (exact decay between chunks, equal weights within one: relative error ~1e-5);
+                                 1: run sample by sample exactly as the reference does, on one lane per stream (slower: +196 608
+                                 dependent updates per frame and stream).  Out of lock it is always exact. */
+  int32_t reserved[1];
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */
@@ -212,6 +224,8 @@ typedef struct {
   float   snr_db_est;        /* OfdmDecoder's LCD SNR (ofdm_decoder.cpp:326-343) after the newest frame's last symbol */
   int32_t last_start_index, cif_count;
   int64_t fib_ok, fib_total, sf_ok, sf_fail, rs_corrected, rs_failed, au_ok, au_bad, cifs_decoded;
+  float   signal_level;      /* SampleReader::sLevel (sample_reader.h:70,95; .cpp:245-248) after the newest frame */
+  float   peak_level;        /* SampleReader::peakLevel (.cpp:247); tracked out of lock and, with exact_level_tracker, in lock */
 } dabx_stats;
 
 void dabx_default_config(dabx_config *cfg);
@@ -222,10 +236,12 @@ void dabx_destroy(dabx_engine *e);
  * slots start their 16-CIF de-interleaver fill at the current CIF; a new largest bit rate re-strides the output rings in
  * place, running services are not disturbed.
  * Streams may carry different layouts: the decoder groups the slots of all streams by protection profile (rebuilt by the
- * next dabx_process after a series of calls).  The 16 profiles with the most decoder work (sub-channels x bit rate) run on the
- * lane-per-trellis kernels; further
- * profiles and classes too small to fill a few wavefronts are decoded by the wave-per-trellis kernel in the same batch -- a
- * throughput distinction only, no limit on the number of different profiles. */
+ * next dabx_process after a series of calls).  At most DABX_MSC_FAST_CLASSES (16) profiles -- those with the most decoder
+ * work, sub-channels x bit rate -- run on the lane-per-trellis kernels; every further profile, and classes smaller than
+ * dabx_config.msc_class_min_jobs, are decoded by the wave-per-trellis kernel in the same batch.  That is a throughput
+ * distinction only: there is NO limit on the number of different profiles per engine and no error code for exceeding 16
+ * (tests/test_gpu_engine.py::test_more_profiles_than_decoder_classes runs 26). */
+#define DABX_MSC_FAST_CLASSES 16
 int  dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *d, int n);
 /* Host IQ -> device ring (IDeviceHandler::getSamples contract, common/device_handler_if.h:47-48).
  * fmt: 0 = cf32, 1 = int16 IQ (/32768, wav_reader.cpp:164), 2 = uint8 IQ ((x-127.38)/128, raw_reader.cpp:66-70).

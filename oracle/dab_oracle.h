@@ -230,6 +230,8 @@ typedef struct {
   float   *snr_db;     /* n_frames : SNR of the LCD statistics after symbol 75, ofdm_decoder.cpp:326-343 */
   int32_t *fic_overflow;  /* n_frames : soft values of symbols 1..3 that left the int16 range (see ora_demap.overflow_count) */
   int32_t *msc_overflow;  /* n_frames : the same for symbols 4..75 */
+  float   *s_level;       /* n_frames : SampleReader::sLevel after the frame's last sample (sample_reader.cpp:245-248) */
+  float   *peak_level;    /* n_frames : SampleReader::peakLevel likewise */
 } ora_rx_capture;
 void ora_rx_enable_soft_capture(ora_receiver *r, int on);
 const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);

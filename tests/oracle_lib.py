@@ -29,7 +29,8 @@ class RxCapture(C.Structure):
                 ("soft", C.POINTER(C.c_int16)), ("start_idx", C.POINTER(C.c_int32)),
                 ("fbb", C.POINTER(C.c_float)), ("sym0_pos", C.POINTER(C.c_int32)),
                 ("fbb_end", C.POINTER(C.c_float)), ("clock_err", C.POINTER(C.c_float)), ("fic_ratio", C.POINTER(C.c_int32)),
-                ("snr_db", C.POINTER(C.c_float)), ("fic_overflow", C.POINTER(C.c_int32)), ("msc_overflow", C.POINTER(C.c_int32))]
+                ("snr_db", C.POINTER(C.c_float)), ("fic_overflow", C.POINTER(C.c_int32)), ("msc_overflow", C.POINTER(C.c_int32)),
+                ("s_level", C.POINTER(C.c_float)), ("peak_level", C.POINTER(C.c_float))]
 
 
 def build_oracle():

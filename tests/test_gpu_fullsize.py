@@ -2,7 +2,7 @@
 
 The oracle needs ~14 ms per frame and stream, so at this size parity is shown through size-independent properties
 (every stream: transmit -> channel -> decode returns the transmitted super frames, every FIB passes its CRC, no RS /
-fire-code / AU failure anywhere; counters add up) plus a bit-exact comparison with the oracle on a sample of the
+fire-code / AU failure anywhere; counters add up) plus a bit-exact comparison with the oracle on a sample of 18+ of the
 streams, whose IQ is read back from the device rings."""
 import os
 import sys
@@ -91,7 +91,11 @@ def test_512_streams_round_trip_and_sampled_oracle_parity():
     # ---- sampled streams: bit-exact against the oracle on the very IQ the device holds
     L = ol.oracle()
     n_ring = RING_FRAMES * ds.TF
-    for s in sorted(set([0, 201, 511] + relocked + late[:3])):
+    # 18 streams spread over the engine (0, 31, 62, ... 496, 511: both base ensembles, every region of the stream axis) plus
+    # every stream that lost lock or had bit errors before the CFO settled; the oracle needs ~0.6 s per stream here
+    sample = sorted(set([31 * i for i in range(17)] + [511] + relocked + late[:6]))
+    assert len(sample) >= 18
+    for s in sample:
         first = (RING_FRAMES - 1 + N_STEPS) * ds.TF - n_ring              # the ring holds the newest n_ring committed samples
         ring = np.roll(eng.read_iq(s, first, n_ring), first % n_ring)   # absolute sample a sits at ring[a % n_ring]
         x = np.tile(ring, (N_STEPS + RING_FRAMES) // RING_FRAMES + 1)[: (N_STEPS + 2) * ds.TF]

@@ -2,8 +2,9 @@
 
 24 streams in ONE engine, each with its own SNR (3.5 .. 28 dB), carrier offset (up to +-36 kHz, i.e. also beyond the
 +-35 kHz the reference follows), timing, level (-60 .. +30 dB), an echo, a drop-out, a sample-clock offset (+-90 ppm) and one
-of three sub-channel layouts.  DABX_FUZZ_SEED / DABX_FUZZ_CFG (threshold, strongest-peak sync, soft-bit generator) and the
-decoder knobs of INTEGRATION.md 7 select other draws, receiver options and the lane-per-trellis MSC path for hunting runs.
+of three sub-channel layouts.  DABX_FUZZ_SEED / DABX_FUZZ_CFG (threshold, strongest-peak sync, soft-bit generator) and
+DABX_FUZZ_FAST (dabx_config.msc_fast_min_jobs / msc_class_min_jobs: the lane-per-trellis MSC path) -- knobs of THIS TEST, read
+here, not by the library -- select other draws, receiver options and decoder kernels for hunting runs (tools/fuzz_hunt.py).
 Whatever the reference's state machine does with such an input -- late lock, loss of lock, no lock at all -- the engine must
 do the same: FIBs and CRC flags of every frame, the logical frames and the super frames of every sub-channel."""
 import os
@@ -78,8 +79,9 @@ def test_random_channels_and_layouts_follow_the_oracle():
         xs.append(np.ascontiguousarray(x, np.complex64))
         cases.append((li, snr, cfo, toff, gain))
 
+    fast = dict(msc_fast_min_jobs=64, msc_class_min_jobs=1) if os.environ.get("DABX_FUZZ_FAST") == "1" else {}
     eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr,
-                    sync_strongest=bool(strongest), soft_bit_type=soft_type)
+                    sync_strongest=bool(strongest), soft_bit_type=soft_type, **fast)
     for s, (li, *_rest) in enumerate(cases):
         eng.set_subchannels(layouts[li], stream=s)
         eng.push_iq(s, xs[s])
@@ -169,20 +171,20 @@ def test_random_channels_and_layouts_follow_the_oracle():
     assert eti_checked >= N_CASES // 4
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
     assert n_bad_diff <= (2 if soft_type != 3 else 6), (n_bad_diff, n_bad)   # generator 3 (no normalisation) is the touchiest
-    assert n_ovf_frames <= 2 * N_CASES, n_ovf_frames                          # overflow frames (excluded above) stay the exception: 528 frames in all
+    # overflow frames (excluded above) stay the exception: 4 of 528 frames with the committed seed; a regression that produced
+    # spurious overflows, or excluded frames wholesale, trips this bound (hunting seeds draw other drop-outs: looser there)
+    assert n_ovf_frames <= (8 if "DABX_FUZZ_SEED" not in os.environ else 2 * N_CASES), n_ovf_frames
     eng.close()
 
 
 @pytest.mark.parametrize("fast", [0, 1])
-def test_random_service_start_stop_schedules(monkeypatch, fast):
+def test_random_service_start_stop_schedules(fast):
     """MscHandler::set_channel / stop_service at random times (msc_handler.cpp:95-146): 5 streams of one engine, each with
     its own channel; between dabx_process calls a random stream gets a new random subset of the 18 services.  A service that
     keeps running is never disturbed, one that (re)starts at CIF c delivers exactly the oracle's logical frames c, c+1, ...
     (its 16-CIF de-interleaver fill starts at c).  fast = 1 routes the MSC through the lane-per-trellis classes, which are
     rebuilt after every change."""
-    if fast:
-        monkeypatch.setenv("DABX_MSC_FAST_MIN_JOBS", "64")
-        monkeypatch.setenv("DABX_MSC_CLASS_MIN_JOBS", "1")
+    kw = dict(msc_fast_min_jobs=64, msc_class_min_jobs=1) if fast else {}
     rng = np.random.default_rng(int(os.environ.get("DABX_FUZZ_SEED", "77")) + fast)
     subch = ds.default_subchannels(18, 64)
     n_streams, n_frames = 5, 30
@@ -192,7 +194,7 @@ def test_random_service_start_stop_schedules(monkeypatch, fast):
     oras = [_oracle(x, subch, (3.0, 0, 1)) for x in xs]
     mk = lambda c: dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0)   # noqa: E731
     empty = dx.SubchDesc(0, 0, 0, 0, 0, 0, 0, 0)
-    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=18, out_frames=4)
+    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=18, out_frames=4, **kw)
     active = [set(int(j) for j in rng.choice(18, 6, replace=False)) for _ in range(n_streams)]
     for s in range(n_streams):
         eng.set_subchannels([mk(subch[j]) if j in active[s] else empty for j in range(18)], stream=s)

@@ -126,6 +126,67 @@ def test_file_replay_matches_pushing_the_same_samples(tmp_path, kind):
     eng.close(); ref.close()
 
 
+@pytest.mark.parametrize("kind,n_sub", [("sdr", 1), ("raw", 1), ("sdr", 18), ("raw", 18)])
+def test_recorded_file_replay_equals_the_oracle_receiver_on_the_quantised_samples(tmp_path, kind, n_sub):
+    """BASELINE configs[0] as worded -- a single recorded .sdr (and .raw) file, Mode I, ONE 64 kbit/s audio sub-channel, the
+    CPU reference path in file-player mode -- and the same with all 18: the file is replayed through the engine
+    (dabx_probe_iq_file + dabx_feed_bytes: bytes over PCIe, conversion on the GPU) and, independently, the oracle's reader
+    (oracle/iqfile.c: the samples the reference's WavReader / RawReader would hand to DabProcessor, int16 / uint8 quantisation
+    included) feeds the oracle RECEIVER.  FIBs and CRC flags of every frame, start indices, every logical frame and every
+    RS-corrected super frame of the service(s) must be identical."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=55)
+    x = ds.channel(ens.iq, snr_db=14.0, cfo_hz=-640.0, timing_offset=41000, seed=12, n_out=16 * ds.TF)
+    g = 0.25 / np.sqrt(np.mean(np.abs(x) ** 2))
+    path = str(tmp_path / ("rec." + {"raw": "iq", "sdr": "sdr"}[kind]))
+    (iqf.write_raw(path, x, g) if kind == "raw" else iqf.write_sdr(path, x, 2048000, g))
+    fmt = dx.probe_iq_file(path)
+    with open(path, "rb") as fh:
+        fh.seek(fmt.data_offset)
+        payload = np.frombuffer(fh.read(fmt.data_bytes), np.uint8)
+    samples = _ora(fmt, payload)
+    unit = {0: 16384, 1: 32768}[fmt.family]                        # the readers drop the last partial block
+    samples = np.ascontiguousarray(samples[:len(samples) // unit * unit])
+    service = subch[:1] if n_sub == 1 else subch                   # one audio service (SubChId 1, CU 0..47), or the whole multiplex
+    L = ol.oracle()
+    rx = L.ora_rx_create(ol.make_descs(service), len(service))
+    n = L.ora_rx_run(rx, samples, len(samples), 10000)
+    cap = L.ora_rx_get_capture(rx).contents
+    o_fibs = np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy()
+    o_crc = np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy()
+    o_start = np.ctypeslib.as_array(cap.start_idx, (n,)).copy()
+    o_msc = [ol.backend_bytes(rx, j, "msc").reshape(-1, 192) for j in range(len(service))]
+    o_sf = [ol.backend_bytes(rx, j, "sf").reshape(-1, 880) for j in range(len(service))]
+    L.ora_rx_destroy(rx)
+    eng = dx.Engine(n_streams=1, ring_frames=10, max_subch=len(service), out_frames=4)
+    eng.set_subchannels(service)
+    fibs, crcs, starts = [], [], []
+
+    def collect(e):
+        st = e.stats(0)
+        new = st["frames"] - len(fibs)
+        if new:
+            f, c = e.read_fibs(0, new)
+            assert len(f) == new
+            fibs.extend(f); crcs.extend(c)
+            starts.append(st["last_start_index"])
+    frames = dx.play_file(eng, 0, path, block_frames=3, on_block=collect)
+    assert frames == len(fibs) and n - 1 <= frames <= n and frames >= 13       # the oracle also counts a last, partially read frame
+    k = frames
+    assert np.array_equal(np.array(crcs), o_crc[:k]) and np.array_equal(np.array(fibs), o_fibs[:k])
+    assert o_crc[6:k].all() and starts[-1] == o_start[k - 1]
+    n_lf = 4 * k - 16
+    for j in range(len(service)):
+        sub = eng.subch_stats(0, j)
+        assert sub["cifs_decoded"] == n_lf
+        m = min(n_lf, 32)
+        assert np.array_equal(eng.read_msc(0, j, m), o_msc[j][n_lf - m:n_lf]), j
+        q = min(4, sub["sf_ok"])
+        assert sub["sf_ok"] >= 5 and np.array_equal(eng.read_superframes(0, j, q), o_sf[j][sub["sf_ok"] - q:sub["sf_ok"]]), j
+        assert any(np.array_equal(eng.read_superframes(0, j, 1)[0], t) for t in ens.superframes[j])      # and it is what was transmitted
+    eng.close()
+
+
 @pytest.mark.parametrize("rate,up,down", [(2000000, 125, 128), (2500000, 625, 512)])
 def test_recording_at_another_rate_decodes_after_gpu_resampling(tmp_path, rate, up, down):
     subch = ds.default_subchannels(18, 64)

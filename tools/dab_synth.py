@@ -403,6 +403,64 @@ def channel(iq: np.ndarray, snr_db: float = 20.0, cfo_hz: float = 0.0, timing_of
     return (gain * x).astype(np.complex64)
 
 
+# Tap sets after the COST 207 profiles the DAB standard's own simulations use (EN 300 401 informative annexes / TR 101 496):
+# delays in microseconds, mean powers in dB.  2.048 samples per microsecond.
+MOBILE_PROFILES = {
+    "TU6": [(0.0, -3.0), (0.2, 0.0), (0.5, -2.0), (1.6, -6.0), (2.3, -8.0), (5.0, -10.0)],      # typical urban
+    "RA4": [(0.0, 0.0), (0.2, -2.0), (0.4, -10.0), (0.6, -20.0)],                               # rural area (Rayleigh variant)
+    "SFN2": [(0.0, 0.0), (73.2, -3.0)],                                                          # two transmitters of a single-frequency network
+    "HT6": [(0.0, 0.0), (0.2, -2.0), (0.4, -4.0), (0.6, -7.0), (15.0, -6.0), (17.2, -12.0)],    # hilly terrain
+}
+
+
+def channel_mobile(iq: np.ndarray, profile="TU6", doppler_hz: float = 50.0, snr_db: float = 20.0, cfo_hz: float = 0.0,
+                   timing_offset: int = 0, gain: float = 0.25, seed: int = 0, n_out: int | None = None,
+                   clock_ppm: float = 0.0, clock_drift_ppm_per_s: float = 0.0) -> np.ndarray:
+    """Time-variant multipath channel: every tap of `profile` (name in MOBILE_PROFILES or a list of (delay_us, power_dB)) is
+    an independent Rayleigh process with the Jakes Doppler spectrum (sum of 16 sinusoids with random arrival angles and
+    phases, maximum Doppler shift `doppler_hz`; 100 Hz is 480 km/h in Band III), normalised to unit mean total power; then
+    a sample clock that is off by `clock_ppm` and drifts by `clock_drift_ppm_per_s` (linear interpolation), CFO, AWGN and
+    gain as in channel().  The tap gains are evaluated every 256 samples (8 kHz, far above the Doppler rate) and interpolated
+    linearly.  complex64."""
+    rng = np.random.default_rng(seed)
+    x = np.roll(iq, timing_offset)
+    if n_out is not None:
+        x = np.tile(x, -(-(n_out + 4096) // len(x)))[: n_out + 4096]
+    x = x.astype(np.complex128)
+    n = len(x)
+    taps = MOBILE_PROFILES[profile] if isinstance(profile, str) else list(profile)
+    pw = np.array([10.0 ** (p / 10.0) for _, p in taps])
+    pw /= pw.sum()
+    step = 256
+    tc = np.arange(0, n + step, step, dtype=np.float64) / FS               # coarse time axis
+    y = np.zeros(n, np.complex128)
+    ti = np.arange(n, dtype=np.float64) / step
+    i0 = np.floor(ti).astype(np.int64)
+    fr = ti - i0
+    for (delay_us, _), p in zip(taps, pw):
+        M = 16
+        alpha = rng.uniform(0.0, 2.0 * np.pi, M)
+        phi = rng.uniform(0.0, 2.0 * np.pi, M)
+        g = np.exp(1j * (2.0 * np.pi * doppler_hz * np.cos(alpha)[:, None] * tc[None, :] + phi[:, None])).sum(axis=0) * np.sqrt(p / M)
+        gi = g[i0] * (1.0 - fr) + g[i0 + 1] * fr
+        d = int(round(delay_us * FS / 1e6))
+        y[d:] += gi[d:] * x[: n - d]
+    if clock_ppm or clock_drift_ppm_per_s:
+        m = n - 4096
+        t = np.arange(m, dtype=np.float64)
+        t = t * (1.0 + clock_ppm * 1e-6) + 0.5 * clock_drift_ppm_per_s * 1e-6 * t * t / FS
+        j0 = np.floor(t).astype(np.int64)
+        f2 = t - j0
+        y = y[j0] * (1.0 - f2) + y[j0 + 1] * f2
+    if n_out is not None:
+        y = y[:n_out]
+    k = np.arange(len(y), dtype=np.float64)
+    y = y * np.exp(2j * np.pi * cfo_hz * k / FS)
+    sigma = np.sqrt(10 ** (-snr_db / 10) / 2)
+    y = y + sigma * (rng.standard_normal(len(y)) + 1j * rng.standard_normal(len(y)))
+    return (gain * y).astype(np.complex64)
+
+
 def to_raw_u8(iq: np.ndarray) -> np.ndarray:
     """.raw/.iq file format read by the reference as (u8 - 127.38)/128 (raw_reader.cpp:66-70)."""
     v = np.empty(2 * len(iq), np.float64)

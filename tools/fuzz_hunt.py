@@ -28,7 +28,7 @@ def main():
         which = "test_random_service_start_stop_schedules" if seed % 7 == 6 else "test_random_channels_and_layouts_follow_the_oracle"
         env = dict(os.environ, DABX_FUZZ_SEED=str(seed), DABX_FUZZ_CFG=cfg)
         if fast:
-            env.update(DABX_MSC_FAST_MIN_JOBS="64", DABX_MSC_CLASS_MIN_JOBS="1")
+            env.update(DABX_FUZZ_FAST="1")
         t0 = time.time()
         p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_fuzz.py", "-k", which],
                            cwd=ROOT, env=env, capture_output=True, text=True)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# One GPU-box session (through gpurun): GPU test suite, same-box A/B of library builds, PMC passes.
+#   tools/gpu_round.sh <tag> [tests|ab|pmc ...]
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for what in "$@"; do
+  case $what in
+    tests) timeout 2400 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
+    ab)    bash tools/ab.sh $OUT/ab 3 "r2|dabstar_amd/_ab/libdabx_r2.so|" "new|-|" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
+    pmc)   bash tools/prof_pmc2.sh $OUT/pmc "k_demap_frame6|k_symbols_persistent|k_demap_fic" > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
+    bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
+    bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
+  esac
+done
