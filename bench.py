@@ -34,9 +34,9 @@ A_KERNEL = {
     "k_msc_vitT": 4 * 55296 + 4 * 3456,                # transposed symbols read, packed logical frames out
     "k_acquire": 0,
     "k_frame_head": 2 * 2048 * 8 + 2048 * 8,          # sync window + symbol 0 in, reference spectrum out
-    "k_symbols": 75 * 2552 * 8 + 75 * 2048 * 8,       # IQ of symbols 1..75 in, spectra out
-    "k_demap_frame": 75 * 2048 * 8 + 75 * 3072 + 86016,   # spectra in, Viterbi symbols out, carry state r+w
-    "k_demap_fic": 3 * 2048 * 8 + 3 * 3072 + 86016,       # the three FIC symbols (own launch since round 2)
+    "k_symbols": 75 * 2552 * 8 + 75 * 1536 * 8,       # IQ of symbols 1..75 in, spectra (1536 used carriers) out
+    "k_demap_frame": 72 * 1536 * 8 + 72 * 3072 + 86016,   # the 72 MSC symbols: spectra (carrier order) in, Viterbi symbols out, carry state r+w
+    "k_demap_fic": 3 * 1536 * 8 + 3 * 3072 + 86016,       # the three FIC symbols (own launch since round 2)
     "k_fic_frame": 9216 + 384,
     "k_frame_tail": 2048 * 8 + 2 * 2048 * 4,
     "k_msc_frame": 4 * 55296 + 4 * 3456,              # time-deinterleaver read, packed logical frames out
@@ -70,7 +70,13 @@ def parse():
 def hip():
     L = C.CDLL("libamdhip64.so")
     L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hipDeviceGetPCIBusId.argtypes = [C.c_char_p, C.c_int, C.c_int]
     return L
+
+
+def shard_mod():
+    from dabstar_amd import shard
+    return shard
 
 
 def mixed_multiplex():
@@ -136,25 +142,29 @@ def load_pcie_inclusive():
 
 
 def host_cpu():
-    """CPU model and physical core count of the host (for the cpu_baseline record)."""
-    model, cores = "unknown", set()
+    """CPU model, physical core count and one logical CPU per physical core (within this process's affinity mask)."""
+    model, cores = "unknown", {}
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
     try:
-        phys = core = None
-        for ln in open("/proc/cpuinfo"):
+        cpu = phys = core = None
+        for ln in list(open("/proc/cpuinfo")) + ["\n"]:
             if ln.startswith("model name") and model == "unknown":
                 model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("processor"):
+                cpu = int(ln.split(":", 1)[1])
             elif ln.startswith("physical id"):
                 phys = ln.split(":", 1)[1].strip()
             elif ln.startswith("core id"):
                 core = ln.split(":", 1)[1].strip()
             elif not ln.strip():
-                if phys is not None and core is not None:
-                    cores.add((phys, core))
-                phys = core = None
+                if cpu is not None and cpu in allowed:
+                    cores.setdefault((phys, core) if phys is not None and core is not None else ("cpu", cpu), cpu)
+                cpu = phys = core = None
     except OSError:
         pass
-    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return model, (len(cores) or logical), logical
+    logical = len(allowed)
+    one_per_core = sorted(cores.values()) or sorted(allowed)
+    return model, len(one_per_core), logical, one_per_core
 
 
 def cpu_baseline(args, subch):
@@ -166,7 +176,7 @@ def cpu_baseline(args, subch):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from tools import dab_synth as ds
-    model, phys_cores, logical = host_cpu()
+    model, phys_cores, logical, core_cpus = host_cpu()
     build = "-O3 -march=native"
     native = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
     try:
@@ -204,8 +214,9 @@ def cpu_baseline(args, subch):
            "variant": "reference-default (scalar demapper, scalar int32 Viterbi)",
            "cpu_model": model, "physical_cores": phys_cores, "logical_cpus": logical}
     out.update(vit.get("default", {}))
-    # reference-best: the reference's own AVX2 Viterbi object inside the same chain (single-threaded: its path metrics are
-    # file-scope arrays)
+    # reference_avx2_object: the reference's own VITERBI_AVX2 object code (oracle/_ref) hooked into the same chain
+    # (single-threaded: its path metrics are file-scope arrays).  NOT the fastest CPU figure: called block by block through the hook
+    # it costs more per block than gcc's auto-vectorised port (viterbi_us_per_block) -- it is here because it IS the reference's code.
     R = ol.ref_viterbi_variant("avx2")
     if R is not None and hasattr(R, "ref_viterbi_cached"):
         L.ora_set_viterbi_hook.argtypes = [C.c_void_p]
@@ -214,20 +225,40 @@ def cpu_baseline(args, subch):
             got_b, dt_b = run_one(n, "best")
         finally:
             L.ora_set_viterbi_hook(None)
-        out["reference_best"] = {"value": round(got_b / dt_b, 3), "unit": "frames/s", "cores": 1, "kind": "port+reference",
-                                 "variant": "reference-best (scalar demapper, the reference's VITERBI_AVX2 object code)",
-                                 "sample": "%d frames of the same stream" % got_b}
-        out["reference_best"].update(vit.get("best", {}))
-    # the same port on every host core (streams are independent: one receiver per thread, ctypes drops the GIL)
+        out["reference_avx2_object"] = {"value": round(got_b / dt_b, 3), "unit": "frames/s", "cores": 1, "kind": "port+reference",
+                                        "variant": "scalar demapper + the reference's VITERBI_AVX2 object code called through a hook (slower than the port's own decoder)",
+                                        "sample": "%d frames of the same stream" % got_b}
+        out["reference_avx2_object"].update(vit.get("best", {}))
+    # port_simd_viterbi: the port decoding with ITS OWN restatement of the AVX2 build's arithmetic (ora_viterbi_simd: uint16
+    # saturating metrics, ties to i + 32; pinned against the AVX2 object code), compiled -O3 -march=native like everything else
+    L.ora_set_viterbi_mode(1)
+    try:
+        got_s, dt_s = run_one(n, "simd")
+    finally:
+        L.ora_set_viterbi_mode(0)
+    out["port_simd_viterbi"] = {"value": round(got_s / dt_s, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                "variant": "scalar demapper + the port's AVX2-semantics Viterbi (ora_viterbi_simd), %s" % build,
+                                "sample": "%d frames of the same stream" % got_s}
+    out["port_simd_viterbi"].update(vit.get("simd", {}))
+    best = max([("reference-default", out["value"]), ("port_simd_viterbi", out["port_simd_viterbi"]["value"])] +
+               ([("reference_avx2_object", out["reference_avx2_object"]["value"])] if "reference_avx2_object" in out else []), key=lambda kv: kv[1])
+    out["best_single_core"] = {"variant": best[0], "value": best[1], "unit": "frames/s"}
+    # the same port on ALL PHYSICAL cores: one receiver per thread (streams are independent, ctypes drops the
+    # GIL), every thread pinned to its own physical core with sched_setaffinity (one logical CPU per core, no SMT sharing)
     import threading
-    ncpu = min(64, logical)
-    if ncpu > 1:
-        n2 = max(20, min(n, int(5.0 * got / dt)))          # about 5 s per thread (bounded even if the threads share cores)
+
+    def all_cores_leg(cpus, label):
+        ncpu = len(cpus)
+        n2 = max(20, min(n, int(5.0 * got / dt)))          # about 5 s per thread
         x2 = x[: (n2 + 3) * TF]
         rxs = [L.ora_rx_create(ol.make_descs(subch), len(subch)) for _ in range(ncpu)]
         done = [0] * ncpu
 
         def work(i):
+            try:
+                os.sched_setaffinity(0, {cpus[i]})          # pid 0 = the calling thread
+            except (AttributeError, OSError):
+                pass
             done[i] = L.ora_rx_run(rxs[i], x2, len(x2), n2)
         th = [threading.Thread(target=work, args=(i,)) for i in range(ncpu)]
         t0 = time.perf_counter()
@@ -238,8 +269,10 @@ def cpu_baseline(args, subch):
         dt2 = time.perf_counter() - t0
         for r in rxs:
             L.ora_rx_destroy(r)
-        out["all_cores"] = {"value": round(sum(done) / dt2, 3), "unit": "frames/s", "cores": ncpu, "variant": "reference-default",
-                            "sample": "%d threads x %d frames, one receiver each" % (ncpu, n2)}
+        return {"value": round(sum(done) / dt2, 3), "unit": "frames/s", "cores": ncpu, "variant": "reference-default", "pinned": label,
+                "sample": "%d threads x %d frames, one receiver each" % (ncpu, n2)}
+    if len(core_cpus) > 1:
+        out["all_cores"] = all_cores_leg(core_cpus, "one thread per physical core (%d of %d logical CPUs)" % (len(core_cpus), logical))
     # the reference's OWN object code where it could be built (oracle/_ref, viterbi_spiral.cpp scalar): its Viterbi alone,
     # as a frame rate (72 MSC blocks of 1542 steps + 4 FIC blocks of 774 per frame)
     if ol.have_ref():
@@ -334,7 +367,7 @@ class DryEngine:
 
 def load_traffic(dom):
     """HBM bytes and VALU instructions per FRAME of kernel `dom` from the committed rocprofv3 --pmc passes (tools/prof_round.sh)."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -377,6 +410,8 @@ def main():
     dry = args.dry_launch
     if dry and os.environ.get("DABX_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies before joining the group
         raise SystemExit(3)
+    if dry and os.environ.get("DABX_BENCH_HANG_RANK") == str(rank):      # test hook: a rank that never joins (launcher timeout path)
+        time.sleep(3600)
     if dry:
         dev = torch.device("cpu")
         sync_dev = lambda: None
@@ -400,6 +435,12 @@ def main():
     n_joined = dist.get_world_size() if dist is not None else 1
     if n_joined != args.gpus:
         raise SystemExit("bench.py: %d ranks joined the process group, --gpus %d" % (n_joined, args.gpus))
+    # which physical device this rank sits on (hipDeviceGetPCIBusId): gathered below so that the line proves N different GPUs
+    pci = (-1, -1, -1, -1)
+    if not dry:
+        buf = C.create_string_buffer(64)
+        if hip().hipDeviceGetPCIBusId(buf, 64, local_rank) == 0:
+            pci = shard_mod().parse_pci_bus_id(buf.value.decode())
     from tools import dab_synth as ds
     subch = ds.default_subchannels(18, 64)
     dx = None
@@ -477,6 +518,17 @@ def main():
     fib_ok, fib_tot = c2["fib_ok"] - c1["fib_ok"], c2["fib_total"] - c1["fib_total"]
     # max over ranks of the elapsed time, sum over ranks of the counters (the only collectives of the path)
     from dabstar_amd import shard
+    import zlib
+    host_id = zlib.crc32(os.uname().nodename.encode()) & 0x7FFFFFFF
+    if dry:      # stand-in device ids (function = rank); test hook: every rank claims the same one
+        pci = (0xD, 0, 0, 0 if os.environ.get("DABX_BENCH_DRY_SAME_DEVICE") == "1" else rank)
+    reports = shard.gather_rank_reports(dist, torch, dev, rank, local_rank, pci, frames, dt, host_id)
+    shared = shard.check_distinct_devices(reports)
+    if shared:
+        raise SystemExit("bench.py: ranks share a GPU (rank, rank, PCI bus id): %s -- not an N-GPU run" % shared)
+    if dry:
+        for r_ in reports:
+            r_["pci_bus_id"] = "dry:rank%d" % r_["rank"]
     dt, (frames, fib_ok, fib_tot, sf_ok, sf_fail, msc_bytes, locked) = shard.reduce_results(
         dist, torch, dev, dt, [frames, fib_ok, fib_tot, c2["sf_ok"] - c1["sf_ok"], c2["sf_fail"] - c1["sf_fail"],
                                c2["msc_bytes"] - c1["msc_bytes"], c2["streams_locked"]])
@@ -494,7 +546,7 @@ def main():
             if tj is not None and tj["streams"] == args.streams:
                 # counters are per frame of work (collected at whole 7-frame batches), scaled to this run's average launch
                 traffic = int(tj["hbm_bytes_per_frame"] * units)
-                traffic_src = tj["file"] + " (per frame x %.1f frames per launch)" % units
+                traffic_src = tj["file"] + " (counters of a separate rocprofv3 --pmc run of that round's build, not re-measured here; per frame x %.1f frames per launch)" % units
                 if tj["valu_per_frame"]:    # issue-rate view of the same launch: wave64 VALU instructions / measured issue peak
                     peak, peak_src = load_valu_peak()
                     vi = tj["valu_per_frame"] * units
@@ -510,7 +562,12 @@ def main():
                               "achieved_GBps": round(A_KERNEL[dom] * sa_units / (sa_ms * 1e-3) / 1e9, 2)}
                 if valu is not None:
                     standalone["valu_util"] = round(tj["valu_per_frame"] * sa_units / (sa_ms * 1e-3) / valu["issue_peak_per_s"], 4)
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
+            # the contract's fields price the kernel against the HBM roofline (algorithmic bytes); `limiting` names the resource the
+            # kernel is actually closest to: the larger of the HBM fraction and the VALU issue utilisation (lane-per-trellis
+            # Viterbi: VALU)
+            hbm_frac = achieved * 1e9 / HBM_PEAK
+            limiting = "valu" if (valu is not None and valu["util"] > hbm_frac) else "hbm"
+            roofline = {"bound": "hbm", "limiting": limiting, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9,
                         "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6), "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": round(units, 2),
                         "avg_launch_ms": round(kern[dom], 4), "valu": valu, "standalone": standalone}
@@ -529,6 +586,10 @@ def main():
             "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
             "streams_locked": locked, "superframes_ok": sf_ok, "superframes_failed": sf_fail, "msc_bytes": msc_bytes,
             "roofline": roofline,
+            "ranks_joined": n_joined, "per_rank": reports, "devices": sorted({r["pci_bus_id"] for r in reports}),
+            "scaling_efficiency": round(value / (n_joined * sorted(r["frames_per_s"] for r in reports)[len(reports) // 2]), 4)
+            if all(r["frames_per_s"] > 0 for r in reports) else None,
+            "collective_backend": (("gloo" if dry else "rccl %s" % ".".join(str(v) for v in torch.cuda.nccl.version())) if dist is not None else None),
             "chain": {"algorithmic_bytes_per_frame": a_frame, "achieved_GBps": round(value / n_joined * a_frame / 1e9, 2),
                       "frac_of_hbm_peak": round(value / n_joined * a_frame / HBM_PEAK, 6),
                       "kernel_ms_per_step_standalone": {k: round(v, 4) for k, v in share.items()}},

@@ -143,11 +143,28 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+REF_VARIANTS = {"ieee": "libdabref.so",                 # CMakeLists.txt:76 minus -ffast-math
+                "fastmath": "libdabref_fastmath.so"}    # the complete flag set of CMakeLists.txt:76
+_ref_variant = "ieee"
+_ref_cache = {}
+
+
+def use_ref_variant(name):
+    """Selects which build of the reference's leaf objects ref() returns; False when that build is absent."""
+    global _ref_variant, _ref
+    path = os.path.join(os.path.dirname(REF_SO), REF_VARIANTS[name])
+    if not os.path.exists(path):
+        return False
+    _ref_variant = name
+    _ref = _ref_cache.get(name)
+    return True
+
+
 def ref():
     global _ref
     if _ref is not None:
         return _ref
-    L = C.CDLL(REF_SO)
+    L = C.CDLL(os.path.join(os.path.dirname(REF_SO), REF_VARIANTS[_ref_variant]))
     L.ref_viterbi.argtypes = [_i16p, C.c_int, _u8p]
     L.ref_viterbi_seconds.argtypes = [_i16p, C.c_int, _u8p, C.c_int]
     L.ref_viterbi_seconds.restype = C.c_double
@@ -177,6 +194,7 @@ def ref():
     L.ref_tii_add.argtypes = [C.c_void_p, _c64p]
     L.ref_tii_process.argtypes = [C.c_void_p, C.c_int, _f32p, C.c_int]
     _ref = L
+    _ref_cache[_ref_variant] = L
     return L
 
 

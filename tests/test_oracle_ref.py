@@ -10,6 +10,17 @@ import oracle_lib as ol
 
 pytestmark = [pytest.mark.ref, pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")]
 
+
+@pytest.fixture(autouse=True, params=["ieee", "fastmath"])
+def ref_build(request):
+    """Every test of this module runs against both builds of the reference's leaf objects: CMakeLists.txt:76's flags without
+    and WITH -ffast-math (the set the reference ships with).  The integer leaves cannot differ; the float ones
+    (phasetable.cpp here, tii_detector.cpp in test_tii.py) are the point."""
+    if not ol.use_ref_variant(request.param):
+        pytest.skip("oracle/_ref/%s not built" % ol.REF_VARIANTS[request.param])
+    yield request.param
+    ol.use_ref_variant("ieee")
+
 UEP = [(32, 5), (32, 1), (48, 3), (56, 2), (64, 5), (64, 4), (80, 1), (96, 3), (112, 4), (128, 1),
        (160, 2), (192, 5), (224, 3), (256, 4), (320, 2)]
 EEP = [(8, 0), (8, 1), (8, 2), (8, 3), (16, 1), (32, 2), (32, 4), (32, 7), (64, 2), (64, 0), (64, 3), (64, 5),

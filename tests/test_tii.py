@@ -71,25 +71,42 @@ def run_ref(collisions, sub_id, thr, rounds):
     return out
 
 
-def same(a, b):
+def same(a, b, rel=0.0, deg=0.0):
+    """rel = deg = 0: bit-identical floats.  Otherwise strength within `rel` (relative) and phase within `deg` degrees."""
     if len(a) != len(b):
         return False
     for x, y in zip(a, b):
         if len(x) != len(y):
             return False
         for p, q in zip(x, y):
-            if p[:2] != q[:2] or p[4] != q[4] or np.float32(p[2]) != np.float32(q[2]) or np.float32(p[3]) != np.float32(q[3]):
+            if p[:2] != q[:2] or p[4] != q[4]:
+                return False
+            if abs(np.float32(p[2]) - np.float32(q[2])) > rel * abs(q[2]) or abs(np.float32(p[3]) - np.float32(q[3])) > deg:
                 return False
     return True
 
 
+@pytest.mark.parametrize("flags", ["ieee", "fastmath"])
 @pytest.mark.parametrize("name", sorted(scenarios()))
-def test_matches_the_reference_object_code(name):
+def test_matches_the_reference_object_code(name, flags):
+    """Against tii_detector.cpp compiled unmodified with CMakeLists.txt:76's flags minus -ffast-math ("ieee") and with the
+    complete set the reference ships with ("fastmath": gcc may then re-associate, contract and use reciprocals)."""
     if not ol.have_ref():
         pytest.skip("oracle/_ref not built (no /root/reference here): the golden test covers it")
-    c, s, thr, rounds = scenarios()[name]
-    got, want = run_dabx(c, s, thr, rounds), run_ref(c, s, thr, rounds)
-    assert same(got, want), (got[-1][:4], want[-1][:4])
+    if not ol.use_ref_variant(flags):
+        pytest.skip("oracle/_ref/%s not built" % ol.REF_VARIANTS[flags])
+    try:
+        c, s, thr, rounds = scenarios()[name]
+        got, want = run_dabx(c, s, thr, rounds), run_ref(c, s, thr, rounds)
+    finally:
+        ol.use_ref_variant("ieee")
+    if flags == "ieee":
+        assert same(got, want), (got[-1][:4], want[-1][:4])
+    else:
+        # -ffast-math lets gcc re-associate the power sums and use reciprocals: every transmitter, id, flag and the order are
+        # still identical, strengths agree to 3e-7 relative (a few ulp) and phases to 1e-4 degrees -- NOT bit for bit.  Which
+        # association the reference's shipped binary uses is the compiler's choice; dabx_tii_* follows the source order.
+        assert same(got, want, rel=3e-7, deg=1e-4), (got[-1][:4], want[-1][:4])
 
 
 def test_matches_the_golden_fixture():
