@@ -158,7 +158,7 @@ int dabx_engine::build_msc_classes()
   fast = sorted;
   fast.min_jobs = (int)std::min<size_t>(min_jobs, 0x7fffffff);
   fast.slots_active = active;
-  have_fast = fast.n_cls > 0 && (size_t)jobs_total >= min_jobs && !d.tie_mode;   // the lane-per-trellis kernel is the canonical arithmetic only
+  have_fast = fast.n_cls > 0 && (size_t)jobs_total >= min_jobs;   // every viterbi_tie_mode has its lane-per-trellis kernel (vit_t.hip)
   DABX_HIP(hipMemcpy(d.subch, subch_host.data(), sizeof(SubchDev) * subch_host.size(), hipMemcpyHostToDevice));
   return 0;
 }

@@ -14,6 +14,7 @@
 // sub-channel layouts are decoded together.
 #include "pipeline.h"
 #include "vit_t_gen.h"
+#include <vector>
 
 namespace dabx {
 
@@ -184,8 +185,22 @@ __device__ __forceinline__ void vt_fetch(VtCycle &c, vt_rsrc in_grp, int lane, v
   }
 }
 
-template <int C>
-__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, uint2 *dec_lane, vt::s2 v2n)
+// ---- the arithmetic of the reference's SIMD builds (cfg.viterbi_tie_mode 1 / 2) on the same register scheme -----------------
+// VITERBI_AVX2 (viterbi_16way.h:9-110): uint16 metrics, saturating adds, a tie goes to predecessor i + 32, and after every
+// second step `renormalize`: if state 0's metric of the step BEFORE exceeds 60000, the minimum of the new metrics is subtracted.
+// VITERBI_SSE2 / NEON (viterbi_8way.h:9-120): int16 metrics saturating at 32767, threshold 30000, ties as in the scalar body.
+// The lane keeps its relative, doubled and centred int16 metrics R and follows the reference's ABSOLUTE level with one int:
+// 2 M_ref = R + C, Coff = C before the first step of the current 6-step cycle; C grows by 1020 per step and by `ref` at a
+// re-centring, and becomes -min(R) at a renormalisation.  A candidate saturates when it exceeds lim = LIMTOP - C.  That can
+// only happen if max(R) + 12240 > LIMTOP - Coff at the start of the cycle (metrics grow by at most 1020 per step while lim
+// falls by 1020): only then does the cycle run the clamped step bodies (four more v_pk_min per butterfly pair).  Model and
+// proof by test: tools/gen_vit_t.py (model_decode_tie against the oracle restatements and the reference's own object code).
+template <int TIE> struct VtTie { static constexpr int LIMTOP = 0, REN2 = 0; };
+template <> struct VtTie<1> { static constexpr int LIMTOP = 2 * 65535, REN2 = 2 * 60000; };
+template <> struct VtTie<2> { static constexpr int LIMTOP = 2 * 32767, REN2 = 2 * 30000; };
+
+template <int C, int TIE = 0, bool CLAMP = false>
+__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, uint2 *dec_lane, vt::s2 v2n, int &Coff)
 {
   // the step's four symbols: dword + byte lane each (the lanes are wave-uniform and end up in SGPR selectors); the packed
   // branch metrics come straight from those (vit_t_gen.h, bm<C>): no scalar extraction, no 32-bit sums
@@ -197,23 +212,59 @@ __device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t
   }
   vt::s2 M[4];
   unsigned acc0, acc1;
-  if constexpr (C == 0) { vt::bm0(w, b, v2n, M); vt::step0(R, M, acc0, acc1); }
-  else if constexpr (C == 1) { vt::bm1(w, b, v2n, M); vt::step1(R, M, acc0, acc1); }
-  else if constexpr (C == 2) { vt::bm2(w, b, v2n, M); vt::step2(R, M, acc0, acc1); }
-  else if constexpr (C == 3) { vt::bm3(w, b, v2n, M); vt::step3(R, M, acc0, acc1); }
-  else if constexpr (C == 4) { vt::bm4(w, b, v2n, M); vt::step4(R, M, acc0, acc1); }
-  else { vt::bm5(w, b, v2n, M); vt::step5(R, M, acc0, acc1); }
+  bool pre = false;
+  vt::s2 lim = vt::pk(0, 0);
+  if constexpr (TIE != 0) {
+    if constexpr ((C & 1) != 0) pre = (int)R[0].x + Coff + 1020 * C > VtTie<TIE>::REN2;      // metrics2[0] > threshold, checked on the step before
+    if constexpr (CLAMP) {
+      int l = VtTie<TIE>::LIMTOP - Coff - 1020 * (C + 1);
+      l = l < 32767 ? l : 32767;
+      lim = vt::pk(l, l);
+    }
+  }
+  if constexpr (C == 0) { vt::bm0(w, b, v2n, M); vt::step0<TIE, CLAMP>(R, M, acc0, acc1, lim); }
+  else if constexpr (C == 1) { vt::bm1(w, b, v2n, M); vt::step1<TIE, CLAMP>(R, M, acc0, acc1, lim); }
+  else if constexpr (C == 2) { vt::bm2(w, b, v2n, M); vt::step2<TIE, CLAMP>(R, M, acc0, acc1, lim); }
+  else if constexpr (C == 3) { vt::bm3(w, b, v2n, M); vt::step3<TIE, CLAMP>(R, M, acc0, acc1, lim); }
+  else if constexpr (C == 4) { vt::bm4(w, b, v2n, M); vt::step4<TIE, CLAMP>(R, M, acc0, acc1, lim); }
+  else { vt::bm5(w, b, v2n, M); vt::step5<TIE, CLAMP>(R, M, acc0, acc1, lim); }
   dec_lane[(size_t)t * 64] = make_uint2(acc0, acc1);
+  if constexpr (TIE != 0 && (C & 1) != 0) {
+    if (__builtin_amdgcn_ballot_w64(pre)) {              // some lane renormalises (wave-uniform branch; every ~100-200 steps per lane)
+      const int mnv = vt::min64(R);
+      if (pre) Coff = -mnv - 1020 * (C + 1);
+    }
+  }
 }
 
-__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane, vt::s2 v2n)
+template <int TIE, bool CLAMP>
+__device__ __forceinline__ void vt_cycle6(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane, vt::s2 v2n, int &Coff)
 {
-  vt_one<0>(R, cy, t0 + 0, dec_lane, v2n);
-  vt_one<1>(R, cy, t0 + 1, dec_lane, v2n);
-  vt_one<2>(R, cy, t0 + 2, dec_lane, v2n);
-  vt_one<3>(R, cy, t0 + 3, dec_lane, v2n);
-  vt_one<4>(R, cy, t0 + 4, dec_lane, v2n);
-  vt_one<5>(R, cy, t0 + 5, dec_lane, v2n);
+  vt_one<0, TIE, CLAMP>(R, cy, t0 + 0, dec_lane, v2n, Coff);
+  vt_one<1, TIE, CLAMP>(R, cy, t0 + 1, dec_lane, v2n, Coff);
+  vt_one<2, TIE, CLAMP>(R, cy, t0 + 2, dec_lane, v2n, Coff);
+  vt_one<3, TIE, CLAMP>(R, cy, t0 + 3, dec_lane, v2n, Coff);
+  vt_one<4, TIE, CLAMP>(R, cy, t0 + 4, dec_lane, v2n, Coff);
+  vt_one<5, TIE, CLAMP>(R, cy, t0 + 5, dec_lane, v2n, Coff);
+}
+template <int TIE, bool ALWAYS_CLAMP>
+__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane, vt::s2 v2n, int &Coff)
+{
+  if constexpr (TIE == 0) vt_cycle6<0, false>(R, cy, t0, dec_lane, v2n, Coff);
+  else {
+    bool clamp = ALWAYS_CLAMP;
+    if constexpr (!ALWAYS_CLAMP) {
+      const int room = VtTie<TIE>::LIMTOP - Coff;
+      // cheap filter first (the spread of the 64 metrics never exceeds 14 240 doubled units), then the exact test on the maximum
+      if (__builtin_amdgcn_ballot_w64((int)R[0].x + 14280 + 12240 > room)) {
+        const int mxv = vt::max64(R);
+        clamp = __builtin_amdgcn_ballot_w64(mxv + 12240 > room) != 0;
+      }
+    }
+    if (clamp) vt_cycle6<TIE, true>(R, cy, t0, dec_lane, v2n, Coff);
+    else vt_cycle6<TIE, false>(R, cy, t0, dec_lane, v2n, Coff);
+    Coff += 6 * 1020;
+  }
 }
 
 // ---- chain-back helpers: one 6-step cycle of decision words in named registers
@@ -254,38 +305,18 @@ __device__ unsigned long long *g_vt_timeline = nullptr;
 __device__ unsigned g_vt_timeline_cap = 0;
 __device__ unsigned g_vt_timeline_n = 0;
 
-// grid = groups, 64 threads.  map: depuncture map with PUNCT remapped to n_in (the 0x7F row).
-__global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs)
+// Forward pass + chain-back of the 64 trellises of one wave.  in_grp: the group's transposed symbols; cmap: depuncture map
+// with PUNCT remapped to the 0x7F row; dec_lane: this lane's column of the group's decision words; out: where the lane's
+// packed, de-dispersed bytes go (nullptr: nothing is stored).
+template <int TIE, bool ALWAYS_CLAMP>
+__device__ __forceinline__ void vt_decode(vt_rsrc in_grp, vt_cmap cmap, int nsteps, uint2 *dec_lane, uint32_t *out, const uint32_t *prbs,
+                                          const unsigned char (*pos_tab)[64], int lane, unsigned long long &t_forward_end, bool want_time)
 {
-  __shared__ unsigned char pos_tab[6][64];
-  const int lane = threadIdx.x;
-  unsigned long long *const tl = g_vt_timeline;
-  unsigned long long tl0 = 0, tl1 = 0;
-  if (tl) tl0 = __builtin_amdgcn_s_memrealtime();
-  // Groups are ordered longest trellis first.  All waves of a launch are resident at once (<= 4 per SIMD), so the work of
-  // a SIMD is the sum over the ~4 "rounds" of 1024 blocks that landed on it: walk every second round backwards
-  // (boustrophedon) so that long and short trellises pair up on the same SIMD.
-  int gg = blockIdx.x;
-  {
-    constexpr int ROUND = 1024;                                    // 256 CUs x 4 SIMDs
-    const int r = gg / ROUND, base = r * ROUND;
-    const int len = ML.groups - base < ROUND ? ML.groups - base : ROUND;
-    if (r & 1) gg = base + (len - 1 - (gg - base));
-  }
-  const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, gg)];
-  const int g = gg - cl.g0;                                       // decoder group within the class
-  const uint16_t *map = cl.map2;
-  for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
-  const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
-  const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
-  const vt_rsrc in_grp = vt_make_rsrc(cl.inT + (size_t)g * rows * 64, (unsigned)rows * 256u);
-  uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
-  const vt_cmap cmap = (vt_cmap)(const void *)map;
-
   vt::s2 R[32];
 #pragma unroll
   for (int r = 0; r < 32; r++) R[r] = vt::pk(2000, 2000);          // viterbi_spiral.cpp:98-101 (0 / 1000), doubled
   R[0] = vt::pk(0, 2000);
+  int Coff = 0;                                                    // tie modes: 2 M_ref = R + Coff before the cycle's first step
   // Two 6-step cycles of symbols are always in flight, fetched UNCONDITIONALLY one cycle ahead (beyond the end the last
   // cycle is fetched again): with no branch around a fetch the number of outstanding loads is static and the compiler
   // waits with s_waitcnt vmcnt(N) for exactly the cycle it is about to consume instead of draining the queue.
@@ -293,8 +324,9 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   VtCycle ca, cb;
   vt_fetch(ca, in_grp, lane, cmap, 0);
   vt_fetch(cb, in_grp, lane, cmap, 6);
-  auto recentre = [&R]() {                                         // every 12 steps on the metric of label 0
+  auto recentre = [&R, &Coff]() {                                  // every 12 steps on the metric of label 0
     const vt::s2 ref = vt::pk(R[0].x, R[0].x);
+    if constexpr (TIE != 0) Coff += (int)R[0].x;
 #pragma unroll
     for (int r = 0; r < 32; r++) R[r] = R[r] - ref;
   };
@@ -303,24 +335,21 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
   int t = 0;
   for (; t + 12 <= nsteps; t += 12) {
     recentre();
-    vt_cycle(R, ca, t, dec_lane, v2n);
+    vt_cycle<TIE, ALWAYS_CLAMP>(R, ca, t, dec_lane, v2n, Coff);
     vt_fetch(ca, in_grp, lane, cmap, t + 12 < last ? t + 12 : last);
-    vt_cycle(R, cb, t + 6, dec_lane, v2n);
+    vt_cycle<TIE, ALWAYS_CLAMP>(R, cb, t + 6, dec_lane, v2n, Coff);
     vt_fetch(cb, in_grp, lane, cmap, t + 18 < last ? t + 18 : last);
   }
   if (t < nsteps) {                                                // odd number of cycles
     recentre();
-    vt_cycle(R, ca, t, dec_lane, v2n);
+    vt_cycle<TIE, ALWAYS_CLAMP>(R, ca, t, dec_lane, v2n, Coff);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (tl) tl1 = __builtin_amdgcn_s_memrealtime();
+  if (want_time) t_forward_end = __builtin_amdgcn_s_memrealtime();
 
-  // chain-back per lane (viterbi_spiral.cpp:114-125 in label space) + PRBS (backend.cpp:155-158) + byte packing
-  uint32_t *out = nullptr;
-  if (q.valid)
-    out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)q.s * e.max_subch + q.j) * MSC_SLOTS + (size_t)(q.out_idx % MSC_SLOTS)) * e.msc_stride);
+  // chain-back per lane (viterbi_spiral.cpp:114-125 in label space) + PRBS (backend.cpp:155-158) + byte packing.
   // The chain is one LDS look-up (bit position of the label's decision in the step's word) and three VALU operations per
   // step and lane; the decision words themselves are fetched two 6-step cycles ahead of their use -- their addresses do not
   // depend on the path, only the bit that is picked does -- so no memory latency sits on the chain.  (Kept in NAMED
@@ -340,6 +369,39 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
     vt_back_one<0>(cur.w0, tc + 0, L, outw, out, prbs, pos_tab[0]);
     cur = nx1; nx1 = nx2;
   }
+}
+
+// grid = groups, 64 threads.  TIE: cfg.viterbi_tie_mode (0 canonical, 1 VITERBI_AVX2, 2 VITERBI_SSE2 arithmetic).
+template <int TIE>
+__device__ __forceinline__ void msc_vitT_body(const EngineDev &e, int cifs, const MscLaunch &ML, const uint32_t *prbs)
+{
+  __shared__ unsigned char pos_tab[6][64];
+  const int lane = threadIdx.x;
+  unsigned long long *const tl = g_vt_timeline;
+  unsigned long long tl0 = 0, tl1 = 0;
+  if (tl) tl0 = __builtin_amdgcn_s_memrealtime();
+  // Groups are ordered longest trellis first.  All waves of a launch are resident at once (<= 4 per SIMD), so the work of
+  // a SIMD is the sum over the ~4 "rounds" of 1024 blocks that landed on it: walk every second round backwards
+  // (boustrophedon) so that long and short trellises pair up on the same SIMD.
+  int gg = blockIdx.x;
+  {
+    constexpr int ROUND = 1024;                                    // 256 CUs x 4 SIMDs
+    const int r = gg / ROUND, base = r * ROUND;
+    const int len = ML.groups - base < ROUND ? ML.groups - base : ROUND;
+    if (r & 1) gg = base + (len - 1 - (gg - base));
+  }
+  const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, gg)];
+  const int g = gg - cl.g0;                                       // decoder group within the class
+  for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
+  const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
+  const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
+  const vt_rsrc in_grp = vt_make_rsrc(cl.inT + (size_t)g * rows * 64, (unsigned)rows * 256u);
+  uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
+  const vt_cmap cmap = (vt_cmap)(const void *)cl.map2;
+  uint32_t *out = nullptr;
+  if (q.valid)
+    out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)q.s * e.max_subch + q.j) * MSC_SLOTS + (size_t)(q.out_idx % MSC_SLOTS)) * e.msc_stride);
+  vt_decode<TIE, false>(in_grp, cmap, nsteps, dec_lane, out, prbs, pos_tab, lane, tl1, tl != nullptr);
   if (tl && lane == 0) {
     const unsigned slot = atomicAdd(&g_vt_timeline_n, 1u);
     if (slot < g_vt_timeline_cap) {
@@ -350,6 +412,80 @@ __global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunc
       o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tl0; o[2] = tl1; o[3] = __builtin_amdgcn_s_memrealtime();
     }
   }
+}
+__global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<0>(e, cifs, ML, prbs); }
+// the same trellises decoded with the arithmetic of the reference's VITERBI_AVX2 / VITERBI_SSE2 builds (cfg.viterbi_tie_mode)
+__global__ __launch_bounds__(64) void k_msc_vitT_avx2(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<1>(e, cifs, ML, prbs); }
+__global__ __launch_bounds__(64) void k_msc_vitT_sse2(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<2>(e, cifs, ML, prbs); }
+
+// ---- stage-level access to the lane-per-trellis decoder (tests): batch trellises of nbits decoded bits, unpunctured ------------
+// symT: [groups][nsteps + 1][64] transposed symbol dwords (row r = mother-code bits 4 r .. 4 r + 3 of the lane's trellis),
+// map: identity (4 t, 4 t + 1, 4 t + 2, 4 t + 3), out: [groups * 64][nbits / 32] packed words, zero PRBS.
+template <int TIE, bool ALWAYS_CLAMP>
+__global__ __launch_bounds__(64) void k_vitT_stage(const uint32_t *symT, const uint16_t *map, int nbits, uint2 *decT, uint32_t *outw, const uint32_t *zeros)
+{
+  __shared__ unsigned char pos_tab[6][64];
+  const int lane = threadIdx.x, g = blockIdx.x;
+  for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
+  const int nsteps = nbits + 6, rows = nsteps + 1;
+  const vt_rsrc in_grp = vt_make_rsrc(symT + (size_t)g * rows * 64, (unsigned)rows * 256u);
+  unsigned long long unused = 0;
+  vt_decode<TIE, ALWAYS_CLAMP>(in_grp, (vt_cmap)(const void *)map, nsteps, decT + (size_t)g * nsteps * 64 + lane,
+                               outw + ((size_t)g * 64 + lane) * (nbits / 32), zeros, pos_tab, lane, unused, false);
+}
+
+// not part of include/dabx.h (tests/test_gpu_viterbi.py): ViterbiSpiral::deconvolve on the lane-per-trellis kernel.
+// soft: batch x 4 (nbits + 6) int16, bits: batch x nbits (one per byte); nbits a multiple of 96; always_clamp != 0 forces the
+// saturating step bodies in every cycle (tie modes: must not change a bit).
+extern "C" int dabx_internal_vitT(const int16_t *soft, int nbits, int batch, int tie_mode, int always_clamp, uint8_t *bits)
+{
+  if (!soft || !bits || batch <= 0 || nbits < 96 || nbits % 96 != 0 || 4 * (nbits + 6) > 65532 || tie_mode < 0 || tie_mode > 2) {
+    set_error("dabx_internal_vitT: bad argument");
+    return DABX_E_ARG;
+  }
+  const int nsteps = nbits + 6, rows = nsteps + 1, groups = (batch + 63) / 64, nw = nbits / 32;
+  std::vector<uint32_t> symT((size_t)groups * rows * 64, 0x7F7F7F7Fu);
+  for (int b = 0; b < batch; b++)
+    for (int r = 0; r < nsteps; r++) {
+      uint32_t v = 0;
+      for (int k = 0; k < 4; k++) {
+        const int16_t sft = soft[(size_t)b * 4 * nsteps + 4 * r + k];
+        int sy = tie_mode ? (int)sft + 127 : (int)(int16_t)(sft + 127);          // viterbi_16way.h:73-76 saturates, viterbi_scalar.h:34-40 wraps
+        sy = sy < 0 ? 0 : (sy > 255 ? 255 : sy);
+        v |= (uint32_t)sy << (8 * k);
+      }
+      symT[((size_t)(b / 64) * rows + r) * 64 + (b % 64)] = v;
+    }
+  std::vector<uint16_t> map((size_t)4 * nsteps + 64);
+  for (size_t i = 0; i < map.size(); i++) map[i] = (uint16_t)(i < (size_t)4 * nsteps ? i : 4 * nsteps);
+  uint32_t *d_sym = nullptr, *d_out = nullptr, *d_zero = nullptr;
+  uint16_t *d_map = nullptr;
+  uint2 *d_dec = nullptr;
+  int rc = DABX_E_HIP;
+  std::vector<uint32_t> outw((size_t)groups * 64 * nw);
+  do {
+    if (hipMalloc(&d_sym, symT.size() * 4) != hipSuccess || hipMalloc(&d_map, map.size() * 2) != hipSuccess ||
+        hipMalloc(&d_dec, (size_t)groups * nsteps * 64 * sizeof(uint2)) != hipSuccess || hipMalloc(&d_out, outw.size() * 4) != hipSuccess ||
+        hipMalloc(&d_zero, (size_t)(nw + 1) * 4) != hipSuccess) break;
+    if (hipMemcpy(d_sym, symT.data(), symT.size() * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (hipMemcpy(d_map, map.data(), map.size() * 2, hipMemcpyHostToDevice) != hipSuccess) break;
+    if (hipMemset(d_zero, 0, (size_t)(nw + 1) * 4) != hipSuccess || hipMemset(d_out, 0, outw.size() * 4) != hipSuccess) break;
+#define VT_STAGE(T, A) hipLaunchKernelGGL((k_vitT_stage<T, A>), dim3(groups), dim3(64), 0, 0, d_sym, d_map, nbits, d_dec, d_out, d_zero)
+    if (tie_mode == 0) VT_STAGE(0, false);
+    else if (tie_mode == 1) { if (always_clamp) VT_STAGE(1, true); else VT_STAGE(1, false); }
+    else { if (always_clamp) VT_STAGE(2, true); else VT_STAGE(2, false); }
+#undef VT_STAGE
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) break;
+    if (hipMemcpy(outw.data(), d_out, outw.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+    rc = 0;
+  } while (false);
+  (void)hipFree(d_sym); (void)hipFree(d_map); (void)hipFree(d_dec); (void)hipFree(d_out); (void)hipFree(d_zero);
+  if (rc) { set_error("dabx_internal_vitT: HIP error"); return rc; }
+  for (int b = 0; b < batch; b++) {
+    const uint8_t *pb = reinterpret_cast<const uint8_t *>(outw.data() + (size_t)b * nw);
+    for (int i = 0; i < nbits; i++) bits[(size_t)b * nbits + i] = (uint8_t)((pb[i >> 3] >> (7 - (i & 7))) & 1);
+  }
+  return 0;
 }
 
 // not part of include/dabx.h: registers (or clears, buf == nullptr) the diagnostic wave-timeline buffer of k_msc_vitT
@@ -379,7 +515,9 @@ int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_
   int rc = get_tables(&t);
   if (rc) return rc;
   mk.begin(7, st);
-  hipLaunchKernelGGL(k_msc_vitT, dim3(L.groups), dim3(64), 0, st, e, cifs, L, t->prbs_words);
+  if (e.tie_mode == 1) hipLaunchKernelGGL(k_msc_vitT_avx2, dim3(L.groups), dim3(64), 0, st, e, cifs, L, t->prbs_words);
+  else if (e.tie_mode == 2) hipLaunchKernelGGL(k_msc_vitT_sse2, dim3(L.groups), dim3(64), 0, st, e, cifs, L, t->prbs_words);
+  else hipLaunchKernelGGL(k_msc_vitT, dim3(L.groups), dim3(64), 0, st, e, cifs, L, t->prbs_words);
   mk.end(7, st);
   DABX_HIP(hipGetLastError());
   return 0;

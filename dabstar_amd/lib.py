@@ -80,6 +80,16 @@ def viterbi(soft, nbits, tie_mode=0):
     return out
 
 
+def viterbi_lane_per_trellis(soft, nbits, tie_mode=0, always_clamp=False):
+    """The same decode on the lane-per-trellis kernel of the MSC path (vit_t.hip) through the library's internal test entry
+    (not part of include/dabx.h): unpunctured trellises, 64 per wavefront.  always_clamp forces the saturating step bodies of
+    the tie modes in every cycle (must not change a bit)."""
+    soft = np.ascontiguousarray(soft, np.int16).reshape(-1, 4 * (nbits + 6))
+    out = np.zeros((soft.shape[0], nbits), np.uint8)
+    check(load().dabx_internal_vitT(_p(soft), nbits, soft.shape[0], int(tie_mode), int(bool(always_clamp)), _p(out)))
+    return out
+
+
 def profile_input_bits(kbps, prot_level, short_form=0):
     return check(load().dabx_profile_input_bits(kbps, prot_level, short_form))
 

@@ -46,6 +46,7 @@ public:
     q.subch_id = d->SubChId; q.cu_start = d->CuStartAddr; q.cu_size = d->CuSize; q.kbps = d->bitRate;
     q.prot_level = d->protLevel; q.short_form = d->shortForm ? 1 : 0;
     q.dab_plus = 0;              // super-frame sync + RS(120,110) stay in the reference's Mp4Processor behind add_to_frame
+    if (q.kbps > 0 && mPacked.size() < (size_t)3 * (size_t)q.kbps) mPacked.resize((size_t)3 * (size_t)q.kbps);   // EEP 4-A reaches 2304 kbit/s
     const int slot = dabx_msc_set_channel(mpMsc, &q);
     if (slot < 0) { std::fprintf(stderr, "dabx shim: MscHandler::set_channel: %s\n", dabx_last_error()); return false; }
     SService s;
@@ -96,5 +97,5 @@ private:
   dabx_msc * mpMsc = nullptr;
   mutable std::mutex mMutex;
   std::vector<SService> mServices;
-  std::array<u8, 3 * 1024> mPacked{};                              // largest logical frame: 3 * bitRate bytes
+  std::vector<u8> mPacked = std::vector<u8>(3 * 384);              // one logical frame, 3 * bitRate bytes: grown by set_channel to the largest configured rate
 };

@@ -139,9 +139,25 @@ def test_mobile_channels_follow_the_oracle(profile, doppler, snr, ppm, drift):
     x = ds.channel_mobile(ens.iq, profile, doppler_hz=doppler, snr_db=snr, cfo_hz=-520.0, timing_offset=9000, seed=33,
                           n_out=30 * ds.TF, clock_ppm=ppm, clock_drift_ppm_per_s=drift)
     ora = _oracle_run(x, subch)
-    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"])
+    eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=18, out_frames=4)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    fibs, crc, starts, fbbs, idle, steps = [], [], [], [], 0, 0
+    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[])
+    while idle < 4 and steps < 400:                                # a fade may cost the lock: acquisition passes are steps without a frame
+        before = eng.stats(0)
+        eng.process(1)
+        st = eng.stats(0)
+        steps += 1
+        idle = idle + 1 if st["samples_consumed"] == before["samples_consumed"] else 0
+        if st["frames"] > before["frames"]:
+            f, c = eng.read_fibs(0, 1)
+            fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
+            eng.scalars["clock_err"].append(st["clock_err_hz"]); eng.scalars["fic_ratio"].append(st["fic_ratio_percent"])
+            eng.scalars["snr_db"].append(st["snr_db_est"])
+    fibs, crc, starts, fbbs = np.array(fibs), np.array(crc), np.array(starts), np.array(fbbs)
     n = min(len(fibs), ora["n"])
-    assert n >= ora["n"] - 1 and n >= 26
+    assert n >= ora["n"] - 1 and n >= 24, (len(fibs), ora["n"], steps)
     assert np.array_equal(starts[:n], ora["start"][:n])
     assert len(set(starts[8:n].tolist())) >= 3                     # the channel does move the timing
     assert np.array_equal(crc[:n], ora["crc"][:n])
@@ -771,7 +787,7 @@ def test_exact_level_tracker_is_bit_identical_to_the_oracle(gain):
     ens = ds.build_ensemble(10, subch, seed=171)
     x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=911.0, timing_offset=77777, gain=gain, seed=17, n_out=30 * ds.TF).copy()
     a, b = int(10.6 * ds.TF), int(12.2 * ds.TF)
-    x[a:b] *= np.float32(1e-3)
+    x[a:b] = 0                                                     # silence: the PRS correlation fails, back to the null-dip search
     ora = _oracle_run(x, subch)
 
     def run(exact):
@@ -1096,6 +1112,43 @@ def test_dab_plus_is_refused_for_rates_the_super_frame_stage_cannot_hold():
             eng.set_subchannels([ok, bad])
         plain = dx.SubchDesc(2, 300, cu, kbps, prot, 0, 0, 0)            # the same sub-channel without the DAB+ stage is fine
         eng.set_subchannels([ok, plain])
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("snr", [4.4, 30.0])
+def test_simd_viterbi_arithmetic_on_the_lane_per_trellis_decoder(mode, snr):
+    """cfg.viterbi_tie_mode 1 / 2 with the MSC on the lane-per-trellis kernels (k_msc_vitT_avx2 / _sse2): 6 streams x 18
+    sub-channels in one engine forced onto that path, against single-stream engines on the wave-per-trellis kernel (which the
+    test below compares with the oracle receiver).  4.4 dB: ties and near-ties decide bits; 30 dB: strong symbols, the metrics
+    sit near the renormalisation threshold for long stretches (saturation zone)."""
+    subch = ds.default_subchannels(18, 64)
+    ens = ds.build_ensemble(10, subch, seed=78)
+    n_streams, n_frames = 6, 24
+    xs = [ds.channel(ens.iq, snr_db=snr + 0.2 * s, cfo_hz=170.0 * (s - 3), timing_offset=5003 * s + 7, seed=780 + s, n_out=(n_frames + 3) * ds.TF)
+          for s in range(n_streams)]
+    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 4, max_subch=18, viterbi_tie_mode=mode, msc_fast_min_jobs=64, msc_class_min_jobs=1)
+    eng.set_subchannels(subch)
+    for s in range(n_streams):
+        eng.push_iq(s, xs[s])
+    dx.check(dx.load().dabx_set_profiling(eng._h, 1))
+    eng.process(n_frames)
+    launches = _kernel_launches(eng)
+    dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+    assert launches["k_msc_vitT"] >= 4 and launches["k_msc_frame"] == 0, launches
+    for s in (0, 3, 5):
+        ref = dx.Engine(n_streams=1, ring_frames=n_frames + 4, max_subch=18, viterbi_tie_mode=mode)
+        ref.set_subchannels(subch)
+        ref.push_iq(0, xs[s])
+        ref.process(n_frames)
+        a, b = eng.stats(s), ref.stats(0)
+        for key in ("frames", "fib_ok", "sf_ok", "sf_fail", "rs_corrected", "rs_failed", "au_ok", "au_bad", "cifs_decoded", "last_start_index"):
+            assert a[key] == b[key], (s, key, a[key], b[key])
+        assert a["frames"] >= n_frames - 2 and (snr < 10 or a["sf_ok"] > 0)
+        for j in range(18):
+            assert np.array_equal(eng.read_msc(s, j, 32), ref.read_msc(0, j, 32)), (s, j)
+            assert np.array_equal(eng.read_superframes(s, j, 4), ref.read_superframes(0, j, 4)), (s, j)
+        ref.close()
     eng.close()
 
 

@@ -101,3 +101,35 @@ def test_avx2_tie_mode_matches_the_references_avx2_build(n, variant, mode):
         assert np.array_equal(canon[i], ol.ora_viterbi(soft[i], n)), i
     other = np.unpackbits(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_viterbi_%s.npz" % ("sse2" if mode == 1 else "avx2")))["bits_%d" % n], axis=1)[:, :n]
     assert not np.array_equal(other, want)
+
+
+@pytest.mark.parametrize("n", [768, 192, 1536, 9216])
+@pytest.mark.parametrize("variant,mode", [("scalar", 0), ("avx2", 1), ("sse2", 2)])
+def test_lane_per_trellis_kernel_matches_the_references_builds(n, variant, mode):
+    """The MSC decoder proper (vit_t.hip: one lane per trellis, 64 per wavefront) on arbitrary soft input through the library's
+    internal stage entry, in all three arithmetics: the canonical scalar body and cfg.viterbi_tie_mode 1 / 2.  Bit-identical to
+    what the reference's own VITERBI_AVX2 / VITERBI_SSE2 object code returned for the adversarial rows of
+    tests/golden/ref_viterbi_{avx2,sse2}.npz (ties, saturating symbols, full-scale random metrics, 9216-bit trellises with
+    dozens of renormalisations), to the oracle restatements, and to the wave-per-trellis kernel; forcing the saturating step
+    bodies into every cycle does not change a bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_viterbi_avx2 as mk
+    soft = mk.rows_for(n)
+    rng = np.random.default_rng(n + mode)
+    m = 4 * (n + 6)
+    # 64 + trellises so that every lane of a wave and a second, partially filled wave are exercised: the golden rows, strong
+    # clean signals (metrics grow slowly: long stretches near the renormalisation threshold), rate-1/2 puncturing patterns
+    extra = [rng.choice([-127, 127], m), np.where(np.arange(m) % 4 < 2, rng.choice([-120, 120], m), 0), rng.integers(-90, 91, m)]
+    rows = [soft[i] for i in range(len(soft))] + [extra[i % 3] if i % 2 else rng.integers(-150, 151, m) for i in range(70 - len(soft))]
+    soft = np.array(rows, np.int16)
+    restate = {0: ol.ora_viterbi, 1: ol.ora_viterbi_simd, 2: ol.ora_viterbi_sse2}[mode]
+    got = dx.viterbi_lane_per_trellis(soft, n, tie_mode=mode)
+    for i in range(len(soft)):
+        assert np.array_equal(got[i], restate(soft[i], n)), (variant, n, i)
+    assert np.array_equal(got, dx.viterbi(soft, n, tie_mode=mode))                       # == the wave-per-trellis kernel
+    if mode:
+        G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_viterbi_%s.npz" % variant))
+        want = np.unpackbits(G["bits_%d" % n], axis=1)[:, :n]
+        assert np.array_equal(got[:len(want)], want)                                     # the reference's own object code
+        assert np.array_equal(dx.viterbi_lane_per_trellis(soft, n, tie_mode=mode, always_clamp=True), got)

@@ -130,6 +130,120 @@ def model_decode(soft, nbits):
     return out
 
 
+# ---- the arithmetic of the reference's SIMD builds on the same register scheme (k_msc_vitT_tie, vit_t.hip) -------------
+# VITERBI_AVX2 (tie = 1, viterbi_16way.h): uint16 metrics, saturating adds (65535), a tie goes to predecessor i + 32,
+# `renormalize` after every second step: if state 0's metric of the step BEFORE exceeds 60000 the minimum of the new metrics
+# is subtracted.  VITERBI_SSE2 / NEON (tie = 2, viterbi_8way.h): int16 metrics saturating at 32767, threshold 30000, ties as
+# in the scalar body.  The lane keeps its relative, doubled and centred int16 metrics R (2 M_ref = R + C) and follows the
+# reference's ABSOLUTE level with one int per lane: Coff = C before the first step of the current 6-step cycle (C grows by
+# 1020 per step, by `ref` at a re-centring, and becomes -min(R) at a renormalisation).  A candidate saturates when it
+# exceeds lim = LIMTOP - C; that can only happen when max(R) + 12240 > LIMTOP - Coff at the start of the cycle, so the
+# clamped step body (four more v_pk_min per butterfly pair) runs only then.
+TIE_CONST = {1: (2 * 65535, 2 * 60000), 2: (2 * 32767, 2 * 30000)}
+
+
+def model_decode_tie(soft, nbits, tie, always_clamp=False, stats=None):
+    import numpy as np
+    LIMTOP, REN2 = TIE_CONST[tie]
+    nst = nbits + 6
+    sym = np.clip(soft.astype(np.int64) + 127, 0, 255).reshape(nst, 4)          # saturating +127 (viterbi_16way.h:73-76)
+    xs = 2 * sym - 255
+
+    def wrap(v):
+        return ((v + 32768) & 0xFFFF) - 32768
+
+    R = [[2000, 2000] for _ in range(32)]
+    R[0][0] = 0
+    Coff = 0
+    dec = []
+    n_slow = n_ren = 0
+    for t0 in range(0, nst, 6):
+        if (t0 // 6) % 2 == 0:
+            ref = R[0][0]
+            R = [[wrap(a - ref), wrap(b - ref)] for a, b in R]
+            Coff += ref
+        mx = max(max(a, b) for a, b in R)
+        clamp_cycle = always_clamp or (mx + 12240 > LIMTOP - Coff)
+        n_slow += clamp_cycle
+        for j in range(6):
+            t = t0 + j
+            pre = (j & 1) and (R[0][0] + Coff + 1020 * j > REN2)
+            lim = min(LIMTOP - Coff - 1020 * (j + 1), 32767)
+            y0, x1, x2 = xs[t, 0] + xs[t, 3], xs[t, 1], xs[t, 2]
+            W = [(1 - 2 * ((q >> 2) & 1)) * y0 + (1 - 2 * ((q >> 1) & 1)) * x1 + (1 - 2 * (q & 1)) * x2 for q in range(8)]
+            pl = PLANS[j]
+            cl = (lambda v: min(v, lim)) if clamp_cycle else (lambda v: v)
+            word = 0
+
+            def decide(a, b, lab):                       # a: path through predecessor i, b: through i + 32
+                nonlocal word
+                d = (wrap(a - b) >= 0) if tie == 1 else (wrap(b - a) < 0)       # tie 1: NOT (a < b); tie 2: b < a
+                if d:
+                    word |= 1 << pl["pos"][lab]
+            if j == 0:
+                for r, q in pl["regs"]:
+                    lo, hi = R[r]
+                    w = W[q]
+                    t1 = (cl(wrap(lo + w)), cl(wrap(hi + w))); t2 = (cl(wrap(lo - w)), cl(wrap(hi - w)))
+                    decide(t1[0], t2[1], r)
+                    decide(t2[0], t1[1], r | 32)
+                    R[r] = [min(t1[0], t2[1]), min(t1[1], t2[0])]
+            else:
+                for ra, rb, ql, qh in pl["pairs"]:
+                    A, B = R[ra], R[rb]
+                    M = (W[ql], W[qh])
+                    a0 = [cl(wrap(A[h] + M[h])) for h in (0, 1)]; b0 = [cl(wrap(B[h] - M[h])) for h in (0, 1)]
+                    a1 = [cl(wrap(A[h] - M[h])) for h in (0, 1)]; b1 = [cl(wrap(B[h] + M[h])) for h in (0, 1)]
+                    for h in (0, 1):
+                        decide(a0[h], b0[h], ra | (32 * h))
+                        decide(a1[h], b1[h], rb | (32 * h))
+                    R[ra] = [min(a0[h], b0[h]) for h in (0, 1)]
+                    R[rb] = [min(a1[h], b1[h]) for h in (0, 1)]
+            dec.append(word)
+            if pre:
+                mn = min(min(a, b) for a, b in R)
+                Coff = -mn - 1020 * (j + 1)
+                n_ren += 1
+        Coff += 6120
+    if stats is not None:
+        stats["slow_cycles"] = n_slow; stats["cycles"] = nst // 6; stats["renorms"] = n_ren
+    L = 0
+    out = np.zeros(nbits, np.uint8)
+    for t in range(nst - 1, 5, -1):
+        c = t % 6
+        k = (dec[t] >> PLANS[c]["pos"][L]) & 1
+        out[t - 6] = k
+        p = PLANS[c]["p"]
+        L = (L & ~(1 << p)) | (k << p)
+    return out
+
+
+def selftest_tie():
+    import os
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import oracle_lib as ol
+    rng = np.random.default_rng(1)
+    ora = {1: ol.ora_viterbi_simd, 2: ol.ora_viterbi_sse2}
+    for tie in (1, 2):
+        slow = tot = ren = 0
+        for n in (768, 1536, 192):
+            for case in range(8):
+                m = 4 * (n + 6)
+                soft = [rng.integers(-200, 201, m), rng.integers(-40, 41, m), rng.choice([-127, 0, 127, 128, -128, 1, -1], m),
+                        rng.choice([-32768, 32767, 32640, -200, 200, 0], m), np.zeros(m),
+                        rng.choice([-127, 127], m), np.where(rng.random(m) < 0.5, 0, rng.choice([-127, 127], m)),     # full-scale: saturation
+                        np.where(np.arange(m) % 4 < 2, rng.choice([-120, 120], m), 0)][case].astype(np.int16)       # rate 1/2 puncturing pattern
+                st = {}
+                a = model_decode_tie(soft, n, tie, stats=st)
+                b = model_decode_tie(soft, n, tie, always_clamp=True)
+                want = ora[tie](soft, n)
+                assert np.array_equal(a, want), (tie, n, case, "conditional clamp")
+                assert np.array_equal(b, want), (tie, n, case, "always clamp")
+                slow += st["slow_cycles"]; tot += st["cycles"]; ren += st["renorms"]
+        print("tie mode %d: lane-per-trellis model == oracle (%d of %d cycles clamped, %d renormalisations)" % (tie, slow, tot, ren))
+
+
 def selftest():
     import os
     import numpy as np
@@ -216,6 +330,18 @@ def emit():
     A("__device__ __forceinline__ s2 s(unsigned v) { return __builtin_bit_cast(s2, v); }")
     A("__device__ __forceinline__ s2 pk(int lo, int hi) { return s(__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u)); }")
     A("__device__ __forceinline__ s2 mn(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }")
+    A("__device__ __forceinline__ s2 mx(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }")
+    A("// smallest / largest of the 64 path metrics of the lane's trellis (tie modes: renormalisation, saturation test)")
+    A("__device__ __forceinline__ int min64(const s2 (&R)[32])")
+    A("{ s2 a[16];")
+    A("  for (int i = 0; i < 16; i++) a[i] = mn(R[i], R[i + 16]);")
+    A("  for (int w = 8; w > 0; w >>= 1) for (int i = 0; i < w; i++) a[i] = mn(a[i], a[i + w]);")
+    A("  return a[0].x < a[0].y ? (int)a[0].x : (int)a[0].y; }")
+    A("__device__ __forceinline__ int max64(const s2 (&R)[32])")
+    A("{ s2 a[16];")
+    A("  for (int i = 0; i < 16; i++) a[i] = mx(R[i], R[i + 16]);")
+    A("  for (int w = 8; w > 0; w >>= 1) for (int i = 0; i < w; i++) a[i] = mx(a[i], a[i + w]);")
+    A("  return a[0].x > a[0].y ? (int)a[0].x : (int)a[0].y; }")
     A("// VOP3P op_sel forms (class 0: the butterfly partner is the other half of the same register)")
     A("__device__ __forceinline__ s2 mn_x(s2 a, s2 b)      // (min(a.lo, b.hi), min(a.hi, b.lo))")
     A("{ s2 r; asm(\"v_pk_min_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\" : \"=v\"(r) : \"v\"(a), \"v\"(b)); return r; }")
@@ -285,7 +411,11 @@ def emit():
         for i, key in enumerate(order):
             A("  M[%d] = %s;   // (W[%d], W[%d])" % (i, finals[key], key[0], key[1]))
         A("}")
-        A("__device__ __forceinline__ void step%d(s2 (&R)[32], const s2 (&M)[4], unsigned &acc0, unsigned &acc1)" % c)
+        # TIE: 0 = scalar body (decision = b < a, a tie keeps predecessor i); 1 = VITERBI_AVX2 (decision = NOT (a < b): a tie goes to
+        # i + 32; the words are inverted at the end of the step); 2 = VITERBI_SSE2 (scalar tie rule).  CLAMP: every candidate is
+        # limited to `lim` first = the saturating adds of the SIMD builds at the lane's current absolute level (vit_t.hip).
+        A("template <int TIE = 0, bool CLAMP = false>")
+        A("__device__ __forceinline__ void step%d(s2 (&R)[32], const s2 (&M)[4], unsigned &acc0, unsigned &acc1, s2 lim = s2{0, 0})" % c)
         A("{")
         if c == 0:
             qs = [q for q, _ in order]
@@ -297,10 +427,13 @@ def emit():
                     q = pl["regs"][r][1]
                     cq, flip = (q, False) if q < 4 else (7 - q, True)
                     # t1 = (a0, b1), t2 = (a1, b0): new = (min(a0, b0), min(b1, a1)), d0 = b0 - a0, d1 = b1 - a1
-                    A("  const s2 t1_%d = R[%d] %s M%d, t2_%d = R[%d] %s M%d;" % (r, r, "-" if flip else "+", cq, r, r, "+" if flip else "-", cq))
+                    A("  s2 t1_%d = R[%d] %s M%d, t2_%d = R[%d] %s M%d;" % (r, r, "-" if flip else "+", cq, r, r, "+" if flip else "-", cq))
+                    A("  if constexpr (CLAMP) { t1_%d = mn(t1_%d, lim); t2_%d = mn(t2_%d, lim); }" % (r, r, r, r))
                     A("  R[%d] = mn_x(t1_%d, t2_%d);" % (r, r, r))
                     names.append((r, "sub_hl(t2_%d, t1_%d)" % (r, r), "sub_lh(t1_%d, t2_%d)" % (r, r)))
-                A("  fold<%d>(acc%d, sg_even(%s, %s) | sg_odd(%s, %s));" % (j % 8, j // 8, names[0][1], names[0][2], names[1][1], names[1][2]))
+                A("  if constexpr (TIE == 1) fold<%d>(acc%d, sg_even(%s, %s) | sg_odd(%s, %s));" %
+                  (j % 8, j // 8, names[0][2], names[0][1], names[1][2], names[1][1]))
+                A("  else fold<%d>(acc%d, sg_even(%s, %s) | sg_odd(%s, %s));" % (j % 8, j // 8, names[0][1], names[0][2], names[1][1], names[1][2]))
         else:
             for (ql, qh), idx in combos.items():
                 A("  const s2 M%d = M[%d];" % (idx, idx))
@@ -309,9 +442,12 @@ def emit():
                 key = (ql, qh) if not flip else (7 - ql, 7 - qh)
                 m = "M%d" % combos[key]
                 pa, pb = ("-", "+") if flip else ("+", "-")
-                A("  { const s2 a0 = R[%d] %s %s, b0 = R[%d] %s %s, a1 = R[%d] %s %s, b1 = R[%d] %s %s;" %
+                A("  { s2 a0 = R[%d] %s %s, b0 = R[%d] %s %s, a1 = R[%d] %s %s, b1 = R[%d] %s %s;" %
                   (ra, pa, m, rb, pb, m, ra, pb, m, rb, pa, m))
-                A("    R[%d] = mn(a0, b0); R[%d] = mn(a1, b1); fold<%d>(acc%d, sg(b0 - a0, b1 - a1)); }" % (ra, rb, k % 8, k // 8))
+                A("    if constexpr (CLAMP) { a0 = mn(a0, lim); b0 = mn(b0, lim); a1 = mn(a1, lim); b1 = mn(b1, lim); }")
+                A("    R[%d] = mn(a0, b0); R[%d] = mn(a1, b1);" % (ra, rb))
+                A("    if constexpr (TIE == 1) fold<%d>(acc%d, sg(a0 - b0, a1 - b1)); else fold<%d>(acc%d, sg(b0 - a0, b1 - a1)); }" % (k % 8, k // 8, k % 8, k // 8))
+        A("  if constexpr (TIE == 1) { acc0 = ~acc0; acc1 = ~acc1; }")
         A("}")
         A("")
     A("}}  // namespace dabx::vt")
@@ -329,3 +465,4 @@ if __name__ == "__main__" and "--emit" in sys.argv:
 
 if __name__ == "__main__" and "--selftest" in sys.argv:
     selftest()
+    selftest_tie()
