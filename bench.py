@@ -63,8 +63,6 @@ def parse():
                          "(no decode, no roofline); prints the same JSON line with \"dry\": true")
     ap.add_argument("--viterbi-tie-mode", type=int, default=0, choices=[0, 1, 2],
                     help="not the headline: decode with the arithmetic of the reference's VITERBI_AVX2 (1) / VITERBI_SSE2 (2) builds")
-    ap.add_argument("--no-taper", action="store_true",
-                    help="issue the steps in plain chunks of 7 (A/B of the tapered tail: see step_chunks)")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
                     help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
                          "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
@@ -295,19 +293,13 @@ def cpu_baseline(args, subch):
     return out
 
 
-def step_chunks(n, taper):
-    """How n steps are handed to dabx_process.  The MSC decode of a chunk's last batch runs behind the front end of the NEXT
-    chunk; behind the last chunk there is nothing to overlap with, so that batch is all tail (2.3 ms for 6-7 frames against a
-    21-ms timed region of 20 steps).  With taper the final 6-7 frames are issued as (4-5, 2): the 4-5-frame batch is decoded
-    under the last two frames' front end and only a 2-frame batch (~1 wave per SIMD) is left to drain.  Same frames, same
-    kernels, same bytes; a long run (or a receiver that never stops) does not see the difference."""
-    chunks = [7] * (n // 7) + ([n % 7] if n % 7 else [])
-    if taper and chunks and chunks[-1] >= 5:
-        last = chunks.pop()
-        chunks += [last - 2, 2]
-    elif taper and len(chunks) >= 2 and chunks[-1] <= 2:
-        pass                           # already a short tail
-    return chunks
+def step_chunks(n):
+    """How n steps are handed to dabx_process: chunks of 7 = MSC_BATCH_FRAMES (a dabx_process call closes its last batch).  The
+    MSC decode of a chunk's last batch runs behind the front end of the NEXT chunk; behind the last chunk there is nothing to
+    overlap with (2.3 ms for 6-7 frames against a 21-ms timed region of 20 steps).  Issuing the final frames as (4, 2) to
+    shorten that tail was measured and is SLOWER (-3 %, profiles/r03_ab/ab2_tapered_tail_steps20.txt): small batches run the
+    lane-per-trellis decoder at one or two waves per SIMD."""
+    return [7] * (n // 7) + ([n % 7] if n % 7 else [])
 
 
 def free_port():
@@ -485,11 +477,11 @@ def main():
             dist.barrier()
         sync_dev()
 
-    def step(n=1, taper=False):
+    def step(n=1):
         # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch (a dabx_process call
         # closes its last batch), so the steps are issued in chunks of 7 (all work of the n steps is complete when the
         # streams are drained)
-        for m in step_chunks(n, taper):
+        for m in step_chunks(n):
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=False)
 
@@ -523,7 +515,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    step(args.steps, taper=not args.no_taper)
+    step(args.steps)
     eng.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -599,7 +591,7 @@ def main():
                        "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
                        "AWGN %g dB, per-stream CFO/timing" % (args.streams, args.snr),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * n_joined,
-                       "step_chunks": step_chunks(args.steps, not args.no_taper), "viterbi_tie_mode": args.viterbi_tie_mode,
+                       "step_chunks": step_chunks(args.steps), "viterbi_tie_mode": args.viterbi_tie_mode,
                        "x_realtime_per_gpu": round(value / n_joined / (2048000.0 / TF), 1),
                        "msamples_per_s": round(value * TF / 1e6, 1)},
             "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),

@@ -2,7 +2,7 @@
 
 24 streams in ONE engine, each with its own SNR (3.5 .. 28 dB), carrier offset (up to +-36 kHz, i.e. also beyond the
 +-35 kHz the reference follows), timing, level (-60 .. +30 dB), an echo, a drop-out, a sample-clock offset (+-90 ppm) and one
-of three sub-channel layouts.  DABX_FUZZ_SEED / DABX_FUZZ_CFG (threshold, strongest-peak sync, soft-bit generator) and
+of three sub-channel layouts; every seventh stream goes through a time-variant multipath channel (channel_mobile).  DABX_FUZZ_SEED / DABX_FUZZ_CFG (threshold, strongest-peak sync, soft-bit generator) and
 DABX_FUZZ_FAST (dabx_config.msc_fast_min_jobs / msc_class_min_jobs: the lane-per-trellis MSC path) -- knobs of THIS TEST, read
 here, not by the library -- select other draws, receiver options and decoder kernels for hunting runs (tools/fuzz_hunt.py).
 Whatever the reference's state machine does with such an input -- late lock, loss of lock, no lock at all -- the engine must
@@ -63,7 +63,14 @@ def test_random_channels_and_layouts_follow_the_oracle():
         cfo = float(rng.uniform(-36000.0, 36000.0)) if i % 3 == 0 else float(rng.uniform(-2500.0, 2500.0))
         toff = int(rng.integers(0, ds.TF))
         gain = float(10 ** rng.uniform(-3.0, 1.5)) * 0.25
-        x = ds.channel(base[li].iq, snr_db=snr, cfo_hz=cfo, timing_offset=toff, gain=gain, seed=700 + i, n_out=(N_FRAMES + 2) * ds.TF)
+        if i % 7 == 4:                                    # a moving receiver: Rayleigh taps with Jakes Doppler, 5 .. 80 Hz, drifting sample clock
+            snr = max(snr, 8.0)
+            prof = ["TU6", "RA4", "SFN2", "HT6"][int(rng.integers(0, 4))]
+            x = ds.channel_mobile(base[li].iq, prof, doppler_hz=float(rng.uniform(5.0, 80.0)), snr_db=snr, cfo_hz=cfo, timing_offset=toff,
+                                  gain=gain, seed=700 + i, n_out=(N_FRAMES + 2) * ds.TF, clock_ppm=float(rng.uniform(-30.0, 30.0)),
+                                  clock_drift_ppm_per_s=float(rng.uniform(-5.0, 5.0)))
+        else:
+            x = ds.channel(base[li].iq, snr_db=snr, cfo_hz=cfo, timing_offset=toff, gain=gain, seed=700 + i, n_out=(N_FRAMES + 2) * ds.TF)
         if i % 4 == 1:                                    # an echo inside the guard interval
             d = int(rng.integers(5, 400))
             x[d:] += np.complex64(rng.uniform(0.2, 0.8) * np.exp(1j * rng.uniform(0, 6.28))) * x[:-d].copy()
