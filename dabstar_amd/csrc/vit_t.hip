@@ -384,27 +384,28 @@ __device__ __forceinline__ void msc_vitT_body(const EngineDev &e, int cifs, cons
   // a SIMD is the sum over the ~4 "rounds" of 1024 blocks that landed on it: walk every second round backwards
   // (boustrophedon) so that long and short trellises pair up on the same SIMD.
   for (int i = lane; i < 6 * 64; i += 64) pos_tab[i / 64][i % 64] = vt::VT_POS[i / 64][i % 64];
-  // (a grid smaller than the number of groups makes the waves persistent: DABX_VIT_GRID_CAP builds, tools/build_variant.sh)
-  for (int gg0 = blockIdx.x; gg0 < ML.groups; gg0 += gridDim.x) {
-    int gg = gg0;
-    {
-      constexpr int ROUND = 1024;                                    // 256 CUs x 4 SIMDs
-      const int r = gg / ROUND, base = r * ROUND;
-      const int len = ML.groups - base < ROUND ? ML.groups - base : ROUND;
-      if (r & 1) gg = base + (len - 1 - (gg - base));
-    }
-    const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, gg)];
-    const int g = gg - cl.g0;                                       // decoder group within the class
-    const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
-    const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
-    const vt_rsrc in_grp = vt_make_rsrc(cl.inT + (size_t)g * rows * 64, (unsigned)rows * 256u);
-    uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
-    const vt_cmap cmap = (vt_cmap)(const void *)cl.map2;
-    uint32_t *out = nullptr;
-    if (q.valid)
-      out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)q.s * e.max_subch + q.j) * MSC_SLOTS + (size_t)(q.out_idx % MSC_SLOTS)) * e.msc_stride);
-    vt_decode<TIE, false>(in_grp, cmap, nsteps, dec_lane, out, prbs, pos_tab, lane, tl1, tl != nullptr);
+  int gg = blockIdx.x;
+  {
+    constexpr int ROUND = 1024;                                    // 256 CUs x 4 SIMDs
+    const int r = gg / ROUND, base = r * ROUND;
+    const int len = ML.groups - base < ROUND ? ML.groups - base : ROUND;
+    if (r & 1) gg = base + (len - 1 - (gg - base));
   }
+  const MscLaunchCls &cl = ML.c[msc_class_of_group(ML, gg)];
+  const int g = gg - cl.g0;                                       // decoder group within the class
+  const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
+  const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
+  const vt_rsrc in_grp = vt_make_rsrc(cl.inT + (size_t)g * rows * 64, (unsigned)rows * 256u);
+  uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
+  const vt_cmap cmap = (vt_cmap)(const void *)cl.map2;
+  uint32_t *out = nullptr;
+  if (q.valid)
+    out = reinterpret_cast<uint32_t *>(e.msc_out + (((size_t)q.s * e.max_subch + q.j) * MSC_SLOTS + (size_t)(q.out_idx % MSC_SLOTS)) * e.msc_stride);
+  // One wave per group, all <= 4 per SIMD resident at once.  Persistent waves at 2 or 3 per SIMD (a grid capped at 2048 / 3072
+  // blocks, each walking several groups) so that the front end of the following frames could co-reside were measured in round 3:
+  // -9 % / -3.5 % on the chain (profiles/r03_ab/ab4_persistent_decoder_grid_cap2048_cap3072.txt): the decoder alone gets 35-50 %
+  // slower and nothing that moves in next to it pays that back.
+  vt_decode<TIE, false>(in_grp, cmap, nsteps, dec_lane, out, prbs, pos_tab, lane, tl1, tl != nullptr);
   if (tl && lane == 0) {
     const unsigned slot = atomicAdd(&g_vt_timeline_n, 1u);
     if (slot < g_vt_timeline_cap) {
@@ -518,11 +519,7 @@ int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_
   int rc = get_tables(&t);
   if (rc) return rc;
   mk.begin(7, st);
-#ifdef DABX_VIT_GRID_CAP            // experiment builds only (tools/build_variant.sh): persistent decoder waves, at most this many
-  const int grid = L.groups < DABX_VIT_GRID_CAP ? L.groups : DABX_VIT_GRID_CAP;
-#else
   const int grid = L.groups;
-#endif
   if (e.tie_mode == 1) hipLaunchKernelGGL(k_msc_vitT_avx2, dim3(grid), dim3(64), 0, st, e, cifs, L, t->prbs_words);
   else if (e.tie_mode == 2) hipLaunchKernelGGL(k_msc_vitT_sse2, dim3(grid), dim3(64), 0, st, e, cifs, L, t->prbs_words);
   else hipLaunchKernelGGL(k_msc_vitT, dim3(grid), dim3(64), 0, st, e, cifs, L, t->prbs_words);
