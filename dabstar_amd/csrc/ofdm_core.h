@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "dabx_internal.h"
 #include "fft_core.h"
+#include "wave_ops.h"
 
 namespace dabx {
 
@@ -12,32 +13,6 @@ __device__ __forceinline__ float cabsf_(float2 z) { return sqrtf(z.x * z.x + z.y
 __device__ __forceinline__ float cabsf_level(float2 z) { return __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y); }
 
 // ---- block reductions (256 threads) -------------------------------------------------------------------
-// Butterfly sum over the 64 lanes of a wave (every lane gets the total; partners at distance 32, 16, 8, 4, 2, 1 in this order --
-// the order is part of the result's rounding and is kept from round 1).  All exchanges stay in the VALU: gfx950's
-// v_permlane32_swap / v_permlane16_swap for the two that cross a 16-lane row, DPP row_ror / row_half_mirror / quad_perm for the
-// rest.  As __shfl_xor (ds_bpermute_b32) the six exchanges were six dependent trips through the LDS pipeline per sum, taken
-// by every wave of a block just before its barrier.
-__device__ __forceinline__ float wave_sum(float v)
-{
-  auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
-  auto u = [](float x) { return __builtin_bit_cast(unsigned, x); };
-  {
-    const auto r = __builtin_amdgcn_permlane32_swap(u(v), u(v), false, false);      // [0]: lanes l % 32, [1]: lanes 32 + l % 32
-    v = f(r[0]) + f(r[1]);
-  }
-  {
-    const auto r = __builtin_amdgcn_permlane16_swap(u(v), u(v), false, false);      // [0]: the even row of each row pair, [1]: the odd one
-    v = f(r[0]) + f(r[1]);
-  }
-  v += f((unsigned)__builtin_amdgcn_update_dpp(0, (int)u(v), 0x128, 0xF, 0xF, true));                                  // xor 8: row_ror:8
-  {
-    const int hm = __builtin_amdgcn_update_dpp(0, (int)u(v), 0x141, 0xF, 0xF, true);                                   // xor 4 = row_half_mirror (i -> 7 - i)
-    v += f((unsigned)__builtin_amdgcn_update_dpp(0, hm, 0x1B, 0xF, 0xF, true));                                         //         then quad_perm [3,2,1,0] (i -> i ^ 3)
-  }
-  v += f((unsigned)__builtin_amdgcn_update_dpp(0, (int)u(v), 0x4E, 0xF, 0xF, true));                                   // xor 2: quad_perm [2,3,0,1]
-  v += f((unsigned)__builtin_amdgcn_update_dpp(0, (int)u(v), 0xB1, 0xF, 0xF, true));                                   // xor 1: quad_perm [1,0,3,2]
-  return v;
-}
 __device__ __forceinline__ float block_sum(float v, float *red /* >= 8 floats of LDS */, int tid)
 {
   v = wave_sum(v);
@@ -75,8 +50,7 @@ __device__ __forceinline__ void block_sum2w(float &a, float &b, float *red /* >=
 }
 __device__ __forceinline__ int block_min_int(int v, int *red, int tid)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
+  v = wave_min_int(v);
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();

@@ -989,8 +989,7 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
           }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { a0 ^= __shfl_xor(a0, o); a1 ^= __shfl_xor(a1, o); a2 ^= __shfl_xor(a2, o); }
+      a0 = wave_xor(a0); a1 = wave_xor(a1); a2 = wave_xor(a2);
       if (lane == 0) syn_or[j] = a0 | a1 | a2;
     }
     __syncthreads();
@@ -1001,8 +1000,7 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
       my_ret = rs_decode_120(CwStrided{win + lane, R}, gf);   // corrects in place
     }
     int corr = my_ret > 0 ? my_ret : 0, fail = my_ret < 0 ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { corr += __shfl_xor(corr, o); fail += __shfl_xor(fail, o); }
+    corr = wave_sum_int(corr); fail = wave_sum_int(fail);
     rs_corr += corr; rs_fail += fail;
     __syncthreads();
     if (lane == 0) {
@@ -1051,8 +1049,7 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
         for (int i = from; i < to; i++) crc = (s_crc[(win[st + i] ^ (crc >> 8)) & 0xFF] ^ (crc << 8)) & 0xFFFFu;
         unsigned acc = from < to ? crc_mulmod(crc, t.crc_xpow[len - to]) : 0u;
         if (lane == 0) acc ^= crc_mulmod(0xFFFFu, t.crc_xpow[len]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc ^= __shfl_xor(acc, o);
+        acc = wave_xor(acc);
         const unsigned want = ((unsigned)win[st + len] << 8) | win[st + len + 1];
         if (((~acc) & 0xFFFFu) == want) good++; else bad++;
       }

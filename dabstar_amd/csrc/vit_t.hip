@@ -324,7 +324,7 @@ __device__ __forceinline__ void vt_decode(vt_rsrc in_grp, vt_cmap cmap, int nste
   VtCycle ca, cb;
   vt_fetch(ca, in_grp, lane, cmap, 0);
   vt_fetch(cb, in_grp, lane, cmap, 6);
-  auto recentre = [&R, &Coff]() {                                  // every 12 steps on the metric of label 0
+  auto recentre = [&]() {                                  // every 12 steps on the metric of label 0
     const vt::s2 ref = vt::pk(R[0].x, R[0].x);
     if constexpr (TIE != 0) Coff += (int)R[0].x;
 #pragma unroll

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wave_ops.h"
 
 namespace dabx {
 
@@ -142,12 +143,7 @@ __device__ __forceinline__ void vit_step_simd(int &m, unsigned &acc, const char 
   if constexpr (RULE == 1) asm("v_cmp_le_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
   else asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
 }
-__device__ __forceinline__ int vit_wave_min(int v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
-  return v;
-}
+__device__ __forceinline__ int vit_wave_min(int v) { return wave_min_int(v); }
 template <int C, int RULE>
 __device__ __forceinline__ void vit_pair_simd(int &m, unsigned &acc, const char *row, const VitLaneConst &k)
 {

@@ -11,7 +11,7 @@ for what in "$@"; do
     ab)    bash tools/ab.sh $OUT/ab 3 "r2|dabstar_amd/_ab/libdabx_r2.so|" "new|-|" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
     pmc)   bash tools/prof_pmc2.sh $OUT/pmc "k_demap_frame6|k_symbols_persistent|k_demap_fic" > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
-    dpp)   bash tools/ab.sh $OUT/abdpp 3 "bpermute|dabstar_amd/_ab/libdabx_r3_bpermute.so|" "dpp|-|" > $OUT/abdpp.txt 2>&1; cat $OUT/abdpp.txt ;;
+    dpp)   bash tools/ab.sh $OUT/abdpp 3 "dpp1|dabstar_amd/_ab/libdabx_r3_dpp1.so|" "waveops|-|" > $OUT/abdpp.txt 2>&1; cat $OUT/abdpp.txt ;;
     tie)   for r in 1 2; do for m in 0 1 2; do
              python3 bench.py --no-cpu-baseline --viterbi-tie-mode $m 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('tie_mode', $m, j['value'], j['fib_crc_match_pct'], j['superframes_failed'], {k: round(v, 3) for k, v in j['chain']['kernel_ms_per_step_standalone'].items() if 'msc' in k})"; done; done > $OUT/tie.txt 2>&1; cat $OUT/tie.txt ;;
     bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
