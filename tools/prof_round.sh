@@ -5,7 +5,7 @@
 # reads 0.5 of the bytes for coalesced 4 / 8 / 16-byte-per-lane streams and 256-B rows (x2) but 1.0 for k_msc_prep's
 # 64-byte runs, one HBM line each (x1); WRITE_SIZE is exact for the coalesced patterns.
 # Usage: tools/prof_round.sh <tag>      -> gpurun_out/<tag>/...
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
