@@ -169,6 +169,21 @@ def host_cpu():
     return model, len(one_per_core), logical, one_per_core
 
 
+def cgroup_cpu_quota():
+    """CPU quota of this container in cores (cgroup v2 cpu.max / v1 cfs_quota_us), None = unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, subch):
     """the CPU port of the reference algorithm (oracle/) on the same workload, on the host cores of this box.
     Built -O3 -march=native here (`make -C oracle native`).  Two variants of the chain: reference-default (scalar
@@ -275,6 +290,9 @@ def cpu_baseline(args, subch):
                 "sample": "%d threads x %d frames, one receiver each" % (ncpu, n2)}
     if len(core_cpus) > 1:
         out["all_cores"] = all_cores_leg(core_cpus, "one thread per physical core (%d of %d logical CPUs)" % (len(core_cpus), logical))
+        # how many cores' worth of work the host really delivered (a container's CPU quota caps it below the cores it shows)
+        out["all_cores"]["speedup_over_one_core"] = round(out["all_cores"]["value"] / out["value"], 1)
+        out["all_cores"]["cgroup_cpu_quota_cores"] = cgroup_cpu_quota()
     # the reference's OWN object code where it could be built (oracle/_ref, viterbi_spiral.cpp scalar): its Viterbi alone,
     # as a frame rate (72 MSC blocks of 1542 steps + 4 FIC blocks of 774 per frame)
     if ol.have_ref():

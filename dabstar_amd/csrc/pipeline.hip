@@ -462,7 +462,12 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
 }
 
 // -------------------------------------------------------------------------------------------------- demap
-constexpr int DEMAP_THREADS = 768, DEMAP_Q = K / DEMAP_THREADS;   // carriers per thread; 12 waves per stream
+#ifndef DABX_DEMAP_Q                 // experiment builds (tools/build_variant.sh -DDABX_DEMAP_Q=4 -DDABX_DEMAP_OCC=3): carriers per thread
+#define DABX_DEMAP_Q 2
+#define DABX_DEMAP_OCC 6
+#endif
+constexpr int DEMAP_Q = DABX_DEMAP_Q, DEMAP_THREADS = K / DEMAP_Q, DEMAP_NP = DEMAP_Q / 2;   // carriers per thread (in pairs); 12 waves per stream
+constexpr int DEMAP_NOUT = (K2 / 4) / DEMAP_THREADS;              // output dwords per thread and symbol
 constexpr int TILE_PLANE = 196;                                   // LDS bytes per plane of the output tile (192 used)
 template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
 __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &t, const int l0, const int l1)
@@ -489,25 +494,24 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   DemapDev &d = e.demap;
   const float *null_power = fs.np_sel ? d.null_power2 : d.null_power;
   const float2 *spectra = e.spectra + (size_t)e.parity * e.n_streams * 75 * K;
-  DemapPair cr;                                            // the thread's two carriers, component-wise (demap_pair)
-  int bin[DEMAP_Q];
-  v2f rel_f;
+  DemapPair cr[DEMAP_NP];                                  // the thread's carriers in pairs, component-wise (demap_pair)
+  v2f rel_f[DEMAP_NP], wk[DEMAP_NP], pacc[DEMAP_NP];
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
-    const int k = tid + DEMAP_THREADS * q;
-    bin[q] = t.perm_bin[k];
-    rel_f[q] = (float)(K / 2 - t.perm_rel[k]);
+    const int k = tid + DEMAP_THREADS * q, p = q >> 1, h = q & 1;
+    const int bin = t.perm_bin[k];
+    rel_f[p][h] = (float)(K / 2 - t.perm_rel[k]);
     // X_(l-1): the phase reference (symbol 0, FFT bin order) or the previous symbol's spectrum (carrier order)
-    const float2 pr = l0 == 0 ? d.phase_ref[(size_t)s * TU + bin[q]] : spectra[((size_t)s * 75 + (l0 - 1)) * K + k];
-    cr.prev_re[q] = pr.x; cr.prev_im[q] = pr.y;
-    cr.integ[q] = d.integ[(size_t)s * K + k];
-    cr.mean_power[q] = d.mean_power[(size_t)s * K + k];
-    cr.mean_sigma_sq[q] = d.mean_sigma[(size_t)s * K + k];
-    cr.null_power[q] = null_power[(size_t)s * TU + bin[q]];
+    const float2 pr = l0 == 0 ? d.phase_ref[(size_t)s * TU + bin] : spectra[((size_t)s * 75 + (l0 - 1)) * K + k];
+    cr[p].prev_re[h] = pr.x; cr[p].prev_im[h] = pr.y;
+    cr[p].integ[h] = d.integ[(size_t)s * K + k];
+    cr[p].mean_power[h] = d.mean_power[(size_t)s * K + k];
+    cr[p].mean_sigma_sq[h] = d.mean_sigma[(size_t)s * K + k];
+    cr[p].null_power[h] = null_power[(size_t)s * TU + bin];
+    wk[p][h] = mpa_weight(k);
+    pacc[p][h] = 0.0f;
   }
   float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
-  const v2f wk = (v2f){mpa_weight(tid), mpa_weight(tid + DEMAP_THREADS)};
-  v2f pacc = (v2f)(0.0f);
   const float ce = fs.clock_err;                          // mClockErrHz of the previous frame, dab_processor.cpp:342
   const long long cif0 = fs.cif0;
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
@@ -519,14 +523,14 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[tid + DEMAP_THREADS * q];
   }
-  // The 3072 Viterbi symbols of an OFDM symbol leave through LDS: every thread drops its four bytes into a tile that is
-  // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barriers of
-  // the mean-value reduction each of the 768 threads stores ONE aligned dword -- 48 consecutive dwords per plane --
-  // instead of four scattered byte stores with their address arithmetic.  Two tiles: a fast thread may already fill the
+  // The 3072 Viterbi symbols of an OFDM symbol leave through LDS: every thread drops its bytes into a tile that is
+  // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barrier of
+  // the mean-value reduction the block stores aligned dwords -- one per thread with 768 threads, 48 consecutive dwords per
+  // plane -- instead of scattered byte stores with their address arithmetic.  Two tiles: a fast thread may already fill the
   // next symbol's tile while a slow one still drains this one.  A plane takes TILE_PLANE = 196 bytes of LDS (49 dwords,
   // odd): the 16 planes a wave's byte stores touch then fall on 16 different banks (with 192 B = 48 dwords they fell on two,
   // an 8-way conflict on each of the four stores per thread and symbol; tools/lds_conflicts.py).
-  static_assert(DEMAP_THREADS == 768 && DEMAP_Q == 2, "tile <-> thread mapping below");
+  static_assert(DEMAP_Q % 2 == 0 && K % DEMAP_Q == 0 && (K2 / 4) % DEMAP_THREADS == 0 && DEMAP_THREADS % 64 == 0, "tile <-> thread mapping below");
   int tpos[2 * DEMAP_Q];                                   // tile byte offsets of (re, im) of this thread's carriers
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
@@ -534,7 +538,6 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     tpos[2 * q] = (k & 15) * TILE_PLANE + (k >> 4);
     tpos[2 * q + 1] = ((K + k) & 15) * TILE_PLANE + ((K + k) >> 4);
   }
-  const int out_plane = tid / 48, out_dw = tid - out_plane * 48;
   for (int l = l0; l < l1; l++) {                         // the demapper state advances on all 75 symbols in every mode
     const float2 *X = spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
@@ -543,16 +546,21 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     float2 xc[DEMAP_Q];
 #pragma unroll
     for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[tid + DEMAP_THREADS * q]; }
-    int16_t sr[2], si[2];
-    v2f pw;
-    const v2f mag = demap_pair<SOFT_TYPE>(cr, (v2f){xc[0].x, xc[1].x}, (v2f){xc[0].y, xc[1].y}, rel_f, ce, w2, sr, si, pw);
-    const float part = mag.x + mag.y;
-    pacc = pacc * mpa_decay() + pw;                         // per carrier: sum_l d^(74-l) p_l, reduced once per frame below
+    float part = 0.f;
 #pragma unroll
-    for (int q = 0; q < DEMAP_Q; q++) {
-      tl[tpos[2 * q]] = soft_to_sym_mode(sr[q], e.tie_mode);
-      tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[q], e.tie_mode);
-      if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[q]; cap[(size_t)l * K2 + K + k] = si[q]; }
+    for (int p = 0; p < DEMAP_NP; p++) {
+      int16_t sr[2], si[2];
+      v2f pw;
+      const v2f mag = demap_pair<SOFT_TYPE>(cr[p], (v2f){xc[2 * p].x, xc[2 * p + 1].x}, (v2f){xc[2 * p].y, xc[2 * p + 1].y}, rel_f[p], ce, w2, sr, si, pw);
+      part = p == 0 ? mag.x + mag.y : part + (mag.x + mag.y);
+      pacc[p] = pacc[p] * mpa_decay() + pw;                 // per carrier: sum_l d^(74-l) p_l, reduced once per frame below
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int q = 2 * p + h;
+        tl[tpos[2 * q]] = soft_to_sym_mode(sr[h], e.tie_mode);
+        tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[h], e.tie_mode);
+        if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[h]; cap[(size_t)l * K2 + K + k] = si[h]; }
+      }
     }
     // mMeanValue (ofdm_decoder.cpp:256,294): block sum in block_sum()'s order -- per-wave butterflies, then the wave partials
     // added in wave order by every thread.  ONE barrier per symbol: the partials (and the tile) are double-buffered by
@@ -567,26 +575,33 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       for (int w = 0; w < DEMAP_THREADS / 64; w++) sum += rp[w];
       mean_value = sum * (1.0f / (float)K);
     }
-    if (l < 3) {                                            // symbols 1..3 -> FIC, linear: bytes 4 tid .. 4 tid + 3
-      uint32_t v = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) { const int i = 4 * tid + b; v |= (uint32_t)tl[(i & 15) * TILE_PLANE + (i >> 4)] << (8 * b); }
-      reinterpret_cast<uint32_t *>(fic + l * K2)[tid] = v;
-    } else {                                                // MSC -> planar time-de-interleaver ring
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * TILE_PLANE + 4 * out_dw);
-      *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
+    for (int j = 0; j < DEMAP_NOUT; j++) {
+      const int dwi = tid + DEMAP_THREADS * j;              // output dword of the symbol
+      if (l < 3) {                                          // symbols 1..3 -> FIC, linear: bytes 4 dwi .. 4 dwi + 3
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int i = 4 * dwi + b; v |= (uint32_t)tl[(i & 15) * TILE_PLANE + (i >> 4)] << (8 * b); }
+        reinterpret_cast<uint32_t *>(fic + l * K2)[dwi] = v;
+      } else {                                              // MSC -> planar time-de-interleaver ring
+        const int out_plane = dwi / 48, out_dw = dwi - out_plane * 48;
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * TILE_PLANE + 4 * out_dw);
+        *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
+      }
     }
   }
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
-    const int k = tid + DEMAP_THREADS * q;
-    d.integ[(size_t)s * K + k] = cr.integ[q];
-    d.mean_power[(size_t)s * K + k] = cr.mean_power[q];
-    d.mean_sigma[(size_t)s * K + k] = cr.mean_sigma_sq[q];
+    const int k = tid + DEMAP_THREADS * q, p = q >> 1, h = q & 1;
+    d.integ[(size_t)s * K + k] = cr[p].integ[h];
+    d.mean_power[(size_t)s * K + k] = cr[p].mean_power[h];
+    d.mean_sigma[(size_t)s * K + k] = cr[p].mean_sigma_sq[h];
   }
   // SNR estimate as the LCD statistics compute it (ofdm_decoder.cpp:326-343) after the last symbol of the frame
   // mMeanPowerOvrAll (ofdm_decoder.cpp:214) over the 75 symbols in closed form: x d^75 + sum_k w_k sum_l d^(74-l) p_(k,l)
-  float ns = cr.null_power.x + cr.null_power.y, wsum = wk.x * pacc.x + wk.y * pacc.y;
+  float ns = cr[0].null_power.x + cr[0].null_power.y, wsum = wk[0].x * pacc[0].x + wk[0].y * pacc[0].y;
+#pragma unroll
+  for (int p = 1; p < DEMAP_NP; p++) { ns += cr[p].null_power.x + cr[p].null_power.y; wsum += wk[p].x * pacc[p].x + wk[p].y * pacc[p].y; }
   block_sum2w(ns, wsum, red, tid);
   if (tid == 0) {
     mpa = mpa * mpa_decay_n(l1 - l0) + wsum;
@@ -598,7 +613,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
 // Built for six waves per SIMD (<= 80 VGPRs, 7 values spilled outside the loop): two 12-wave blocks share a CU instead of
 // taking turns (at 94 VGPRs only one fitted: 0.32 -> 0.24 ms per step).
 template <int SOFT_TYPE>
-__global__ __launch_bounds__(DEMAP_THREADS, 6) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
+__global__ __launch_bounds__(DEMAP_THREADS, DABX_DEMAP_OCC) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
 // the FIC symbols alone (first launch of a frame in the overlapped schedule): its own kernel symbol so that rocprofv3's
 // per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
 template <int SOFT_TYPE>

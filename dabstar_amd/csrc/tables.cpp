@@ -190,20 +190,65 @@ static void host_dft(std::vector<double> &re, std::vector<double> &im, bool inve
   re.swap(ore); im.swap(oim);
 }
 
+// frequency interleaver, freq_interleaver.cpp:40-76 + the index fold of ofdm_decoder.cpp:171-179: carrier k -> FFT bin, relative index
+static void host_freq_interleaver(std::vector<uint16_t> &bin, std::vector<int16_t> &rel)
+{
+  bin.clear(); rel.clear();
+  int v = 0;
+  for (int i = 0; i < TU; i++) {
+    if (i > 0) v = (13 * v + 511) % TU;
+    if (v == TU / 2 || v < 256 || v > 256 + K) continue;
+    const int k = v - TU / 2;
+    bin.push_back((uint16_t)(k < 0 ? k + TU : k));
+    rel.push_back((int16_t)(k < 0 ? k + K / 2 : k + K / 2 - 1));
+  }
+}
+
+// LDS slots of k_symbols' frequency de-interleave.  Thread tid of the 256-thread transform holds bins tid + 256 u and scatters
+// them (ds_write_b64: groups of 16 contiguous lanes, bank = slot mod 16), then reads carriers tid + 256 u back in order
+// (ds_read_b64: groups of 32 lanes, bank = slot mod 32).  slot(k) = (k & ~15) | sigma(k) keeps every aligned run of 16
+// carriers in place, so the read-back is conflict-free for ANY set of permutations sigma; the scatter is conflict-free
+// iff the carriers written by one 16-lane group get 16 different sigma.  That is an edge colouring of the bipartite
+// multigraph (write group) -- carrier k -- (run k >> 4) with 16 colours, which exists because no vertex has more
+// than 16 edges (Koenig); built with alternating-path recolouring.  Deterministic.
+static void host_carrier_slots(const std::vector<uint16_t> &bin, std::vector<int> &sigma)
+{
+  sigma.assign(K, -1);
+  const int NG = 8 * 16, NB = K / 16, NC = 16;
+  std::vector<int> at_g((size_t)NG * NC, -1), at_b((size_t)NB * NC, -1);      // edge (carrier) using colour c at the vertex
+  auto group_of = [&](int k) { const int b = bin[k]; return (b >> 8) * 16 + ((b & 255) >> 4); };   // (u, tid >> 4)
+  for (int k = 0; k < K; k++) {
+    const int g = group_of(k), b = k >> 4;
+    int cg = 0, cb = 0;
+    while (at_g[(size_t)g * NC + cg] >= 0) cg++;
+    while (at_b[(size_t)b * NC + cb] >= 0) cb++;
+    if (at_b[(size_t)b * NC + cg] >= 0) {
+      // cg is taken at b: swap cg <-> cb along the alternating path that starts at b with colour cg (it cannot reach g)
+      std::vector<int> path;
+      int v_is_b = 1, v = b, want = cg;
+      for (;;) {
+        const int e = v_is_b ? at_b[(size_t)v * NC + want] : at_g[(size_t)v * NC + want];
+        if (e < 0) break;
+        path.push_back(e);
+        v = v_is_b ? group_of(e) : (e >> 4);
+        v_is_b ^= 1;
+        want = want == cg ? cb : cg;
+      }
+      for (int e : path) { at_g[(size_t)group_of(e) * NC + sigma[e]] = -1; at_b[(size_t)(e >> 4) * NC + sigma[e]] = -1; }
+      for (int e : path) {
+        sigma[e] = sigma[e] == cg ? cb : cg;
+        at_g[(size_t)group_of(e) * NC + sigma[e]] = e; at_b[(size_t)(e >> 4) * NC + sigma[e]] = e;
+      }
+    }
+    sigma[k] = cg;
+    at_g[(size_t)g * NC + cg] = k; at_b[(size_t)b * NC + cg] = k;
+  }
+}
+
 static int build_tables(DevTables &t)
 {
-  // frequency interleaver, freq_interleaver.cpp:40-76 + the index fold of ofdm_decoder.cpp:171-179
   std::vector<uint16_t> bin; std::vector<int16_t> rel;
-  {
-    int v = 0;
-    for (int i = 0; i < TU; i++) {
-      if (i > 0) v = (13 * v + 511) % TU;
-      if (v == TU / 2 || v < 256 || v > 256 + K) continue;
-      const int k = v - TU / 2;
-      bin.push_back((uint16_t)(k < 0 ? k + TU : k));
-      rel.push_back((int16_t)(k < 0 ? k + K / 2 : k + K / 2 - 1));
-    }
-  }
+  host_freq_interleaver(bin, rel);
   if ((int)bin.size() != K) { set_error("frequency interleaver table has %zu entries", bin.size()); return DABX_E_ARG; }
   // PRS and coarse-CFO reference, phasetable.cpp:87-101, phasereference.cpp:58-66
   std::vector<float2> prs(TU, make_float2(0.f, 0.f)), argc(TU);
@@ -302,45 +347,8 @@ static int build_tables(DevTables &t)
     std::vector<int16_t> inv(TU, (int16_t)-1);
     for (int k = 0; k < K; k++) inv[bin[k]] = (int16_t)k;
     if ((rc = upload(&t.bin_to_k, inv))) return rc;
-    // k_symbols de-interleaves through LDS: thread tid of the 256-thread transform holds bins tid + 256 u and scatters them
-    // (ds_write_b64: groups of 16 contiguous lanes, bank = slot mod 16), then reads carriers tid + 256 u back in order
-    // (ds_read_b64: groups of 32 lanes, bank = slot mod 32).  slot(k) = (k & ~15) | sigma(k) keeps every aligned run of 16
-    // carriers in place, so the read-back is conflict-free for ANY set of permutations sigma; the scatter is conflict-free
-    // iff the carriers written by one 16-lane group get 16 different sigma.  That is an edge colouring of the bipartite
-    // multigraph (write group) -- carrier k -- (run k >> 4) with 16 colours, which exists because no vertex has more
-    // than 16 edges (Koenig); built with alternating-path recolouring.
-    std::vector<int> sigma(K, -1);
-    {
-      const int NG = 8 * 16, NB = K / 16, NC = 16;
-      std::vector<int> at_g((size_t)NG * NC, -1), at_b((size_t)NB * NC, -1);      // edge (carrier) using colour c at the vertex
-      auto group_of = [&](int k) { const int b = bin[k]; return (b >> 8) * 16 + ((b & 255) >> 4); };   // (u, tid >> 4)
-      for (int k = 0; k < K; k++) {
-        const int g = group_of(k), b = k >> 4;
-        int cg = 0, cb = 0;
-        while (at_g[(size_t)g * NC + cg] >= 0) cg++;
-        while (at_b[(size_t)b * NC + cb] >= 0) cb++;
-        if (at_b[(size_t)b * NC + cg] >= 0) {
-          // cg is taken at b: swap cg <-> cb along the alternating path that starts at b with colour cg (it cannot reach g)
-          std::vector<int> path;
-          int v_is_b = 1, v = b, want = cg;
-          for (;;) {
-            const int e = v_is_b ? at_b[(size_t)v * NC + want] : at_g[(size_t)v * NC + want];
-            if (e < 0) break;
-            path.push_back(e);
-            v = v_is_b ? group_of(e) : (e >> 4);
-            v_is_b ^= 1;
-            want = want == cg ? cb : cg;
-          }
-          for (int e : path) { at_g[(size_t)group_of(e) * NC + sigma[e]] = -1; at_b[(size_t)(e >> 4) * NC + sigma[e]] = -1; }
-          for (int e : path) {
-            sigma[e] = sigma[e] == cg ? cb : cg;
-            at_g[(size_t)group_of(e) * NC + sigma[e]] = e; at_b[(size_t)(e >> 4) * NC + sigma[e]] = e;
-          }
-        }
-        sigma[k] = cg;
-        at_g[(size_t)g * NC + cg] = k; at_b[(size_t)b * NC + cg] = k;
-      }
-    }
+    std::vector<int> sigma;
+    host_carrier_slots(bin, sigma);
     std::vector<int16_t> slot8((size_t)TU);
     for (int tid = 0; tid < 256; tid++)
       for (int u = 0; u < 8; u++) {
@@ -413,3 +421,27 @@ int get_profile_map(int kbps, int prot, int short_form, const uint16_t **dev_map
 }
 
 }  // namespace dabx
+
+// Host only, not part of include/dabx.h (tests/test_lds_layouts.py): the tables k_symbols uses for its frequency de-interleave
+// through LDS -- bin_to_slot8[256][8] (LDS slot of the carrier of bin tid + 256 u, -1 for unused bins), carrier_slot_rd[256]
+// (six 4-bit sigma per thread) and perm_bin[1536] (carrier -> FFT bin) -- exactly as build_tables uploads them.
+extern "C" int dabx_internal_carrier_slots(int16_t *slot8, uint32_t *rd, uint16_t *perm_bin)
+{
+  using namespace dabx;
+  if (!slot8 || !rd || !perm_bin) return DABX_E_ARG;
+  std::vector<uint16_t> bin; std::vector<int16_t> rel;
+  host_freq_interleaver(bin, rel);
+  std::vector<int> sigma;
+  host_carrier_slots(bin, sigma);
+  std::vector<int16_t> inv(TU, (int16_t)-1);
+  for (int k = 0; k < K; k++) { inv[bin[k]] = (int16_t)k; perm_bin[k] = bin[k]; }
+  for (int tid = 0; tid < 256; tid++) {
+    rd[tid] = 0;
+    for (int u = 0; u < 8; u++) {
+      const int k = inv[tid + 256 * u];
+      slot8[tid * 8 + u] = (int16_t)(k < 0 ? -1 : ((k & ~15) | sigma[k]));
+    }
+    for (int u = 0; u < K / 256; u++) rd[tid] |= (uint32_t)sigma[tid + 256 * u] << (4 * u);
+  }
+  return 0;
+}

@@ -14,7 +14,8 @@ for what in "$@"; do
     ingest) python3 tools/bench_ingest.py > $OUT/ingest.json 2> $OUT/ingest.err; tail -5 $OUT/ingest.json ;;
     fuzz)  python3 tools/fuzz_hunt.py --seeds ${FUZZ_SEEDS:-4000:4030} > $OUT/fuzz_log.jsonl 2> $OUT/fuzz.err; tail -2 $OUT/fuzz_log.jsonl ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
-    dpp)   bash tools/ab.sh $OUT/abdpp 3 "dpp1|dabstar_amd/_ab/libdabx_r3_dpp1.so|" "waveops|-|" > $OUT/abdpp.txt 2>&1; cat $OUT/abdpp.txt ;;
+    q4)    bash tools/ab.sh $OUT/abq4 3 "q2|-|" "q4occ3|dabstar_amd/_ab/libdabx_q4occ3.so|" "q4occ4|dabstar_amd/_ab/libdabx_q4occ4.so|" > $OUT/abq4.txt 2>&1; cat $OUT/abq4.txt ;;
+    rccl)  DABX_BENCH_FORCE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/rccl_one_rank.json 2> $OUT/rccl.err; tail -c 1500 $OUT/rccl_one_rank.json ;;
     tie)   for r in 1 2; do for m in 0 1 2; do
              python3 bench.py --no-cpu-baseline --viterbi-tie-mode $m 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('tie_mode', $m, j['value'], j['fib_crc_match_pct'], j['superframes_failed'], {k: round(v, 3) for k, v in j['chain']['kernel_ms_per_step_standalone'].items() if 'msc' in k})"; done; done > $OUT/tie.txt 2>&1; cat $OUT/tie.txt ;;
     bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
