@@ -413,13 +413,34 @@ def load_traffic(dom):
     return None
 
 
+_VALU_PEAK_LIVE = None
+
+
+def measure_valu_peak():
+    """Runs tools/_build/valu_peak (tools/valu_peak.hip, compiled by __graft_entry__.build()) as a CHILD process on this GPU,
+    before the engine exists: the issue rate of the decoder's own instruction mix at 4 waves per SIMD on THIS box, in THIS run."""
+    global _VALU_PEAK_LIVE
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "_build", "valu_peak")
+    if not os.path.exists(exe):
+        return
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120, check=True).stdout
+        rows = [r for r in json.loads(out)["rows"] if r["inst"].startswith("mix: butterfly pair + decisions") and r["waves_per_simd"] == 4]
+        _VALU_PEAK_LIVE = float(rows[0]["wave_insts_per_s"])
+    except Exception:
+        _VALU_PEAK_LIVE = None
+
+
 def load_valu_peak():
-    """Measured chip-wide wave64 VALU issue rate (tools/valu_peak.hip -> profiles/r02_valu_peak.json): the rate of the
-    decoder's own instruction mix at 4 waves per SIMD; falls back to the guide's 2 cycles per wave64 instruction."""
+    """Chip-wide wave64 VALU issue rate of the decoder's own instruction mix at 4 waves per SIMD (tools/valu_peak.hip): measured
+    live in this run when the tool is built, else the stored round-2 measurement, else the guide's 2 cycles per instruction."""
+    if _VALU_PEAK_LIVE:
+        return _VALU_PEAK_LIVE, "tools/valu_peak.hip run on this GPU in this bench invocation: decoder instruction mix, 4 waves/SIMD, all CUs"
     try:
         vj = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_peak.json")))
         rows = [r for r in vj["rows"] if r["inst"].startswith("mix: butterfly pair + decisions") and r["waves_per_simd"] == 4]
-        return float(rows[0]["wave_insts_per_s"]), "profiles/r02_valu_peak.json: decoder instruction mix, 4 waves/SIMD, all CUs (measured)"
+        return float(rows[0]["wave_insts_per_s"]), "profiles/r02_valu_peak.json: decoder instruction mix, 4 waves/SIMD, all CUs (measured in round 2, not in this run)"
     except Exception:
         return VALU_ISSUE_PEAK, "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md; not measured)"
 
@@ -473,6 +494,8 @@ def main():
     from tools import dab_synth as ds
     subch = ds.default_subchannels(18, 64)
     dx = None
+    if not dry and rank == 0 and n_joined == 1:
+        measure_valu_peak()                          # child process, done before this process creates its engine
     if dry:
         eng = DryEngine(args.streams)
         ring_frames = 10
