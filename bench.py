@@ -656,10 +656,14 @@ def main():
             out["roofline"] = None
         if n_joined == 1 and not dry and not args.no_cpu_baseline and args.layout == "uniform":
             out["cpu_baseline"] = cpu_baseline(args, subch)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     eng.close()
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()          # RCCL prints its version banner to stdout here: the JSON line goes out after it, last
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
