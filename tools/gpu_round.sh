@@ -13,6 +13,7 @@ for what in "$@"; do
     prof)  bash tools/prof_round.sh $TAG > $OUT/prof_round.log 2>&1; tail -3 $OUT/prof_round.log ;;
     ingest) python3 tools/bench_ingest.py > $OUT/ingest.json 2> $OUT/ingest.err; tail -5 $OUT/ingest.json ;;
     fuzz)  python3 tools/fuzz_hunt.py --seeds ${FUZZ_SEEDS:-4000:4030} > $OUT/fuzz_log.jsonl 2> $OUT/fuzz.err; tail -2 $OUT/fuzz_log.jsonl ;;
+    soak)  python3 bench.py --steps 30002 --warmup 14 --no-cpu-baseline > $OUT/soak.json 2> $OUT/soak.err; tail -c 600 $OUT/soak.json ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     q4)    bash tools/ab.sh $OUT/abq4 3 "q2|-|" "q4occ3|dabstar_amd/_ab/libdabx_q4occ3.so|" "q4occ4|dabstar_amd/_ab/libdabx_q4occ4.so|" > $OUT/abq4.txt 2>&1; cat $OUT/abq4.txt ;;
     rccl)  DABX_BENCH_FORCE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/rccl_one_rank.json 2> $OUT/rccl.err; tail -c 1500 $OUT/rccl_one_rank.json ;;
