@@ -632,7 +632,7 @@ def main():
                        "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
                        "AWGN %g dB, per-stream CFO/timing" % (args.streams, args.snr),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * n_joined,
-                       "step_chunks": step_chunks(args.steps), "viterbi_tie_mode": args.viterbi_tie_mode,
+                       "step_chunks": step_chunks(args.steps) if args.steps <= 70 else "%d x 7 + %d" % (args.steps // 7, args.steps % 7), "viterbi_tie_mode": args.viterbi_tie_mode,
                        "x_realtime_per_gpu": round(value / n_joined / (2048000.0 / TF), 1),
                        "msamples_per_s": round(value * TF / 1e6, 1)},
             "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),

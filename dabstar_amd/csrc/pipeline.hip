@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 // ------------------------------------------------------------------------------------------------ symbols
 // Symbols 1..75 of a frame: NCO mix, cyclic-prefix correlation, FFT, frequency de-interleave (dab_processor.cpp:304-341).
 // (The null symbol is handled by k_frame_tail: it needs the fine-CFO update that depends on all 75 correlations.)
-// PERSISTENT blocks, grid (SYM_G, S): a block walks symbols l = g, g + SYM_G, ... of its stream, requests the NEXT symbol's
+// PERSISTENT blocks, grid (G, S), G = sym_blocks_per_stream(S): a block walks symbols l = g, g + G, ... of its stream, requests the NEXT symbol's
 // twelve samples per thread (4 for the cyclic-prefix correlation sum x[Tu+i] conj(x[i]), i < 504, taken on the RAW samples --
 // the NCO contributes the constant factor e^{-j 2 pi f Tu / fs}, which k_frame_tail applies once -- and 8 for the transform;
 // coalesced 8-byte loads) before it transforms the current one, and keeps everything that depends on the thread index only --
@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
 // Frequency de-interleaving rides on the way out (freq_interleaver.cpp:40-76): each bin goes to its carrier's slot in LDS
 // (the transform's exchange buffer is free again), the 1536 used carriers are then stored contiguously; the demapper reads
 // carrier k of every symbol with coalesced loads, the 512 unused bins are never written.
-constexpr int SYM_G = 15;                                    // blocks per stream: 5 symbols each
+// blocks per stream (a divisor of 75): 15 blocks of 5 symbols each fill the chip from ~50 streams up (3 resident per CU); with
+// fewer streams the symbols of a frame are spread over more blocks so that the kernel's latency, not its throughput, shrinks
+// (one stream: 75 blocks of one symbol -- the single-ensemble configurations are latency-bound on the frame's serial chain)
+__host__ __device__ constexpr int sym_blocks_per_stream(int n_streams) { return n_streams >= 48 ? 15 : (n_streams >= 16 ? 25 : 75); }
 // 3 waves per SIMD: 170 VGPRs without spills (bounded to 4 it spills 8 registers and runs 25 % slower)
 __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevTables t)
 {
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
 #pragma unroll
     for (int u = 0; u < 8; u++) v[u] = nx[4 + u];
     const double2 base_now = nco_base;
-    const int l_next = l + SYM_G;
+    const int l_next = l + (int)gridDim.x;
     if (l_next < 75) {                                       // block-uniform
       off = uniform_load(e.sym_off + (size_t)s * 76 + l_next);
       nco_base = uniform_load(e.nco_sym + (size_t)s * 76 + l_next);
@@ -624,11 +627,8 @@ struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depun
   const uint8_t *sym;
   const uint16_t *map;
   __device__ int one(uint16_t idx) const { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : sym[idx]); }
-  __device__ VitSyms operator()(int t) const
-  {
-    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
-    return {one(m.x), one(m.y), one(m.z), one(m.w)};
-  }
+  __device__ ushort4 key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
+  __device__ VitSyms syms(ushort4 m, int) const { return {one(m.x), one(m.y), one(m.z), one(m.w)}; }
 };
 
 // FIC blocks [first, first + count) of the frame: the engine decodes all four at once (first = 0, count = 4); the
@@ -648,6 +648,10 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
   if (!c.frame_ok) return;
   s_crc[threadIdx.x] = t.crc_ccitt[threadIdx.x];
   const int fic = first + wave;             // this wave's FIC block
+#ifdef DABX_FIC_TIMING
+  const unsigned long long T0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long T1 = 0, T2 = 0, T3 = 0;
+#endif
   if (wave < count) {
     SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + fic * FIC_IN, t.fic_map};
     uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + fic) * (size_t)e.vit_stride;
@@ -657,12 +661,21 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     else vit_forward<0>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
+#ifdef DABX_FIC_TIMING
+    T1 = __builtin_amdgcn_s_memrealtime();
+#endif
     vit_traceback(dec, FIC_OUT, lane, raw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef DABX_FIC_TIMING
+    T2 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (lane < 24) fibw[fic][lane] = vit_output_word(raw[wave], lane) ^ t.prbs_words[lane];   // fic_decoder.cpp:219-222
   }
   __syncthreads();
+#ifdef DABX_FIC_TIMING
+  T3 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int slot = (int)(c.frames % e.out_frames);
   uint8_t *fo = e.fib_out + ((size_t)s * e.out_frames + slot) * 12 * 32;
   const int fib0 = 3 * first, nfib = 3 * count;
@@ -696,6 +709,12 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     c.fic_ratio = ratio; c.cif_count = cif_count;
     c.fib_ok += ok; c.fib_total += nfib;
   }
+#ifdef DABX_FIC_TIMING
+  if (s == 0 && lane == 0 && wave < count) {
+    const unsigned long long T4 = __builtin_amdgcn_s_memrealtime();
+    printf("fic wave %d: forward %llu traceback %llu to-barrier %llu tail %llu (x10 ns)\n", wave, T1 - T0, T2 - T1, T3 - T2, T4 - T3);
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------- frame tail
@@ -891,11 +910,8 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
     const long long q = r - 16 + m;
     return vit_sym_from_u8(tdi[tdi_off(q, base + idx)]);
   }
-  __device__ VitSyms operator()(int t) const
-  {
-    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
-    return {one(m.x), one(m.y), one(m.z), one(m.w)};
-  }
+  __device__ ushort4 key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
+  __device__ VitSyms syms(ushort4 m, int) const { return {one(m.x), one(m.y), one(m.z), one(m.w)}; }
 };
 
 // fast_mask: bit c set = class c + 1 is decoded by the lane-per-trellis kernels in this batch (vit_t.hip)
@@ -1121,7 +1137,7 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
   hipStream_t st = ss.a;
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
-  mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(SYM_G, e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+  mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
   auto demap = [&](hipStream_t q, int l0, int l1) {
     if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame6<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
     else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame6<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);

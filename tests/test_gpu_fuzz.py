@@ -50,12 +50,11 @@ def _oracle(x, subch, cfg):
     return res
 
 
-def test_random_channels_and_layouts_follow_the_oracle():
+def draw_streams(seed, only=None):
+    """The N_CASES random streams of one seed: (layouts, cases, xs).  only = i: the draw stops after stream i (tools/debug_fuzz_case.py)."""
     layouts = _layouts()
     base = [ds.build_ensemble(10, lay, seed=500 + i) for i, lay in enumerate(layouts)]
-    rng = np.random.default_rng(int(os.environ.get("DABX_FUZZ_SEED", "20260101")))      # other seeds: hunting runs
-    # receiver options (sync threshold, strongest-peak sync, soft-bit generator 1..3): DABX_FUZZ_CFG="4.0,1,2"
-    thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), os.environ.get("DABX_FUZZ_CFG", "3.0,0,1").split(","))]
+    rng = np.random.default_rng(seed)
     cases, xs = [], []
     for i in range(N_CASES):
         li = int(rng.integers(0, 3))
@@ -85,6 +84,15 @@ def test_random_channels_and_layouts_follow_the_oracle():
             x = np.concatenate([(x[i0] * (1 - fr) + x[i0 + 1] * fr).astype(np.complex64), x[-1000:]])
         xs.append(np.ascontiguousarray(x, np.complex64))
         cases.append((li, snr, cfo, toff, gain))
+        if only is not None and i == only:
+            break
+    return layouts, cases, xs, rng
+
+
+def test_random_channels_and_layouts_follow_the_oracle():
+    # receiver options (sync threshold, strongest-peak sync, soft-bit generator 1..3): DABX_FUZZ_CFG="4.0,1,2"
+    thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), os.environ.get("DABX_FUZZ_CFG", "3.0,0,1").split(","))]
+    layouts, cases, xs, rng = draw_streams(int(os.environ.get("DABX_FUZZ_SEED", "20260101")))      # other seeds: hunting runs
 
     fast = dict(msc_fast_min_jobs=64, msc_class_min_jobs=1) if os.environ.get("DABX_FUZZ_FAST") == "1" else {}
     eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr,
@@ -177,7 +185,10 @@ def test_random_channels_and_layouts_follow_the_oracle():
             eti_checked += 1
     assert eti_checked >= N_CASES // 4
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
-    assert n_bad_diff <= (2 if soft_type != 3 else 6), (n_bad_diff, n_bad)   # generator 3 (no normalisation) is the touchiest
+    # FIBs that fail their CRC on both sides: a soft bit that differs by one LSB (2-4 in 10^5) anywhere in a FIC block
+    # that is noise anyway changes its junk.  A few per thousand failing FIBs (the fading streams produce hundreds of them);
+    # generator 3 (no normalisation) is the touchiest
+    assert n_bad_diff <= max(2 if soft_type != 3 else 6, 0.03 * n_bad), (n_bad_diff, n_bad)
     # overflow frames (excluded above) stay the exception: 4 of 528 frames with the committed seed; a regression that produced
     # spurious overflows, or excluded frames wholesale, trips this bound (hunting seeds draw other drop-outs: looser there)
     assert n_ovf_frames <= (8 if "DABX_FUZZ_SEED" not in os.environ else 2 * N_CASES), n_ovf_frames
