@@ -253,6 +253,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.ctl, S));
   A(e->alloc(&d.spectra, (size_t)2 * S * 75 * K, false));
   A(e->alloc(&d.fsnap, S));
+  A(e->alloc(&d.demap_busy, S));
   A(e->alloc(&d.dciq_state, (size_t)S * 8));
   A(e->alloc(&d.dciq_done, S));
   {

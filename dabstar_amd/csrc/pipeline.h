@@ -41,6 +41,8 @@ struct StreamCtl {
   long long fib_ok, fib_total, sync_lost;
   float head_abs_a, head_abs_b;   // sum |x| over the T_u correlation window / the start_index samples read after it (level tracker)
   int32_t np_sel;                 // which noise-power buffer (DemapDev::null_power / null_power2) is current; k_frame_tail flips it
+  int32_t pad_;
+  unsigned long long step_rd0;    // rd when the current step began: a step consumes at most about one frame of samples per stream
 };
 
 struct SubchDev {
@@ -81,6 +83,8 @@ struct EngineDev {
   float2 *spectra;                // [2][S][75][1536]: symbols 1..75 in CARRIER order (frequency de-interleaved by k_symbols); two
                                   // buffers by step parity: k_symbols of step n + 1 runs while step n's MSC symbols are demapped
   FrameSnap *fsnap;               // [S]
+  int32_t *demap_busy;            // [S] 1 while the demapper launches of the stream's newest frame have not all finished (they run on
+                                  //     their own HIP stream next to the NEXT frame's head: k_frame_head must not reset the demapper under them)
   float *dciq_state;              // [S][8] meanI, meanQ, meanII, meanQQ, meanIQ of SampleReader's DC / IQ correction (sample_reader.h:102-106)
   unsigned long long *dciq_done;  // [S] absolute index of the first sample not yet corrected
   int32_t parity;                 // step parity (host sets it per launch)

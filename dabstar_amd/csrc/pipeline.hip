@@ -172,36 +172,31 @@ int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------ acquire
-// Sample-serial by nature (IIR level + 50-tap moving sum with data-dependent stop): lane 0 walks the
-// stream while the wave prefetches 256 samples at a time.  Only runs out of lock.
-__global__ __launch_bounds__(64) void k_acquire(EngineDev e)
+// WAIT_FOR_TIME_SYNC_MARKER of one stream (dab_processor.cpp:146-160 + timesyncer.cpp:40-90): decoder reset, then the null-dip
+// search.  Sample-serial by nature (IIR level + 50-tap moving sum with data-dependent stop): thread 0 walks the stream while
+// the block prefetches |x| of 256 samples at a time.  Called by every thread of the block (64 in k_acquire, 256 in
+// k_frame_head's retry loop); chunk[256], env[64], sh[3] are LDS.  Leaves c.state = ST_EVAL_SYNC when a dip ended.
+__device__ __forceinline__ void acquire_body(EngineDev &e, int s, int tid, int nthreads, unsigned long long budget_samples,
+                                             float *chunk, float *env, int *sh)
 {
-  const int s = blockIdx.x, lane = threadIdx.x;
   StreamCtl &c = e.ctl[s];
   const int st = c.state;
-  if (lane == 0) c.frame_ok = 0;
-  e.sym_off[(size_t)s * 76 + lane] = -1;
-  if (lane < 12) e.sym_off[(size_t)s * 76 + 64 + lane] = -1;
-  if (st == ST_EVAL_SYNC) return;
   const unsigned long long avail = e.wr[s] - c.rd;
-  if (avail < (unsigned long long)ACQ_NEED) return;
+  if (st == ST_EVAL_SYNC || avail < (unsigned long long)ACQ_NEED) return;
   // WAIT_FOR_TIME_SYNC_MARKER entry (dab_processor.cpp:146-153): decoder reset
-  for (int i = lane; i < K; i += 64) {
+  for (int i = tid; i < K; i += nthreads) {
     e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
   }
-  for (int i = lane; i < TU; i += 64) { e.demap.null_power[(size_t)s * TU + i] = 0.f; e.demap.null_power2[(size_t)s * TU + i] = 0.f; }
-  if (lane == 0) e.demap.mean_power_all[s] = 1.0f;
+  for (int i = tid; i < TU; i += nthreads) { e.demap.null_power[(size_t)s * TU + i] = 0.f; e.demap.null_power2[(size_t)s * TU + i] = 0.f; }
+  if (tid == 0) e.demap.mean_power_all[s] = 1.0f;
   if (e.tii_acc) {                     // mTiiDetector.reset(); mTiiCounter = 0 (dab_processor.cpp:150-152)
-    for (int i = lane; i < TU; i += 64) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
-    if (lane == 0) { e.tii_cnt[2 * s] = 0; e.tii_cnt[2 * s + 1]++; }
+    for (int i = tid; i < TU; i += nthreads) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
+    if (tid == 0) { e.tii_cnt[2 * s] = 0; e.tii_cnt[2 * s + 1]++; }
   }
-
-  __shared__ float chunk[256];
-  __shared__ float env[64];
-  __shared__ int s_done, s_consumed, s_ok;
+  int &s_done = sh[0], &s_consumed = sh[1], &s_ok = sh[2];
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  if (lane == 0) { s_done = 0; s_consumed = 0; s_ok = 0; }
-  // lane-0 state machine
+  if (tid == 0) { s_done = 0; s_consumed = 0; s_ok = 0; }
+  // thread-0 state machine
   int phase = (st == ST_INIT) ? 0 : 1;     // 0 seed level, 1 first 50, 2 wait for dip, 3 wait for end of dip
   int remain = (st == ST_INIT) ? 20 * TU : 50, counter = 0, idx = 0;
   float s_level = c.s_level, peak_level = c.peak_level, level = 0.f;
@@ -210,13 +205,12 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
   int consumed = 0;
   __syncthreads();
   while (true) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const float2 v = rv.at(pos + lane + 64 * q);
-      chunk[lane + 64 * q] = sqrtf(v.x * v.x + v.y * v.y);
+    for (int q = tid; q < 256; q += nthreads) {
+      const float2 v = rv.at(pos + q);
+      chunk[q] = sqrtf(v.x * v.x + v.y * v.y);
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
       for (int i = 0; i < 256 && !s_done; i++) {
         // loop conditions are evaluated BEFORE the next sample is read (timesyncer.cpp:58,74)
         if (phase == 2 && !(level / 50.f > 0.55f * s_level)) { phase = 3; counter = 0; }
@@ -236,9 +230,9 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
           ++counter;
           if ((phase == 2 && counter > TF) || (phase == 3 && counter > TN + 50 + 20)) {   // NO_DIP_FOUND / NO_END_OF_DIP_FOUND
             // dab_processor.cpp:154-160 tries again at once.  Do the same inside this step while the next attempt's
-            // worst case is still in the ring and less than a frame has gone by: a stream in a drop-out then walks
-            // through it at the pace of the others (one attempt is only T_n + 121 samples long in silence).
-            if (avail - (unsigned long long)consumed >= (unsigned long long)ACQ_NEED && consumed < TF) {
+            // worst case is still in the ring and the step's sample budget (one frame) is not used up: a stream in a
+            // drop-out then walks through it at the pace of the others (one attempt is only T_n + 121 samples long in silence).
+            if (avail - (unsigned long long)consumed >= (unsigned long long)ACQ_NEED && (unsigned long long)consumed < budget_samples) {
               phase = 1; remain = 50; counter = 0; idx = 0; level = 0.f;
             } else { s_done = 1; s_ok = 0; }
           }
@@ -250,7 +244,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
     if (s_done) break;
     pos += 256;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     c.rd += (unsigned long long)s_consumed;     // frequency offset is 0 while searching: NCO phase unchanged
     c.s_level = s_level; c.peak_level = peak_level;
     c.sample_count = 0;
@@ -258,6 +252,21 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
     c.clock_err = 0.0f;
     c.state = s_ok ? ST_EVAL_SYNC : ST_WAIT_SYNC;
   }
+}
+
+// First kernel of a step: marks "no frame yet", notes where the stream's cursor stands (the step's sample budget) and, out of
+// lock, runs one acquisition.
+__global__ __launch_bounds__(64) void k_acquire(EngineDev e)
+{
+  const int s = blockIdx.x, lane = threadIdx.x;
+  StreamCtl &c = e.ctl[s];
+  if (lane == 0) { c.frame_ok = 0; c.step_rd0 = c.rd; }
+  e.sym_off[(size_t)s * 76 + lane] = -1;
+  if (lane < 12) e.sym_off[(size_t)s * 76 + 64 + lane] = -1;
+  __shared__ float chunk[256];
+  __shared__ float env[64];
+  __shared__ int sh[3];
+  acquire_body(e, s, lane, 64, (unsigned long long)TF, chunk, env, sh);
 }
 
 // --------------------------------------------------------------------------------------------- frame head
@@ -270,27 +279,34 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
   __shared__ float mag[160];
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
-  if (c.state != ST_EVAL_SYNC) return;
-  const unsigned long long avail = e.wr[s] - c.rd;
-  if (avail < (unsigned long long)FRAME_NEED) return;
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  const unsigned long long rd = c.rd;
-  const int phase0 = c.nco_phase;
-  const int f = (int)roundf(c.f_bb);                       // sample_reader.cpp:211
-
+  // One frame per step at most -- but a failed PRS correlation (:396-400) does not end the step: like the reference, which
+  // goes straight back to the null-dip search, the block runs the next acquisition itself and evaluates the next candidate,
+  // as long as the step has consumed less than a frame of samples and the ring still holds an attempt's worst case.  (One
+  // attempt per step starved streams in deep fades: false dips every few thousand samples, a few per cent of a frame consumed
+  // per step -- fuzz seed 5001: 62 steps for 3.7 frames -- while their producer keeps delivering a frame per step.)
+  unsigned long long rd;
+  int phase0, f, start;
   float2 v[8];
   Nco nco;
-  nco.init(phase0, f, tid);
-  const RingView rv(ring, e.ring_len, rd);
-  float abs_a = 0.f, abs_b = 0.f;                          // level tracker: sum |x| of what this frame head reads
+  float abs_a, abs_b = 0.f;                                // level tracker: sum |x| of what this frame head reads
+  for (;;) {
+    if (c.state != ST_EVAL_SYNC) return;
+    if (e.wr[s] - c.rd < (unsigned long long)FRAME_NEED) return;
+    rd = c.rd;
+    phase0 = c.nco_phase;
+    f = (int)roundf(c.f_bb);                               // sample_reader.cpp:211
+    nco.init(phase0, f, tid);
+    const RingView rv(ring, e.ring_len, rd);
+    abs_a = 0.f;
 #pragma unroll
-  for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); abs_a += cabsf_level(x); v[u] = nco.mix(x); nco.step(); }
-  const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
-  __syncthreads();
-  if (start < 0) {                                         // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER
-    // the T_u samples just read went through SampleReader's level tracker (sample_reader.cpp:245-248): run it exactly,
-    // sample by sample -- right after start-up the level is still far from settled (it starts at 0.1) and the null-dip
-    // detector of the next attempt compares against it
+    for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); abs_a += cabsf_level(x); v[u] = nco.mix(x); nco.step(); }
+    start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
+    __syncthreads();
+    if (start >= 0) break;
+    // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER.  The T_u samples just read went through SampleReader's level tracker
+    // (sample_reader.cpp:245-248): run it exactly, sample by sample -- right after start-up the level is still far from
+    // settled (it starts at 0.1) and the null-dip detector of the next attempt compares against it
 #pragma unroll
     for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); peak[tid + 256 * u] = sqrtf(x.x * x.x + x.y * x.y); }
     __syncthreads();
@@ -306,9 +322,25 @@ __global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
       c.nco_phase = nco_advance(phase0, f, TU);
       c.state = ST_WAIT_SYNC;
       c.sync_lost++;
+      __threadfence_block();
     }
-    return;
+    __syncthreads();
+    const unsigned long long used = c.rd - c.step_rd0;
+    if (used >= (unsigned long long)TF || e.wr[s] - c.rd < (unsigned long long)(ACQ_NEED + FRAME_NEED)) return;
+    // The acquisition resets the demapper (dab_processor.cpp:146-153).  The MSC symbols of the PREVIOUS frame may still be
+    // going through it on their own HIP stream (this kernel overlaps with them by design): then the retry waits for the next
+    // step, whose k_acquire is ordered behind them by the host.  (Without this the reset raced with that launch's final state
+    // stores: a loss of lock right after a decoded frame left stale IIR states -- found by the fuzz test as garbage FIBs that
+    // differed from the oracle's, differently on every run.)  A stream that is starving has no frame in flight.
+    int *busy_seen = reinterpret_cast<int *>(red) + 7;       // one thread looks, everyone follows (a flag that flips meanwhile must not split the block)
+    if (tid == 0) *busy_seen = __hip_atomic_load(&e.demap_busy[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*busy_seen) return;
+    acquire_body(e, s, tid, 256, (unsigned long long)TF - used, peak, peak + 256, reinterpret_cast<int *>(red));
+    __threadfence_block();
+    __syncthreads();
   }
+  const RingView rv(ring, e.ring_len, rd);
   // symbol 0 = samples [start, start + Tu) of the same (mixed) stream, :402-411
   nco.init(phase0, f, (long long)start + tid);
 #pragma unroll
@@ -491,7 +523,10 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   FrameSnap fs;
   if (l0 == 0) {
     fs.cif0 = c.cif_no; fs.clock_err = c.clock_err; fs.frame_ok = c.frame_ok; fs.np_sel = c.np_sel; fs.pad_ = 0;
-    if (tid == 0) e.fsnap[s] = fs;
+    if (tid == 0) {
+      e.fsnap[s] = fs;
+      if (fs.frame_ok && e.demap_busy) __hip_atomic_store(&e.demap_busy[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else fs = e.fsnap[s];
   if (!fs.frame_ok) return;
   DemapDev &d = e.demap;
@@ -611,6 +646,12 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa;
     if (l1 == 75) c.snr_db = snr_db_from(mpa, ns);
   }
+  if (l1 == 75 && e.demap_busy) {
+    // the frame's last demapper launch is done with the stream's state: every thread's stores are ordered before the flag
+    // (block barrier, then a device-scope release by the thread that clears it)
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&e.demap_busy[s], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Built for six waves per SIMD (<= 80 VGPRs, 7 values spilled outside the loop): two 12-wave blocks share a CU instead of
@@ -627,8 +668,11 @@ struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depun
   const uint8_t *sym;
   const uint16_t *map;
   __device__ int one(uint16_t idx) const { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : sym[idx]); }
-  __device__ ushort4 key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
-  __device__ VitSyms syms(ushort4 m, int) const { return {one(m.x), one(m.y), one(m.z), one(m.w)}; }
+  __device__ VitSyms operator()(int t) const
+  {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
+    return {one(m.x), one(m.y), one(m.z), one(m.w)};
+  }
 };
 
 // FIC blocks [first, first + count) of the frame: the engine decodes all four at once (first = 0, count = 4); the
@@ -910,8 +954,11 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
     const long long q = r - 16 + m;
     return vit_sym_from_u8(tdi[tdi_off(q, base + idx)]);
   }
-  __device__ ushort4 key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
-  __device__ VitSyms syms(ushort4 m, int) const { return {one(m.x), one(m.y), one(m.z), one(m.w)}; }
+  __device__ VitSyms operator()(int t) const
+  {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
+    return {one(m.x), one(m.y), one(m.z), one(m.w)};
+  }
 };
 
 // fast_mask: bit c set = class c + 1 is decoded by the lane-per-trellis kernels in this batch (vit_t.hip)

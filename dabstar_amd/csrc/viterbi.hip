@@ -7,8 +7,7 @@ namespace dabx {
 struct SrcI16 {                       // ViterbiSpiral::deconvolve input: 4*(n+6) int16, already depunctured
   const int16_t *soft;
   int sat;                            // AVX2 body: saturating symbol conversion
-  __device__ int key(int) const { return 0; }            // no map: the symbols are addressed by the step itself
-  __device__ VitSyms syms(int, int t) const
+  __device__ VitSyms operator()(int t) const
   {
     const short4 v = *reinterpret_cast<const short4 *>(soft + 4 * t);
     if (sat) return {vit_sym_from_i16_sat(v.x), vit_sym_from_i16_sat(v.y), vit_sym_from_i16_sat(v.z), vit_sym_from_i16_sat(v.w)};
@@ -20,8 +19,11 @@ struct SrcI16Map {                    // Protection::deconvolve input: punctured
   const int16_t *in;
   const uint16_t *map;
   __device__ int one(uint16_t idx) const { return vit_sym_from_i16(idx == PUNCT ? (int16_t)0 : in[idx]); }
-  __device__ ushort4 key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
-  __device__ VitSyms syms(ushort4 m, int) const { return {one(m.x), one(m.y), one(m.z), one(m.w)}; }
+  __device__ VitSyms operator()(int t) const
+  {
+    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
+    return {one(m.x), one(m.y), one(m.z), one(m.w)};
+  }
 };
 
 template <class Src>

@@ -161,23 +161,15 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
 {
   int m = RULE ? (lane == 0 ? 0 : 1000) : (lane == 0 ? 0 : 2000);   // viterbi_spiral.cpp:98-101 (0 / 1000); doubled in the canonical form
   const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
-  // A step's symbols take two DEPENDENT global loads: the depuncture map entry (src.key), then the soft symbols it points
-  // to (src.syms).  Both are requested ahead of use and one block apart -- the map entries of block b + 2 and the symbols of
-  // block b + 1 before the 60 add-compare-select steps of block b run -- so neither round trip is on the chain and they do
-  // not add up either (fetched together one block ahead, the pair of round trips was longer than a block's 60 steps on a
-  // lightly loaded chip, i.e. for the single-ensemble configurations).
-  using Key = decltype(src.key(0));
+  // The symbols of block b + 1 (two dependent global loads: depuncture map, then the soft symbols) are requested before
+  // the 60 add-compare-select steps of block b run and only consumed afterwards: their latency is off the chain.
   VitSyms s = {0, 0, 0, 0};
-  Key kn{};
-  if (lane < VIT_BLK && lane < nsteps) s = src.syms(src.key(lane), lane);
-  if (lane < VIT_BLK && VIT_BLK + lane < nsteps) kn = src.key(VIT_BLK + lane);
+  if (lane < VIT_BLK && lane < nsteps) s = src(lane);
   for (int b = 0; b < nblk; b++) {
     VitSyms sn = {0, 0, 0, 0};
-    Key kn2{};
     {
-      const int tn = (b + 1) * VIT_BLK + lane, tn2 = tn + VIT_BLK;
-      if (lane < VIT_BLK && tn < nsteps) sn = src.syms(kn, tn);
-      if (lane < VIT_BLK && tn2 < nsteps) kn2 = src.key(tn2);
+      const int tn = (b + 1) * VIT_BLK + lane;
+      if (lane < VIT_BLK && tn < nsteps) sn = src(tn);
     }
     if (lane < VIT_BLK) {
       const int y0 = s.x0 + s.x3;
@@ -217,7 +209,7 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
       acc = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    s = sn; kn = kn2;
+    s = sn;
   }
 }
 

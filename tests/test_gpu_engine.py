@@ -819,6 +819,40 @@ def test_exact_level_tracker_is_bit_identical_to_the_oracle(gain):
     assert np.abs(lv0[:n].astype(np.float64) - ora["s_level"][:n]).max() <= 1e-4 * ora["s_level"][:n].max()
 
 
+def test_failed_sync_attempts_do_not_starve_a_stream():
+    """A stream whose candidates keep failing the PRS correlation (fuzz seed 5001, stream 18: a fading channel 25 carriers off
+    frequency, strongest-peak sync with threshold 4 -- false null dips every few thousand samples; the oracle needs 7.7 frames of
+    failed attempts before its first lock) must still move through its samples at about a frame per step, like the reference,
+    which goes straight back to the null-dip search (dab_processor.cpp:154-160, 396-400): the engine retries inside the step
+    until a frame of samples is consumed.  (One attempt per step consumed 3.7 frames in 62 steps.)  The walk itself is the
+    oracle's: same start indices, same FIBs."""
+    import test_gpu_fuzz as F
+    layouts, cases, xs, _ = F.draw_streams(5001, only=18)
+    x, subch = xs[18], layouts[cases[18][0]]
+    ora = _oracle_run(x, subch, config=(4.0, 1, 2))
+    assert ora["n"] >= 14 and ora["start"][0] > 0
+    eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=len(subch), out_frames=4, sync_threshold=4.0, sync_strongest=True, soft_bit_type=2)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    fibs, crc, starts = [], [], []
+    for step in range(1, 27):
+        before = eng.stats(0)
+        eng.process(1)
+        st = eng.stats(0)
+        if step == 7:
+            assert st["frames"] == 0 and st["samples_consumed"] >= 5.5 * ds.TF, st        # seven steps of nothing but failed attempts: > 5.5 frames walked
+        if st["frames"] > before["frames"]:
+            f, c = eng.read_fibs(0, 1)
+            fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"])
+    n = min(len(fibs), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 13, (len(fibs), ora["n"])
+    assert np.array_equal(np.array(starts)[:n], ora["start"][:n])
+    assert np.array_equal(np.array(crc)[:n], ora["crc"][:n])
+    ok = ora["crc"][:n].astype(bool)
+    assert np.array_equal(np.array(fibs)[:n][ok], ora["fibs"][:n][ok])
+    eng.close()
+
+
 def test_streams_in_different_states_and_configurations_do_not_interact():
     """One engine, four streams: a different ensemble and sub-channel set on each (per-stream dabx_set_subchannels), one
     stream that receives its samples late, one with a drop-out, one left without any samples.  Every stream must produce

@@ -15,11 +15,13 @@ for what in "$@"; do
     fuzz)  python3 tools/fuzz_hunt.py --seeds ${FUZZ_SEEDS:-4000:4030} > $OUT/fuzz_log.jsonl 2> $OUT/fuzz.err; tail -2 $OUT/fuzz_log.jsonl ;;
     soak)  python3 bench.py --steps 30002 --warmup 14 --no-cpu-baseline > $OUT/soak.json 2> $OUT/soak.err; tail -c 600 $OUT/soak.json ;;
     dbg)   python3 tools/debug_fuzz_case.py ${DBG_ARGS} > $OUT/debug_case.txt 2>&1; tail -80 $OUT/debug_case.txt ;;
+    fz)    for v in new head; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v = head ] && cp dabstar_amd/_ab/libdabx_r3_head.so dabstar_amd/libdabx.so;
+             echo "=== $v"; DABX_FUZZ_VERBOSE=1 python3 -m pytest tests/test_gpu_fuzz.py -q -s -m gpu -k random_channels 2>&1 | grep -E "garbage|passed|failed|Assertion" ; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/fz.txt 2>&1; cat $OUT/fz.txt ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
-    fictime) for v in before after; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; cp dabstar_amd/_ab/libdabx_fictime_$v.so dabstar_amd/libdabx.so;
-             for st in 1 512; do echo "== $v streams $st"; python3 bench.py --streams $st --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^fic wave" | tail -8; done; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/fictime.txt 2>&1; cat $OUT/fictime.txt ;;
-    pf)    bash tools/ab.sh $OUT/abpf 3 "prefetch1|dabstar_amd/_ab/libdabx_r3_prefetch1.so|" "prefetch2|-|" > $OUT/abpf.txt 2>&1; cat $OUT/abpf.txt;
-           for v in prefetch1 new; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v = prefetch1 ] && cp dabstar_amd/_ab/libdabx_r3_prefetch1.so dabstar_amd/libdabx.so;
+    fictime) cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; cp dabstar_amd/_ab/libdabx_fictime_after.so dabstar_amd/libdabx.so;
+             for st in 1 512; do echo "== streams $st"; python3 bench.py --streams $st --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^fic wave" | tail -8; done > $OUT/fictime.txt 2>&1; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; cat $OUT/fictime.txt ;;
+    pf)    bash tools/ab.sh $OUT/abpf 3 "head|dabstar_amd/_ab/libdabx_r3_head.so|" "wvprefetch|-|" > $OUT/abpf.txt 2>&1; cat $OUT/abpf.txt;
+           for v in head new; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v = head ] && cp dabstar_amd/_ab/libdabx_r3_head.so dabstar_amd/libdabx.so;
              for r in 1 2 3; do python3 bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('$v', 'streams 1', j['value'])"; python3 bench.py --streams 1 --fic-only --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('$v', 'streams 1 fic-only', j['value'])"; done; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/single.txt 2>&1; cat $OUT/single.txt ;;
     rccl)  DABX_BENCH_FORCE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/rccl_one_rank.json 2> $OUT/rccl.err; tail -c 1500 $OUT/rccl_one_rank.json ;;
     tie)   for r in 1 2; do for m in 0 1 2; do
