@@ -279,6 +279,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.subch, (size_t)S * std::max(1, d.max_subch)));
   A(e->alloc(&d.fib_out, (size_t)S * d.out_frames * 12 * 32));
   A(e->alloc(&d.fib_crc, (size_t)S * d.out_frames * 12));
+  A(e->alloc(&d.frame_pos, (size_t)S * d.out_frames));
+  A(e->alloc(&d.frame_start, (size_t)S * d.out_frames));
   if (d.capture_soft) A(e->alloc(&d.soft_cap, (size_t)S * 75 * K2));
   // demapper state (constructor defaults: ofdm_decoder.h:101-104)
   A(demap_alloc(d.demap, S));
@@ -640,6 +642,23 @@ int dabx_read_fibs(dabx_engine *e, int stream, int n_frames, uint8_t *fibs, uint
     const int slot = (int)(fr % e->dev.out_frames);
     DABX_HIP(hipMemcpy(fibs + (size_t)i * 384, e->dev.fib_out + ((size_t)stream * e->dev.out_frames + slot) * 384, 384, hipMemcpyDeviceToHost));
     DABX_HIP(hipMemcpy(crc + (size_t)i * 12, e->dev.fib_crc + ((size_t)stream * e->dev.out_frames + slot) * 12, 12, hipMemcpyDeviceToHost));
+  }
+  return have;
+}
+
+int dabx_read_frame_info(dabx_engine *e, int stream, int n_frames, int64_t *sym0_pos, int32_t *start_index)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || n_frames <= 0 || n_frames > e->dev.out_frames || (!sym0_pos && !start_index)) return DABX_E_ARG;
+  if (!e->dev.frame_pos) { set_error("dabx_read_frame_info: engine keeps no frame records"); return DABX_E_STATE; }
+  StreamCtl c;
+  int rc = fetch_ctl(e, stream, &c);
+  if (rc) return rc;
+  const int have = (int)std::min<long long>(c.frames, n_frames);
+  for (int i = 0; i < have; i++) {            // oldest first
+    const long long fr = c.frames - have + i;
+    const size_t slot = (size_t)stream * e->dev.out_frames + (size_t)(fr % e->dev.out_frames);
+    if (sym0_pos) DABX_HIP(hipMemcpy(sym0_pos + i, e->dev.frame_pos + slot, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (start_index) DABX_HIP(hipMemcpy(start_index + i, e->dev.frame_start + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
   }
   return have;
 }

@@ -100,6 +100,8 @@ struct EngineDev {
   SubchDev *subch;                // [S][max_subch]
   uint8_t *fib_out;               // [S][out_frames][12][32]
   uint8_t *fib_crc;               // [S][out_frames][12]
+  long long *frame_pos;           // [S][out_frames] absolute sample index of the T_u part of symbol 0 of the frame in that output slot
+  int32_t *frame_start;           // [S][out_frames] its start index (PRS correlation peak, dab_processor.cpp:394)
   uint8_t *msc_out;               // [S][max_subch][MSC_SLOTS][msc_stride]
   uint8_t *sf_out;                // [S][max_subch][SF_SLOTS][sf_stride]
   int16_t *soft_cap;              // [S][75][3072] or null

@@ -867,6 +867,10 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
       upd(an * (1.0f / (float)TN), __expf((float)TN * LNQ));
       if (!e.exact_level) c.s_level = lv;                  // cfg.exact_level_tracker: k_level_exact walks the frame's samples instead
     }
+    if (e.frame_pos) {                                      // per-frame record next to the FIBs (dabx_read_frame_info)
+      const size_t slot = (size_t)s * e.out_frames + (size_t)(c.frames % e.out_frames);
+      e.frame_pos[slot] = (long long)c.sym0_pos; e.frame_start[slot] = c.start_index;
+    }
     c.sample_count = sample_count;
     c.rd = base + TN;
     c.nco_phase = nco_advance(phase_null, f2, TN);

@@ -387,6 +387,13 @@ class Engine:
         n = check(load().dabx_read_fibs(self._h, stream, n_frames, _p(fibs), _p(crc)))
         return fibs[:n], crc[:n]
 
+    def read_frame_info(self, stream, n_frames=1):
+        """(sym0_pos int64[n], start_index int32[n]) of the newest frames, oldest first (dabx_read_frame_info)."""
+        pos = np.zeros(n_frames, np.int64)
+        st = np.zeros(n_frames, np.int32)
+        n = check(load().dabx_read_frame_info(self._h, stream, n_frames, _p(pos), _p(st)))
+        return pos[:n], st[:n]
+
     def discover_subchannels(self, stream, max_out=64):
         out = (SubchDesc * max_out)()
         n = check(load().dabx_discover_subchannels(self._h, stream, out, max_out))

@@ -269,6 +269,12 @@ int  dabx_synchronize(dabx_engine *e);
 void *dabx_hip_stream(dabx_engine *e);
 /* Results of the most recent frames (host copies). fibs: n x 12 x 32, crc: n x 12 */
 int  dabx_read_fibs(dabx_engine *e, int stream, int n_frames, uint8_t *fibs, uint8_t *crc_ok);
+/* Where the newest n_frames frames (n_frames <= out_frames, oldest first, the frames dabx_read_fibs returns) sit in the stream's
+ * sample sequence: sym0_pos = index, counted from the first sample ever committed, of the first sample of the useful part of the
+ * frame's phase reference symbol; start_index = the PRS correlation peak that placed it (DabProcessor's startIndex,
+ * dab_processor.cpp:394-411).  Either array may be NULL.  Returns the number of frames written.  Time-stamps frames for a host
+ * that knows when it committed which samples; lets a test compare the receiver's walk through the samples frame by frame. */
+int  dabx_read_frame_info(dabx_engine *e, int stream, int n_frames, int64_t *sym0_pos, int32_t *start_index);
 /* Sub-channel table announced in the FIBs of the newest frames of `stream` (dabx_parse_fibs over the FIB ring);
  * feed the result to dabx_set_subchannels to decode "everything found in the FIC" like EtiGenerator does. */
 int  dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);

@@ -41,6 +41,8 @@ def _oracle(x, subch, cfg):
     cap = L.ora_rx_get_capture(rx).contents
     res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy() if n else np.zeros((0, 12, 32), np.uint8),
                crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy() if n else np.zeros((0, 12), np.uint8),
+               start=np.ctypeslib.as_array(cap.start_idx, (n,)).copy() if n else np.zeros(0, np.int32),
+               sym0=np.ctypeslib.as_array(cap.sym0_pos, (n,)).copy() if n else np.zeros(0, np.int32),
                fic_ovf=np.ctypeslib.as_array(cap.fic_overflow, (n,)).copy() if n else np.zeros(0, np.int32),
                msc_ovf=np.ctypeslib.as_array(cap.msc_overflow, (n,)).copy() if n else np.zeros(0, np.int32),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
@@ -102,6 +104,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
         eng.push_iq(s, xs[s])
     fibs = [[] for _ in range(N_CASES)]
     crcs = [[] for _ in range(N_CASES)]
+    walk = [[] for _ in range(N_CASES)]                  # (position of symbol 0, start index) of every frame: the receiver's walk
     frames_seen = [0] * N_CASES
     steps = 0
     while steps < N_FRAMES + 40:                          # failed acquisition attempts cost steps too
@@ -116,6 +119,8 @@ def test_random_channels_and_layouts_follow_the_oracle():
                 a, b = eng.read_fibs(s, new)
                 assert len(a) == new
                 fibs[s].extend(a); crcs[s].extend(b)
+                pos, sti = eng.read_frame_info(s, new)
+                walk[s].extend(zip(pos.tolist(), sti.tolist()))
 
     locked = n_bad = n_bad_diff = compared = eti_checked = n_ovf_frames = 0
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
@@ -131,6 +136,9 @@ def test_random_channels_and_layouts_follow_the_oracle():
         # demapper's means have followed) are outside the comparison: the reference's `(i16)` cast is undefined behaviour
         # there, the x86 wrap-around both sides reproduce turns a last-ulp float difference into a full-scale one, and the
         # decoder's answer to such symbols is arbitrary (fuzz seed 3003: one FIB of one frame).
+        # the walk through the samples: every frame found at the same sample with the same start index, whatever the state
+        # machine did in between (failed correlations, false dips, losses of lock) -- also for streams that never decode a FIB
+        assert [w[0] for w in walk[s][:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[s][:n]] == ora["start"][:n].tolist(), tag
         clean = ora["fic_ovf"][:n] == 0
         n_ovf_frames += int((~clean).sum())
         assert np.array_equal(np.array(crcs[s])[:n][clean], ora["crc"][:n][clean]), tag
