@@ -270,7 +270,10 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
 }
 
 // --------------------------------------------------------------------------------------------- frame head
-__global__ __launch_bounds__(256, 4) void k_frame_head(EngineDev e, DevTables t)
+#ifndef DABX_HEAD_OCC
+#define DABX_HEAD_OCC 4
+#endif
+__global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, DevTables t)
 {
   front_prio();
   __shared__ float2 lds[FFT_LDS_FLOAT2];
