@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void k_acquire(EngineDev e)
 
 // --------------------------------------------------------------------------------------------- frame head
 #ifndef DABX_HEAD_OCC
-#define DABX_HEAD_OCC 4
+#define DABX_HEAD_OCC 3      // 166 VGPRs, no scratch: with the in-step retry loop the 128-VGPR build spilled 30 registers (+2 % chain, profiles/r03_ab/ab9)
 #endif
 __global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, DevTables t)
 {

@@ -17,7 +17,7 @@ for what in "$@"; do
     dbg)   python3 tools/debug_fuzz_case.py ${DBG_ARGS} > $OUT/debug_case.txt 2>&1; tail -80 $OUT/debug_case.txt ;;
     fz)    for v in new head; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v = head ] && cp dabstar_amd/_ab/libdabx_r3_head.so dabstar_amd/libdabx.so;
              echo "=== $v"; DABX_FUZZ_VERBOSE=1 python3 -m pytest tests/test_gpu_fuzz.py -q -s -m gpu -k random_channels 2>&1 | grep -E "garbage|passed|failed|Assertion" ; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/fz.txt 2>&1; cat $OUT/fz.txt ;;
-    headocc) bash tools/ab.sh $OUT/abhead 3 "occ4|-|" "occ3|dabstar_amd/_ab/libdabx_headocc3.so|" "occ2|dabstar_amd/_ab/libdabx_headocc2.so|" "demap7|dabstar_amd/_ab/libdabx_demapocc7.so|" > $OUT/abhead.txt 2>&1; cat $OUT/abhead.txt ;;
+    demap1) bash tools/ab.sh $OUT/abdemap1 3 "two_blocks|-|" "one_block|dabstar_amd/_ab/libdabx_demapocc5.so|" > $OUT/abdemap1.txt 2>&1; cat $OUT/abdemap1.txt ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     fictime) cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; cp dabstar_amd/_ab/libdabx_fictime_after.so dabstar_amd/libdabx.so;
              for st in 1 512; do echo "== streams $st"; python3 bench.py --streams $st --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^fic wave" | tail -8; done > $OUT/fictime.txt 2>&1; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; cat $OUT/fictime.txt ;;
