@@ -63,6 +63,7 @@ def parse():
                          "(no decode, no roofline); prints the same JSON line with \"dry\": true")
     ap.add_argument("--viterbi-tie-mode", type=int, default=0, choices=[0, 1, 2],
                     help="not the headline: decode with the arithmetic of the reference's VITERBI_AVX2 (1) / VITERBI_SSE2 (2) builds")
+    ap.add_argument("--chunk", type=int, default=7, help="frames per dabx_process call (= MSC_BATCH_FRAMES of the library build; A/B of batch sizes)")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
                     help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
                          "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
@@ -311,13 +312,13 @@ def cpu_baseline(args, subch):
     return out
 
 
-def step_chunks(n):
+def step_chunks(n, chunk=7):
     """How n steps are handed to dabx_process: chunks of 7 = MSC_BATCH_FRAMES (a dabx_process call closes its last batch).  The
     MSC decode of a chunk's last batch runs behind the front end of the NEXT chunk; behind the last chunk there is nothing to
     overlap with (2.3 ms for 6-7 frames against a 21-ms timed region of 20 steps).  Issuing the final frames as (4, 2) to
     shorten that tail was measured and is SLOWER (-3 %, profiles/r03_ab/ab2_tapered_tail_steps20.txt): small batches run the
     lane-per-trellis decoder at one or two waves per SIMD."""
-    return [7] * (n // 7) + ([n % 7] if n % 7 else [])
+    return [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
 
 
 def free_port():
@@ -522,7 +523,7 @@ def main():
         # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch (a dabx_process call
         # closes its last batch), so the steps are issued in chunks of 7 (all work of the n steps is complete when the
         # streams are drained)
-        for m in step_chunks(n):
+        for m in step_chunks(n, args.chunk):
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=False)
 
@@ -632,7 +633,7 @@ def main():
                        "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
                        "AWGN %g dB, per-stream CFO/timing" % (args.streams, args.snr),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * n_joined,
-                       "step_chunks": step_chunks(args.steps) if args.steps <= 70 else "%d x 7 + %d" % (args.steps // 7, args.steps % 7), "viterbi_tie_mode": args.viterbi_tie_mode,
+                       "step_chunks": step_chunks(args.steps, args.chunk) if args.steps <= 70 else "%d x %d + %d" % (args.steps // args.chunk, args.chunk, args.steps % args.chunk), "viterbi_tie_mode": args.viterbi_tie_mode,
                        "x_realtime_per_gpu": round(value / n_joined / (2048000.0 / TF), 1),
                        "msamples_per_s": round(value * TF / 1e6, 1)},
             "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
