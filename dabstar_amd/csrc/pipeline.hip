@@ -610,7 +610,8 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       float *rp = red + 16 * (l & 1);
       const float pw_sum = wave_sum(part);
       if ((tid & 63) == 0) rp[tid >> 6] = pw_sum;
-      __syncthreads();                                      // the tile is complete behind it, too
+      __syncthreads();                                      // the tile is complete behind it, too.  (The barrier is not what the kernel waits
+                                                            // for: a timing build without it is no faster, profiles/r03_ab/ab12.)
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < DEMAP_THREADS / 64; w++) sum += rp[w];
