@@ -410,7 +410,10 @@ __global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, 
 // blocks per stream (a divisor of 75): 15 blocks of 5 symbols each fill the chip from ~50 streams up (3 resident per CU); with
 // fewer streams the symbols of a frame are spread over more blocks so that the kernel's latency, not its throughput, shrinks
 // (one stream: 75 blocks of one symbol -- the single-ensemble configurations are latency-bound on the frame's serial chain)
-__host__ __device__ constexpr int sym_blocks_per_stream(int n_streams) { return n_streams >= 48 ? 15 : (n_streams >= 16 ? 25 : 75); }
+#ifndef DABX_SYM_G
+#define DABX_SYM_G 15
+#endif
+__host__ __device__ constexpr int sym_blocks_per_stream(int n_streams) { return n_streams >= 48 ? DABX_SYM_G : (n_streams >= 16 ? 25 : 75); }
 // 3 waves per SIMD: 170 VGPRs without spills (bounded to 4 it spills 8 registers and runs 25 % slower)
 __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevTables t)
 {

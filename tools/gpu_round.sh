@@ -22,6 +22,8 @@ for what in "$@"; do
              python3 bench.py --steps 48 --warmup 12 --chunk $b --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('batch', $b, j['value'], j['fib_crc_match_pct'], j['superframes_failed'])"; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done; done > $OUT/batch.txt 2>&1; cat $OUT/batch.txt ;;
     nobar) for v in base nobarrier; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v != base ] && cp dabstar_amd/_ab/libdabx_$v.so dabstar_amd/libdabx.so;
              python3 bench.py --steps 14 --warmup 7 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('$v', j['value'], j['fib_crc_match_pct'], {k: round(v, 4) for k, v in j['chain']['kernel_ms_per_step_standalone'].items()})"; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/nobar.txt 2>&1; cat $OUT/nobar.txt ;;
+    membound) tools/_build/sym_mem_bound > $OUT/sym_mem_bound.jsonl 2>&1; cat $OUT/sym_mem_bound.jsonl ;;
+    symg)  bash tools/ab.sh $OUT/absymg 3 "g15|-|" "g25|dabstar_amd/_ab/libdabx_symg25.so|" "g75|dabstar_amd/_ab/libdabx_symg75.so|" > $OUT/absymg.txt 2>&1; cat $OUT/absymg.txt ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     fictime) cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; cp dabstar_amd/_ab/libdabx_fictime_after.so dabstar_amd/libdabx.so;
              for st in 1 512; do echo "== streams $st"; python3 bench.py --streams $st --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^fic wave" | tail -8; done > $OUT/fictime.txt 2>&1; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; cat $OUT/fictime.txt ;;

@@ -101,6 +101,27 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void k_stub_persistent(const flo
   }
 }
 
+// (d) the same traffic with 16-byte accesses: a thread loads five float4 (two consecutive samples each; the symbol's first
+// sample is only 8-byte aligned in the ring, MISALIGN = 1 shifts the slice by one sample) and stores three float4.
+template <int MISALIGN>
+__global__ __launch_bounds__(256, 8) void k_stub16(const float2 *iq, float2 *spectra, int frame)
+{
+  const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
+  const float2 *ring = iq + (size_t)s * RING;
+  const unsigned off = ((unsigned)(((size_t)frame * TF + 2656 + (size_t)l * TS) % RING) & ~1u) + MISALIGN;
+  float4 v[5];
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    unsigned i = off + 2 * (tid + 256 * u);
+    if (i + 1 >= RING) i = 0;
+    v[u] = (tid + 256 * u) < TS / 2 ? *reinterpret_cast<const float4 *>(ring + i) : make_float4(0, 0, 0, 0);
+  }
+  const float acc = v[4].x * 1e-9f;
+  float4 *dst = reinterpret_cast<float4 *>(spectra + ((size_t)s * 75 + l) * K);
+#pragma unroll
+  for (int u = 0; u < 3; u++) dst[tid + 256 * u] = make_float4(v[u].x * 0.5f + acc, v[u].y, v[u].z * 0.25f, v[u].w + v[(u + 1) % 5].x);
+}
+
 template <int WPE, int WORK> static void run_persistent(const float2 *iq, float2 *sp, int G, hipEvent_t a, hipEvent_t b)
 {
   std::vector<float> ms;
@@ -139,6 +160,21 @@ int main()
     const double med = ms[ms.size() / 2], bytes = (double)S * 75 * (TS + K) * 8;
     printf("{\"variant\": \"%s\", \"median_ms\": %.4f, \"min_ms\": %.4f, \"GBps\": %.0f, \"bytes\": %.0f}\n",
            skel ? "loads + 3 LDS exchanges with barriers + store" : "loads + store", med, ms[0], bytes / med / 1e6, bytes);
+  }
+  for (int mis = 0; mis < 2; mis++) {
+    std::vector<float> ms;
+    for (int it = 0; it < 24; it++) {
+      CK(hipEventRecord(a));
+      if (mis) hipLaunchKernelGGL(k_stub16<1>, dim3(75, S), dim3(256), 0, 0, iq, sp, it % 10);
+      else hipLaunchKernelGGL(k_stub16<0>, dim3(75, S), dim3(256), 0, 0, iq, sp, it % 10);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float t; CK(hipEventElapsedTime(&t, a, b));
+      if (it >= 4) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double med = ms[ms.size() / 2], bytes = (double)S * 75 * (TS + K) * 8;
+    printf("{\"variant\": \"16-byte loads and stores, %s\", \"median_ms\": %.4f, \"min_ms\": %.4f, \"GBps\": %.0f}\n",
+           mis ? "slice 8-byte aligned only" : "slice 16-byte aligned", med, ms[0], bytes / med / 1e6);
   }
   run_persistent<8, 0>(iq, sp, 15, a, b);
   run_persistent<4, 0>(iq, sp, 15, a, b);
