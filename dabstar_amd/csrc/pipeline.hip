@@ -699,10 +699,6 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
   if (!c.frame_ok) return;
   s_crc[threadIdx.x] = t.crc_ccitt[threadIdx.x];
   const int fic = first + wave;             // this wave's FIC block
-#ifdef DABX_FIC_TIMING
-  const unsigned long long T0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long T1 = 0, T2 = 0, T3 = 0;
-#endif
   if (wave < count) {
     SrcFic src{e.fic_sym + (size_t)s * 3 * K2 + fic * FIC_IN, t.fic_map};
     uint32_t *dec = e.vit_scratch + ((size_t)s * 4 + fic) * (size_t)e.vit_stride;
@@ -712,21 +708,12 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     else vit_forward<0>(src, FIC_OUT + 6, wtab[wave], dec, lane, k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
-#ifdef DABX_FIC_TIMING
-    T1 = __builtin_amdgcn_s_memrealtime();
-#endif
     vit_traceback(dec, FIC_OUT, lane, raw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#ifdef DABX_FIC_TIMING
-    T2 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (lane < 24) fibw[fic][lane] = vit_output_word(raw[wave], lane) ^ t.prbs_words[lane];   // fic_decoder.cpp:219-222
   }
   __syncthreads();
-#ifdef DABX_FIC_TIMING
-  T3 = __builtin_amdgcn_s_memrealtime();
-#endif
   const int slot = (int)(c.frames % e.out_frames);
   uint8_t *fo = e.fib_out + ((size_t)s * e.out_frames + slot) * 12 * 32;
   const int fib0 = 3 * first, nfib = 3 * count;
@@ -760,12 +747,6 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     c.fic_ratio = ratio; c.cif_count = cif_count;
     c.fib_ok += ok; c.fib_total += nfib;
   }
-#ifdef DABX_FIC_TIMING
-  if (s == 0 && lane == 0 && wave < count) {
-    const unsigned long long T4 = __builtin_amdgcn_s_memrealtime();
-    printf("fic wave %d: forward %llu traceback %llu to-barrier %llu tail %llu (x10 ns)\n", wave, T1 - T0, T2 - T1, T3 - T2, T4 - T3);
-  }
-#endif
 }
 
 // --------------------------------------------------------------------------------------------- frame tail
