@@ -246,13 +246,41 @@ __device__ __forceinline__ int16_t cvt_i16_x86(float x)
   return (int16_t)(uint16_t)(uint32_t)(int32_t)x;
 }
 
-// atan2 for the demapper: octant reduction + Abramowitz-Stegun 4.4.49 (|err| <= 2e-8 rad on [0,1]); the phase only
-// feeds the +-20 degree integrator with gain 1e-3, so this is far inside the soft-bit tolerance.
-__device__ __forceinline__ float atan2_as(float y, float x)
+// Four of them at once (the soft bits of a carrier pair).  v_cvt_i32_f32 saturates; it differs from cvttss2si's "integer
+// indefinite" in the low 16 bits only for x >= 2^31 (0x7fffffff against 0x80000000; x <= -2^31 gives 0x80000000 and NaN gives
+// 0 on both) -- so one v_max3 + v_max + compare guards all four and the per-value repair sits behind a branch that is
+// practically never taken, instead of a compare and a select per value.
+__device__ __forceinline__ int cvt_i32_sat(float x)
 {
-  const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(ax, ay), mnv = fminf(ax, ay);
-  const float t = mnv * __builtin_amdgcn_rcpf(mx);
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ void cvt4_i16_x86(float a, float b, float c, float d, int16_t &ra, int16_t &rb, int16_t &rc, int16_t &rd)
+{
+  int ia = cvt_i32_sat(a), ib = cvt_i32_sat(b), ic = cvt_i32_sat(c), id = cvt_i32_sat(d);
+  float m;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
+  if (__builtin_expect(m >= 2147483648.0f, 0)) {
+    if (a >= 2147483648.0f) ia = 0;
+    if (b >= 2147483648.0f) ib = 0;
+    if (c >= 2147483648.0f) ic = 0;
+    if (d >= 2147483648.0f) id = 0;
+  }
+  ra = (int16_t)(uint16_t)(uint32_t)ia; rb = (int16_t)(uint16_t)(uint32_t)ib;
+  rc = (int16_t)(uint16_t)(uint32_t)ic; rd = (int16_t)(uint16_t)(uint32_t)id;
+}
+
+// The phase detector of the demapper (ofdm_decoder.cpp:197-202, glob_defs.h:173-182): fmod(arg(b) [+ pi if negative], pi/2)
+// - pi/4, the distance of the received phase from the diagonal of its quadrant.  With r = atan(min(|x|,|y|) / max(|x|,|y|))
+// in [0, pi/4] (Abramowitz-Stegun 4.4.49, |err| <= 2e-8 rad) the folded angle is r or pi/2 - r, so the result is
+// -(pi/4 - r) or +(pi/4 - r): ONE magnitude and a sign = NOT[(|y| > |x|) xor (x < 0) xor (y < 0)], taken from the sign bits of
+// |y| - |x|, x and y.  On an axis (min = 0, incl. b = 0 with either sign of zero) the reference's fmod returns 0, i.e. -pi/4:
+// the sign is forced there.  No quadrant selects, no compares (the value only feeds the +-20 degree integrator with gain
+// 1e-3: far inside the soft-bit tolerance).
+__device__ __forceinline__ float atan_octant_poly(float t)
+{
   const float z = t * t;
   float p = 0.0028662257f;
   p = __builtin_fmaf(p, z, -0.0161657367f);
@@ -262,11 +290,36 @@ __device__ __forceinline__ float atan2_as(float y, float x)
   p = __builtin_fmaf(p, z, -0.1420889944f);
   p = __builtin_fmaf(p, z, 0.1999355085f);
   p = __builtin_fmaf(p, z, -0.3333314528f);
-  float r = __builtin_fmaf(p * z, t, t);
-  if (mx == 0.0f) r = 0.0f;
-  if (ay > ax) r = 1.57079632679489661923f - r;
-  if (x < 0.0f) r = 3.14159265358979323846f - r;
-  return y < 0.0f ? -r : r;
+  return __builtin_fmaf(p * z, t, t);
+}
+__device__ __forceinline__ float phase_fold_sign(float u, float d, float x, float y, float t)
+{
+  // (u & 0x7fffffff) | (sign of d ^ x ^ y, forced to 1 where t == +0): two xor, an add, an or and one v_bfi_b32
+  const unsigned w = (__float_as_uint(d) ^ __float_as_uint(x) ^ __float_as_uint(y)) | (__float_as_uint(t) - 1u);
+  float r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x7fffffffu), "v"(u), "v"(w));
+  return r;
+}
+// v_max3_f32 / v_min_f32 on |x|, |y| as single instructions (fmaxf / fminf on the result of an integer `and` make the compiler
+// add a canonicalising v_max x, x per operand in IEEE mode)
+__device__ __forceinline__ float max3_abs(float x, float y, float floor_)
+{
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(x), "v"(y), "s"(floor_));
+  return r;
+}
+__device__ __forceinline__ float min_abs(float x, float y)
+{
+  float r;
+  asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ float phase_offset_from_diagonal(float y, float x)
+{
+  // max(.., FLT_MIN): b = 0 gives t = 0 * finite = 0 instead of 0 * inf
+  const float t = min_abs(x, y) * __builtin_amdgcn_rcpf(max3_abs(x, y, 1.17549435e-38f));
+  const float r = atan_octant_poly(t);
+  return phase_fold_sign(r - 0.78539816339744830962f, fabsf(y) - fabsf(x), x, y, t);
 }
 
 // One carrier of one symbol.  Returns |r1| (summand of mMeanValue); writes the two soft bits.
@@ -277,7 +330,7 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
                                            int soft_type, int16_t &soft_re, int16_t &soft_im, float &power_out)
 {
   constexpr float ALPHA = 0.005f;
-  const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
+  const float F_PI = 3.14159265358979323846f;
   const float F_RAD_PER_DEG = 0.01745329251994329577f, F_SQRT1_2 = 0.70710678118654752440f;
   const float2 pr = c.prev;
   const float pr_sq = pr.x * pr.x + pr.y * pr.y;
@@ -293,13 +346,9 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   float2 b;
   b.x = raw.x * cosine - raw.y * sine;
   b.y = raw.x * sine + raw.y * cosine;
-  float ph = atan2_as(b.y, b.x);                                // :197
-  if (ph < 0.0f) ph += F_PI;                                    // glob_defs.h:173-182
-  // fmod(ph, pi/2) for ph in [0, pi]: pi_f == 2 * (pi/2)_f exactly and ph - n*c is exact (Sterbenz)
-  const float aph = ph < F_PI_2 ? ph : (ph < F_PI ? ph - F_PI_2 : ph - F_PI);
-  c.integ += 0.2f * ALPHA * (aph - F_PI_4);                     // :201-202
+  const float off = phase_offset_from_diagonal(b.y, b.x);      // :197-201: fmod(arg(b) in [0, pi], pi/2) - pi/4
   const float lim = F_RAD_PER_DEG * 20.0f;
-  if (c.integ > lim) c.integ = lim; else if (c.integ < -lim) c.integ = -lim;
+  c.integ = __builtin_amdgcn_fmed3f(c.integ + 0.2f * ALPHA * off, -lim, lim);   // :201-202 (limit())
   const float power = b.x * b.x + b.y * b.y;                    // :211-213
   power_out = power;
   c.mean_power += ALPHA * (power - c.mean_power);
@@ -343,10 +392,10 @@ __device__ __forceinline__ v2f v2_rcp(v2f a) { return (v2f){__builtin_amdgcn_rcp
 __device__ __forceinline__ v2f v2_abs(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
 __device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-__device__ __forceinline__ v2f atan2_as2(v2f y, v2f x)
+__device__ __forceinline__ v2f phase_offset_from_diagonal2(v2f y, v2f x, v2f ay, v2f ax)   // ay = |y|, ax = |x| (the caller has them)
 {
-  const v2f ax = v2_abs(x), ay = v2_abs(y);
-  const v2f mx = (v2f){fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)}, mnv = (v2f){fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+  const v2f mx = (v2f){max3_abs(x.x, y.x, 1.17549435e-38f), max3_abs(x.y, y.y, 1.17549435e-38f)};
+  const v2f mnv = (v2f){min_abs(x.x, y.x), min_abs(x.y, y.y)};
   const v2f t = mnv * v2_rcp(mx);
   const v2f z = t * t;
   v2f p = (v2f)(0.0028662257f);
@@ -357,11 +406,9 @@ __device__ __forceinline__ v2f atan2_as2(v2f y, v2f x)
   p = v2_fma(p, z, (v2f)(-0.1420889944f));
   p = v2_fma(p, z, (v2f)(0.1999355085f));
   p = v2_fma(p, z, (v2f)(-0.3333314528f));
-  v2f r = v2_fma(p * z, t, t);
-  r = (mx == 0.0f) ? (v2f)(0.0f) : r;
-  r = (ay > ax) ? 1.57079632679489661923f - r : r;
-  r = (x < 0.0f) ? 3.14159265358979323846f - r : r;
-  return (y < 0.0f) ? -r : r;
+  const v2f r = v2_fma(p * z, t, t);
+  const v2f u = r - 0.78539816339744830962f, d = ay - ax;
+  return (v2f){phase_fold_sign(u.x, d.x, x.x, y.x, t.x), phase_fold_sign(u.y, d.y, x.y, y.y, t.y)};
 }
 
 template <int SOFT_TYPE>
@@ -369,7 +416,7 @@ __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f 
                                           int16_t (&soft_re)[2], int16_t (&soft_im)[2], v2f &power_out)
 {
   constexpr float ALPHA = 0.005f;
-  const float F_PI = 3.14159265358979323846f, F_PI_4 = 0.78539816339744830962f, F_PI_2 = 1.57079632679489661923f;
+  const float F_PI = 3.14159265358979323846f;
   const float F_RAD_PER_DEG = 0.01745329251994329577f, F_SQRT1_2 = 0.70710678118654752440f;
   const v2f pr_re = c.prev_re, pr_im = c.prev_im;
   const v2f pr_sq = pr_re * pr_re + pr_im * pr_im;
@@ -383,19 +430,17 @@ __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f 
   const v2f cosine = 0.9994032382965087890625f + x2 * (x2 * 3.679168224334716796875e-2f + -0.495580852031707763671875f);
   const v2f b_re = raw_re * cosine - raw_im * sine;
   const v2f b_im = raw_re * sine + raw_im * cosine;
-  v2f ph = atan2_as2(b_im, b_re);                                 // :197
-  ph = (ph < 0.0f) ? ph + F_PI : ph;                              // glob_defs.h:173-182
-  const v2f aph = (ph < F_PI_2) ? ph : ((ph < F_PI) ? ph - F_PI_2 : ph - F_PI);
-  v2f integ = c.integ + 0.2f * ALPHA * (aph - F_PI_4);            // :201-202
+  const v2f abs_re = v2_abs(b_re), abs_im = v2_abs(b_im);
+  const v2f off = phase_offset_from_diagonal2(b_im, b_re, abs_im, abs_re);   // :197-201: fmod(arg(b) in [0, pi], pi/2) - pi/4
+  const v2f integ = c.integ + 0.2f * ALPHA * off;                 // :201-202
   const float lim = F_RAD_PER_DEG * 20.0f;
-  integ = (integ > lim) ? (v2f)(lim) : ((integ < -lim) ? (v2f)(-lim) : integ);
-  c.integ = integ;
+  c.integ = (v2f){__builtin_amdgcn_fmed3f(integ.x, -lim, lim), __builtin_amdgcn_fmed3f(integ.y, -lim, lim)};
   const v2f power = b_re * b_re + b_im * b_im;                    // :211-213
   power_out = power;
   c.mean_power += ALPHA * (power - c.mean_power);
   const v2f mean_level = v2_sqrt(c.mean_power);                   // :217-223
   const v2f at_axis = mean_level * F_SQRT1_2;
-  const v2f rd = v2_abs(b_re) - at_axis, id = v2_abs(b_im) - at_axis;
+  const v2f rd = abs_re - at_axis, id = abs_im - at_axis;
   const v2f sigma_sq = rd * rd + id * id;
   c.mean_sigma_sq += ALPHA * (sigma_sq - c.mean_sigma_sq);
   v2f signal_power = c.mean_power - c.null_power;                 // :225-226
@@ -408,8 +453,7 @@ __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f 
   else w1 = v2_sqrt(babs * pr_abs) * mean_level * v2_rcp(nsr * (c.mean_sigma_sq * babs));   // :243-251
   const v2f r1_re = b_re * w1, r1_im = b_im * w1;
   const v2f s_re = r1_re * w2, s_im = r1_im * w2;                 // :254-255
-  soft_re[0] = cvt_i16_x86(s_re.x); soft_re[1] = cvt_i16_x86(s_re.y);
-  soft_im[0] = cvt_i16_x86(s_im.x); soft_im[1] = cvt_i16_x86(s_im.y);
+  cvt4_i16_x86(s_re.x, s_re.y, s_im.x, s_im.y, soft_re[0], soft_re[1], soft_im[0], soft_im[1]);
   c.prev_re = x_re; c.prev_im = x_im;                             // :354
   return babs * w1;
 }

@@ -10,6 +10,7 @@
 //   k_frame_tail   fine CFO, null symbol, clock error, cursor bookkeeping (dab_processor.cpp:226-302)
 //   k_msc_frame    time de-interleave + depuncture + Viterbi + PRBS per (CIF, sub-channel) (backend.cpp:129-161)
 //   k_dabplus      super-frame sync, RS(120,110), fire code, AU CRCs (mp4processor.cpp:96-333)
+#include <type_traits>
 #include "pipeline.h"
 #include "ofdm_core.h"
 #include "viterbi_core.h"
@@ -510,7 +511,9 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
 constexpr int DEMAP_Q = DABX_DEMAP_Q, DEMAP_THREADS = K / DEMAP_Q, DEMAP_NP = DEMAP_Q / 2;   // carriers per thread (in pairs); 12 waves per stream
 constexpr int DEMAP_NOUT = (K2 / 4) / DEMAP_THREADS;              // output dwords per thread and symbol
 constexpr int TILE_PLANE = 196;                                   // LDS bytes per plane of the output tile (192 used)
-template <int SOFT_TYPE>      // ESoftBitType 1..3 as a compile-time constant: no per-carrier branches on it
+// ESoftBitType 1..3 and the symbol conversion (SAT: the SIMD builds' saturating one, cfg.viterbi_tie_mode != 0) as compile-time
+// constants: no per-carrier branches on either
+template <int SOFT_TYPE, bool SAT>
 __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &t, const int l0, const int l1)
 {
   // symbols [l0, l1) of the frame (0-based: l = symbol index - 1).  The engine runs [0, 3) -- the FIC symbols -- first so
@@ -562,11 +565,11 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
   float2 xn[DEMAP_Q];                                           // spectrum values of the next symbol (gather latency off the chain)
-  {
-    const float2 *X0 = spectra + ((size_t)s * 75 + l0) * K;
+  // one pointer into the middle of the thread's carriers, stepped by a symbol per iteration: the DEMAP_Q loads of a symbol are
+  // immediate offsets of +- (DEMAP_Q / 2 - 1/2) * DEMAP_THREADS elements from it, no 64-bit address arithmetic in the loop
+  const float2 *xp = spectra + ((size_t)s * 75 + l0) * K + tid + (DEMAP_Q / 2) * DEMAP_THREADS;
 #pragma unroll
-    for (int q = 0; q < DEMAP_Q; q++) xn[q] = X0[tid + DEMAP_THREADS * q];
-  }
+  for (int q = 0; q < DEMAP_Q; q++) xn[q] = xp[(q - DEMAP_Q / 2) * DEMAP_THREADS];
   // The 3072 Viterbi symbols of an OFDM symbol leave through LDS: every thread drops its bytes into a tile that is
   // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barrier of
   // the mean-value reduction the block stores aligned dwords -- one per thread with 768 threads, 48 consecutive dwords per
@@ -582,14 +585,16 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     tpos[2 * q] = (k & 15) * TILE_PLANE + (k >> 4);
     tpos[2 * q + 1] = ((K + k) & 15) * TILE_PLANE + ((K + k) >> 4);
   }
-  for (int l = l0; l < l1; l++) {                         // the demapper state advances on all 75 symbols in every mode
-    const float2 *X = spectra + ((size_t)s * 75 + (l < 74 ? l + 1 : l)) * K;
+  // one symbol; PAR = (l - l0) & 1 selects the tile and the partial-sum buffer at compile time (LDS immediate offsets)
+  auto symbol = [&](const int l, auto par) {
+    constexpr int PAR = decltype(par)::value;
+    if (l < 74) xp += K;                                   // the symbol after the last one: fetched again, never used
     const int m = l - 3, cif = m / 18, blk = m % 18;       // msc_handler.cpp:148-168 : 18 symbols per CIF
     const float w2 = demap_w2(mean_value, SOFT_TYPE);
-    uint8_t *tl = tile[l & 1];
+    uint8_t *tl = tile[PAR];
     float2 xc[DEMAP_Q];
 #pragma unroll
-    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = X[tid + DEMAP_THREADS * q]; }
+    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = xp[(q - DEMAP_Q / 2) * DEMAP_THREADS]; }
     float part = 0.f;
 #pragma unroll
     for (int p = 0; p < DEMAP_NP; p++) {
@@ -601,8 +606,8 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int q = 2 * p + h;
-        tl[tpos[2 * q]] = soft_to_sym_mode(sr[h], e.tie_mode);
-        tl[tpos[2 * q + 1]] = soft_to_sym_mode(si[h], e.tie_mode);
+        tl[tpos[2 * q]] = SAT ? soft_to_sym_sat(sr[h]) : soft_to_sym(sr[h]);
+        tl[tpos[2 * q + 1]] = SAT ? soft_to_sym_sat(si[h]) : soft_to_sym(si[h]);
         if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[h]; cap[(size_t)l * K2 + K + k] = si[h]; }
       }
     }
@@ -610,7 +615,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     // added in wave order by every thread.  ONE barrier per symbol: the partials (and the tile) are double-buffered by
     // symbol parity, so what a thread still reads of symbol l cannot be overwritten before the barrier of symbol l + 1.
     {
-      float *rp = red + 16 * (l & 1);
+      float *rp = red + 16 * PAR;
       const float pw_sum = wave_sum(part);
       if ((tid & 63) == 0) rp[tid >> 6] = pw_sum;
       __syncthreads();                                      // the tile is complete behind it, too.  (The barrier is not what the kernel waits
@@ -634,6 +639,11 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
         *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
       }
     }
+  };
+  {                                                       // the demapper state advances on all 75 symbols in every mode
+    int l = l0;
+    for (; l + 1 < l1; l += 2) { symbol(l, std::integral_constant<int, 0>{}); symbol(l + 1, std::integral_constant<int, 1>{}); }
+    if (l < l1) symbol(l, std::integral_constant<int, 0>{});
   }
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
@@ -663,12 +673,12 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
 
 // Built for six waves per SIMD (<= 80 VGPRs, 7 values spilled outside the loop): two 12-wave blocks share a CU instead of
 // taking turns (at 94 VGPRs only one fitted: 0.32 -> 0.24 ms per step).
-template <int SOFT_TYPE>
-__global__ __launch_bounds__(DEMAP_THREADS, DABX_DEMAP_OCC) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE>(e, t, l0, l1); }
+template <int SOFT_TYPE, bool SAT>
+__global__ __launch_bounds__(DEMAP_THREADS, DABX_DEMAP_OCC) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE, SAT>(e, t, l0, l1); }
 // the FIC symbols alone (first launch of a frame in the overlapped schedule): its own kernel symbol so that rocprofv3's
 // per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
-template <int SOFT_TYPE>
-__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE>(e, t, 0, 3); }
+template <int SOFT_TYPE, bool SAT>
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT>(e, t, 0, 3); }
 
 // ---------------------------------------------------------------------------------------------------- FIC
 struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map
@@ -1177,17 +1187,27 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
   mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
   mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+  // kernel instance by (ESoftBitType, symbol conversion of the canonical / SIMD builds)
+#define DABX_DEMAP_DISPATCH(KERNEL, ...)                                                                                         \
+  do {                                                                                                                          \
+    const int st_ = e.demap.soft_type == 3 ? 3 : e.demap.soft_type == 2 ? 2 : 1;                                                \
+    if (e.tie_mode) {                                                                                                           \
+      if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, true>), __VA_ARGS__);                                                         \
+      else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__);                                                    \
+      else hipLaunchKernelGGL((KERNEL<1, true>), __VA_ARGS__);                                                                  \
+    } else {                                                                                                                    \
+      if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, false>), __VA_ARGS__);                                                        \
+      else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, false>), __VA_ARGS__);                                                   \
+      else hipLaunchKernelGGL((KERNEL<1, false>), __VA_ARGS__);                                                                 \
+    }                                                                                                                           \
+  } while (0)
   auto demap = [&](hipStream_t q, int l0, int l1) {
-    if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_frame6<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
-    else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_frame6<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
-    else hipLaunchKernelGGL(k_demap_frame6<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
+    DABX_DEMAP_DISPATCH(k_demap_frame6, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
   };
   if (ss.d) {
     if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
     mk.begin(10, st);
-    if (e.demap.soft_type == 3) hipLaunchKernelGGL(k_demap_fic<3>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-    else if (e.demap.soft_type == 2) hipLaunchKernelGGL(k_demap_fic<2>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
-    else hipLaunchKernelGGL(k_demap_fic<1>, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
+    DABX_DEMAP_DISPATCH(k_demap_fic, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
     mk.end(10, st);
     DABX_HIP(hipEventRecord(ss.fic_go, st));
     DABX_HIP(hipStreamWaitEvent(ss.d, ss.fic_go, 0));

@@ -122,6 +122,38 @@ __global__ __launch_bounds__(256, 8) void k_stub16(const float2 *iq, float2 *spe
   for (int u = 0; u < 3; u++) dst[tid + 256 * u] = make_float4(v[u].x * 0.5f + acc, v[u].y, v[u].z * 0.25f, v[u].w + v[(u + 1) % 5].x);
 }
 
+// (e) does the memory-side cache (256 MB) keep a group's spectra between the producer and the consumer?  k_consume reads a
+// group's spectra the way the demapper does (every float2 once).  Full: producer over 512 streams, consumer over 512 streams
+// (472 MB of spectra in between).  Grouped: NG groups of 512 / NG streams, each produced into the SAME spectra region and
+// consumed right away (118 MB for NG = 4).  Equal times = the round trip goes to HBM either way.
+__global__ __launch_bounds__(256, 8) void k_consume(const float2 *spectra, float *sink)
+{
+  const int s = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
+  const float2 *src = spectra + ((size_t)s * 75 + l) * K;
+  float acc = 0.0f;
+#pragma unroll
+  for (int u = 0; u < K / 256; u++) { const float2 v = src[tid + 256 * u]; acc += v.x + v.y; }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+static void run_grouped(const float2 *iq, float2 *sp, float *sink, int NG, hipEvent_t a, hipEvent_t b)
+{
+  std::vector<float> ms;
+  const int Sg = S / NG;
+  for (int it = 0; it < 24; it++) {
+    CK(hipEventRecord(a));
+    for (int g = 0; g < NG; g++) {
+      hipLaunchKernelGGL(k_stub<0>, dim3(75, Sg), dim3(256), 0, 0, iq + (size_t)g * Sg * RING, NG == 1 ? sp : sp, it % 10);
+      hipLaunchKernelGGL(k_consume, dim3(75, Sg), dim3(256), 0, 0, sp, sink);
+    }
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float t; CK(hipEventElapsedTime(&t, a, b));
+    if (it >= 4) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  printf("{\"variant\": \"producer + consumer, %d group(s) of %d streams through one %d-MB spectra region\", \"median_ms\": %.4f, \"min_ms\": %.4f}\n",
+         NG, Sg, (int)((size_t)Sg * 75 * K * 8 >> 20), ms[ms.size() / 2], ms[0]);
+}
+
 template <int WPE, int WORK> static void run_persistent(const float2 *iq, float2 *sp, int G, hipEvent_t a, hipEvent_t b)
 {
   std::vector<float> ms;
@@ -176,6 +208,9 @@ int main()
     printf("{\"variant\": \"16-byte loads and stores, %s\", \"median_ms\": %.4f, \"min_ms\": %.4f, \"GBps\": %.0f}\n",
            mis ? "slice 8-byte aligned only" : "slice 16-byte aligned", med, ms[0], bytes / med / 1e6);
   }
+  float *sink;
+  CK(hipMalloc(&sink, 64));
+  for (int ng : {1, 2, 4, 8, 16}) run_grouped(iq, sp, sink, ng, a, b);
   run_persistent<8, 0>(iq, sp, 15, a, b);
   run_persistent<4, 0>(iq, sp, 15, a, b);
   run_persistent<4, 0>(iq, sp, 25, a, b);
