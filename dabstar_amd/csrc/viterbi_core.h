@@ -88,34 +88,57 @@ struct VitLaneConst {
   int pat[6];        // LDS byte offset of this lane's branch metric within a step row, per class
   int sgn[6];        // +1 where this lane holds the lower predecessor of its butterfly in class c, -1 where the upper
   int lane;
+  unsigned inv30;    // canonical body: bits of a 30-step decision word this lane accumulates INVERTED (see vit_step)
 };
 
 __device__ __forceinline__ VitLaneConst vit_lane_const(int lane)
 {
   VitLaneConst k;
+  k.inv30 = 0;
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     k.pat[c] = vit_pat_off(lane, c);
-    k.sgn[c] = ((lane >> ((5 - c) % 6)) & 1) ? -1 : 1;
+    const int upper = (lane >> ((5 - c) % 6)) & 1;
+    k.sgn[c] = upper ? -1 : 1;
+    if (c >= 2 && upper)                               // DPP classes only (the swap classes produce the decision directly)
+#pragma unroll
+      for (int s = c; s < VIT_DW; s += 6) k.inv30 |= 1u << (VIT_DW - 1 - s);
   }
   k.lane = lane;
   return k;
 }
 
+// One add-compare-select step of class C.  viterbi_scalar.h:25-26: decision = (value through predecessor i) > (value through
+// predecessor i + 32), ties -> predecessor i.  A lower lane of the pair owns predecessor i (co = own + w), an upper lane owns
+// predecessor i + 32, so the test is co > cp below and cp > co above.  What sits on the wave's dependent-instruction chain is
+// only  m -> partner's m (DPP operand of the subtraction, or a permlane swap) -> min:
+//  * DPP classes (C = 2..5): cp = dpp(m) - w and  g = (co + u > cp)  with u = 1 in upper lanes: below that is the decision,
+//    above it is (co >= cp), the decision's complement -- the lane accumulates g and the complement is undone with one xor
+//    per 30-step word (inv30).  co + u = m + (w + u): w + u does not depend on m.
+//  * swap classes (C = 0, 1: partner 32 / 16 lanes away): v_permlane{32,16}_swap(m, m) leaves {own, partner} in r[0], r[1] in
+//    lane-dependent order (own first in the lower lanes).  With the lane's signed w:  x0 = r[0] + sgn w, x1 = r[1] - sgn w  is
+//    (co, cp) below and (cp, co) above -- min(x0, x1) is the new metric and x0 > x1 is the decision in BOTH halves: no select
+//    after the swap, no complement.
+// (Round 3: the select after the swap and the chain  co - cp -> * sgn -> compare -> add-with-carry  made a lone wave's step 72
+// cycles; profiles/r03_fic_phase_timing.txt.)
 template <int C>
 __device__ __forceinline__ void vit_step(int &m, unsigned &acc, const char *wrow, const VitLaneConst &k)
 {
   const int w = *reinterpret_cast<const int16_t *>(wrow + k.pat[C]);
-  const int partner = vit_exchange<C>(m, k.lane);
-  const int co = m + w, cp = partner - w;
-  // decision = (value through predecessor i) > (value through predecessor i+32), viterbi_scalar.h:25-26.  A lower lane of
-  // the pair owns predecessor i (co), an upper lane owns predecessor i+32: the test is co > cp below and cp > co above,
-  // i.e. (co - cp) * (+1 | -1) > 0 with the lane's sign for this step class (the metric spread of a K = 7 trellis with
-  // |branch metric| <= 1020 stays below 2^15, so the 24-bit multiply is exact).  One compare into vcc, consumed as the
-  // carry-in of acc = 2 acc + decision: the whole step stays in the VALU (no ballot masks merged on the scalar unit).
-  const int dd = __mul24(co - cp, k.sgn[C]);
-  m = co < cp ? co : cp;
-  asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(dd) : "vcc");
+  if constexpr (C >= 2) {
+    const int w2 = w - (k.sgn[C] >> 1);                  // + 1 in upper lanes (sgn = -1), loop invariant
+    const int co = m + w, co2 = m + w2;
+    const int cp = vit_exchange<C>(m, k.lane) - w;
+    m = co < cp ? co : cp;
+    asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(co2), "v"(cp) : "vcc");
+  } else {
+    const int ws = __mul24(w, k.sgn[C]);
+    int x0, x1;
+    if constexpr (C == 1) { const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false); x0 = (int)r[0] + ws; x1 = (int)r[1] - ws; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false); x0 = (int)r[0] + ws; x1 = (int)r[1] - ws; }
+    m = x0 < x1 ? x0 : x1;
+    asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x0), "v"(x1) : "vcc");
+  }
 }
 
 // ---- the reference's SIMD builds (VITERBI_AVX2: viterbi_16way.h; VITERBI_SSE2 / NEON: viterbi_8way.h) -------------
@@ -205,7 +228,7 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
           vit_step<5>(m, acc, row + 5 * 16, k);
         }
       }
-      dec[(size_t)(b * (VIT_BLK / VIT_DW) + h) * 64 + lane] = acc;
+      dec[(size_t)(b * (VIT_BLK / VIT_DW) + h) * 64 + lane] = RULE == 0 ? acc ^ k.inv30 : acc;
       acc = 0;
     }
     __builtin_amdgcn_wave_barrier();
@@ -221,44 +244,83 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
 // word, written by lane 0); vit_pack_output() turns them into MSB-first packed bytes afterwards.
 constexpr int VIT_RAW_WORDS = 312;          // >= vit_words(9216) + 3
 
-template <int S> __device__ __forceinline__ void vit_tb_step(unsigned hist, int &j, unsigned &acc)
+// Six steps (one cycle of the step classes 5..0, exchange bits 0..5) of the chain-back.
+//  * vit_tb_masks<G>: the decisions of steps 6 G + 5 .. 6 G of a 30-step word as six wave masks in SGPR pairs (a v_bfe + v_cmp
+//    per step, independent of the path: issued a whole group ahead of the chain that consumes them).
+//  * vit_tb_chain: on the scalar unit, per step  SCC = mask[j];  j = SCC ? j | bit : j & ~bit;  acc = 2 acc + SCC  -- two
+//    dependent scalar instructions per step (s_bitcmp1 -> s_cselect).
+// (Round 3, before: v_readlane of the lane's 30-step word with the path's lane as selector -- 4 wait states after the scalar
+// write of j -- then bfe / shift / andn2 / or: 72 cycles per step, profiles/r03_fic_phase_timing.txt.)
+struct VitMask6 { unsigned long long m5, m4, m3, m2, m1, m0; };    // named members: stay in SGPRs
+template <int G> __device__ __forceinline__ VitMask6 vit_tb_masks(unsigned hist)
 {
-  // Written in SALU form by hand: hipcc otherwise keeps j in a VGPR and pays ~6 VALU per step.
-  // s_nop 3: SALU write of the lane-select SGPR -> v_readlane needs 4 wait states (hipcc pads nothing in asm).
-  constexpr int P = (5 - (S % 6)) % 6;
-  constexpr int BFE = (1 << 16) | (VIT_DW - 1 - S);      // s_bfe_u32: width 1, offset = bit of step S
-  unsigned hv, k;
-  asm volatile("s_nop 3\n\t"
-               "v_readlane_b32 %[hv], %[hist], %[j]\n\t"
-               "s_bfe_u32 %[k], %[hv], %[bfe]\n\t"
-               "s_lshl1_add_u32 %[acc], %[acc], %[k]\n\t"
-               "s_lshl_b32 %[k], %[k], %[p]\n\t"
-               "s_andn2_b32 %[j], %[j], %[bit]\n\t"
-               "s_or_b32 %[j], %[j], %[k]"
-               : [hv] "=&s"(hv), [k] "=&s"(k), [acc] "+s"(acc), [j] "+s"(j)
-               : [hist] "v"(hist), [bfe] "n"(BFE), [p] "n"(P), [bit] "n"(1 << P)
+  VitMask6 r;
+  r.m5 = __builtin_amdgcn_ballot_w64(((hist >> (VIT_DW - 1 - (6 * G + 5))) & 1u) != 0u);
+  r.m4 = __builtin_amdgcn_ballot_w64(((hist >> (VIT_DW - 1 - (6 * G + 4))) & 1u) != 0u);
+  r.m3 = __builtin_amdgcn_ballot_w64(((hist >> (VIT_DW - 1 - (6 * G + 3))) & 1u) != 0u);
+  r.m2 = __builtin_amdgcn_ballot_w64(((hist >> (VIT_DW - 1 - (6 * G + 2))) & 1u) != 0u);
+  r.m1 = __builtin_amdgcn_ballot_w64(((hist >> (VIT_DW - 1 - (6 * G + 1))) & 1u) != 0u);
+  r.m0 = __builtin_amdgcn_ballot_w64(((hist >> (VIT_DW - 1 - (6 * G + 0))) & 1u) != 0u);
+  return r;
+}
+__device__ __forceinline__ void vit_tb_chain(const VitMask6 &q, int &j, unsigned &acc)
+{
+  int jc, js;
+#define DABX_TB_STEP(M, BIT)                                                                                                    \
+  "s_andn2_b32 %[jc], %[j], " #BIT "\n\ts_or_b32 %[js], %[j], " #BIT "\n\ts_bitcmp1_b64 %[" #M "], %[j]\n\t"                        \
+  "s_cselect_b32 %[j], %[js], %[jc]\n\ts_addc_u32 %[acc], %[acc], %[acc]\n\t"
+  asm volatile(DABX_TB_STEP(m5, 1) DABX_TB_STEP(m4, 2) DABX_TB_STEP(m3, 4) DABX_TB_STEP(m2, 8) DABX_TB_STEP(m1, 16) DABX_TB_STEP(m0, 32)
+               : [jc] "=&s"(jc), [js] "=&s"(js), [acc] "+s"(acc), [j] "+s"(j)
+               : [m5] "s"(q.m5), [m4] "s"(q.m4), [m3] "s"(q.m3), [m2] "s"(q.m2), [m1] "s"(q.m1), [m0] "s"(q.m0)
                : "scc");
+#undef DABX_TB_STEP
+}
+// groups NG - 1 .. 0 of one word; `ahead` = the masks of group NG - 1 (made while the previous word's chain ran); returns the
+// masks of the next word's top group (`nxt`, group 4) made while this word's last chain runs
+template <int NG>
+__device__ __forceinline__ VitMask6 vit_tb_word(unsigned hist, unsigned nxt, VitMask6 ahead, int &j, unsigned &acc)
+{
+  VitMask6 a = ahead;
+  if constexpr (NG >= 5) { const VitMask6 b = vit_tb_masks<3>(hist); vit_tb_chain(a, j, acc); a = b; }
+  if constexpr (NG >= 4) { const VitMask6 b = vit_tb_masks<2>(hist); vit_tb_chain(a, j, acc); a = b; }
+  if constexpr (NG >= 3) { const VitMask6 b = vit_tb_masks<1>(hist); vit_tb_chain(a, j, acc); a = b; }
+  if constexpr (NG >= 2) { const VitMask6 b = vit_tb_masks<0>(hist); vit_tb_chain(a, j, acc); a = b; }
+  const VitMask6 b = vit_tb_masks<4>(nxt);
+  vit_tb_chain(a, j, acc);
+  return b;
 }
 
 __device__ __forceinline__ void vit_traceback(const uint32_t *dec, int nbits, int lane, uint32_t *raw)
 {
-  const int nsteps = nbits + 6;
+  const int nsteps = __builtin_amdgcn_readfirstlane(nbits + 6);   // wave-uniform by contract; tell the compiler (j, acc live in SGPRs)
   int j = 0;                                   // lane of the terminal state 0
   int wi = (nsteps - 1) / VIT_DW;
   unsigned hist = dec[(size_t)wi * 64 + lane];
-  {                                            // top (possibly partial) word: run-time step range
+  VitMask6 ahead;
+  {                                            // top (possibly partial) word
     const unsigned nxt = wi > 0 ? dec[(size_t)(wi - 1) * 64 + lane] : 0u;
     unsigned acc = 0;
-    const int s_top = (nsteps - 1) - wi * VIT_DW;
-    for (int s = s_top; s >= 0; --s) {
-      const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, __builtin_amdgcn_readfirstlane(j));
-      const unsigned k = (hv >> (VIT_DW - 1 - s)) & 1u;
-      acc = (acc << 1) | k;
-      const int p = (5 - (s % 6)) % 6;
-      j = (j & ~(1 << p)) | ((int)k << p);
+    const int n_top = nsteps - wi * VIT_DW;    // 1 .. 30 steps
+    if (n_top % 6 == 0) {                      // every legal DAB trellis (nbits + 6 is a multiple of 6): whole groups
+      switch (n_top / 6) {
+        case 5: ahead = vit_tb_word<5>(hist, nxt, vit_tb_masks<4>(hist), j, acc); break;
+        case 4: ahead = vit_tb_word<4>(hist, nxt, vit_tb_masks<3>(hist), j, acc); break;
+        case 3: ahead = vit_tb_word<3>(hist, nxt, vit_tb_masks<2>(hist), j, acc); break;
+        case 2: ahead = vit_tb_word<2>(hist, nxt, vit_tb_masks<1>(hist), j, acc); break;
+        default: ahead = vit_tb_word<1>(hist, nxt, vit_tb_masks<0>(hist), j, acc); break;
+      }
+    } else {                                   // arbitrary lengths of the stage-level entry point: step by step
+      for (int s = n_top - 1; s >= 0; --s) {
+        const unsigned hv = (unsigned)__builtin_amdgcn_readlane((int)hist, __builtin_amdgcn_readfirstlane(j));
+        const unsigned k = (hv >> (VIT_DW - 1 - s)) & 1u;
+        acc = (acc << 1) | k;
+        const int p = (5 - (s % 6)) % 6;
+        j = (j & ~(1 << p)) | ((int)k << p);
+      }
+      j = __builtin_amdgcn_readfirstlane(j);
+      acc = __builtin_amdgcn_readfirstlane(acc);
+      ahead = vit_tb_masks<4>(nxt);
     }
-    j = __builtin_amdgcn_readfirstlane(j);
-    acc = __builtin_amdgcn_readfirstlane(acc);
     if (lane == 0) { raw[wi] = acc; raw[wi + 1] = 0; raw[wi + 2] = 0; }
     hist = nxt;
     --wi;
@@ -266,16 +328,7 @@ __device__ __forceinline__ void vit_traceback(const uint32_t *dec, int nbits, in
   for (; wi >= 0; --wi) {
     const unsigned nxt = wi > 0 ? dec[(size_t)(wi - 1) * 64 + lane] : 0u;
     unsigned acc = 0;
-    vit_tb_step<29>(hist, j, acc); vit_tb_step<28>(hist, j, acc); vit_tb_step<27>(hist, j, acc);
-    vit_tb_step<26>(hist, j, acc); vit_tb_step<25>(hist, j, acc); vit_tb_step<24>(hist, j, acc);
-    vit_tb_step<23>(hist, j, acc); vit_tb_step<22>(hist, j, acc); vit_tb_step<21>(hist, j, acc);
-    vit_tb_step<20>(hist, j, acc); vit_tb_step<19>(hist, j, acc); vit_tb_step<18>(hist, j, acc);
-    vit_tb_step<17>(hist, j, acc); vit_tb_step<16>(hist, j, acc); vit_tb_step<15>(hist, j, acc);
-    vit_tb_step<14>(hist, j, acc); vit_tb_step<13>(hist, j, acc); vit_tb_step<12>(hist, j, acc);
-    vit_tb_step<11>(hist, j, acc); vit_tb_step<10>(hist, j, acc); vit_tb_step<9>(hist, j, acc);
-    vit_tb_step<8>(hist, j, acc);  vit_tb_step<7>(hist, j, acc);  vit_tb_step<6>(hist, j, acc);
-    vit_tb_step<5>(hist, j, acc);  vit_tb_step<4>(hist, j, acc);  vit_tb_step<3>(hist, j, acc);
-    vit_tb_step<2>(hist, j, acc);  vit_tb_step<1>(hist, j, acc);  vit_tb_step<0>(hist, j, acc);
+    ahead = vit_tb_word<5>(hist, nxt, ahead, j, acc);
     if (lane == 0) raw[wi] = acc;
     hist = nxt;
   }
