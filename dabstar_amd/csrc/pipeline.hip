@@ -681,15 +681,16 @@ template <int SOFT_TYPE, bool SAT>
 __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT>(e, t, 0, 3); }
 
 // ---------------------------------------------------------------------------------------------------- FIC
-struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map
+struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map (viterbi_core.h: key / raw / syms)
   const uint8_t *sym;
   const uint16_t *map;
-  __device__ int one(uint16_t idx) const { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : sym[idx]); }
-  __device__ VitSyms operator()(int t) const
-  {
-    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
-    return {one(m.x), one(m.y), one(m.z), one(m.w)};
-  }
+  typedef ushort4 Key;
+  struct Raw { uint8_t a, b, c, d; };
+  __device__ Key key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
+  __device__ uint8_t ld(uint16_t idx) const { return sym[idx == PUNCT ? 0 : idx]; }
+  __device__ Raw raw(Key m) const { return {ld(m.x), ld(m.y), ld(m.z), ld(m.w)}; }
+  __device__ static int cv(uint8_t v, uint16_t idx) { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : v); }
+  __device__ VitSyms syms(Raw r, Key m) const { return {cv(r.a, m.x), cv(r.b, m.y), cv(r.c, m.z), cv(r.d, m.w)}; }
 };
 
 // FIC blocks [first, first + count) of the frame: the engine decodes all four at once (first = 0, count = 4); the
@@ -942,25 +943,26 @@ __global__ __launch_bounds__(64) void k_level_exact(EngineDev e)
 }
 
 // ---------------------------------------------------------------------------------------------------- MSC
-struct SrcMsc {                        // time de-interleaver read + depuncture (backend.cpp:131-139, protection.cpp:46-59)
+struct SrcMsc {                        // time de-interleaver read + depuncture (backend.cpp:131-139, protection.cpp:46-59); key / raw / syms
   const uint8_t *tdi;                  // this stream's ring
   const uint16_t *map;
   long long r;                         // CIF being output
   int base;                            // cu_start * 64
-  __device__ int one(uint16_t idx) const
+  typedef ushort4 Key;
+  struct Raw { uint8_t a, b, c, d; };
+  __device__ Key key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
+  __device__ uint8_t ld(uint16_t idx_in) const
   {
-    if (idx == PUNCT) return vit_sym_from_u8(127);
+    const int idx = idx_in == PUNCT ? 0 : idx_in;
     // out_r[i] = in_{r-16+map[i&15]}[i], map = {0,8,4,12,2,10,6,14,1,9,5,13,3,11,7,15} (bit reversal of 4 bits)
     const int i4 = idx & 15;
     const int m = ((i4 & 1) << 3) | ((i4 & 2) << 1) | ((i4 & 4) >> 1) | ((i4 & 8) >> 3);
     const long long q = r - 16 + m;
-    return vit_sym_from_u8(tdi[tdi_off(q, base + idx)]);
+    return tdi[tdi_off(q, base + idx)];
   }
-  __device__ VitSyms operator()(int t) const
-  {
-    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
-    return {one(m.x), one(m.y), one(m.z), one(m.w)};
-  }
+  __device__ Raw raw(Key m) const { return {ld(m.x), ld(m.y), ld(m.z), ld(m.w)}; }
+  __device__ static int cv(uint8_t v, uint16_t idx) { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : v); }
+  __device__ VitSyms syms(Raw q, Key m) const { return {cv(q.a, m.x), cv(q.b, m.y), cv(q.c, m.z), cv(q.d, m.w)}; }
 };
 
 // fast_mask: bit c set = class c + 1 is decoded by the lane-per-trellis kernels in this batch (vit_t.hip)

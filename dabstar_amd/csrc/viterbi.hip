@@ -4,12 +4,15 @@
 
 namespace dabx {
 
-struct SrcI16 {                       // ViterbiSpiral::deconvolve input: 4*(n+6) int16, already depunctured
+struct SrcI16 {                       // ViterbiSpiral::deconvolve input: 4*(n+6) int16, already depunctured (viterbi_core.h: key / raw / syms)
   const int16_t *soft;
   int sat;                            // AVX2 body: saturating symbol conversion
-  __device__ VitSyms operator()(int t) const
+  typedef int Key;
+  typedef short4 Raw;
+  __device__ Key key(int t) const { return t; }
+  __device__ Raw raw(Key t) const { return *reinterpret_cast<const short4 *>(soft + 4 * t); }
+  __device__ VitSyms syms(Raw v, Key) const
   {
-    const short4 v = *reinterpret_cast<const short4 *>(soft + 4 * t);
     if (sat) return {vit_sym_from_i16_sat(v.x), vit_sym_from_i16_sat(v.y), vit_sym_from_i16_sat(v.z), vit_sym_from_i16_sat(v.w)};
     return {vit_sym_from_i16(v.x), vit_sym_from_i16(v.y), vit_sym_from_i16(v.z), vit_sym_from_i16(v.w)};
   }
@@ -18,12 +21,13 @@ struct SrcI16 {                       // ViterbiSpiral::deconvolve input: 4*(n+6
 struct SrcI16Map {                    // Protection::deconvolve input: punctured int16 + depuncture map
   const int16_t *in;
   const uint16_t *map;
-  __device__ int one(uint16_t idx) const { return vit_sym_from_i16(idx == PUNCT ? (int16_t)0 : in[idx]); }
-  __device__ VitSyms operator()(int t) const
-  {
-    const ushort4 m = *reinterpret_cast<const ushort4 *>(map + 4 * t);
-    return {one(m.x), one(m.y), one(m.z), one(m.w)};
-  }
+  typedef ushort4 Key;
+  typedef short4 Raw;
+  __device__ Key key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
+  __device__ int16_t ld(uint16_t idx) const { return in[idx == PUNCT ? 0 : idx]; }
+  __device__ Raw raw(Key m) const { short4 r; r.x = ld(m.x); r.y = ld(m.y); r.z = ld(m.z); r.w = ld(m.w); return r; }
+  __device__ static int cv(int16_t v, uint16_t idx) { return vit_sym_from_i16(idx == PUNCT ? (int16_t)0 : v); }
+  __device__ VitSyms syms(Raw v, Key m) const { return {cv(v.x, m.x), cv(v.y, m.y), cv(v.z, m.z), cv(v.w, m.w)}; }
 };
 
 template <class Src>

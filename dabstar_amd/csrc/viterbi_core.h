@@ -184,16 +184,25 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
 {
   int m = RULE ? (lane == 0 ? 0 : 1000) : (lane == 0 ? 0 : 2000);   // viterbi_spiral.cpp:98-101 (0 / 1000); doubled in the canonical form
   const int nblk = (nsteps + VIT_BLK - 1) / VIT_BLK;
-  // The symbols of block b + 1 (two dependent global loads: depuncture map, then the soft symbols) are requested before
-  // the 60 add-compare-select steps of block b run and only consumed afterwards: their latency is off the chain.
-  VitSyms s = {0, 0, 0, 0};
-  if (lane < VIT_BLK && lane < nsteps) s = src(lane);
+  // A symbol source delivers a step's four soft symbols in three phases so that no memory latency sits between the blocks:
+  //   key(t)      the step's depuncture-map entry (one load; a source without a map returns t)
+  //   raw(key)    the four symbol loads, UNCONDITIONAL (a punctured position reads index 0) and unconverted: nothing waits
+  //   syms(raw, key)   conversion to 2 sym - 255, punctured positions -> the neutral value
+  // The key of block b + 2 and the raw symbols of block b + 1 are requested before the 60 add-compare-select steps of block b
+  // run; syms() is applied afterwards.  (Round 3: with the one-call source the compiler waited for the map, then for each of
+  // the four symbol loads in turn -- five serial memory latencies per 60-step block, half of the forward pass of a FIC block.)
+  const bool fetcher = lane < VIT_BLK;
+  auto tclamp = [&](int t) { return t < nsteps ? t : 0; };
+  typename Src::Key k1 = src.key(tclamp(lane));
+  typename Src::Raw rw = src.raw(k1);
+  VitSyms s = src.syms(rw, k1);
+  if (!(fetcher && lane < nsteps)) s = VitSyms{0, 0, 0, 0};
+  k1 = src.key(tclamp(VIT_BLK + lane));
   for (int b = 0; b < nblk; b++) {
-    VitSyms sn = {0, 0, 0, 0};
-    {
-      const int tn = (b + 1) * VIT_BLK + lane;
-      if (lane < VIT_BLK && tn < nsteps) sn = src(tn);
-    }
+    const int tn = (b + 1) * VIT_BLK + lane;
+    const typename Src::Raw rn = src.raw(k1);                      // block b + 1
+    const typename Src::Key kn = k1;
+    k1 = src.key(tclamp(tn + VIT_BLK));                            // block b + 2
     if (lane < VIT_BLK) {
       const int y0 = s.x0 + s.x3;
       short v[8];
@@ -232,7 +241,8 @@ __device__ __forceinline__ void vit_forward(const Src &src, int nsteps, char *wt
       acc = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    s = sn;
+    s = src.syms(rn, kn);
+    if (!(fetcher && tn < nsteps)) s = VitSyms{0, 0, 0, 0};
   }
 }
 
