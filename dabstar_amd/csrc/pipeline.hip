@@ -523,7 +523,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   // are not once they are demapped on their own HIP stream, and then they yield to the FIC decoder running next to them but
   // stay above the batched MSC decoder (+1.7 % same-box against priority 3, profiles/r02_ab/ab11.json).
   if (l0 == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
-  __shared__ float red[32];
+  __shared__ __attribute__((aligned(16))) float red[32];
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][16 * TILE_PLANE];
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
@@ -560,7 +560,10 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   }
   float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
   const float ce = fs.clock_err;                          // mClockErrHz of the previous frame, dab_processor.cpp:342
-  const long long cif0 = fs.cif0;
+  // block-uniform (every thread loaded the same word): in SGPRs, so that the CIF slot / block offset of the ring address below
+  // is scalar arithmetic and the store address is one 64-bit add per symbol
+  const long long cif0 = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)fs.cif0 >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fs.cif0));
   uint8_t *fic = e.fic_sym + (size_t)s * 3 * K2;
   uint8_t *tdi = e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS;
   int16_t *cap = e.capture_soft ? e.soft_cap + (size_t)s * 75 * K2 : nullptr;
@@ -611,8 +614,8 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
         if (cap) { const int k = tid + DEMAP_THREADS * q; cap[(size_t)l * K2 + k] = sr[h]; cap[(size_t)l * K2 + K + k] = si[h]; }
       }
     }
-    // mMeanValue (ofdm_decoder.cpp:256,294): block sum in block_sum()'s order -- per-wave butterflies, then the wave partials
-    // added in wave order by every thread.  ONE barrier per symbol: the partials (and the tile) are double-buffered by
+    // mMeanValue (ofdm_decoder.cpp:256,294): block sum -- per-wave butterflies (wave_sum), then the wave partials added by every
+    // thread, pairwise in packed form.  ONE barrier per symbol: the partials (and the tile) are double-buffered by
     // symbol parity, so what a thread still reads of symbol l cannot be overwritten before the barrier of symbol l + 1.
     {
       float *rp = red + 16 * PAR;
@@ -621,8 +624,14 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       __syncthreads();                                      // the tile is complete behind it, too.  (The barrier is not what the kernel waits
                                                             // for: a timing build without it is no faster, profiles/r03_ab/ab12.)
       float sum = 0.f;
+      if constexpr (DEMAP_THREADS / 64 == 12) {               // twelve wave partials as six packed pairs: 5 v_pk_add_f32 + 1 add
+        const v2f *rp2 = reinterpret_cast<const v2f *>(rp);
+        const v2f a = ((rp2[0] + rp2[1]) + (rp2[2] + rp2[3])) + (rp2[4] + rp2[5]);
+        sum = a.x + a.y;
+      } else {
 #pragma unroll
-      for (int w = 0; w < DEMAP_THREADS / 64; w++) sum += rp[w];
+        for (int w = 0; w < DEMAP_THREADS / 64; w++) sum += rp[w];
+      }
       mean_value = sum * (1.0f / (float)K);
     }
 #pragma unroll
@@ -636,7 +645,12 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       } else {                                              // MSC -> planar time-de-interleaver ring
         const int out_plane = dwi / 48, out_dw = dwi - out_plane * 48;
         const uint32_t v = *reinterpret_cast<const uint32_t *>(tl + out_plane * TILE_PLANE + 4 * out_dw);
-        *reinterpret_cast<uint32_t *>(tdi + tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 * out_dw) = v;
+        // tdi_off(cif0 + cif, blk * K2 + out_plane) + 4 out_dw, split into the thread's constant part (plane, dword) and the
+        // block-uniform part (CIF slot, position of the symbol's 192 bytes within the plane): one 64-bit add per store
+        static_assert(K2 % 16 == 0, "a symbol is a whole number of positions in every plane");
+        uint8_t *const tdi_thr = tdi + (size_t)out_plane * (CIF_BITS / 16) + 4 * out_dw;
+        const size_t uoff = (size_t)((cif0 + cif) & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)blk * (K2 / 16);
+        *reinterpret_cast<uint32_t *>(tdi_thr + uoff) = v;
       }
     }
   };
