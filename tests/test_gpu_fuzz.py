@@ -91,6 +91,27 @@ def draw_streams(seed, only=None):
     return layouts, cases, xs, rng
 
 
+def _rerun_exact_level(x, subch, cfg):
+    """One stream alone on an engine with cfg.exact_level_tracker: FIBs, CRC flags and the walk of all its frames."""
+    thr, strongest, soft_type = cfg
+    eng = dx.Engine(n_streams=1, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr, sync_strongest=bool(strongest),
+                    soft_bit_type=soft_type, exact_level_tracker=1)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    fibs, crcs, walk = [], [], []
+    seen = 0
+    for _ in range(N_FRAMES + 40):
+        eng.process(1)
+        f = eng.stats(0)["frames"]
+        if f > seen:
+            a, b = eng.read_fibs(0, f - seen)
+            pos, sti = eng.read_frame_info(0, f - seen)
+            fibs.extend(a); crcs.extend(b); walk.extend(zip(pos.tolist(), sti.tolist()))
+            seen = f
+    eng.close()
+    return fibs, crcs, walk
+
+
 def test_random_channels_and_layouts_follow_the_oracle():
     # receiver options (sync threshold, strongest-peak sync, soft-bit generator 1..3): DABX_FUZZ_CFG="4.0,1,2"
     thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), os.environ.get("DABX_FUZZ_CFG", "3.0,0,1").split(","))]
@@ -123,6 +144,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
                 walk[s].extend(zip(pos.tolist(), sti.tolist()))
 
     locked = n_bad = n_bad_diff = compared = eti_checked = n_ovf_frames = 0
+    level_approx_streams = []
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
         tag = (s, li, round(snr, 1), round(cfo), toff, gain)
         subch = layouts[li]
@@ -138,7 +160,19 @@ def test_random_channels_and_layouts_follow_the_oracle():
         # decoder's answer to such symbols is arbitrary (fuzz seed 3003: one FIB of one frame).
         # the walk through the samples: every frame found at the same sample with the same start index, whatever the state
         # machine did in between (failed correlations, false dips, losses of lock) -- also for streams that never decode a FIB
-        assert [w[0] for w in walk[s][:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[s][:n]] == ora["start"][:n].tolist(), tag
+        same_walk = [w[0] for w in walk[s][:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[s][:n]] == ora["start"][:n].tolist()
+        if not same_walk:
+            # The one deliberate approximation of the state machine: in lock the level tracker advances chunk by
+            # chunk, not sample by sample, which moves s_level by ~1e-5 relative -- the size of the float noise of the
+            # reference's own 196 608-step recurrence.  On a stream that only ever locks on false peaks the null-dip detector
+            # of a later attempt can then fall on the other side of its threshold (hunt 5000-5047: seed 5030, stream 18 of
+            # 1 152, a carrier offset outside the +-35 kHz range, no FIB ever decoded).  Such a stream must follow the oracle
+            # with cfg.exact_level_tracker -- the approximation is then the proven cause -- and stays the exception.
+            level_approx_streams.append(tag)
+            fibs[s], crcs[s], walk[s] = _rerun_exact_level(xs[s], subch, (thr, strongest, soft_type))
+            n = min(len(fibs[s]), ora["n"])
+            assert abs(len(fibs[s]) - ora["n"]) <= 1, (tag, len(fibs[s]), ora["n"])
+            assert [w[0] for w in walk[s][:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[s][:n]] == ora["start"][:n].tolist(), tag
         clean = ora["fic_ovf"][:n] == 0
         n_ovf_frames += int((~clean).sum())
         assert np.array_equal(np.array(crcs[s])[:n][clean], ora["crc"][:n][clean]), tag
@@ -155,7 +189,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
         # MSC bytes are compared where the signal is decodable.  Below ~6 dB the EEP 3-A sub-channels decode with residual
         # errors, and a soft bit that differs by one LSB (float demapper) can tip a survivor path: seen once in
         # 2 600 streams, at 3.7 dB, identically on both MSC decoder kernels.
-        if n < 7 or not okm[n - 7:].all() or snr < 6.0 or ora["msc_ovf"][max(0, n - 9):n].any():
+        if n < 7 or not okm[n - 7:].all() or snr < 6.0 or ora["msc_ovf"][max(0, n - 9):n].any() or not same_walk:
             continue                                       # the newest 16 logical
         eng.subch = list(subch)                            # frames reach back 32 CIFs = 8 frames, of which the last 7 are clean here
         compared += 1
@@ -175,7 +209,7 @@ def test_random_channels_and_layouts_follow_the_oracle():
         # the layout (UEP / EEP-A / EEP-B TPL fields), FIC, MST, CRCs -- against the oracle's assembly of the oracle's bytes
         kmin = min(eng.subch_stats(s, j)["cifs_decoded"] for j in range(len(subch)))
         frames_eti, _lost = eng.read_eti(s, 32)                    # everything the rings still hold: the last one is the newest CIF
-        if kmin >= 16 and len(frames_eti) >= 4 and all(eng.subch_stats(s, j)["cifs_decoded"] == kmin for j in range(len(subch))):
+        if same_walk and kmin >= 16 and len(frames_eti) >= 4 and all(eng.subch_stats(s, j)["cifs_decoded"] == kmin for j in range(len(subch))):
             import test_eti as te
             descs = [dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, int(c.dab_plus), 0) for c in subch]
             Lf = len(frames_eti)
@@ -191,6 +225,9 @@ def test_random_channels_and_layouts_follow_the_oracle():
                 want, _ = te._ora_frame(hi, lo, q, descs, fib[96 * q:96 * q + 96], msc_r)
                 assert np.array_equal(frames_eti[i], want), (tag, i, r)
             eti_checked += 1
+    assert len(level_approx_streams) <= (0 if "DABX_FUZZ_SEED" not in os.environ else 1), level_approx_streams
+    if level_approx_streams and os.environ.get("DABX_FUZZ_VERBOSE"):
+        print("walk differs with the chunk-wise level tracker, equal with the exact one:", level_approx_streams)
     assert eti_checked >= N_CASES // 4
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
     # FIBs that fail their CRC on both sides: a soft bit that differs by one LSB (2-4 in 10^5) anywhere in a FIC block

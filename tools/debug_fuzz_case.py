@@ -15,6 +15,7 @@ from dabstar_amd import lib as dx
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seed", type=int, required=True); ap.add_argument("--cfg", default="3.0,0,1"); ap.add_argument("--stream", type=int, required=True)
+ap.add_argument("--exact-level", type=int, default=0, help="cfg.exact_level_tracker")
 a = ap.parse_args()
 thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), a.cfg.split(","))]
 N_CASES, N_FRAMES = F.N_CASES, F.N_FRAMES
@@ -35,7 +36,7 @@ o_soft = np.ctypeslib.as_array(cap.soft, (n, 75 * 3072)).copy()
 print("oracle: %d frames; start indices %s; symbol 0 at (frames) %s; s_level %s" % (n, o_start.tolist(),
       (np.ctypeslib.as_array(cap.sym0_pos, (n,)) / ds.TF).round(3).tolist(), np.ctypeslib.as_array(cap.s_level, (n,)).round(5).tolist()))
 eng = dx.Engine(n_streams=1, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr, sync_strongest=bool(strongest),
-                soft_bit_type=soft_type, capture_soft=True)
+                soft_bit_type=soft_type, capture_soft=True, exact_level_tracker=a.exact_level)
 eng.set_subchannels(subch); eng.push_iq(0, x)
 k = 0
 for _ in range(N_FRAMES + 40):

@@ -17,6 +17,7 @@ for what in "$@"; do
     fuzz)  python3 tools/fuzz_hunt.py --seeds ${FUZZ_SEEDS:-4000:4030} > $OUT/fuzz_log.jsonl 2> $OUT/fuzz.err; tail -2 $OUT/fuzz_log.jsonl ;;
     soak)  python3 bench.py --steps 30002 --warmup 14 --no-cpu-baseline > $OUT/soak.json 2> $OUT/soak.err; tail -c 600 $OUT/soak.json ;;
     dbg)   python3 tools/debug_fuzz_case.py ${DBG_ARGS} > $OUT/debug_case.txt 2>&1; tail -80 $OUT/debug_case.txt ;;
+    bisect) cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; for v in ${BISECT_LIBS}; do [ $v != new ] && cp dabstar_amd/_ab/libdabx_$v.so dabstar_amd/libdabx.so; echo "=== $v"; python3 tools/debug_fuzz_case.py ${DBG_ARGS} 2>/dev/null | grep -E "^frame|^oracle" | head -${BISECT_LINES:-8} | cut -c1-200; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/bisect.txt 2>&1; cat $OUT/bisect.txt ;;
     fz)    for v in new head; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v = head ] && cp dabstar_amd/_ab/libdabx_r3_head.so dabstar_amd/libdabx.so;
              echo "=== $v"; DABX_FUZZ_VERBOSE=1 python3 -m pytest tests/test_gpu_fuzz.py -q -s -m gpu -k random_channels 2>&1 | grep -E "garbage|passed|failed|Assertion" ; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/fz.txt 2>&1; cat $OUT/fz.txt ;;
     demap1) bash tools/ab.sh $OUT/abdemap1 3 "two_blocks|-|" "one_block|dabstar_amd/_ab/libdabx_demapocc5.so|" > $OUT/abdemap1.txt 2>&1; cat $OUT/abdemap1.txt ;;
@@ -35,6 +36,8 @@ for what in "$@"; do
     rccl)  DABX_BENCH_FORCE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/rccl_one_rank.json 2> $OUT/rccl.err; tail -c 1500 $OUT/rccl_one_rank.json ;;
     tie)   for r in 1 2; do for m in 0 1 2; do
              python3 bench.py --no-cpu-baseline --viterbi-tie-mode $m 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('tie_mode', $m, j['value'], j['fib_crc_match_pct'], j['superframes_failed'], {k: round(v, 3) for k, v in j['chain']['kernel_ms_per_step_standalone'].items() if 'msc' in k})"; done; done > $OUT/tie.txt 2>&1; cat $OUT/tie.txt ;;
+    variants) for cfg in "--layout mixed" "--streams 1 --steps 200 --warmup 20" "--streams 1 --fic-only --steps 200 --warmup 20" "--streams 1024 --steps 28 --warmup 7" "--fic-only"; do
+             python3 bench.py $cfg --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('$cfg', '->', j['value'], j['unit'], 'crc', j['fib_crc_match_pct'], 'sf_fail', j.get('superframes_failed'))"; done > $OUT/variants.txt 2>&1; cat $OUT/variants.txt ;;
     bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
   esac
 done
