@@ -397,7 +397,7 @@ class DryEngine:
 
 def load_traffic(dom):
     """HBM bytes and VALU instructions per FRAME of kernel `dom` from the committed rocprofv3 --pmc passes (tools/prof_round.sh)."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic_final.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
