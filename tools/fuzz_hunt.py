@@ -26,16 +26,20 @@ def main():
         cfg = CFGS[seed % len(CFGS)]
         fast = seed % 4 == 3                     # every fourth run through the lane-per-trellis classes
         which = "test_random_service_start_stop_schedules" if seed % 7 == 6 else "test_random_channels_and_layouts_follow_the_oracle"
-        env = dict(os.environ, DABX_FUZZ_SEED=str(seed), DABX_FUZZ_CFG=cfg)
+        env = dict(os.environ, DABX_FUZZ_SEED=str(seed), DABX_FUZZ_CFG=cfg, DABX_FUZZ_VERBOSE="1")
         if fast:
             env.update(DABX_FUZZ_FAST="1")
         t0 = time.time()
-        p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_fuzz.py", "-k", which],
+        p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "tests/test_gpu_fuzz.py", "-k", which],
                            cwd=ROOT, env=env, capture_output=True, text=True)
         ok = p.returncode == 0
         n_pass += ok; n_fail += (not ok)
         rec = {"seed": seed, "test": which, "cfg_threshold_strongest_softtype": cfg, "lane_per_trellis_classes": bool(fast),
                "passed": ok, "seconds": round(time.time() - t0, 1)}
+        # streams whose walk needed the exact level tracker to follow the oracle (tests/test_gpu_fuzz.py)
+        lv = [l for l in p.stdout.splitlines() if l.startswith("walk differs with the chunk-wise level tracker")]
+        if lv:
+            rec["level_tracker_streams"] = lv[0].split(":", 1)[1].strip()
         if not ok:
             rec["tail"] = p.stdout[-1500:]
         print(json.dumps(rec), flush=True)
