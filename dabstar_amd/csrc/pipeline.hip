@@ -742,30 +742,36 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
   const int slot = (int)(c.frames % e.out_frames);
   uint8_t *fo = e.fib_out + ((size_t)s * e.out_frames + slot) * 12 * 32;
   const int fib0 = 3 * first, nfib = 3 * count;
-  if ((int)threadIdx.x < nfib) {              // one lane per FIB: CRC (crc.cpp:98-132 == CCITT over 30 bytes vs the last 2)
+  __shared__ int fib_cif[12];                 // CIF counter a FIB's FIG 0/0 carries (-1: none, or the FIB failed its CRC)
+  if ((int)threadIdx.x < nfib) {              // one lane per FIB: CRC (crc.cpp:98-132 == CCITT over 30 bytes vs the last 2) and its FIG walk
     const int fibi = fib0 + threadIdx.x;
     const uint8_t *b = reinterpret_cast<const uint8_t *>(&fibw[fibi / 3][0]) + (fibi % 3) * 32;
-    crc_ok[fibi] = crc16_check_bytes(b, 30, s_crc);
+    const uint8_t good = crc16_check_bytes(b, 30, s_crc);
+    crc_ok[fibi] = good;
+    e.fib_crc[((size_t)s * e.out_frames + slot) * 12 + fibi] = good;
+    int cif = -1;
+    if (good) {
+      int p = 0;                            // fib_decoder.cpp:59-110
+      while (p < 30) {
+        const int type = b[p] >> 5, len = b[p] & 0x1F;
+        if (type == 7 && len == 0x1F) break;
+        if (type == 0 && p + 5 < 32 && (b[p + 1] & 0x1F) == 0)                       // FIG 0/0, fib_decoder_fig0.cpp:89-101
+          cif = (b[p + 4] & 0x1F) * 250 + b[p + 5];
+        p += len + 1;
+      }
+    }
+    fib_cif[fibi] = cif;
   }
   for (int i = threadIdx.x; i < 24 * count; i += 256) reinterpret_cast<uint32_t *>(fo)[24 * first + i] = fibw[first + i / 24][i % 24];
   __syncthreads();
   if (threadIdx.x == 0) {
-    // per-FIB bookkeeping in FIB order (fic_decoder.cpp:234-261) + FIG walk for the CIF counter
+    // per-FIB bookkeeping in FIB order (fic_decoder.cpp:234-261): the CIF counter is that of the last good FIB that carries one
     int ratio = c.fic_ratio, cif_count = c.cif_count;
     long long ok = 0;
     for (int fibi = fib0; fibi < fib0 + nfib; fibi++) {
-      e.fib_crc[((size_t)s * e.out_frames + slot) * 12 + fibi] = crc_ok[fibi];
       if (crc_ok[fibi]) {
         ok++;
-        const uint8_t *b = reinterpret_cast<const uint8_t *>(&fibw[fibi / 3][0]) + (fibi % 3) * 32;
-        int p = 0;                          // fib_decoder.cpp:59-110
-        while (p < 30) {
-          const int type = b[p] >> 5, len = b[p] & 0x1F;
-          if (type == 7 && len == 0x1F) break;
-          if (type == 0 && p + 5 < 32 && (b[p + 1] & 0x1F) == 0)                       // FIG 0/0, fib_decoder_fig0.cpp:89-101
-            cif_count = (b[p + 4] & 0x1F) * 250 + b[p + 5];
-          p += len + 1;
-        }
+        if (fib_cif[fibi] >= 0) cif_count = fib_cif[fibi];
         if (ratio < 10) ratio++;
       } else if (ratio > 0) ratio--;
     }
@@ -784,6 +790,18 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
+  // The null symbol's samples do not depend on the fine-CFO update below, only their mixing does: request them first so that the
+  // HBM latency runs behind the reductions (they were the first thing after the block-wide barrier).
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned long long base = c.sym0_pos + TU + 75ull * TS;
+  const RingView rv(ring, e.ring_len, base);
+  float2 xr[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) xr[u] = rv.at(TG + tid + 256 * u);
+  constexpr int N_REST = (TN - TU + 255) / 256;            // the rest of the T_n samples read (guard interval and tail of the null symbol)
+  float2 xq[N_REST];
+#pragma unroll
+  for (int k = 0; k < N_REST; k++) { const int i = tid + 256 * k; xq[k] = i < TN - TU ? rv.at(i < TG ? i : i + TU) : make_float2(0.f, 0.f); }
   // fine CFO from the 75 cyclic-prefix correlations (dab_processor.cpp:366, 236-242)
   const float LNQ = -1.00000500003333e-5f;                 // ln(1 - 1e-5): decay of the level tracker per sample
   float cre = 0.f, cim = 0.f, sym_w = 0.f;
@@ -810,23 +828,21 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   }
   __syncthreads();
   // null symbol (dab_processor.cpp:267-302): T_n samples with the updated frequency, FFT of [Tg, Tg+Tu)
-  const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  const unsigned long long base = c.sym0_pos + TU + 75ull * TS;
   const int phase_null = nco_advance(c.phase_sym1, f, 75LL * TS);
   const int f2 = (int)roundf(s_fbb);
   float2 v[8];
   Nco nco;
   nco.init(phase_null, f2, TG + tid);
-  float an = 0.f;
-  const RingView rv(ring, e.ring_len, base);
+  float an = 0.f;                                          // sum of this thread's |x|: transform samples first, then the rest
 #pragma unroll
   for (int u = 0; u < 8; u++) {
-    const float2 x = rv.at(TG + tid + 256 * u);
+    const float2 x = xr[u];
     an += cabsf_level(x);
     v[u] = nco.mix(x);
     nco.step();
   }
-  for (int i = tid; i < TN - TU; i += 256) an += cabsf_level(rv.at(i < TG ? i : i + TU));   // the rest of the T_n samples read
+#pragma unroll
+  for (int k = 0; k < N_REST; k++) if (tid + 256 * k < TN - TU) an += cabsf_level(xq[k]);
   an = block_sum(an, red, tid);
   fft2048<false>(v, lds, t.twiddle, tid);
   const bool is_tii = (c.cif_count & 7) >= 4;              // :274

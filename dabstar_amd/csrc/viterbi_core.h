@@ -257,8 +257,8 @@ constexpr int VIT_RAW_WORDS = 312;          // >= vit_words(9216) + 3
 // Six steps (one cycle of the step classes 5..0, exchange bits 0..5) of the chain-back.
 //  * vit_tb_masks<G>: the decisions of steps 6 G + 5 .. 6 G of a 30-step word as six wave masks in SGPR pairs (a v_bfe + v_cmp
 //    per step, independent of the path: issued a whole group ahead of the chain that consumes them).
-//  * vit_tb_chain: on the scalar unit, per step  SCC = mask[j];  j = SCC ? j | bit : j & ~bit;  acc = 2 acc + SCC  -- two
-//    dependent scalar instructions per step (s_bitcmp1 -> s_cselect).
+//  * vit_tb_chain: on the scalar unit, per step  SCC = mask[j];  j = SCC ? j | bit : j & ~bit  -- four scalar instructions, two
+//    of them dependent (s_bitcmp1 -> s_cselect); the output bits are read off j once per group.
 // (Round 3, before: v_readlane of the lane's 30-step word with the path's lane as selector -- 4 wait states after the scalar
 // write of j -- then bfe / shift / andn2 / or: 72 cycles per step, profiles/r03_fic_phase_timing.txt.)
 struct VitMask6 { unsigned long long m5, m4, m3, m2, m1, m0; };    // named members: stay in SGPRs
@@ -275,11 +275,15 @@ template <int G> __device__ __forceinline__ VitMask6 vit_tb_masks(unsigned hist)
 }
 __device__ __forceinline__ void vit_tb_chain(const VitMask6 &q, int &j, unsigned &acc)
 {
+  // After the six steps every bit of j has been rewritten once: bit p of j IS the decision of the step with exchange bit p, the
+  // first one of the group (p = 0) being the oldest in `acc` order -- so the six output bits are bitreverse6(j), appended once
+  // per group instead of one add-with-carry per step.
   int jc, js;
 #define DABX_TB_STEP(M, BIT)                                                                                                    \
   "s_andn2_b32 %[jc], %[j], " #BIT "\n\ts_or_b32 %[js], %[j], " #BIT "\n\ts_bitcmp1_b64 %[" #M "], %[j]\n\t"                        \
-  "s_cselect_b32 %[j], %[js], %[jc]\n\ts_addc_u32 %[acc], %[acc], %[acc]\n\t"
+  "s_cselect_b32 %[j], %[js], %[jc]\n\t"
   asm volatile(DABX_TB_STEP(m5, 1) DABX_TB_STEP(m4, 2) DABX_TB_STEP(m3, 4) DABX_TB_STEP(m2, 8) DABX_TB_STEP(m1, 16) DABX_TB_STEP(m0, 32)
+               "s_brev_b32 %[jc], %[j]\n\ts_lshl_b32 %[acc], %[acc], 6\n\ts_lshr_b32 %[jc], %[jc], 26\n\ts_or_b32 %[acc], %[acc], %[jc]"
                : [jc] "=&s"(jc), [js] "=&s"(js), [acc] "+s"(acc), [j] "+s"(j)
                : [m5] "s"(q.m5), [m4] "s"(q.m4), [m3] "s"(q.m3), [m2] "s"(q.m2), [m1] "s"(q.m1), [m0] "s"(q.m0)
                : "scc");

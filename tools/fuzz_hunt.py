@@ -20,9 +20,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="1000:1030")
     a = ap.parse_args()
-    lo, hi = [int(v) for v in a.seeds.split(":")]
+    # "lo:hi" or a comma-separated list of seeds
+    seeds = [int(v) for v in a.seeds.split(",")] if "," in a.seeds or ":" not in a.seeds else list(range(*[int(v) for v in a.seeds.split(":")]))
     n_pass = n_fail = 0
-    for seed in range(lo, hi):
+    for seed in seeds:
         cfg = CFGS[seed % len(CFGS)]
         fast = seed % 4 == 3                     # every fourth run through the lane-per-trellis classes
         which = "test_random_service_start_stop_schedules" if seed % 7 == 6 else "test_random_channels_and_layouts_follow_the_oracle"
@@ -40,6 +41,9 @@ def main():
         lv = [l for l in p.stdout.splitlines() if l.startswith("walk differs with the chunk-wise level tracker")]
         if lv:
             rec["level_tracker_streams"] = lv[0].split(":", 1)[1].strip()
+        mf = [l for l in p.stdout.splitlines() if l.startswith("logical frames compared:")]
+        if mf:
+            rec["msc"] = mf[0]
         if not ok:
             rec["tail"] = p.stdout[-1500:]
         print(json.dumps(rec), flush=True)
