@@ -790,8 +790,13 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
   if (!c.frame_ok) return;
-  // The null symbol's samples do not depend on the fine-CFO update below, only their mixing does: request them first so that the
-  // HBM latency runs behind the reductions (they were the first thing after the block-wide barrier).
+  // fine CFO from the 75 cyclic-prefix correlations (dab_processor.cpp:366, 236-242): their loads go first (vmcnt counts in order)
+  const float LNQ = -1.00000500003333e-5f;                 // ln(1 - 1e-5): decay of the level tracker per sample
+  float2 cpp = make_float2(0.f, 0.f);
+  float absp = 0.f;
+  if (tid < 75) { cpp = e.cp_part[(size_t)s * 75 + tid]; absp = e.abs_part[(size_t)s * 76 + tid]; }
+  // The null symbol's samples do not depend on the fine-CFO update below, only their mixing does: requested here, behind the
+  // two loads above, so that their HBM latency runs behind the reductions (they used to be the first thing after the barrier).
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
   const unsigned long long base = c.sym0_pos + TU + 75ull * TS;
   const RingView rv(ring, e.ring_len, base);
@@ -801,15 +806,14 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
   constexpr int N_REST = (TN - TU + 255) / 256;            // the rest of the T_n samples read (guard interval and tail of the null symbol)
   float2 xq[N_REST];
 #pragma unroll
-  for (int k = 0; k < N_REST; k++) { const int i = tid + 256 * k; xq[k] = i < TN - TU ? rv.at(i < TG ? i : i + TU) : make_float2(0.f, 0.f); }
-  // fine CFO from the 75 cyclic-prefix correlations (dab_processor.cpp:366, 236-242)
-  const float LNQ = -1.00000500003333e-5f;                 // ln(1 - 1e-5): decay of the level tracker per sample
-  float cre = 0.f, cim = 0.f, sym_w = 0.f;
-  if (tid < 75) {
-    const float2 p = e.cp_part[(size_t)s * 75 + tid]; cre = p.x; cim = p.y;
-    // level tracker (see the end of this kernel): chunk mean of symbol tid + 1, weighted by the decay over the symbols after it
-    sym_w = e.abs_part[(size_t)s * 76 + tid] * (1.0f / (float)TS) * __expf((float)((74 - tid) * TS) * LNQ);
+  for (int k = 0; k < N_REST; k++) {                       // unconditional (index clamped; the sum below skips the surplus): no branch, no wait between the requests
+    const int i = min(tid + 256 * k, TN - TU - 1);
+    xq[k] = rv.at(i < TG ? i : i + TU);
   }
+  asm volatile("" ::: "memory");                           // keep the order of the requests
+  float cre = cpp.x, cim = cpp.y, sym_w = 0.f;
+  // level tracker (see the end of this kernel): chunk mean of symbol tid + 1, weighted by the decay over the symbols after it
+  if (tid < 75) sym_w = absp * (1.0f / (float)TS) * __expf((float)((74 - tid) * TS) * LNQ);
   block_sum2(cre, cim, red, tid);
   sym_w = block_sum(sym_w, red, tid);
   const int f = c.f_frame;
