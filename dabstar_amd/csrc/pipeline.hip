@@ -1060,6 +1060,19 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
     for (int i = lane; i < 512; i += 64) gexp[i] = t.gf_exp[i];
     for (int i = lane; i < 256; i += 64) { glog[i] = t.gf_log[i]; s_crc[i] = t.crc_ccitt[i]; s_fc[i] = t.fc_crctab[i]; }
   }
+  unsigned syn_ex[2][3];                      // (r (119 - k)) mod 255 for r = 0..9 as bytes, k = lane + 64 h: the syndrome sums' exponents
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int m = 119 - (lane + 64 * h);
+    int ex = 0;
+    syn_ex[h][0] = syn_ex[h][1] = syn_ex[h][2] = 0;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+      syn_ex[h][r >> 2] |= (unsigned)ex << (8 * (r & 3));
+      ex += m;
+      if (ex >= 255) ex -= 255;
+    }
+  }
   __syncthreads();
   for (long long n = 0; n < n_new; n++) {
     const long long newest = cif_out;        // index of the logical frame just added
@@ -1076,10 +1089,17 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
     blocks_in_buf = 0;                       // :147
     // ---- stage the window (coalesced 4-byte loads) and the GF tables
     __syncthreads();
-    for (int f = 0; f < 5; f++) {
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + (size_t)((oldest + f) % MSC_SLOTS) * e.msc_stride);
-      uint32_t *dst = reinterpret_cast<uint32_t *>(win + f * nbytes);
-      for (int i = lane; i < nbytes / 4; i += 64) dst[i] = src[i];
+    {                                         // the five frames' loads of a chunk in flight together (they were five memory latencies in a row)
+      const uint32_t *src[5];
+#pragma unroll
+      for (int f = 0; f < 5; f++) src[f] = reinterpret_cast<const uint32_t *>(ring + (size_t)((oldest + f) % MSC_SLOTS) * e.msc_stride);
+      for (int i = lane; i < nbytes / 4; i += 64) {
+        uint32_t w[5];
+#pragma unroll
+        for (int f = 0; f < 5; f++) w[f] = src[f][i];
+#pragma unroll
+        for (int f = 0; f < 5; f++) reinterpret_cast<uint32_t *>(win + f * nbytes)[i] = w[f];
+      }
     }
     if (lane < 12) hdr0[lane] = 0;
     __syncthreads();
@@ -1094,14 +1114,11 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
         const int k = lane + 64 * h;
         const int b = k < 120 ? win[j + k * R] : 0;
         if (b) {
-          const int lg = glog[b], m = 119 - k;
-          int ex = 0;
+          const int lg = glog[b];
 #pragma unroll
-          for (int r = 0; r < 10; r++) {
-            const unsigned v = gexp[lg + ex];
+          for (int r = 0; r < 10; r++) {                      // exponents r (119 - k) mod 255: per-lane constants (syn_ex), no running sum on the look-up chain
+            const unsigned v = gexp[lg + (int)((syn_ex[h][r >> 2] >> (8 * (r & 3))) & 0xFFu)];
             if (r < 4) a0 ^= v << (8 * r); else if (r < 8) a1 ^= v << (8 * (r - 4)); else a2 ^= v << (8 * (r - 8));
-            ex += m;
-            if (ex >= 255) ex -= 255;
           }
         }
       }
@@ -1161,10 +1178,12 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
         const int st = s_au[a], len = s_au[a + 1] - st - 2;
         if (len > 960 || len < 0 || st + len + 2 > 110 * R) { bad++; continue; }
         const int per = (len + 63) >> 6, from = lane * per, to = min(len, from + per);
+        // the two table words this lane needs, requested before the look-up chain over its slice runs
+        const unsigned xp_slice = t.crc_xpow[from < to ? len - to : 0], xp_all = t.crc_xpow[len];
         unsigned crc = 0;
         for (int i = from; i < to; i++) crc = (s_crc[(win[st + i] ^ (crc >> 8)) & 0xFF] ^ (crc << 8)) & 0xFFFFu;
-        unsigned acc = from < to ? crc_mulmod(crc, t.crc_xpow[len - to]) : 0u;
-        if (lane == 0) acc ^= crc_mulmod(0xFFFFu, t.crc_xpow[len]);
+        unsigned acc = from < to ? crc_mulmod(crc, xp_slice) : 0u;
+        if (lane == 0) acc ^= crc_mulmod(0xFFFFu, xp_all);
         acc = wave_xor(acc);
         const unsigned want = ((unsigned)win[st + len] << 8) | win[st + len + 1];
         if (((~acc) & 0xFFFFu) == want) good++; else bad++;
