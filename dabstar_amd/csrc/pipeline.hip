@@ -1052,6 +1052,7 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
   __shared__ __attribute__((aligned(16))) uint8_t win[120 * 48 + 16];   // 5 logical frames (<= 384 kbit/s)
   __shared__ uint8_t gexp[512], glog[256];
   __shared__ uint16_t s_crc[256], s_fc[256];                // CCITT and fire-code CRC tables (serial look-up chains: keep them in LDS)
+  __shared__ __attribute__((aligned(16))) uint16_t s_xpow[1024];   // x^(8 m) mod P, m <= 960: two look-ups per access unit sat behind an L2 round trip each
   __shared__ unsigned syn_or[48];                           // != 0: some syndrome of the code word is non-zero
   __shared__ uint8_t hdr0[12];
   __shared__ int s_flag;
@@ -1059,6 +1060,7 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
   if (sc.dab_plus) {
     for (int i = lane; i < 512; i += 64) gexp[i] = t.gf_exp[i];
     for (int i = lane; i < 256; i += 64) { glog[i] = t.gf_log[i]; s_crc[i] = t.crc_ccitt[i]; s_fc[i] = t.fc_crctab[i]; }
+    for (int i = lane; i < 128; i += 64) reinterpret_cast<uint4 *>(s_xpow)[i] = reinterpret_cast<const uint4 *>(t.crc_xpow)[i];
   }
   unsigned syn_ex[2][3];                      // (r (119 - k)) mod 255 for r = 0..9 as bytes, k = lane + 64 h: the syndrome sums' exponents
 #pragma unroll
@@ -1107,8 +1109,9 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
     // ---- syndromes S_r(j) = XOR_k c_k alpha^(r (119 - k)), r < 10: the Horner recursion of reed_solomon.cpp:254-290 written
     //      as a sum, lanes over the byte index k (no 120-step dependent look-up chain); only "all ten are zero" is needed
     //      here, the full decoder below recomputes them for the code words that are not clean
-    for (int j = 0; j < R; j++) {
-      unsigned a0 = 0, a1 = 0, a2 = 0;                        // ten 8-bit sums packed into three words
+    // one code word's partial sums of this lane: ten 8-bit sums packed into three words
+    auto syn_partial = [&](int j, unsigned &a0, unsigned &a1, unsigned &a2) {
+      a0 = a1 = a2 = 0;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int k = lane + 64 * h;
@@ -1122,8 +1125,20 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
           }
         }
       }
+    };
+    int cw = 0;
+    for (; cw + 1 < R; cw += 2) {                               // two code words at a time: their look-up and reduction chains interleave
+      unsigned a0, a1, a2, b0, b1, b2;
+      syn_partial(cw, a0, a1, a2);
+      syn_partial(cw + 1, b0, b1, b2);
+      a0 = wave_xor(a0); b0 = wave_xor(b0); a1 = wave_xor(a1); b1 = wave_xor(b1); a2 = wave_xor(a2); b2 = wave_xor(b2);
+      if (lane == 0) { syn_or[cw] = a0 | a1 | a2; syn_or[cw + 1] = b0 | b1 | b2; }
+    }
+    if (cw < R) {
+      unsigned a0, a1, a2;
+      syn_partial(cw, a0, a1, a2);
       a0 = wave_xor(a0); a1 = wave_xor(a1); a2 = wave_xor(a2);
-      if (lane == 0) syn_or[j] = a0 | a1 | a2;
+      if (lane == 0) syn_or[cw] = a0 | a1 | a2;
     }
     __syncthreads();
     // ---- full decoder only where needed (one lane per dirty code word)
@@ -1178,8 +1193,7 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
         const int st = s_au[a], len = s_au[a + 1] - st - 2;
         if (len > 960 || len < 0 || st + len + 2 > 110 * R) { bad++; continue; }
         const int per = (len + 63) >> 6, from = lane * per, to = min(len, from + per);
-        // the two table words this lane needs, requested before the look-up chain over its slice runs
-        const unsigned xp_slice = t.crc_xpow[from < to ? len - to : 0], xp_all = t.crc_xpow[len];
+        const unsigned xp_slice = s_xpow[from < to ? len - to : 0], xp_all = s_xpow[len];
         unsigned crc = 0;
         for (int i = from; i < to; i++) crc = (s_crc[(win[st + i] ^ (crc >> 8)) & 0xFF] ^ (crc << 8)) & 0xFFFFu;
         unsigned acc = from < to ? crc_mulmod(crc, xp_slice) : 0u;
