@@ -39,7 +39,7 @@ for what in "$@"; do
     variants) for cfg in "--layout mixed" "--streams 1 --steps 200 --warmup 20" "--streams 1 --fic-only --steps 200 --warmup 20" "--streams 1024 --steps 28 --warmup 7" "--fic-only"; do
              python3 bench.py $cfg --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('$cfg', '->', j['value'], j['unit'], 'crc', j['fib_crc_match_pct'], 'sf_fail', j.get('superframes_failed'))"; done > $OUT/variants.txt 2>&1; cat $OUT/variants.txt ;;
     phasetime) cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; cp dabstar_amd/_ab/libdabx_phasetime.so dabstar_amd/libdabx.so;
-             for st in 1 512; do echo "== streams $st"; python3 bench.py --streams $st --steps 14 --warmup 7 --no-cpu-baseline 2>/dev/null | grep -E "^(head|tail|demap_fic|dabplus):" | tail -6; done > $OUT/phasetime.txt 2>&1; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; cat $OUT/phasetime.txt ;;
+             for st in 1 512; do echo "== streams $st"; python3 bench.py --streams $st --steps 14 --warmup 7 --no-cpu-baseline 2>/dev/null | grep -E "^(head|tail|demap_fic|dabplus|correlate):" | tail -6; done > $OUT/phasetime.txt 2>&1; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; cat $OUT/phasetime.txt ;;
     smoke) python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
     bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
   esac
