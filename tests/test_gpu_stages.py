@@ -154,6 +154,37 @@ def _frame_spectra(n_frames, seed, snr=20.0):
     return spec
 
 
+@pytest.mark.parametrize("soft_type", [1, 3])
+def test_demapper_phase_detector_on_the_axes(soft_type):
+    """The phase detector fmod(arg(b), pi/2) - pi/4 (ofdm_decoder.cpp:197-202) is discontinuous exactly where a noise-free
+    D-QPSK symbol with a quarter-turn constellation lands: on the axes.  The device code takes the sign from sign bits and forces
+    the reference's fmod result there (ofdm_core.h, phase_offset_from_diagonal); a wrong side on the FIRST symbol -- the only one
+    that sits exactly on an axis, the integrator then tilts every carrier -- sends that carrier's integrator to the opposite
+    20-degree stop, 3.4 degrees within this frame, far outside the soft-bit tolerance.  All four axes, both signs of zero."""
+    rng = np.random.default_rng(5 + soft_type)
+    spec = np.zeros((77, 2048), np.complex64)
+    used = np.r_[1:769, 2048 - 768:2048]
+    spec[0, used] = (0.5 + rng.random(len(used))).astype(np.float32)
+    turns = np.array([1, 1j, -1, -1j], np.complex64)
+    for l in range(1, 76):
+        spec[l, used] = spec[l - 1, used] * turns[rng.integers(0, 4, len(used))]
+    assert (spec[1, used].real == 0).sum() > 300 and (spec[1, used].imag == 0).sum() > 300
+    L = ol.oracle()
+    od = L.ora_demap_new()
+    L.ora_demap_set_type(od, soft_type)
+    dm = dx.Demap(1)
+    dm.set_soft_bit_gen_type(soft_type)
+    L.ora_demap_store_ref(od, spec[0])
+    dm.store_reference_symbol_0(spec[0])
+    exp = np.zeros((75, 3072), np.int16)
+    for l in range(75):
+        L.ora_demap_symbol(od, spec[1 + l], np.float32(0.0), exp[l])
+    got = dm.decode_symbols(spec[1:76], np.float32(0.0))[0]
+    d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+    L.ora_demap_free(od)
+    assert (d > 1).mean() <= 1e-3 and d.max() <= 3, ((d > 1).mean(), d.max(), np.nonzero(d.max(axis=1) > 3)[0][:5])
+
+
 @pytest.mark.parametrize("soft_type", [1, 2, 3])
 def test_demapper_matches_oracle(soft_type):
     """Same FFT inputs to both: soft bits equal within 1 LSB on >= 99.9 % and never differ by more than 2
