@@ -43,6 +43,7 @@ for what in "$@"; do
     nodec) for v in base nodec; do cp dabstar_amd/libdabx.so /tmp/libdabx_keep.so; [ $v != base ] && cp dabstar_amd/_ab/libdabx_$v.so dabstar_amd/libdabx.so;
              python3 bench.py --steps 14 --warmup 7 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('$v', j['value'], {k: round(v, 4) for k, v in j['chain']['kernel_ms_per_step_standalone'].items() if 'msc' in k}, j['roofline']['standalone'])"; cp /tmp/libdabx_keep.so dabstar_amd/libdabx.so; done > $OUT/nodec.txt 2>&1; cat $OUT/nodec.txt ;;
     chunkorder) for r in 1 2 3 4; do for v in 0 1; do DABX_BENCH_SHORT_CHUNK_LAST=$v python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print('short chunk last' if $v else 'short chunk first', j['value'], j['config']['step_chunks'])"; done; done > $OUT/chunkorder.txt 2>&1; cat $OUT/chunkorder.txt ;;
+    chunklist) for r in 1 2 3; do for v in 6,7,7 3,3,7,7 2,4,7,7 5,1,7,7 6,7,7; do DABX_BENCH_CHUNKS=$v python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().splitlines()[-1]); print(j['config']['step_chunks'], j['value'])"; done; done > $OUT/chunklist.txt 2>&1; cat $OUT/chunklist.txt ;;
     smoke) python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
     bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
   esac
