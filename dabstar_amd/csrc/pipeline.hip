@@ -1186,18 +1186,22 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
       const int n_au = s_au[7];
       // :318-333 AU CRCs.  The CRC register is linear in the message: every lane runs the table recursion over its own
       // slice from state 0, the slice results are moved to the end of the AU by multiplying with x^(8 n) mod P
-      // (t.crc_xpow) and XOR-ed together with the contribution of the 0xFFFF start value -- calc_crc (crc.cpp:75-86)
+      // (crc_xpow, in LDS) and XOR-ed together; the 0xFFFF start value rides on the first two bytes -- calc_crc (crc.cpp:75-86)
       // without a several-hundred-step look-up chain on one lane.
       int good = 0, bad = 0;
       for (int a = 0; a < n_au; a++) {
         const int st = s_au[a], len = s_au[a + 1] - st - 2;
         if (len > 960 || len < 0 || st + len + 2 > 110 * R) { bad++; continue; }
         const int per = (len + 63) >> 6, from = lane * per, to = min(len, from + per);
-        const unsigned xp_slice = s_xpow[from < to ? len - to : 0], xp_all = s_xpow[len];
+        const unsigned xp_slice = s_xpow[from < to ? len - to : 0];
+        // The 0xFFFF start value of a 16-bit CRC is the same as complementing the first two message bytes and starting from 0
+        // (the register only ever shifts the start value through those two steps): the lanes that own bytes 0 and 1 do that, and
+        // the second crc_mulmod that lane 0 ran for the start value's contribution -- with the other 63 lanes waiting -- is gone.
+        const unsigned first2 = len >= 2 ? 0xFFu : 0u;
         unsigned crc = 0;
-        for (int i = from; i < to; i++) crc = (s_crc[(win[st + i] ^ (crc >> 8)) & 0xFF] ^ (crc << 8)) & 0xFFFFu;
+        for (int i = from; i < to; i++) crc = (s_crc[(win[st + i] ^ (i < 2 ? first2 : 0u) ^ (crc >> 8)) & 0xFF] ^ (crc << 8)) & 0xFFFFu;
         unsigned acc = from < to ? crc_mulmod(crc, xp_slice) : 0u;
-        if (lane == 0) acc ^= crc_mulmod(0xFFFFu, xp_all);
+        if (len < 2 && lane == 0) acc ^= crc_mulmod(0xFFFFu, s_xpow[len]);      // a message shorter than the register: the start value's contribution as it was
         acc = wave_xor(acc);
         const unsigned want = ((unsigned)win[st + len] << 8) | win[st + len + 1];
         if (((~acc) & 0xFFFFu) == want) good++; else bad++;

@@ -9,7 +9,7 @@ for what in "$@"; do
   case $what in
     tests) timeout 2400 python3 -m pytest tests -m gpu -q --maxfail=10 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
     tq)    timeout 2400 python3 -m pytest ${PYTEST_ARGS:-tests/test_gpu_engine.py tests/test_gpu_ofdm.py} -m gpu -q --maxfail=10 > $OUT/pytest_gpu_subset.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu_subset.log; tail -5 $OUT/pytest_gpu_subset.log ;;
-    abhead) bash tools/ab.sh $OUT/abhead 3 "head|dabstar_amd/_ab/libdabx_head.so|" "new|-|" > $OUT/abhead.txt 2>&1; cat $OUT/abhead.txt ;;
+    abhead) bash tools/ab.sh $OUT/abhead ${AB_REPS:-3} "head|dabstar_amd/_ab/libdabx_head.so|" "new|-|" > $OUT/abhead.txt 2>&1; cat $OUT/abhead.txt ;;
     ab)    bash tools/ab.sh $OUT/ab 3 "r2|dabstar_amd/_ab/libdabx_r2.so|" "new|-|" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
     pmc)   bash tools/prof_pmc2.sh $OUT/pmc "k_demap_frame6|k_symbols_persistent|k_demap_fic" > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
     prof)  bash tools/prof_round.sh $TAG > $OUT/prof_round.log 2>&1; tail -3 $OUT/prof_round.log ;;
