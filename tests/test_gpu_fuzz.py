@@ -115,10 +115,18 @@ def _rerun_exact_level(x, subch, cfg):
     return fibs, crcs, walk
 
 
-def test_random_channels_and_layouts_follow_the_oracle():
+# The committed draws: three seeds, each with its own receiver options, all under the strict rules (no stream may need the exact
+# level tracker, no logical frame may differ where the oracle delivers the transmitted one).  DABX_FUZZ_SEED (tools/fuzz_hunt.py)
+# replaces them by one hunting draw under the tolerant rules.
+COMMITTED = [(20260101, "3.0,0,1"), (7003, "4.0,1,2"), (9003, "2.5,0,3")]
+OVF_FRAMES_SEEN = {20260101: 4, 7003: 25, 9003: 8}     # frames with FIC soft-bit overflow in each committed draw (excluded from the FIB comparison)
+
+
+@pytest.mark.parametrize("seed,cfg", COMMITTED if "DABX_FUZZ_SEED" not in os.environ else [(int(os.environ["DABX_FUZZ_SEED"]), os.environ.get("DABX_FUZZ_CFG", "3.0,0,1"))])
+def test_random_channels_and_layouts_follow_the_oracle(seed, cfg):
     # receiver options (sync threshold, strongest-peak sync, soft-bit generator 1..3): DABX_FUZZ_CFG="4.0,1,2"
-    thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), os.environ.get("DABX_FUZZ_CFG", "3.0,0,1").split(","))]
-    layouts, cases, xs, rng = draw_streams(int(os.environ.get("DABX_FUZZ_SEED", "20260101")))      # other seeds: hunting runs
+    thr, strongest, soft_type = [t(v) for t, v in zip((float, int, int), cfg.split(","))]
+    layouts, cases, xs, rng = draw_streams(seed)
 
     fast = dict(msc_fast_min_jobs=64, msc_class_min_jobs=1) if os.environ.get("DABX_FUZZ_FAST") == "1" else {}
     eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr,
@@ -267,9 +275,10 @@ def test_random_channels_and_layouts_follow_the_oracle():
     # that is noise anyway changes its junk.  A few per thousand failing FIBs (the fading streams produce hundreds of them);
     # generator 3 (no normalisation) is the touchiest
     assert n_bad_diff <= max(2 if soft_type != 3 else 6, 0.03 * n_bad), (n_bad_diff, n_bad)
-    # overflow frames (excluded above) stay the exception: 4 of 528 frames with the committed seed; a regression that produced
+    # overflow frames (excluded above) stay the exception: 4 of 528 frames with the first committed seed (25 with the second, whose
+    # drop-outs are longer); a regression that produced
     # spurious overflows, or excluded frames wholesale, trips this bound (hunting seeds draw other drop-outs: looser there)
-    assert n_ovf_frames <= (8 if "DABX_FUZZ_SEED" not in os.environ else 2 * N_CASES), n_ovf_frames
+    assert n_ovf_frames <= (OVF_FRAMES_SEEN[seed] + 4 if "DABX_FUZZ_SEED" not in os.environ else 2 * N_CASES), n_ovf_frames
     eng.close()
 
 
