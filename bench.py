@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--viterbi-tie-mode", type=int, default=0, choices=[0, 1, 2],
                     help="not the headline: decode with the arithmetic of the reference's VITERBI_AVX2 (1) / VITERBI_SSE2 (2) builds")
     ap.add_argument("--chunk", type=int, default=7, help="frames per dabx_process call (= MSC_BATCH_FRAMES of the library build; A/B of batch sizes)")
+    ap.add_argument("--unlocked", type=int, default=0,
+                    help="not the headline: the last N streams of every GPU carry no signal (see --unlocked-kind) and search for a null "
+                         "symbol all the time; shows what streams in a drop-out cost the streams in lock")
+    ap.add_argument("--unlocked-kind", choices=["silence", "floor"], default="silence",
+                    help="silence: all-zero samples; floor: the ensemble 60 dB down under its (unchanged) noise")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
                     help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
                          "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
@@ -121,6 +126,10 @@ def fill_rings(eng, torch, dev, args, rank, subch):
         ph = (2.0 * np.pi * cfo / 2048000.0) * t
         rot = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64)
         noise = torch.complex(torch.randn(n, device=dev, generator=gen), torch.randn(n, device=dev, generator=gen)) * sigma
+        if s >= args.streams - getattr(args, "unlocked", 0):          # a stream in a drop-out: nothing to lock on
+            x = x * (0.0 if args.unlocked_kind == "silence" else 1e-3)
+            if args.unlocked_kind == "silence":
+                noise = noise * 0.0
         y = ((x * rot + noise) * 0.25).to(torch.complex64).contiguous()
         ptr, cap = eng.ring_ptr(s)
         assert cap == n
@@ -528,17 +537,23 @@ def main():
             dist.barrier()
         sync_dev()
 
-    def step(n=1):
+    host_time = [0.0]
+
+    def step(n=1, sync=False):
         # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch (a dabx_process call
         # closes its last batch), so the steps are issued in chunks of 7 (all work of the n steps is complete when the
-        # streams are drained)
+        # streams are drained).  sync=False is the pipelined form of dabx_process: streams out of lock are searched on a HIP
+        # stream of their own and never hold up a step of the others; sync=True (priming only) searches them in step.
         for m in step_chunks(n, args.chunk):
+            h0 = time.perf_counter()
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
-            eng.process(m, sync=False)
+            eng.process(m, sync=sync)
+            host_time[0] += time.perf_counter() - h0      # host time inside the two calls (launches, event traffic): no device wait when sync=False
 
     # priming (untimed, not part of warmup): acquisition, CFO pull-in, 16-CIF de-interleaver fill, super-frame sync
     eng.commit(ring_frames * TF - TF)
-    step(40)
+    step(14, sync=True)                # in step: all streams acquire together
+    step(26)
     eng.synchronize()
     # Still priming: one whole MSC batch (7 steps) with every kernel instrumented and the host waiting for each one
     # (dabx_set_profiling -1: one kernel on the chip at a time) -- the per-kernel STAND-ALONE breakdown, whose largest entry is
@@ -565,8 +580,10 @@ def main():
     c1 = eng.counters()
 
     barrier()
+    host_time[0] = 0.0
     t0 = time.perf_counter()
     step(args.steps)
+    host_s = host_time[0]
     eng.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -600,7 +617,7 @@ def main():
         if not dry:
             kern = {names[i].decode(): (ms[i] / cnt[i]) for i in range(nk) if cnt[i]}          # average launch duration (timed region)
             launches = {names[i].decode(): int(cnt[i]) for i in range(nk) if cnt[i]}
-            units = args.streams * args.steps / launches[dom]      # frames one launch of that kernel processes (average)
+            units = (args.streams - args.unlocked) * args.steps / launches[dom]      # frames one launch of that kernel processes (average)
             achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
             traffic = valu = traffic_src = None
             tj = load_traffic(dom)
@@ -636,7 +653,11 @@ def main():
         out = {
             "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            # CPU time this rank spent inside dabx_commit_iq + dabx_process per step (kernel launches and event traffic, no device
+            # wait): what one of N rank processes needs from its host core per step
+            "host_us_per_step": round(1e6 * host_s / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32+i32", "data": "synthetic",
             "config": {"workload": ("FIC only, " if args.fic_only else "") +
                        "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
@@ -661,6 +682,12 @@ def main():
         if dry:
             out["dry"] = True
             out["data"] = "none (dry launch: control flow only)"
+        if getattr(args, "unlocked", 0):
+            n_lock = max(1, args.streams - args.unlocked)
+            out["config"]["workload"] += "; the last %d streams per GPU carry %s (never in lock)" % (
+                args.unlocked, "silence" if args.unlocked_kind == "silence" else "the ensemble 60 dB down under its noise")
+            out["unlocked_streams_per_gpu"] = args.unlocked
+            out["frames_per_s_per_locked_stream"] = round(value / (n_joined * n_lock), 3)
         if args.layout == "mixed":       # the byte model above is the uniform layout's: no roofline claim for this variant
             out["config"]["workload"] = out["config"]["workload"].replace("18x64 kbit/s EEP 3-A DAB+ each", "alternating 18x64 kbit/s EEP 3-A and a 16-service multiplex of 7 profiles (32..128 kbit/s, EEP 2-A/3-A/3-B)")
             out["roofline"] = None

@@ -11,7 +11,7 @@
 #include <vector>
 
 namespace dabx {
-int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk);
+int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool async_acquire);
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk);
 int launch_dciq(const EngineDev &e, int mode, hipStream_t st);
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
@@ -179,6 +179,8 @@ static int sync_all(dabx_engine *e)
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
   if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
+  if (e->ss.q) DABX_HIP(hipStreamSynchronize(e->ss.q));
+  e->ss.acq_in_flight = false;
   return 0;
 }
 
@@ -206,7 +208,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   if (!cfg || !out || cfg->n_streams <= 0 || cfg->ring_frames < 2 || cfg->max_subch < 0 || cfg->max_subch > MAX_SUBCH ||
       cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3 || cfg->dc_iq_correction < 0 || cfg->dc_iq_correction > 2 ||
       cfg->viterbi_tie_mode < 0 || cfg->viterbi_tie_mode > 2 || cfg->schedule < 0 || cfg->schedule > 1 ||
-      cfg->msc_fast_min_jobs < 0 || cfg->msc_class_min_jobs < 0 || cfg->exact_level_tracker < 0 || cfg->exact_level_tracker > 1) {
+      cfg->msc_fast_min_jobs < 0 || cfg->msc_class_min_jobs < 0 || cfg->exact_level_tracker < 0 || cfg->exact_level_tracker > 1 ||
+      cfg->acquire_mode < 0 || cfg->acquire_mode > 2) {
     set_error("dabx_create: bad configuration");
     return DABX_E_ARG;
   }
@@ -233,6 +236,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    // streams out of lock are searched on q next to the steps of the others (dabx_process with sync == 0)
+    H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, prio_lo));
+    H(hipEventCreateWithFlags(&e->ss.acq_done, hipEventDisableTiming | hipEventReleaseToDevice));
   }
   H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
   H(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
@@ -318,6 +324,8 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.prep_b_done) (void)hipEventDestroy(e->ss.prep_b_done);
   if (e->ss.d) { (void)hipStreamSynchronize(e->ss.d); (void)hipStreamDestroy(e->ss.d); }
   if (e->ss.demap_done) (void)hipEventDestroy(e->ss.demap_done);
+  if (e->ss.q) { (void)hipStreamSynchronize(e->ss.q); (void)hipStreamDestroy(e->ss.q); }
+  if (e->ss.acq_done) (void)hipEventDestroy(e->ss.acq_done);
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
@@ -597,13 +605,16 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     if (int rc = e->build_msc_classes()) return rc;
     e->classes_dirty = false;
   }
+  // Streams out of lock: searched in step (every step waits for them) when the caller waits for the call's result anyway, next to
+  // the steps on their own HIP stream when it does not (pipelined use); cfg.acquire_mode 1 / 2 fixes either form.
+  const bool async_acquire = e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync);
   for (int i = 0; i < max_frames; i++) {
     // the 5th frame after a batch starts rewriting time-de-interleaver slots the previous batch's k_msc_prep (stream b) reads
     if (e->ss.prep_pending && e->pending_frames >= 4) {
       DABX_HIP(hipStreamWaitEvent(e->stream, e->ss.prep_b_done, 0));
       e->ss.prep_pending = false;
     }
-    int rc = launch_front_step(e->dev, e->ss, e->mk);
+    int rc = launch_front_step(e->dev, e->ss, e->mk, async_acquire);
     if (rc) return rc;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
       e->dev.snap = e->snap_buf[e->ss.batch_parity];

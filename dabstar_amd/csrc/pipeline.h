@@ -139,6 +139,10 @@ struct MscLaunch { int n, groups; MscLaunchCls c[MSC_MAX_CLASSES]; };
 // while `a` already demodulates the frames of batch n+1.
 struct EngineStreams {
   hipStream_t a = nullptr, b = nullptr, d = nullptr;   // d: demapper of the MSC symbols of the frame in flight; b, d null = serial schedule
+  hipStream_t q = nullptr;                             // k_acquire of dabx_process(sync == 0): streams out of lock are searched next to the steps of the others
+  hipEvent_t acq_done = nullptr;
+  bool acq_in_flight = false;                          // a pass on q may still be running
+  int acq_credit = 0;                                  // steps since the last pass was launched (its budget in frames)
   hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
   unsigned step_count = 0;

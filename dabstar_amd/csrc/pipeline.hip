@@ -174,177 +174,381 @@ int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
 
 // ------------------------------------------------------------------------------------------------ acquire
 // WAIT_FOR_TIME_SYNC_MARKER of one stream (dab_processor.cpp:146-160 + timesyncer.cpp:40-90): decoder reset, then the null-dip
-// search.  Sample-serial by nature (IIR level + 50-tap moving sum with data-dependent stop): thread 0 walks the stream while
-// the block prefetches |x| of 256 samples at a time.  Called by every thread of the block (64 in k_acquire, 256 in
-// k_frame_head's retry loop); chunk[256], env[64], sh[3] are LDS.  Leaves c.state = ST_EVAL_SYNC when a dip ended.
-__device__ __forceinline__ void acquire_body(EngineDev &e, int s, int tid, int nthreads, unsigned long long budget_samples,
-                                             float *chunk, float *env, int *sh)
+// search.  The reference walks the stream one sample at a time through two float recurrences,
+//     sLevel += 0.00001f * (|x| - sLevel)                                  (sample_reader.cpp:245-248, every sample read)
+//     level  += |x| - |x 50 samples earlier|                               (timesyncer.cpp:64-66, 78-80: 50-tap moving sum)
+// and tests  level / 50 > 0.55 sLevel  (dip begins)  /  level / 50 < 0.75 sLevel  (dip ends)  BEFORE it reads the next sample.
+// Only the two recurrences are serial; everything else is a function of their values:
+//   * |x| and the moving sum's increments d[n] = |x[n]| - |x[n - 50]| (the same float subtraction) are computed by the whole
+//     block, 1024 samples at a time, into LDS;
+//   * ONE lane walks the chunk: three dependent float operations per sample for sLevel, one for level, operands and results as
+//     float4 in LDS -- no flag polled, no divergence, nothing else on the chain (the rest of the block meanwhile loads the next
+//     chunk's samples and takes their magnitudes);
+//   * the two comparisons of all 1024 positions are evaluated by the block from the stored (level, sLevel) pairs -- the IEEE
+//     division included -- and collected with ballots into bit masks; the phase machine (first dip begin, first dip end behind
+//     it, the two time-outs) is a few scalar bit scans per chunk.  A chunk never reaches across a time-out: the sample at which
+//     an attempt would give up is known when the chunk starts (T_F + 50 samples after the attempt's start without a dip,
+//     T_n + 70 after the dip's begin without an end), so the chunk ends there and the next attempt starts chunk-aligned;
+//   * peakLevel is a maximum: taken in parallel over the samples consumed.
+// Same float operations in the same order on the same values as the sample-serial form, so sLevel, the sample the search stops
+// at and every decision are bit-identical to it (and to the oracle); a frame of silence (70 attempts) is walked in ~2 ms
+// instead of ~80 (round 3: one thread, every operand an LDS round trip behind a polled flag: ~1000 cycles per sample).
+constexpr int ACQ_CH = 1024;
+struct AcqLds {
+  __attribute__((aligned(16))) float a[2][64 + ACQ_CH + 32];  // |x|: a[b][64 + i] = sample i of the chunk, a[b][0..63] = the 64 samples before it
+  __attribute__((aligned(16))) float d[ACQ_CH + 32];          // increments of the moving sum
+  __attribute__((aligned(16))) float S[ACQ_CH + 8];           // sLevel after sample i at S[4 + i]; S[3] = before the chunk
+  __attribute__((aligned(16))) float L[ACQ_CH + 8];           // level likewise
+  unsigned long long dip_begin[ACQ_CH / 64], dip_end[ACQ_CH / 64];
+  float red[8];
+  int flag[4];
+};
+
+// The serial part, one LANE per recurrence (sLevel on wave 0, level on wave 1: two SIMDs, side by side).  A lone wave issues
+// an instruction every ~6 cycles whether it depends on the last one or not (tools/acq_walk_bench.hip: three dependent
+// operations per sample walk at 20 cycles per sample, and every further instruction in the loop costs its 6), so the loop is
+// nothing but the recurrence: 16 samples per iteration, operands as four 16-byte LDS reads requested one half-iteration ahead,
+// results as four 16-byte writes, waits counted so that neither is ever waited for (LDS operations complete in order: at each
+// wait the two newest reads and the two newest writes may still be on their way).  Written out as one asm block: the
+// compiler's version of this loop waits for its own stores at the loop head (s_waitcnt lgkmcnt(0): 77 cycles per sample).
+// a / out: LDS, 16-byte aligned, readable / writable up to n16 * 16 + 16 floats.  Only in k_acquire (two waves per SIMD: the
+// block's 34 fixed registers v200..v233 lie within its budget).
+#define DABX_ACQ_SKELETON(STEP)                                                                                                 \
+  "ds_read_b128 v[200:203], %[ap]\n\t"                                                                                         \
+  "ds_read_b128 v[204:207], %[ap] offset:16\n\t"                                                                               \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  "1:\n\t"                                                                                                                      \
+  "ds_read_b128 v[208:211], %[ap] offset:32\n\t"                                                                               \
+  "ds_read_b128 v[212:215], %[ap] offset:48\n\t"                                                                               \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
+  STEP("v200", "v216", "%[x]") STEP("v201", "v217", "v216") STEP("v202", "v218", "v217") STEP("v203", "v219", "v218")           \
+  "ds_write_b128 %[op], v[216:219]\n\t"                                                                                        \
+  STEP("v204", "v220", "v219") STEP("v205", "v221", "v220") STEP("v206", "v222", "v221") STEP("v207", "v223", "v222")           \
+  "ds_write_b128 %[op], v[220:223] offset:16\n\t"                                                                              \
+  "ds_read_b128 v[200:203], %[ap] offset:64\n\t"                                                                               \
+  "ds_read_b128 v[204:207], %[ap] offset:80\n\t"                                                                               \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
+  STEP("v208", "v226", "v223") STEP("v209", "v227", "v226") STEP("v210", "v228", "v227") STEP("v211", "v229", "v228")           \
+  "ds_write_b128 %[op], v[226:229] offset:32\n\t"                                                                              \
+  STEP("v212", "v230", "v229") STEP("v213", "v231", "v230") STEP("v214", "v232", "v231") STEP("v215", "v233", "v232")           \
+  "ds_write_b128 %[op], v[230:233] offset:48\n\t"                                                                              \
+  "v_mov_b32 %[x], v233\n\t"                                                                                                   \
+  "v_add_u32 %[ap], 64, %[ap]\n\t"                                                                                             \
+  "v_add_u32 %[op], 64, %[op]\n\t"                                                                                             \
+  "s_sub_u32 %[n], %[n], 1\n\t"                                                                                                \
+  "s_cmp_lg_u32 %[n], 0\n\t"                                                                                                   \
+  "s_cbranch_scc1 1b\n\t"                                                                                                      \
+  "s_waitcnt lgkmcnt(0)\n\t"
+#define DABX_ACQ_CLOBBERS "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", \
+                          "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", \
+                          "v228", "v229", "v230", "v231", "v232", "v233", "scc", "memory"
+// sLevel += 0.00001f * (|x| - sLevel), sample_reader.cpp:248 (three roundings, no contraction)
+#define DABX_ACQ_STEP_S(A, R, P) "v_sub_f32 v224, " A ", " P "\n\tv_mul_f32 v224, %[c], v224\n\tv_add_f32 " R ", " P ", v224\n\t"
+// level += d, timesyncer.cpp:66, 80
+#define DABX_ACQ_STEP_L(A, R, P) "v_add_f32 " R ", " P ", " A "\n\t"
+__device__ __forceinline__ unsigned lds_addr(const void *p)
 {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+__device__ __forceinline__ void acq_walk_S(const float *a, float *out, int n16, float S)
+{
+  unsigned ap = lds_addr(a), op = lds_addr(out);
+  asm volatile(DABX_ACQ_SKELETON(DABX_ACQ_STEP_S) : [ap] "+v"(ap), [op] "+v"(op), [n] "+s"(n16), [x] "+v"(S) : [c] "s"(0.00001f) : DABX_ACQ_CLOBBERS);
+}
+__device__ __forceinline__ void acq_walk_L(const float *d, float *out, int n16, float L)
+{
+  unsigned ap = lds_addr(d), op = lds_addr(out);
+  asm volatile(DABX_ACQ_SKELETON(DABX_ACQ_STEP_L) : [ap] "+v"(ap), [op] "+v"(op), [n] "+s"(n16), [x] "+v"(L) : : DABX_ACQ_CLOBBERS);
+}
+// sLevel alone over m samples (the T_u window of a failed correlation): loads only, the compiler's loop is as fast as the chain
+__device__ __forceinline__ float level_walk(const float *__restrict__ a, int m, float S)
+{
+  const float4 *a4 = reinterpret_cast<const float4 *>(a);
+  for (int i = 0; i < (m >> 2); i++) {
+    const float4 av = a4[i];
+    S += 0.00001f * (av.x - S);
+    S += 0.00001f * (av.y - S);
+    S += 0.00001f * (av.z - S);
+    S += 0.00001f * (av.w - S);
+  }
+  return S;
+}
+// maximum of non-negative floats over the block (red: >= 8 floats of LDS; every thread gets the result)
+__device__ __forceinline__ float block_max_nonneg(float v, float *red, int tid)
+{
+  const unsigned w = wave_butterfly_u32(__builtin_bit_cast(unsigned, v), [](unsigned x, unsigned y) { return x > y ? x : y; });   // order of non-negative floats = order of their bits
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = __builtin_bit_cast(float, w);
+  __syncthreads();
+  float r = red[0];
+  for (int q = 1; q < (int)(blockDim.x >> 6); q++) r = fmaxf(r, red[q]);
+  return r;
+}
+__device__ __forceinline__ int first_bit_from(const unsigned long long *mask, int from, int m)
+{
+  for (int wd = from >> 6; wd * 64 < m; wd++) {
+    unsigned long long v = mask[wd];
+    if (wd == (from >> 6)) v &= ~0ull << (from & 63);
+    if (v) return wd * 64 + __builtin_ctzll(v);
+  }
+  return -1;
+}
+
+// One pass of the search for stream s (whole block, T = 256 threads, uniform control flow).  The caller owns the stream (it is
+// not in ST_EVAL_SYNC and no demapper launch of it is in flight).  wr = the committed-sample count this kernel works with.
+// Returns -1: nothing done (too few samples), 0: searched, no end of a null symbol yet, 1: a null symbol ended at c.rd.
+__device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int st, unsigned long long wr,
+                                              unsigned long long budget_samples, AcqLds &w)
+{
+  constexpr int T = 256;
   StreamCtl &c = e.ctl[s];
-  const int st = c.state;
-  const unsigned long long avail = e.wr[s] - c.rd;
-  if (st == ST_EVAL_SYNC || avail < (unsigned long long)ACQ_NEED) return;
+  const unsigned long long rd0 = c.rd, avail = wr - rd0;
+  if (avail < (unsigned long long)ACQ_NEED) return -1;
   // WAIT_FOR_TIME_SYNC_MARKER entry (dab_processor.cpp:146-153): decoder reset
-  for (int i = tid; i < K; i += nthreads) {
+  for (int i = tid; i < K; i += T) {
     e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
   }
-  for (int i = tid; i < TU; i += nthreads) { e.demap.null_power[(size_t)s * TU + i] = 0.f; e.demap.null_power2[(size_t)s * TU + i] = 0.f; }
+  for (int i = tid; i < TU; i += T) { e.demap.null_power[(size_t)s * TU + i] = 0.f; e.demap.null_power2[(size_t)s * TU + i] = 0.f; }
   if (tid == 0) e.demap.mean_power_all[s] = 1.0f;
   if (e.tii_acc) {                     // mTiiDetector.reset(); mTiiCounter = 0 (dab_processor.cpp:150-152)
-    for (int i = tid; i < TU; i += nthreads) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < TU; i += T) e.tii_acc[(size_t)s * TU + i] = make_float2(0.f, 0.f);
     if (tid == 0) { e.tii_cnt[2 * s] = 0; e.tii_cnt[2 * s + 1]++; }
   }
-  int &s_done = sh[0], &s_consumed = sh[1], &s_ok = sh[2];
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  if (tid == 0) { s_done = 0; s_consumed = 0; s_ok = 0; }
-  // thread-0 state machine
-  int phase = (st == ST_INIT) ? 0 : 1;     // 0 seed level, 1 first 50, 2 wait for dip, 3 wait for end of dip
-  int remain = (st == ST_INIT) ? 20 * TU : 50, counter = 0, idx = 0;
-  float s_level = c.s_level, peak_level = c.peak_level, level = 0.f;
-  const RingView rv(ring, e.ring_len, c.rd);
-  unsigned pos = 0;
-  int consumed = 0;
-  __syncthreads();
-  while (true) {
-    for (int q = tid; q < 256; q += nthreads) {
-      const float2 v = rv.at(pos + q);
-      chunk[q] = sqrtf(v.x * v.x + v.y * v.y);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int i = 0; i < 256 && !s_done; i++) {
-        // loop conditions are evaluated BEFORE the next sample is read (timesyncer.cpp:58,74)
-        if (phase == 2 && !(level / 50.f > 0.55f * s_level)) { phase = 3; counter = 0; }
-        if (phase == 3 && !(level / 50.f < 0.75f * s_level)) { s_done = 1; s_ok = 1; break; }
-        const float a = chunk[i];
-        if (a > peak_level) peak_level = a;                  // sample_reader.cpp:246-248
-        s_level += 0.00001f * (a - s_level);
-        consumed++;
-        if (phase == 0) { if (--remain == 0) { phase = 1; remain = 50; level = 0.f; idx = 0; } }
-        else if (phase == 1) {
-          env[idx & 63] = a; level += a; ++idx;
-          if (--remain == 0) phase = 2;
-        } else {
-          env[idx & 63] = a;
-          level += a - env[(idx - 50) & 63];
-          ++idx;
-          ++counter;
-          if ((phase == 2 && counter > TF) || (phase == 3 && counter > TN + 50 + 20)) {   // NO_DIP_FOUND / NO_END_OF_DIP_FOUND
-            // dab_processor.cpp:154-160 tries again at once.  Do the same inside this step while the next attempt's
-            // worst case is still in the ring and the step's sample budget (one frame) is not used up: a stream in a
-            // drop-out then walks through it at the pace of the others (one attempt is only T_n + 121 samples long in silence).
-            if (avail - (unsigned long long)consumed >= (unsigned long long)ACQ_NEED && (unsigned long long)consumed < budget_samples) {
-              phase = 1; remain = 50; counter = 0; idx = 0; level = 0.f;
-            } else { s_done = 1; s_ok = 0; }
-          }
-        }
+  const unsigned len = (unsigned)e.ring_len, base = (unsigned)(rd0 % (unsigned long long)e.ring_len);
+  // |x| of samples [p0, p0 + ACQ_CH) of this pass by threads t0, t0 + nt, ...; nothing beyond the committed samples is touched
+  // (a line fetched before its samples were committed would stay in this CU's cache for the rest of the kernel)
+  auto mags = [&](unsigned long long p0, float *dst, int t0, int nt) {
+    const unsigned o0 = (unsigned)((base + p0) % len);     // one 64-bit modulo per chunk, then add + conditional subtract
+    for (int q = t0; q < ACQ_CH; q += nt) {
+      float a = 0.f;
+      if (p0 + (unsigned)q < avail) {
+        unsigned o = o0 + (unsigned)q;
+        if (o >= len) o -= len;
+        const float2 v = ring[o];
+        a = sqrtf(v.x * v.x + v.y * v.y);
       }
-      s_consumed = consumed;
+      dst[q] = a;
+    }
+  };
+  float S = c.s_level, L = 0.f, pk = 0.f;
+  int phase = (st == ST_INIT) ? 0 : 1;   // 0: seeding the level (20 T_u samples, dab_processor.cpp:130-139); 1: looking for the begin of a dip; 3: for its end
+  int nb = 0;                            // index of the chunk's first sample within the seed / within the attempt
+  int n2 = 0;                            // attempt-relative index at which the dip began
+  unsigned long long consumed = 0;
+  int ok = 0, b = 0;
+  mags(0, w.a[0] + 64, tid, T);
+  if (tid < 64) w.a[0][tid] = 0.f;
+  __syncthreads();
+  for (;;) {
+    // the chunk ends where the attempt would time out: NO_DIP_FOUND after reading sample T_F + 50 of the attempt (counter > T_F,
+    // timesyncer.cpp:68-71), NO_END_OF_DIP_FOUND after sample n2 + T_n + 70 (counter > T_n + 50 + 20, :82-85)
+    const int last = phase == 0 ? 20 * TU : (phase == 3 ? n2 + TN + 71 : TF + 51);
+    const int m = min(ACQ_CH, last - nb);
+    const float *ab = w.a[b] + 64;
+    if (phase != 0)
+      for (int q = tid; q < m; q += T) {
+        const float a = ab[q];
+        w.d[q] = nb + q < 50 ? a : a - ab[q - 50];                           // :64-66 (first 50), :78-80
+      }
+    if (tid == 0) { w.S[3] = S; w.L[3] = L; }
+    __syncthreads();
+    if (tid == 0) acq_walk_S(ab, w.S + 4, (m + 15) >> 4, S);
+    else if (tid == 64) { if (phase != 0) acq_walk_L(w.d, w.L + 4, (m + 15) >> 4, L); }
+    else if (tid >= 128) mags(consumed + (unsigned)m, w.a[b ^ 1] + 64, tid - 128, T - 128);
+    __syncthreads();
+    if (tid < 64) w.a[b ^ 1][tid] = w.a[b][m + tid];                        // the 64 samples before the next chunk
+    if (phase != 0) {
+      for (int q0 = (tid & ~63); q0 < m; q0 += T) {
+        const int q = q0 + (tid & 63);
+        const float Lp = w.L[3 + q], Sp = w.S[3 + q];                        // the state BEFORE sample q is read (:58, :74)
+        const bool valid = q < m && nb + q >= 50;
+        const float mean = Lp / 50.f;
+        const unsigned long long mb = __ballot(valid && !(mean > 0.55f * Sp)), me = __ballot(valid && !(mean < 0.75f * Sp));
+        if ((tid & 63) == 0) { w.dip_begin[q0 >> 6] = mb; w.dip_end[q0 >> 6] = me; }
+      }
     }
     __syncthreads();
-    if (s_done) break;
-    pos += 256;
+    int lim = m;                                                             // samples of this chunk that are consumed
+    if (phase != 0) {
+      int from = 0;
+      if (phase != 3) {
+        const int i2 = first_bit_from(w.dip_begin, 0, m);
+        if (i2 >= 0) { phase = 3; n2 = nb + i2; from = i2; }
+      }
+      if (phase == 3) {
+        const int i3 = first_bit_from(w.dip_end, from, m);
+        if (i3 >= 0) { lim = i3; ok = 1; }
+      }
+    }
+    for (int q = tid; q < lim; q += T) pk = fmaxf(pk, ab[q]);                // sample_reader.cpp:247
+    consumed += (unsigned)lim;
+    S = w.S[3 + lim]; L = w.L[3 + lim];
+    if (ok) break;
+    nb += m;
+    if (nb == last) {
+      if (phase == 0) { phase = 1; nb = 0; L = 0.f; }
+      else {
+        // NO_DIP_FOUND / NO_END_OF_DIP_FOUND: dab_processor.cpp:154-160 tries again at once.  The same here while the next attempt's
+        // worst case is still in the ring and the pass's sample budget is not used up (one attempt is only T_n + 121 samples
+        // long in silence): a stream in a drop-out walks through it a frame of samples per pass.
+        if (avail - consumed >= (unsigned long long)ACQ_NEED && consumed < budget_samples) { phase = 1; nb = 0; L = 0.f; }
+        else break;
+      }
+    }
+    b ^= 1;
+    __syncthreads();
   }
+  pk = block_max_nonneg(pk, w.red, tid);
   if (tid == 0) {
-    c.rd += (unsigned long long)s_consumed;     // frequency offset is 0 while searching: NCO phase unchanged
-    c.s_level = s_level; c.peak_level = peak_level;
+    c.rd = rd0 + consumed;             // frequency offset is 0 while searching: NCO phase unchanged
+    c.s_level = S; c.peak_level = fmaxf(c.peak_level, pk);
     c.sample_count = 0;
     c.sync_thr = e.threshold;
     c.clock_err = 0.0f;
-    c.state = s_ok ? ST_EVAL_SYNC : ST_WAIT_SYNC;
   }
+  __syncthreads();
+  return ok;
 }
 
-// First kernel of a step: marks "no frame yet", notes where the stream's cursor stands (the step's sample budget) and, out of
-// lock, runs one acquisition.
-__global__ __launch_bounds__(64) void k_acquire(EngineDev e)
+// A phase-reference correlation failed at rd (dab_processor.cpp:396-400 -> WAIT_FOR_TIME_SYNC_MARKER): the T_u samples just read
+// went through SampleReader's level tracker (sample_reader.cpp:245-248) -- run it exactly, sample by sample: right after
+// start-up the level is still far from settled (it starts at 0.1) and the null-dip detector of the next attempt compares
+// against it.  buf: >= T_u floats of LDS (16-byte aligned), red: >= 8.  The caller changes c.state.
+__device__ __forceinline__ void sync_failed(EngineDev &e, int s, int tid, const RingView &rv, unsigned long long rd, int phase0, int f,
+                                            float *buf, float *red)
 {
-  const int s = blockIdx.x, lane = threadIdx.x;
   StreamCtl &c = e.ctl[s];
-  if (lane == 0) { c.frame_ok = 0; c.step_rd0 = c.rd; }
-  e.sym_off[(size_t)s * 76 + lane] = -1;
-  if (lane < 12) e.sym_off[(size_t)s * 76 + 64 + lane] = -1;
-  __shared__ float chunk[256];
-  __shared__ float env[64];
-  __shared__ int sh[3];
-  acquire_body(e, s, lane, 64, (unsigned long long)TF, chunk, env, sh);
+  float pk = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const float2 x = rv.at(tid + 256 * u);
+    const float a = sqrtf(x.x * x.x + x.y * x.y);
+    buf[tid + 256 * u] = a;
+    pk = fmaxf(pk, a);
+  }
+  pk = block_max_nonneg(pk, red, tid);                     // (its barriers also publish buf)
+  if (tid == 0) {
+    c.s_level = level_walk(buf, TU, c.s_level);
+    c.peak_level = fmaxf(c.peak_level, pk);
+    c.rd = rd + TU;
+    c.nco_phase = nco_advance(phase0, f, TU);
+    c.sync_lost++;
+  }
+  __syncthreads();
+}
+
+// Acquisition kernel: one block per stream, does something only for streams that are NOT in lock.  Ownership of a stream's
+// control record follows c.state: ST_EVAL_SYNC = the frame chain (k_frame_head ... k_frame_tail on HIP stream a), anything
+// else = this kernel.  It therefore runs either in step (on stream a, before k_frame_head: every step waits for the streams
+// that are searching -- the contract of dabx_process(sync != 0)) or on its own HIP stream next to the steps of the streams in
+// lock (dabx_process(sync == 0): a step never waits for it; k_frame_head passes over a stream that is still being searched and
+// picks it up in the first step after the search has handed it back).  Hand-over in both directions is one release store of
+// c.state behind everything else the owner wrote, read with acquire by the other side.
+// A pass = up to budget_frames frames of samples: null-dip search, phase-reference correlation of the candidate, and after a
+// failed correlation straight back to the search like the reference (one candidate per step starved streams in deep fades:
+// false dips every few thousand samples -- fuzz seed 5001).  A candidate that correlates is left at ST_EVAL_SYNC with the read
+// cursor in front of it: k_frame_head repeats the correlation (same samples, same threshold, same result) and decodes the frame.
+__global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, int budget_frames)
+{
+  __shared__ AcqLds w;
+  __shared__ float2 lds[FFT_LDS_FLOAT2];
+  __shared__ __attribute__((aligned(16))) float peak[TU];
+  __shared__ float red[8];
+  __shared__ unsigned long long s_wr;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  StreamCtl &c = e.ctl[s];
+  if (tid == 0) {                                          // one thread looks, everyone follows (a flag that flips meanwhile must not split the block)
+    const int st0 = __hip_atomic_load(&c.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    // The search resets the demapper (dab_processor.cpp:146-153).  The MSC symbols of the stream's last frame may still be going
+    // through it on their own HIP stream: then this pass is skipped (no new launch for the stream can start while it is out of lock)
+    const int busy = e.demap_busy ? __hip_atomic_load(&e.demap_busy[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    w.flag[0] = (st0 != ST_EVAL_SYNC && !busy) ? 1 : 0;
+    w.flag[1] = st0;
+    s_wr = e.wr[s];
+  }
+  __syncthreads();
+  if (!w.flag[0]) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  int st = w.flag[1], new_state = -1;
+  const unsigned long long wr = s_wr, rd_start = c.rd, budget = (unsigned long long)budget_frames * TF;
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  for (;;) {
+    const unsigned long long used = c.rd - rd_start;
+    if (used >= budget) break;
+    const int r = acquire_stream(e, s, tid, st, wr, budget - used, w);
+    if (r < 0) break;
+    st = new_state = ST_WAIT_SYNC;
+    if (r == 0) break;
+    new_state = ST_EVAL_SYNC;
+    if (wr - c.rd < (unsigned long long)FRAME_NEED) break;   // k_frame_head correlates when the frame's samples are there
+    const unsigned long long rd = c.rd;
+    const int phase0 = c.nco_phase, f = (int)roundf(c.f_bb);
+    Nco nco;
+    nco.init(phase0, f, tid);
+    const RingView rv(ring, e.ring_len, rd);
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { v[u] = nco.mix(rv.at(tid + 256 * u)); nco.step(); }
+    const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // dab_processor.cpp:394
+    __syncthreads();
+    if (start >= 0) break;
+    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red);
+    new_state = ST_WAIT_SYNC;
+    if (wr - c.rd < (unsigned long long)(ACQ_NEED + FRAME_NEED)) break;
+  }
+  if (new_state < 0) return;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&c.state, new_state, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // --------------------------------------------------------------------------------------------- frame head
 #ifndef DABX_HEAD_OCC
-#define DABX_HEAD_OCC 3      // 166 VGPRs, no scratch: with the in-step retry loop the 128-VGPR build spilled 30 registers (+2 % chain, profiles/r03_ab/ab9)
+#define DABX_HEAD_OCC 3      // 166 VGPRs, no scratch
 #endif
 __global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, DevTables t)
 {
   front_prio();
   __shared__ float2 lds[FFT_LDS_FLOAT2];
-  __shared__ float peak[TU];
+  __shared__ __attribute__((aligned(16))) float peak[TU];
   __shared__ float red[8];
   __shared__ float mag[160];
+  __shared__ int s_state;
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  // One frame per step at most -- but a failed PRS correlation (:396-400) does not end the step: like the reference, which
-  // goes straight back to the null-dip search, the block runs the next acquisition itself and evaluates the next candidate,
-  // as long as the step has consumed less than a frame of samples and the ring still holds an attempt's worst case.  (One
-  // attempt per step starved streams in deep fades: false dips every few thousand samples, a few per cent of a frame consumed
-  // per step -- fuzz seed 5001: 62 steps for 3.7 frames -- while their producer keeps delivering a frame per step.)
-  unsigned long long rd;
-  int phase0, f, start;
+  // first kernel of a step: "no frame yet"
+  if (tid < 76) e.sym_off[(size_t)s * 76 + tid] = -1;
+  if (tid == 0) {
+    c.frame_ok = 0;
+    // a stream out of lock belongs to k_acquire (which may be running right now on its own HIP stream): pass over it
+    s_state = __hip_atomic_load(&c.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_state != ST_EVAL_SYNC) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (e.wr[s] - c.rd < (unsigned long long)FRAME_NEED) return;
+  const unsigned long long rd = c.rd;
+  const int phase0 = c.nco_phase;
+  const int f = (int)roundf(c.f_bb);                       // sample_reader.cpp:211
   float2 v[8];
   Nco nco;
-  float abs_a, abs_b = 0.f;                                // level tracker: sum |x| of what this frame head reads
-  for (;;) {
-    if (c.state != ST_EVAL_SYNC) return;
-    if (e.wr[s] - c.rd < (unsigned long long)FRAME_NEED) return;
-    rd = c.rd;
-    phase0 = c.nco_phase;
-    f = (int)roundf(c.f_bb);                               // sample_reader.cpp:211
-    nco.init(phase0, f, tid);
-    const RingView rv(ring, e.ring_len, rd);
-    abs_a = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); abs_a += cabsf_level(x); v[u] = nco.mix(x); nco.step(); }
-    start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
-    __syncthreads();
-    if (start >= 0) break;
-    // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER.  The T_u samples just read went through SampleReader's level tracker
-    // (sample_reader.cpp:245-248): run it exactly, sample by sample -- right after start-up the level is still far from
-    // settled (it starts at 0.1) and the null-dip detector of the next attempt compares against it
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); peak[tid + 256 * u] = sqrtf(x.x * x.x + x.y * x.y); }
-    __syncthreads();
-    if (tid == 0) {
-      float s_level = c.s_level, peak_level = c.peak_level;
-      for (int i = 0; i < TU; i++) {
-        const float a = peak[i];
-        if (a > peak_level) peak_level = a;
-        s_level += 0.00001f * (a - s_level);
-      }
-      c.s_level = s_level; c.peak_level = peak_level;
-      c.rd = rd + TU;
-      c.nco_phase = nco_advance(phase0, f, TU);
-      c.state = ST_WAIT_SYNC;
-      c.sync_lost++;
-      __threadfence_block();
-    }
-    __syncthreads();
-    const unsigned long long used = c.rd - c.step_rd0;
-    if (used >= (unsigned long long)TF || e.wr[s] - c.rd < (unsigned long long)(ACQ_NEED + FRAME_NEED)) return;
-    // The acquisition resets the demapper (dab_processor.cpp:146-153).  The MSC symbols of the PREVIOUS frame may still be
-    // going through it on their own HIP stream (this kernel overlaps with them by design): then the retry waits for the next
-    // step, whose k_acquire is ordered behind them by the host.  (Without this the reset raced with that launch's final state
-    // stores: a loss of lock right after a decoded frame left stale IIR states -- found by the fuzz test as garbage FIBs that
-    // differed from the oracle's, differently on every run.)  A stream that is starving has no frame in flight.
-    int *busy_seen = reinterpret_cast<int *>(red) + 7;       // one thread looks, everyone follows (a flag that flips meanwhile must not split the block)
-    if (tid == 0) *busy_seen = __hip_atomic_load(&e.demap_busy[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*busy_seen) return;
-    acquire_body(e, s, tid, 256, (unsigned long long)TF - used, peak, peak + 256, reinterpret_cast<int *>(red));
-    __threadfence_block();
-    __syncthreads();
-  }
+  nco.init(phase0, f, tid);
   const RingView rv(ring, e.ring_len, rd);
+  float abs_a = 0.f, abs_b = 0.f;                          // level tracker: sum |x| of what this frame head reads
+#pragma unroll
+  for (int u = 0; u < 8; u++) { const float2 x = rv.at(tid + 256 * u); abs_a += cabsf_level(x); v[u] = nco.mix(x); nco.step(); }
+  const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // :394
+  __syncthreads();
+  if (start < 0) {
+    // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER: the stream goes over to k_acquire
+    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&c.state, (int)ST_WAIT_SYNC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   // symbol 0 = samples [start, start + Tu) of the same (mixed) stream, :402-411
   nco.init(phase0, f, (long long)start + tid);
 #pragma unroll
@@ -1249,7 +1453,7 @@ const char *const kStepKernelNames[11] = {"k_acquire", "k_frame_head", "k_symbol
 // chain) and the frame tail follow on a, while the 72 MSC symbols are demapped on stream d: nothing on the chain of the NEXT
 // frame needs them, so a goes on to frame n + 1 while d is busy; the next frame's first demapper launch (and the MSC batch)
 // wait for d.  Serial schedule (cfg.schedule = 1, ss.d null): every kernel on a in program order.
-int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
+int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool async_acquire)
 {
   const DevTables *t;
   int rc = get_tables(&t);
@@ -1257,7 +1461,22 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk)
   EngineDev e = e_in;
   e.parity = (int)(ss.step_count++ & 1u);               // spectra buffer of this step
   hipStream_t st = ss.a;
-  mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(64), 0, st, e); mk.end(0, st);
+  // Streams out of lock (k_acquire).  In step: on the front-end stream, before the frame head -- every step then offers every
+  // stream a frame's worth of search.  Asynchronous: on HIP stream q; a pass is launched when the previous one has finished
+  // (hipEventQuery, no wait), with the steps that went by meanwhile as its budget (at most two frames of samples per pass).
+  if (async_acquire && ss.q) {
+    ss.acq_credit = ss.acq_credit < 2 ? ss.acq_credit + 1 : 2;
+    if (!ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess) {
+      mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, ss.acq_credit); mk.end(0, ss.q);
+      DABX_HIP(hipEventRecord(ss.acq_done, ss.q));
+      ss.acq_in_flight = true;
+      ss.acq_credit = 0;
+    }
+  } else {
+    if (ss.acq_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); ss.acq_in_flight = false; }   // a pass of an earlier, asynchronous call
+    ss.acq_credit = 0;
+    mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, st, e, *t, 1); mk.end(0, st);
+  }
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
   mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
   // kernel instance by (ESoftBitType, symbol conversion of the canonical / SIMD builds)

@@ -216,7 +216,7 @@ class Config(C.Structure):
                 ("sync_threshold", C.c_float), ("sync_strongest", C.c_int32), ("soft_bit_type", C.c_int32),
                 ("fic_only", C.c_int32), ("capture_soft", C.c_int32), ("viterbi_tie_mode", C.c_int32), ("dc_iq_correction", C.c_int32),
                 ("schedule", C.c_int32), ("msc_fast_min_jobs", C.c_int32), ("msc_class_min_jobs", C.c_int32),
-                ("exact_level_tracker", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("exact_level_tracker", C.c_int32), ("acquire_mode", C.c_int32)]
 
 
 class SubchDesc(C.Structure):
@@ -305,7 +305,7 @@ class Engine:
 
     def __init__(self, n_streams=1, ring_frames=4, max_subch=18, out_frames=4, fic_only=False, capture_soft=False,
                  sync_threshold=3.0, soft_bit_type=1, sync_strongest=False, viterbi_tie_mode=0, dc_iq_correction=0,
-                 schedule=0, msc_fast_min_jobs=0, msc_class_min_jobs=0, exact_level_tracker=False):
+                 schedule=0, msc_fast_min_jobs=0, msc_class_min_jobs=0, exact_level_tracker=False, acquire_mode=0):
         L = load()
         cfg = Config()
         L.dabx_default_config(C.byref(cfg))
@@ -316,6 +316,7 @@ class Engine:
         cfg.dc_iq_correction = int(dc_iq_correction)
         cfg.schedule, cfg.msc_fast_min_jobs, cfg.msc_class_min_jobs = int(schedule), int(msc_fast_min_jobs), int(msc_class_min_jobs)
         cfg.exact_level_tracker = int(exact_level_tracker)
+        cfg.acquire_mode = int(acquire_mode)
         self.cfg = cfg
         self._h = C.c_void_p()
         check(L.dabx_create(C.byref(cfg), C.byref(self._h)))

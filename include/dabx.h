@@ -205,7 +205,12 @@ typedef struct {
                                  chunk (exact decay between chunks, equal weights within one: relative error ~1e-5);
                                  1: run sample by sample exactly as the reference does, on one lane per stream (slower: +196 608
                                  dependent updates per frame and stream).  Out of lock it is always exact. */
-  int32_t reserved[1];
+  int32_t acquire_mode;       /* streams OUT of lock (null-symbol search + candidate correlations, k_acquire): 0 (default) -- by the
+                                 way dabx_process is called: sync != 0 searches in step (every step first gives every such stream a
+                                 frame's worth of search, exactly DabProcessor's order of events per stream), sync == 0 searches on
+                                 a HIP stream of its own next to the steps of the streams in lock, which never wait for it (a
+                                 stream joins the first step after its search has finished); 1: always in step; 2: always
+                                 asynchronous.  Same samples, same decisions, same frames either way -- only WHEN differs. */
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */

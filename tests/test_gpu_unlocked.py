@@ -1,0 +1,38 @@
+"""Streams out of lock must not hold up the streams in lock ("Next round" 1).
+
+Round 3 searched for the null symbol on the front-end HIP stream, one thread per stream at about real time: ONE stream in a
+drop-out turned every 1-ms step of the other 511 into an 80-ms step.  Now the search walks a frame of samples in ~2 ms
+(pipeline.hip, k_acquire) and, for dabx_process(sync = 0), runs on its own HIP stream next to the steps.  This test runs the
+measured configuration (bench.py, 512 streams, the driver's --steps 20 --warmup 5) twice -- all streams in lock, and with 8
+streams that carry silence -- and requires the frame rate PER LOCKED STREAM to stay within 10 %."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def _bench(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_eight_streams_in_a_drop_out_cost_the_other_504_less_than_ten_per_cent():
+    base = _bench()
+    assert base["streams_locked"] == 512
+    per_stream = base["value"] / 512
+    for kind in ("silence", "floor"):
+        r = _bench("--unlocked", "8", "--unlocked-kind", kind)
+        assert r["streams_locked"] == 504 and r["unlocked_streams_per_gpu"] == 8, r["streams_locked"]
+        assert r["fib_crc_match_pct"] == 100.0 and r["superframes_failed"] == 0
+        ratio = r["frames_per_s_per_locked_stream"] / per_stream
+        print("unlocked 8 (%s): %.1f frames/s, %.3f of the all-locked rate per locked stream" % (kind, r["value"], ratio))
+        assert ratio >= 0.90, (kind, r["value"], base["value"], ratio)
