@@ -35,6 +35,8 @@ struct dabx_engine {
   std::vector<int> subch_id_host;              // [S][max_subch] SubChId (host only: ETI STC field)
   struct EtiCursor { long long next_cif = -1; int hi = -1, lo = -1; long long fib_frames_seen = 0; };
   std::vector<EtiCursor> eti;                  // [S]
+  std::vector<dabx_fibdec *> fibdec;           // [S] FIB decoders (current / next configuration), created on first dabx_follow_fic
+  std::vector<long long> fib_frames_fed;       // [S] frames whose FIBs the decoder has seen
   std::vector<dabx_tii *> tii;                 // [S] detectors, created on first dabx_read_tii
   std::vector<int> tii_epoch;                  // [S] reset epoch seen by the detector
   std::vector<void *> allocs;
@@ -277,6 +279,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.tii_acc, (size_t)S * TU));
   A(e->alloc(&d.tii_cnt, (size_t)S * 2));
   e->tii.assign((size_t)S, nullptr);
+  e->fibdec.assign((size_t)S, nullptr);
+  e->fib_frames_fed.assign((size_t)S, 0);
   e->tii_epoch.assign((size_t)S, 0);
   A(e->alloc(&d.cp_part, (size_t)S * 75));
   A(e->alloc(&d.abs_part, (size_t)S * 76));
@@ -329,6 +333,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
+  for (dabx_fibdec *f : e->fibdec) dabx_fibdec_destroy(f);
   if (e->ingest) { (void)hipStreamSynchronize(e->ingest); (void)hipStreamDestroy(e->ingest); }
   if (e->ingest2) { (void)hipStreamSynchronize(e->ingest2); (void)hipStreamDestroy(e->ingest2); }
   if (e->ingest_done) (void)hipEventDestroy(e->ingest_done);
@@ -344,7 +349,7 @@ void dabx_destroy(dabx_engine *e)
   delete e;
 }
 
-int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc, int n)
+static int set_subchannels_impl(dabx_engine *e, int stream, const dabx_subch_desc *desc, int n, long long at_cif /* < 0: the next CIF */)
 {
   if (!e || n < 0 || n > e->dev.max_subch || (n > 0 && !desc) || stream >= e->dev.n_streams) {
     set_error("dabx_set_subchannels: bad argument");
@@ -356,6 +361,11 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
   // current CIF counters (Backend construction time, backend.cpp:38-70)
   std::vector<StreamCtl> ctl(d.n_streams);
   DABX_HIP(hipMemcpy(ctl.data(), d.ctl, sizeof(StreamCtl) * d.n_streams, hipMemcpyDeviceToHost));
+  if (at_cif >= 0 && (stream < 0 || at_cif < ctl[stream].cif_no || at_cif > ctl[stream].cif_no + 3)) {
+    set_error("dabx_set_subchannels_at: CIF %lld is not in the coming frame of stream %d (next CIF %lld)", at_cif, stream,
+              stream < 0 ? -1ll : ctl[stream].cif_no);
+    return DABX_E_ARG;
+  }
   // refresh the host mirror: the device owns the dynamic fields (cif_out, super-frame state, counters)
   DABX_HIP(hipMemcpy(e->subch_host.data(), d.subch, sizeof(SubchDev) * e->subch_host.size(), hipMemcpyDeviceToHost));
   int max_kbps = e->max_kbps;
@@ -419,7 +429,7 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
     if (stream >= 0 && s != stream) continue;
     for (int j = 0; j < d.max_subch; j++) {
       SubchDev sc = j < n ? row[j] : SubchDev{};
-      sc.start_cif = ctl[s].cif_no;
+      sc.start_cif = at_cif >= 0 ? at_cif : ctl[s].cif_no;
       // a slot whose description does not change keeps running (MscHandler::set_channel only adds a Backend,
       // msc_handler.cpp:95-131): its de-interleaver history, super-frame state and counters stay
       const SubchDev &old = e->subch_host[(size_t)s * d.max_subch + j];
@@ -436,6 +446,13 @@ int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc
   e->have_fast = false;
   e->classes_dirty = true;            // the decoder classes are rebuilt by the next dabx_process (one rebuild for a series of per-stream calls)
   return 0;
+}
+
+int dabx_set_subchannels(dabx_engine *e, int stream, const dabx_subch_desc *desc, int n) { return set_subchannels_impl(e, stream, desc, n, -1); }
+int dabx_set_subchannels_at(dabx_engine *e, int stream, const dabx_subch_desc *desc, int n, int64_t at_cif)
+{
+  if (at_cif < 0 || stream < 0) { set_error("dabx_set_subchannels_at: bad argument"); return DABX_E_ARG; }
+  return set_subchannels_impl(e, stream, desc, n, at_cif);
 }
 
 int dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *cap)
@@ -821,6 +838,58 @@ int dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, 
   const int have = dabx_read_fibs(e, stream, nf, fibs.data(), crc.data());
   if (have < 0) return have;
   return dabx_parse_fibs(fibs.data(), crc.data(), have * 12, out, max_out, nullptr);
+}
+
+int dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !out) return DABX_E_ARG;
+  memset(out, 0, sizeof(*out));
+  out->at_cif = out->last_change_cif = -1;
+  StreamCtl c;
+  int rc = fetch_ctl(e, stream, &c);
+  if (rc) return rc;
+  dabx_fibdec *&fd = e->fibdec[(size_t)stream];
+  if (!fd && (rc = dabx_fibdec_create(&fd))) return rc;
+  long long &fed = e->fib_frames_fed[(size_t)stream];
+  const EngineDev &d = e->dev;
+  if (c.frames - fed > d.out_frames) {                      // frames that have left the FIB ring: their FIGs are lost to the decoder
+    out->frames_missed = (int32_t)std::min<long long>(c.frames - fed - d.out_frames, 0x7fffffff);
+    fed = c.frames - d.out_frames;
+  }
+  // FIB k of frame f is FIB 12 f + k of the stream: the decoder counts the FIBs of missed frames as skipped
+  dabx_fibdec_info inf;
+  dabx_fibdec_get_info(fd, &inf);
+  if (inf.fibs_processed < 12 * fed) {
+    std::vector<uint8_t> z((size_t)(12 * fed - inf.fibs_processed) * 32, 0), zc((size_t)(12 * fed - inf.fibs_processed), 0);
+    dabx_fibdec_process(fd, z.data(), zc.data(), (int)zc.size());
+  }
+  std::vector<uint8_t> fb(384), fc(12);
+  for (; fed < c.frames; fed++) {
+    const size_t slot = (size_t)stream * d.out_frames + (size_t)(fed % d.out_frames);
+    DABX_HIP(hipMemcpy(fb.data(), d.fib_out + slot * 384, 384, hipMemcpyDeviceToHost));
+    DABX_HIP(hipMemcpy(fc.data(), d.fib_crc + slot * 12, 12, hipMemcpyDeviceToHost));
+    dabx_fibdec_process(fd, fb.data(), fc.data(), 12);
+  }
+  dabx_fibdec_get_info(fd, &inf);
+  out->frames_fed = fed;
+  out->n_changes = inf.n_changes;
+  // FIB i of the stream belongs to frame i / 12 and, within its FIC, to the CIF (i % 12) / 3 (three FIBs per CIF in Mode I)
+  auto cif_of_fib = [](long long i) { return 4 * (i / 12) + (i % 12) / 3; };
+  if (inf.last_change_fib >= 0) out->last_change_cif = cif_of_fib(inf.last_change_fib);
+  if (inf.change_flags != 0 && inf.fig00_fib >= 0) {
+    out->pending = 1;
+    // the announcing FIG 0/0 carried the counter of ITS CIF: the change applies (occurrence - lo) mod 250 CIFs later
+    out->at_cif = cif_of_fib(inf.fig00_fib) + ((inf.occurrence_change - inf.cif_count_lo) % 250 + 250) % 250;
+  }
+  return 0;
+}
+
+int dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !out || max_out <= 0) return DABX_E_ARG;
+  dabx_fibdec *fd = e->fibdec[(size_t)stream];
+  if (!fd) { set_error("dabx_next_subchannels: call dabx_follow_fic first"); return DABX_E_STATE; }
+  return dabx_fibdec_subchannels(fd, 1, out, max_out);
 }
 
 int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)

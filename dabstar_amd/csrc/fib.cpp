@@ -1,12 +1,13 @@
 // fib.cpp -- host-side subset of the FIB/FIG parser: sub-channel organisation (FIG 0/1), service components
-// (FIG 0/2) and the CIF counter (FIG 0/0).  SURVEY.md 8(f) rank 1: makes the engine self-configuring the way
+// (FIG 0/2) and ensemble information (FIG 0/0: CIF counter, change flags), for the CURRENT and the NEXT multiplex
+// configuration, with the swap of the two that fib_decoder_fig0.cpp:102-111 makes when the change flags go 3 -> 0.  SURVEY.md 8(f) rank 1: makes the engine self-configuring the way
 // EtiGenerator is (eti_handler/eti_generator.cpp:132-134, 335-380): decode every sub-channel announced in the FIC.
 // Follows decoder/fib_decoder.cpp:59-110 (FIG walk), fib_decoder_fig0.cpp:142-224 (FIG 0/1), :230-293 (FIG 0/2),
 // fib_table.h:44-117 (short-form table) and fib_decoder.cpp:547-557, 673-691 (getters).  Tiny, branchy, per-FIB:
 // stays on the host ("OUT OF SCOPE for GPU").
 #include "dabx_internal.h"
 #include <cstring>
-#include <map>
+#include <vector>
 
 namespace dabx {
 
@@ -29,33 +30,72 @@ static unsigned bits(const uint8_t *b, int off, int n)   // MSB-first bit field 
   return v;
 }
 
-struct FibTable {
-  std::map<int, dabx_subch_desc> subch;     // by SubChId, first description wins (fib_decoder_fig0.cpp:151-153)
-  std::vector<int> order;                   // SubChIds in order of first appearance (the reference's vector order)
-  std::map<int, int> ascty;                 // SubChId -> ASCTy of its audio component (FIG 0/2, TMId 0)
-  int cif_count = -1;
-  bool restart = false;
+// FibConfigFig0 (fib_config_fig0.h) as far as the path needs it: the FIG 0/1 and FIG 0/2 vectors of ONE multiplex configuration.
+struct FibConfig {
+  std::vector<dabx_subch_desc> subch;       // Fig0s1_BasicSubChannelOrganizationVec: in order of first appearance, first description of a SubChId wins
+  struct Comp { uint32_t sid; int idx, tmid, ascty, subch_id; };
+  std::vector<Comp> comps;                  // Fig0s2_BasicService_ServiceCompDefVec: first definition of (SId, component index) wins
+  void reset() { subch.clear(); comps.clear(); }
+  const dabx_subch_desc *find(int id) const { for (auto &q : subch) if (q.subch_id == id) return &q; return nullptr; }
 };
 
-// one FIB (30 data bytes; the CRC has been checked by the caller, fic_decoder.cpp:234-243)
-static void walk_fib(const uint8_t *fib, FibTable &t)
+}  // namespace dabx
+
+// FibDecoder (fib_decoder.h) as far as the path needs it: the current and the next configuration, the FIG 0/0 scalars and the
+// change-flag memory that swaps the two (fib_decoder_fig0.cpp:89-112).
+struct dabx_fibdec {
+  dabx::FibConfig cfg[2];
+  int cur = 0;                              // cfg[cur] = mpFibConfigFig0Curr, cfg[cur ^ 1] = mpFibConfigFig0Next
+  int cif_count = -1, cif_hi = -1, cif_lo = -1;
+  int change_flags = 0, occurrence = 0, prev_change_flag = 0;
+  long long fibs = 0, fig00_fib = -1, last_change_fib = -1;
+  int n_changes = 0, n_restarts = 0;
+  bool restart = false;                     // mRestartFibDecoding
+  void reset_scalars() { cif_count = cif_hi = cif_lo = -1; change_flags = occurrence = prev_change_flag = 0; fig00_fib = -1; }   // FibDecoder::_reset
+  void reset_all() { cfg[0].reset(); cfg[1].reset(); reset_scalars(); }
+  void restart_decoding() { reset_all(); n_restarts++; restart = true; }            // _restart_fib_decoding, fib_decoder.cpp:131-141
+};
+
+namespace dabx {
+
+// one FIB (30 data bytes; the CRC has been checked by the caller, fic_decoder.cpp:234-243): FibDecoder::process_FIB, fib_decoder.cpp:59-106
+static void walk_fib(const uint8_t *fib, dabx_fibdec &t)
 {
+  t.restart = false;
   int p = 0;
-  while (p < 30) {                                                   // fib_decoder.cpp:74-103
+  while (p < 30 && !t.restart) {                                     // fib_decoder.cpp:74-103
     const int type = fib[p] >> 5, len = fib[p] & 0x1F;
     if (type == 7 && len == 0x1F) break;
     if (p + 1 + len > 30) break;                                       // FIG runs past the FIB data field
     if (type == 0 && len >= 1) {
       const uint8_t *d = fib + p;
       const int ext = d[1] & 0x1F, pd = (d[1] >> 5) & 1, cn = (d[1] >> 7) & 1;
-      if (ext == 0 && len >= 5) t.cif_count = (d[4] & 0x1F) * 250 + d[5];          // fib_decoder_fig0.cpp:89-101
-      else if (ext == 1 && cn == 0) {                                                // :142-224 (current configuration)
+      FibConfig &cfg = t.cfg[cn == 0 ? t.cur : t.cur ^ 1];             // _get_config_ptr(CN_Flag), fib_decoder.h:97
+      if (ext == 0 && len >= 5) {                                      // _process_Fig0s0, fib_decoder_fig0.cpp:89-112
+        const int flags = (int)bits(d, 32, 2);
+        t.cif_hi = (int)bits(d, 35, 5); t.cif_lo = (int)bits(d, 40, 8);
+        t.cif_count = t.cif_hi * 250 + t.cif_lo;
+        t.occurrence = len >= 6 ? (int)bits(d, 48, 8) : 0;             // OccurrenceChange: present while the change flags are set
+        t.change_flags = flags;
+        t.fig00_fib = t.fibs;
+        if (flags == 0 && t.prev_change_flag == 3) {                   // :103-110: the next configuration becomes the current one
+          t.cur ^= 1;
+          t.cfg[t.cur ^ 1].reset();
+          t.n_changes++;
+          t.last_change_fib = t.fibs;
+        }
+        t.prev_change_flag = flags;
+      } else if (ext == 1) {                                           // _subprocess_Fig0s1, :142-224
         int used = 2;
         while (used <= len) {
           const int o = used * 8;
           if (used + 3 > len + 1) break;
           dabx_subch_desc q{};
           q.subch_id = (int)bits(d, o, 6);
+          if (const dabx_subch_desc *known = cfg.find(q.subch_id)) {                  // :151-153, 219-223: described already, step over it
+            used += known->short_form ? 3 : 4;                                        //   (by the STORED entry's form, like the reference)
+            continue;
+          }
           q.cu_start = (int)bits(d, o + 6, 10);
           const bool short_form = bits(d, o + 16, 1) == 0;
           if (short_form) {
@@ -73,25 +113,31 @@ static void walk_fib(const uint8_t *fib, FibTable &t)
             else q.kbps = 0;
             used += 4;
           }
-          if (q.cu_start + q.cu_size > 864) { t.restart = true; return; }              // :198-202
-          if (!t.subch.count(q.subch_id)) {
-            for (auto &kv : t.subch)                                                  // :204-209 overlap -> restart
-              if (q.cu_start < kv.second.cu_start + kv.second.cu_size && kv.second.cu_start < q.cu_start + q.cu_size) { t.restart = true; return; }
-            t.subch[q.subch_id] = q;
-            t.order.push_back(q.subch_id);
-          }
+          if (q.cu_start + q.cu_size > 864) { t.restart_decoding(); break; }           // :198-202
+          bool collide = false;
+          for (auto &k : cfg.subch)                                                  // :204-209 overlap -> restart
+            if (q.cu_start < k.cu_start + k.cu_size && k.cu_start < q.cu_start + q.cu_size) collide = true;
+          if (collide) { t.restart_decoding(); break; }
+          cfg.subch.push_back(q);
         }
-      } else if (ext == 2 && cn == 0) {                                              // :230-293
+      } else if (ext == 2) {                                           // _subprocess_Fig0s2, :230-293
         int used = 2;
         while (used <= len) {
-          int o = used * 8 + (pd ? 32 : 16);
-          if (o / 8 + 1 > len + 1) break;                   // service header (SId + component count) runs past the FIG
+          int o = used * 8;
+          if ((o + (pd ? 32 : 16)) / 8 + 1 > len + 1) break;  // service header (SId + component count) runs past the FIG
+          const uint32_t sid = bits(d, o, pd ? 32 : 16);
+          o += pd ? 32 : 16;
           const int ncomp = (int)bits(d, o + 4, 4);
           o += 8;
           for (int c = 0; c < ncomp; c++, o += 16) {
             if ((o + 16) / 8 > len + 1) break;
-            const int tmid = (int)bits(d, o, 2);
-            if (tmid == 0) t.ascty[(int)bits(d, o + 8, 6)] = (int)bits(d, o + 2, 6);
+            bool known = false;
+            for (auto &k : cfg.comps) if (k.sid == sid && k.idx == c) known = true;
+            if (known) continue;
+            FibConfig::Comp k{sid, c, (int)bits(d, o, 2), -1, -1};
+            if (k.tmid == 0) { k.ascty = (int)bits(d, o + 2, 6); k.subch_id = (int)bits(d, o + 8, 6); }
+            else if (k.tmid == 1) k.subch_id = (int)bits(d, o + 8, 6);
+            cfg.comps.push_back(k);
           }
           used = o / 8;
         }
@@ -99,6 +145,20 @@ static void walk_fib(const uint8_t *fib, FibTable &t)
     }
     p += len + 1;
   }
+  t.fibs++;
+}
+
+static int table_out(const FibConfig &cfg, dabx_subch_desc *out, int max_out)
+{
+  int n = 0;
+  for (const auto &s : cfg.subch) {
+    if (n >= max_out) break;
+    dabx_subch_desc q = s;
+    q.dab_plus = -1;                                                  // ASCTy 63 = DAB+ (backend_driver.cpp:41-50); -1 = no FIG 0/2 for it yet
+    for (const auto &k : cfg.comps) if (k.tmid == 0 && k.subch_id == q.subch_id) { q.dab_plus = k.ascty == 63 ? 1 : 0; break; }
+    out[n++] = q;
+  }
+  return n;
 }
 
 // FIG 0/0 of one FIB -> CIF counter halves (mCifCount_hi / _lo, fib_decoder_fig0.cpp:89-101); false if the FIB has none
@@ -122,28 +182,56 @@ using namespace dabx;
 
 extern "C" {
 
-// fibs: n x 32 bytes, crc_ok: n flags.  Returns the number of sub-channels written to out (in order of first appearance, like
-// FibDecoder::get_sub_channel_id_list, fib_decoder.cpp:547-557),
-// dab_plus = 1 when FIG 0/2 announces ASCTy 63 for it (backend_driver.cpp:41-50), -1 when unknown yet.
+int dabx_fibdec_create(dabx_fibdec **out)
+{
+  if (!out) { set_error("dabx_fibdec_create: bad argument"); return DABX_E_ARG; }
+  *out = new dabx_fibdec();
+  return 0;
+}
+void dabx_fibdec_destroy(dabx_fibdec *d) { delete d; }
+int dabx_fibdec_reset(dabx_fibdec *d)            // FibDecoder::connect_channel, fib_decoder.cpp:143-150
+{
+  if (!d) return DABX_E_ARG;
+  *d = dabx_fibdec();
+  return 0;
+}
+int dabx_fibdec_process(dabx_fibdec *d, const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs)
+{
+  if (!d || !fibs || !crc_ok || n_fibs < 0) { set_error("dabx_fibdec_process: bad argument"); return DABX_E_ARG; }
+  const int before = d->n_changes;
+  for (int i = 0; i < n_fibs; i++) {
+    if (crc_ok[i]) walk_fib(fibs + (size_t)i * 32, *d);                // fic_decoder.cpp:234-243: only FIBs that pass their CRC reach process_FIB
+    else d->fibs++;
+  }
+  return d->n_changes - before;
+}
+int dabx_fibdec_get_info(const dabx_fibdec *d, dabx_fibdec_info *out)
+{
+  if (!d || !out) return DABX_E_ARG;
+  memset(out, 0, sizeof(*out));
+  out->fibs_processed = d->fibs; out->cif_count = d->cif_count; out->change_flags = d->change_flags;
+  out->occurrence_change = d->occurrence; out->fig00_fib = d->fig00_fib; out->n_changes = d->n_changes;
+  out->last_change_fib = d->last_change_fib; out->n_restarts = d->n_restarts;
+  out->cif_count_hi = d->cif_hi; out->cif_count_lo = d->cif_lo;
+  return 0;
+}
+int dabx_fibdec_subchannels(const dabx_fibdec *d, int next, dabx_subch_desc *out, int max_out)
+{
+  if (!d || (!out && max_out > 0) || max_out < 0) return DABX_E_ARG;
+  return table_out(d->cfg[next ? d->cur ^ 1 : d->cur], out, max_out);
+}
+
+// fibs: n x 32 bytes, crc_ok: n flags.  Returns the number of sub-channels of the CURRENT configuration written to out (in order of
+// first appearance, like FibDecoder::get_sub_channel_id_list, fib_decoder.cpp:547-557),
+// dab_plus = 1 when FIG 0/2 announces ASCTy 63 for it (backend_driver.cpp:41-50), -1 when unknown yet.  One-shot form of
+// dabx_fibdec_process on a fresh decoder.
 int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, dabx_subch_desc *out, int max_out, int32_t *cif_count)
 {
   if (!fibs || !crc_ok || n_fibs < 0 || (!out && max_out > 0)) { set_error("dabx_parse_fibs: bad argument"); return DABX_E_ARG; }
-  FibTable t;
-  for (int i = 0; i < n_fibs; i++) {
-    if (!crc_ok[i]) continue;
-    walk_fib(fibs + (size_t)i * 32, t);
-    if (t.restart) { t = FibTable{}; }                       // fib_decoder.cpp:131-141: throw everything away
-  }
+  dabx_fibdec t;
+  for (int i = 0; i < n_fibs; i++) if (crc_ok[i]) walk_fib(fibs + (size_t)i * 32, t); else t.fibs++;
   if (cif_count) *cif_count = t.cif_count;
-  int n = 0;
-  for (int id : t.order) {
-    if (n >= max_out) break;
-    dabx_subch_desc q = t.subch[id];
-    const auto it = t.ascty.find(q.subch_id);
-    q.dab_plus = it == t.ascty.end() ? -1 : (it->second == 63 ? 1 : 0);
-    out[n++] = q;
-  }
-  return n;
+  return table_out(t.cfg[t.cur], out, max_out);
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 #include "ofdm_core.h"
 #include "viterbi_core.h"
 #include "fec_core.h"
+#include "acq_walk.h"
 
 namespace dabx {
 
@@ -178,88 +179,36 @@ int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
 //     sLevel += 0.00001f * (|x| - sLevel)                                  (sample_reader.cpp:245-248, every sample read)
 //     level  += |x| - |x 50 samples earlier|                               (timesyncer.cpp:64-66, 78-80: 50-tap moving sum)
 // and tests  level / 50 > 0.55 sLevel  (dip begins)  /  level / 50 < 0.75 sLevel  (dip ends)  BEFORE it reads the next sample.
-// Only the two recurrences are serial; everything else is a function of their values:
-//   * |x| and the moving sum's increments d[n] = |x[n]| - |x[n - 50]| (the same float subtraction) are computed by the whole
-//     block, 1024 samples at a time, into LDS;
-//   * ONE lane walks the chunk: three dependent float operations per sample for sLevel, one for level, operands and results as
-//     float4 in LDS -- no flag polled, no divergence, nothing else on the chain (the rest of the block meanwhile loads the next
-//     chunk's samples and takes their magnitudes);
-//   * the two comparisons of all 1024 positions are evaluated by the block from the stored (level, sLevel) pairs -- the IEEE
-//     division included -- and collected with ballots into bit masks; the phase machine (first dip begin, first dip end behind
-//     it, the two time-outs) is a few scalar bit scans per chunk.  A chunk never reaches across a time-out: the sample at which
-//     an attempt would give up is known when the chunk starts (T_F + 50 samples after the attempt's start without a dip,
-//     T_n + 70 after the dip's begin without an end), so the chunk ends there and the next attempt starts chunk-aligned;
-//   * peakLevel is a maximum: taken in parallel over the samples consumed.
-// Same float operations in the same order on the same values as the sample-serial form, so sLevel, the sample the search stops
-// at and every decision are bit-identical to it (and to the oracle); a frame of silence (70 attempts) is walked in ~2 ms
-// instead of ~80 (round 3: one thread, every operand an LDS round trip behind a polled flag: ~1000 cycles per sample).
+// Only the two recurrences are serial, and sLevel -- three dependent float operations per sample -- depends on nothing but
+// the samples.  So the four waves of the block form a pipeline over blocks of 1024 samples, one barrier per block:
+//   wave 0, one lane: sLevel over block i, operands and results as 16-byte LDS accesses -- it never waits for anything else
+//                     and sets the pace (acq_walk_S: ~24 cycles per sample for a lone wave, tools/acq_walk_bench.hip);
+//   wave 1:           everything else about block i - 1: the moving sum's increments d[n] = |x[n]| - |x[n - 50]| (64 lanes, the
+//                     same float subtraction), level (one lane, one add per sample), then the two comparisons of all 1024
+//                     positions from the stored (level, sLevel) pairs -- the IEEE division included -- collected with ballots;
+//                     the phase machine (first dip begin, first dip end at or behind it, the two time-outs, the next attempt)
+//                     is scalar code on those masks.  The sample at which an attempt gives up is known in advance (T_F + 50
+//                     samples after its start without a dip, T_n + 70 after the dip's begin without an end): the block is cut
+//                     there and the next attempt's level restarts from zero mid-block;
+//   waves 2, 3:       |x| of block i + 1 (coalesced loads, square roots);
+//   peakLevel is a maximum: taken in parallel over the samples consumed.
+// Same float operations in the same order on the same values as the sample-serial form: sLevel, the sample the search stops at
+// and every decision are bit-identical to it (and to the oracle).  A frame of silence (70 attempts) is walked in ~2 ms; round 3
+// (one thread, every operand an LDS round trip behind a polled flag, ~1000 cycles per sample) took 80-100.
 constexpr int ACQ_CH = 1024;
 struct AcqLds {
-  __attribute__((aligned(16))) float a[2][64 + ACQ_CH + 32];  // |x|: a[b][64 + i] = sample i of the chunk, a[b][0..63] = the 64 samples before it
-  __attribute__((aligned(16))) float d[ACQ_CH + 32];          // increments of the moving sum
-  __attribute__((aligned(16))) float S[ACQ_CH + 8];           // sLevel after sample i at S[4 + i]; S[3] = before the chunk
-  __attribute__((aligned(16))) float L[ACQ_CH + 8];           // level likewise
-  unsigned long long dip_begin[ACQ_CH / 64], dip_end[ACQ_CH / 64];
+  __attribute__((aligned(16))) float a[3][64 + ACQ_CH + 32];  // |x| of three consecutive blocks: a[j % 3][64 + i] = sample i of block j, [0..63] = the 64 samples before it
+  __attribute__((aligned(16))) float S[2][ACQ_CH + 8];        // sLevel after sample i of block j at S[j & 1][4 + i]; [3] = before the block
+  __attribute__((aligned(16))) float d[2][ACQ_CH + 32];       // increments of the moving sum |x[n]| - |x[n - 50]| of block j in d[j & 1]
+  float bmax[3][4];                                           // maximum of a[j % 3] in four parts
+  __attribute__((aligned(16))) float L[ACQ_CH + 8];           // level after sample i at L[4 + i]
+  unsigned long long consumed;                                // results of the pass (wave 1 -> everyone)
+  float s_final, pk;
+  int done, ok;
   float red[8];
   int flag[4];
 };
 
-// The serial part, one LANE per recurrence (sLevel on wave 0, level on wave 1: two SIMDs, side by side).  A lone wave issues
-// an instruction every ~6 cycles whether it depends on the last one or not (tools/acq_walk_bench.hip: three dependent
-// operations per sample walk at 20 cycles per sample, and every further instruction in the loop costs its 6), so the loop is
-// nothing but the recurrence: 16 samples per iteration, operands as four 16-byte LDS reads requested one half-iteration ahead,
-// results as four 16-byte writes, waits counted so that neither is ever waited for (LDS operations complete in order: at each
-// wait the two newest reads and the two newest writes may still be on their way).  Written out as one asm block: the
-// compiler's version of this loop waits for its own stores at the loop head (s_waitcnt lgkmcnt(0): 77 cycles per sample).
-// a / out: LDS, 16-byte aligned, readable / writable up to n16 * 16 + 16 floats.  Only in k_acquire (two waves per SIMD: the
-// block's 34 fixed registers v200..v233 lie within its budget).
-#define DABX_ACQ_SKELETON(STEP)                                                                                                 \
-  "ds_read_b128 v[200:203], %[ap]\n\t"                                                                                         \
-  "ds_read_b128 v[204:207], %[ap] offset:16\n\t"                                                                               \
-  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
-  "1:\n\t"                                                                                                                      \
-  "ds_read_b128 v[208:211], %[ap] offset:32\n\t"                                                                               \
-  "ds_read_b128 v[212:215], %[ap] offset:48\n\t"                                                                               \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
-  STEP("v200", "v216", "%[x]") STEP("v201", "v217", "v216") STEP("v202", "v218", "v217") STEP("v203", "v219", "v218")           \
-  "ds_write_b128 %[op], v[216:219]\n\t"                                                                                        \
-  STEP("v204", "v220", "v219") STEP("v205", "v221", "v220") STEP("v206", "v222", "v221") STEP("v207", "v223", "v222")           \
-  "ds_write_b128 %[op], v[220:223] offset:16\n\t"                                                                              \
-  "ds_read_b128 v[200:203], %[ap] offset:64\n\t"                                                                               \
-  "ds_read_b128 v[204:207], %[ap] offset:80\n\t"                                                                               \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
-  STEP("v208", "v226", "v223") STEP("v209", "v227", "v226") STEP("v210", "v228", "v227") STEP("v211", "v229", "v228")           \
-  "ds_write_b128 %[op], v[226:229] offset:32\n\t"                                                                              \
-  STEP("v212", "v230", "v229") STEP("v213", "v231", "v230") STEP("v214", "v232", "v231") STEP("v215", "v233", "v232")           \
-  "ds_write_b128 %[op], v[230:233] offset:48\n\t"                                                                              \
-  "v_mov_b32 %[x], v233\n\t"                                                                                                   \
-  "v_add_u32 %[ap], 64, %[ap]\n\t"                                                                                             \
-  "v_add_u32 %[op], 64, %[op]\n\t"                                                                                             \
-  "s_sub_u32 %[n], %[n], 1\n\t"                                                                                                \
-  "s_cmp_lg_u32 %[n], 0\n\t"                                                                                                   \
-  "s_cbranch_scc1 1b\n\t"                                                                                                      \
-  "s_waitcnt lgkmcnt(0)\n\t"
-#define DABX_ACQ_CLOBBERS "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", \
-                          "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", \
-                          "v228", "v229", "v230", "v231", "v232", "v233", "scc", "memory"
-// sLevel += 0.00001f * (|x| - sLevel), sample_reader.cpp:248 (three roundings, no contraction)
-#define DABX_ACQ_STEP_S(A, R, P) "v_sub_f32 v224, " A ", " P "\n\tv_mul_f32 v224, %[c], v224\n\tv_add_f32 " R ", " P ", v224\n\t"
-// level += d, timesyncer.cpp:66, 80
-#define DABX_ACQ_STEP_L(A, R, P) "v_add_f32 " R ", " P ", " A "\n\t"
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
-}
-__device__ __forceinline__ void acq_walk_S(const float *a, float *out, int n16, float S)
-{
-  unsigned ap = lds_addr(a), op = lds_addr(out);
-  asm volatile(DABX_ACQ_SKELETON(DABX_ACQ_STEP_S) : [ap] "+v"(ap), [op] "+v"(op), [n] "+s"(n16), [x] "+v"(S) : [c] "s"(0.00001f) : DABX_ACQ_CLOBBERS);
-}
-__device__ __forceinline__ void acq_walk_L(const float *d, float *out, int n16, float L)
-{
-  unsigned ap = lds_addr(d), op = lds_addr(out);
-  asm volatile(DABX_ACQ_SKELETON(DABX_ACQ_STEP_L) : [ap] "+v"(ap), [op] "+v"(op), [n] "+s"(n16), [x] "+v"(L) : : DABX_ACQ_CLOBBERS);
-}
 // sLevel alone over m samples (the T_u window of a failed correlation): loads only, the compiler's loop is as fast as the chain
 __device__ __forceinline__ float level_walk(const float *__restrict__ a, int m, float S)
 {
@@ -284,18 +233,9 @@ __device__ __forceinline__ float block_max_nonneg(float v, float *red, int tid)
   for (int q = 1; q < (int)(blockDim.x >> 6); q++) r = fmaxf(r, red[q]);
   return r;
 }
-__device__ __forceinline__ int first_bit_from(const unsigned long long *mask, int from, int m)
-{
-  for (int wd = from >> 6; wd * 64 < m; wd++) {
-    unsigned long long v = mask[wd];
-    if (wd == (from >> 6)) v &= ~0ull << (from & 63);
-    if (v) return wd * 64 + __builtin_ctzll(v);
-  }
-  return -1;
-}
 
-// One pass of the search for stream s (whole block, T = 256 threads, uniform control flow).  The caller owns the stream (it is
-// not in ST_EVAL_SYNC and no demapper launch of it is in flight).  wr = the committed-sample count this kernel works with.
+// One pass of the search for stream s (whole block, 256 threads).  The caller owns the stream (it is not in ST_EVAL_SYNC and
+// no demapper launch of it is in flight).  wr = the committed-sample count this kernel works with.
 // Returns -1: nothing done (too few samples), 0: searched, no end of a null symbol yet, 1: a null symbol ended at c.rd.
 __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int st, unsigned long long wr,
                                               unsigned long long budget_samples, AcqLds &w)
@@ -316,10 +256,15 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   }
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
   const unsigned len = (unsigned)e.ring_len, base = (unsigned)(rd0 % (unsigned long long)e.ring_len);
-  // |x| of samples [p0, p0 + ACQ_CH) of this pass by threads t0, t0 + nt, ...; nothing beyond the committed samples is touched
-  // (a line fetched before its samples were committed would stay in this CU's cache for the rest of the kernel)
-  auto mags = [&](unsigned long long p0, float *dst, int t0, int nt) {
-    const unsigned o0 = (unsigned)((base + p0) % len);     // one 64-bit modulo per chunk, then add + conditional subtract
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the roles below branch on the scalar unit
+  // |x| of block j of this pass (and, in front of it, the last 64 magnitudes of block j - 1) by threads t0, t0 + nt, ...; nothing
+  // beyond the committed samples is touched (a line fetched before its samples were committed would stay in this CU's cache
+  // for the rest of the kernel)
+  auto mags = [&](int j, int t0, int nt) {
+    float *dst = w.a[j % 3];
+    const unsigned long long p0 = (unsigned long long)j * ACQ_CH;
+    const unsigned o0 = (unsigned)((base + p0) % len);     // one 64-bit modulo per block, then add + conditional subtract
+    float mx = 0.f;
     for (int q = t0; q < ACQ_CH; q += nt) {
       float a = 0.f;
       if (p0 + (unsigned)q < avail) {
@@ -328,85 +273,145 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
         const float2 v = ring[o];
         a = sqrtf(v.x * v.x + v.y * v.y);
       }
-      dst[q] = a;
+      dst[64 + q] = a;
+      mx = fmaxf(mx, a);
     }
+    if (j > 0) for (int q = t0; q < 64; q += nt) dst[q] = w.a[(j - 1) % 3][ACQ_CH + q];
+    mx = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, mx), [](unsigned x, unsigned y) { return x > y ? x : y; }));
+    if (lane == 0) w.bmax[j % 3][wave] = mx;               // (order of non-negative floats = order of their bits)
+    if (nt < T && tid < 128 + 2) w.bmax[j % 3][tid - 128] = 0.f;   // two waves fill the block: the other two parts are empty
   };
-  float S = c.s_level, L = 0.f, pk = 0.f;
-  int phase = (st == ST_INIT) ? 0 : 1;   // 0: seeding the level (20 T_u samples, dab_processor.cpp:130-139); 1: looking for the begin of a dip; 3: for its end
-  int nb = 0;                            // index of the chunk's first sample within the seed / within the attempt
-  int n2 = 0;                            // attempt-relative index at which the dip began
-  unsigned long long consumed = 0;
-  int ok = 0, b = 0;
-  mags(0, w.a[0] + 64, tid, T);
-  if (tid < 64) w.a[0][tid] = 0.f;
+  // the increments of block j as they are in the middle of an attempt (its first 50 samples are patched by the search, below)
+  auto incs = [&](int j, int t0, int nt) {
+    const float *ab = w.a[j % 3] + 64;
+    float *dst = w.d[j & 1];
+    for (int q = t0; q < ACQ_CH; q += nt) dst[q] = ab[q] - ab[q - 50];       // timesyncer.cpp:78-80
+  };
+  if (tid == 0) { w.done = 0; w.ok = 0; }
+  mags(0, tid, T);
   __syncthreads();
-  for (;;) {
-    // the chunk ends where the attempt would time out: NO_DIP_FOUND after reading sample T_F + 50 of the attempt (counter > T_F,
-    // timesyncer.cpp:68-71), NO_END_OF_DIP_FOUND after sample n2 + T_n + 70 (counter > T_n + 50 + 20, :82-85)
-    const int last = phase == 0 ? 20 * TU : (phase == 3 ? n2 + TN + 71 : TF + 51);
-    const int m = min(ACQ_CH, last - nb);
-    const float *ab = w.a[b] + 64;
-    if (phase != 0)
-      for (int q = tid; q < m; q += T) {
-        const float a = ab[q];
-        w.d[q] = nb + q < 50 ? a : a - ab[q - 50];                           // :64-66 (first 50), :78-80
+  incs(0, tid, T);                       // (block 0 has no samples in front of it: its first 50 increments are never used as they are)
+  __syncthreads();
+  // wave 0: sLevel
+  float S = c.s_level;
+  // wave 1: the search proper (all of it wave-uniform)
+  int phase = (st == ST_INIT) ? 0 : 1;   // 0: seeding the level (20 T_u samples, dab_processor.cpp:130-139); 1: looking for the begin of a dip; 3: for its end
+  int nb = 0;                            // samples of the seed / of the attempt evaluated so far
+  int n2 = 0;                            // attempt-relative index at which the dip began
+  float L = 0.f, pk = 0.f;
+#ifdef DABX_ACQ_TIMING                   // experiment builds only (tools/build_variant.sh): where a block's time goes, per wave role
+  long long tm[6] = {0, 0, 0, 0, 0, 0}, t_loop = clock64();
+#define ACQ_T0 const long long t0_ = clock64();
+#define ACQ_T(k) tm[k] += clock64() - t0_;
+#else
+#define ACQ_T0
+#define ACQ_T(k)
+#endif
+  int i = 0;
+  for (;; i++) {
+    if (wave == 0) {
+      if (lane == 0) {
+        ACQ_T0
+        w.S[i & 1][3] = S;
+        S = acq_walk_S(w.a[i % 3] + 64, w.S[i & 1] + 4, ACQ_CH / 16, S);
+        ACQ_T(0)
       }
-    if (tid == 0) { w.S[3] = S; w.L[3] = L; }
-    __syncthreads();
-    if (tid == 0) acq_walk_S(ab, w.S + 4, (m + 15) >> 4, S);
-    else if (tid == 64) { if (phase != 0) acq_walk_L(w.d, w.L + 4, (m + 15) >> 4, L); }
-    else if (tid >= 128) mags(consumed + (unsigned)m, w.a[b ^ 1] + 64, tid - 128, T - 128);
-    __syncthreads();
-    if (tid < 64) w.a[b ^ 1][tid] = w.a[b][m + tid];                        // the 64 samples before the next chunk
-    if (phase != 0) {
-      for (int q0 = (tid & ~63); q0 < m; q0 += T) {
-        const int q = q0 + (tid & 63);
-        const float Lp = w.L[3 + q], Sp = w.S[3 + q];                        // the state BEFORE sample q is read (:58, :74)
-        const bool valid = q < m && nb + q >= 50;
-        const float mean = Lp / 50.f;
-        const unsigned long long mb = __ballot(valid && !(mean > 0.55f * Sp)), me = __ballot(valid && !(mean < 0.75f * Sp));
-        if ((tid & 63) == 0) { w.dip_begin[q0 >> 6] = mb; w.dip_end[q0 >> 6] = me; }
+    } else if (wave == 1) {
+      if (i > 0) {
+        const int jb = i - 1;
+        const float *ab = w.a[jb % 3] + 64, *Sb = w.S[jb & 1];
+        const unsigned long long P = (unsigned long long)jb * ACQ_CH;
+        int q = 0, stop = 0, ok = 0;
+        while (q < ACQ_CH && !stop) {
+          // the segment ends where the attempt would time out: NO_DIP_FOUND after reading sample T_F + 50 of the attempt (counter > T_F,
+          // timesyncer.cpp:68-71), NO_END_OF_DIP_FOUND after sample n2 + T_n + 70 (counter > T_n + 50 + 20, :82-85)
+          const int last = phase == 0 ? 20 * TU : (phase == 3 ? n2 + TN + 71 : TF + 51);
+          const int m = min(ACQ_CH - q, last - nb);
+          int lim = m;                                                       // samples of the segment that are consumed
+          if (phase != 0) {
+            // An attempt that starts mid-block starts its level at zero: the walk begins at the 16-sample boundary below q with
+            // zero increments up to q (what it writes there belongs to positions already evaluated)
+            const int q16 = q & ~15;
+            float *db = w.d[jb & 1];
+            { ACQ_T0
+            if (nb < 50 || q16 < q)                                          // the attempt's first 50 samples: level += |x| (:64-66)
+              for (int p = q16 + lane; p < q16 + 128; p += 64) {
+                if (p < q) db[p] = 0.f;
+                else if (p < q + m && nb + (p - q) < 50) db[p] = ab[p];
+              }
+            ACQ_T(1) }
+            { ACQ_T0
+            if (lane == 0) {
+              w.L[3 + q] = L;
+              acq_walk_L(db + q16, w.L + 4 + q16, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L);
+            }
+            __builtin_amdgcn_wave_barrier();
+            ACQ_T(2) }
+            ACQ_T0
+            for (int p0 = q; p0 < q + m; p0 += 64) {
+              const int p = p0 + lane;
+              const float Lp = w.L[3 + p], Sp = Sb[3 + p];                   // the state BEFORE sample p is read (:58, :74)
+              const bool valid = p < q + m && nb + (p - q) >= 50;
+              const float mean = Lp / 50.f;
+              const unsigned long long mb = __ballot(valid && !(mean > 0.55f * Sp));
+              unsigned long long me = __ballot(valid && !(mean < 0.75f * Sp));
+              if (phase != 3 && mb) {
+                const int i2 = __builtin_ctzll(mb);
+                phase = 3; n2 = nb + (p0 + i2 - q);
+                me &= ~0ull << i2;                                           // the dip's end is looked for from the same sample on (:74)
+              }
+              if (phase == 3 && me) { lim = p0 + __builtin_ctzll(me) - q; ok = 1; stop = 1; break; }
+            }
+            ACQ_T(3)
+          }
+          q += lim;
+          if (ok) break;
+          nb += m;
+          L = w.L[3 + q];
+          if (nb == last) {
+            if (phase == 0) { phase = 1; nb = 0; L = 0.f; }
+            else {
+              // NO_DIP_FOUND / NO_END_OF_DIP_FOUND: dab_processor.cpp:154-160 tries again at once.  The same here while the next
+              // attempt's worst case is still in the ring and the pass's sample budget is not used up (one attempt is only
+              // T_n + 121 samples long in silence): a stream in a drop-out walks through it a frame of samples per pass.
+              const unsigned long long consumed = P + (unsigned)q;
+              if (avail - consumed >= (unsigned long long)ACQ_NEED && consumed < budget_samples) { phase = 1; nb = 0; L = 0.f; }
+              else stop = 1;
+            }
+          }
+        }
+        // sample_reader.cpp:247: peakLevel over the samples consumed -- the whole block's maximum, or its first q samples at the end
+        { ACQ_T0
+        if (!stop) pk = fmaxf(pk, lane < 4 ? w.bmax[jb % 3][lane] : 0.f);
+        else for (int p = lane; p < q; p += 64) pk = fmaxf(pk, ab[p]);
+        ACQ_T(4) }
+        if (stop) {
+          const float pkw = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, pk), [](unsigned x, unsigned y) { return x > y ? x : y; }));
+          if (lane == 0) { w.consumed = P + (unsigned)q; w.s_final = Sb[3 + q]; w.pk = pkw; w.ok = ok; w.done = 1; }
+        }
       }
+    } else {
+      ACQ_T0
+      mags(i + 1, tid - 128, T - 128);
+      if (i > 0) incs(i, tid - 128, T - 128);             // block i's magnitudes are complete since the last barrier
+      ACQ_T(5)
     }
     __syncthreads();
-    int lim = m;                                                             // samples of this chunk that are consumed
-    if (phase != 0) {
-      int from = 0;
-      if (phase != 3) {
-        const int i2 = first_bit_from(w.dip_begin, 0, m);
-        if (i2 >= 0) { phase = 3; n2 = nb + i2; from = i2; }
-      }
-      if (phase == 3) {
-        const int i3 = first_bit_from(w.dip_end, from, m);
-        if (i3 >= 0) { lim = i3; ok = 1; }
-      }
-    }
-    for (int q = tid; q < lim; q += T) pk = fmaxf(pk, ab[q]);                // sample_reader.cpp:247
-    consumed += (unsigned)lim;
-    S = w.S[3 + lim]; L = w.L[3 + lim];
-    if (ok) break;
-    nb += m;
-    if (nb == last) {
-      if (phase == 0) { phase = 1; nb = 0; L = 0.f; }
-      else {
-        // NO_DIP_FOUND / NO_END_OF_DIP_FOUND: dab_processor.cpp:154-160 tries again at once.  The same here while the next attempt's
-        // worst case is still in the ring and the pass's sample budget is not used up (one attempt is only T_n + 121 samples
-        // long in silence): a stream in a drop-out walks through it a frame of samples per pass.
-        if (avail - consumed >= (unsigned long long)ACQ_NEED && consumed < budget_samples) { phase = 1; nb = 0; L = 0.f; }
-        else break;
-      }
-    }
-    b ^= 1;
-    __syncthreads();
+    if (w.done) break;
   }
-  pk = block_max_nonneg(pk, w.red, tid);
+#ifdef DABX_ACQ_TIMING
+  if (s == 0 && lane == 0 && wave < 3)
+    printf("acq wave %d: %d blocks, %lld cycles in all; S walk %lld, increments %lld, level walk %lld, comparisons %lld, peak %lld, magnitudes %lld (cycles per block)\n",
+           wave, i + 1, clock64() - t_loop, tm[0] / (i + 1), tm[1] / (i + 1), tm[2] / (i + 1), tm[3] / (i + 1), tm[4] / (i + 1), tm[5] / (i + 1));
+#endif
   if (tid == 0) {
-    c.rd = rd0 + consumed;             // frequency offset is 0 while searching: NCO phase unchanged
-    c.s_level = S; c.peak_level = fmaxf(c.peak_level, pk);
+    c.rd = rd0 + w.consumed;           // frequency offset is 0 while searching: NCO phase unchanged
+    c.s_level = w.s_final; c.peak_level = fmaxf(c.peak_level, w.pk);
     c.sample_count = 0;
     c.sync_thr = e.threshold;
     c.clock_err = 0.0f;
   }
+  const int ok = w.ok;
   __syncthreads();
   return ok;
 }

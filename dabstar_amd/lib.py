@@ -14,7 +14,10 @@ class DabxError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libdabx.so")
+    """The product library.  DABX_LIB (read by this test/bench binding only -- the library itself reads no environment variable) names
+    an experiment build instead (tools/build_variant.sh -> dabstar_amd/_ab/*.so, same-box A/B runs of tools/ab.sh): nothing ever
+    overwrites libdabx.so."""
+    return os.environ.get("DABX_LIB") or os.path.join(HERE, "libdabx.so")
 
 
 def load(build_if_missing=True):
@@ -22,7 +25,7 @@ def load(build_if_missing=True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    if build_if_missing:
+    if build_if_missing and not os.environ.get("DABX_LIB"):
         from . import build as _b
         if _b.needs_build():
             _b.build()

@@ -172,6 +172,33 @@ int dabx_coarse_cfo(const dabx_cf32 *fft_sym0, int batch, int32_t *hz);
 struct dabx_subch_desc_s;
 int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, struct dabx_subch_desc_s *out, int max_out,
                     int32_t *cif_count);
+/* The same as a running decoder (FibDecoder::process_FIB, fib_decoder.cpp:59-106, fed FIB by FIB in transmission order): it keeps
+ * the CURRENT and the NEXT multiplex configuration -- FIG 0/1 and 0/2 are filed under _get_config_ptr(C/N flag),
+ * fib_decoder.h:97, fib_decoder_fig0.cpp:149, 240 -- and swaps them when the change flags of FIG 0/0 go from 3 back to 0
+ * (fib_decoder_fig0.cpp:102-111: std::swap(curr, next); next->reset()).  A sub-channel that reaches beyond the CIF or overlaps a
+ * known one restarts the collection (fib_decoder.cpp:131-141), as in the reference. */
+typedef struct dabx_fibdec dabx_fibdec;
+typedef struct {
+  int64_t fibs_processed;     /* FIBs handed to dabx_fibdec_process so far (those with a failed CRC are counted and skipped) */
+  int64_t fig00_fib;          /* index, counted like fibs_processed, of the FIB that carried the newest FIG 0/0; -1: none yet */
+  int64_t last_change_fib;    /* ... of the FIB whose FIG 0/0 made the newest swap; -1: none yet */
+  int32_t cif_count;          /* newest FIG 0/0: CIFCountHi * 250 + CIFCountLo (mCifCount); -1: none yet */
+  int32_t cif_count_hi, cif_count_lo;
+  int32_t change_flags;       /* its ChangeFlags (EN 300 401 6.4.1: 0 none, 1 sub-channel, 2 service organisation, 3 both) */
+  int32_t occurrence_change;  /* its OccurrenceChange: low byte (0..249) of the CIF count from which the next configuration applies;
+                                 meaningful while change_flags != 0 */
+  int32_t n_changes;          /* swaps so far */
+  int32_t n_restarts;         /* _restart_fib_decoding calls so far */
+  int32_t reserved[3];
+} dabx_fibdec_info;
+int  dabx_fibdec_create(dabx_fibdec **out);
+void dabx_fibdec_destroy(dabx_fibdec *d);
+int  dabx_fibdec_reset(dabx_fibdec *d);                              /* FibDecoder::connect_channel, fib_decoder.cpp:143-150 */
+/* n_fibs x 32 bytes + CRC flags (what dabx_read_fibs / dabx_fic_decode deliver); returns the number of swaps made in this call */
+int  dabx_fibdec_process(dabx_fibdec *d, const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs);
+int  dabx_fibdec_get_info(const dabx_fibdec *d, dabx_fibdec_info *out);
+/* sub-channel table of the current (next = 0) or the next (next = 1) configuration, like dabx_parse_fibs */
+int  dabx_fibdec_subchannels(const dabx_fibdec *d, int next, struct dabx_subch_desc_s *out, int max_out);
 
 /* ===================================================================================== engine level
  * Stream-batched receiver: the device-side equivalent of DabProcessor::run
@@ -283,6 +310,28 @@ int  dabx_read_frame_info(dabx_engine *e, int stream, int n_frames, int64_t *sym
 /* Sub-channel table announced in the FIBs of the newest frames of `stream` (dabx_parse_fibs over the FIB ring);
  * feed the result to dabx_set_subchannels to decode "everything found in the FIC" like EtiGenerator does. */
 int  dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
+/* Multiplex reconfiguration (EN 300 401 6.4.1, 6.5; FibDecoder's current / next tables).  The engine keeps one dabx_fibdec per
+ * stream; dabx_follow_fic feeds it the FIBs of the frames decoded since the last call (in order; frames that have already left
+ * the FIB ring of out_frames frames are reported in frames_missed) and says where the stream stands:
+ *   pending      the newest FIG 0/0 carries change flags != 0: a reconfiguration is announced;
+ *   at_cif       ... and takes effect from this CIF on, counted like the engine counts CIFs (4 per frame from the first frame
+ *                decoded: CIF 4 f + k is the k-th of frame f) -- the CIF whose counter's low byte equals OccurrenceChange, at or
+ *                after the CIF that carried the announcement;
+ *   n_changes / last_change_cif   swaps the decoder has made (change flags 3 -> 0) and the engine CIF of the FIB group that made the
+ *                newest one, i.e. the first CIF of the new configuration as the reference sees it.
+ * dabx_next_subchannels returns the announced (next) table.  To follow a reconfiguration: call dabx_process up to the frame that
+ * holds at_cif (frames = at_cif / 4 - frames decoded), then dabx_set_subchannels_at(..., at_cif) with the table wanted from then
+ * on, and go on -- slots whose description does not change keep running, slots that end deliver their logical frames up to
+ * CIF at_cif - 1, new ones start their 16-CIF de-interleaver fill at at_cif (tests/test_gpu_reconfig.py). */
+typedef struct {
+  int32_t pending, n_changes, frames_missed, reserved;
+  int64_t at_cif, last_change_cif, frames_fed;
+} dabx_reconf;
+int  dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out);
+int  dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
+/* dabx_set_subchannels whose new and changed slots start at CIF at_cif instead of at the next CIF to be demodulated:
+ * next CIF <= at_cif <= next CIF + 3 (a reconfiguration inside the coming frame).  stream >= 0. */
+int  dabx_set_subchannels_at(dabx_engine *e, int stream, const dabx_subch_desc *d, int n, int64_t at_cif);
 /* Decoded logical frames of a sub-channel: n_cifs x 3*kbps bytes, newest last; returns #CIFs valid. */
 int  dabx_read_msc(dabx_engine *e, int stream, int subch_idx, int n_cifs, uint8_t *bytes);
 /* RS-corrected DAB+ super frames (110*kbps/8 bytes each), newest last; returns count copied. */

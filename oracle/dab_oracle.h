@@ -157,6 +157,13 @@ void ora_backend_stats(const ora_backend *b, long out[8]);
 /* FIB/FIG subset (fib.c): FIG 0/0, 0/1, 0/2 -- decoder/fib_decoder.cpp:59-110, fib_decoder_fig0.cpp */
 int ora_parse_fibs(const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs, ora_subch_desc *out, int *dab_plus, int max_out,
                    int *cif_count);
+/* the same as a running decoder with a current and a next configuration (fib_decoder_fig0.cpp:102-111) */
+typedef struct ora_fibdec ora_fibdec;
+ora_fibdec *ora_fibdec_new(void);
+void ora_fibdec_free(ora_fibdec *t);
+int ora_fibdec_process(ora_fibdec *t, const uint8_t *fib_bytes, const uint8_t *crc_ok, int n_fibs);   /* returns swaps made */
+void ora_fibdec_info(const ora_fibdec *t, long long info[10]);
+int ora_fibdec_subchannels(const ora_fibdec *t, int next, ora_subch_desc *out, int *dab_plus, int max_out);
 
 /* ETI(NI) frame of one CIF (eti.c): eti_generator.cpp:169-199, :207-308; returns the bytes used before the 0x55 padding */
 int ora_eti_frame(int hi, int lo, int minor, const ora_subch_desc *sc, int nst, const uint8_t *fic96, const uint8_t *const *msc, uint8_t *eti);

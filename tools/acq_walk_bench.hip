@@ -3,10 +3,11 @@
 //     L += d                       one
 // operands in LDS, results back to LDS (the block evaluates the dip comparisons from them afterwards).  Variants of the loop's
 // data layout / instruction selection; prints ns and cycles per sample for a lone wave (what an out-of-lock stream gets).
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/_build/acq_walk_bench tools/acq_walk_bench.hip
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/_build/acq_walk_bench tools/acq_walk_bench.hip   (__graft_entry__.build())
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include "../dabstar_amd/csrc/acq_walk.h"      // (5), (6): the product's loops
 
 constexpr int CH = 1024;
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -84,10 +85,10 @@ __device__ __forceinline__ void walk_s_only(const float *__restrict__ a, int m, 
 template <int V>
 __global__ __launch_bounds__(256) void k_walk(const float *src, float *dst, int reps)
 {
-  __shared__ __attribute__((aligned(16))) float a[CH + 8], d[CH + 8], So[CH + 8], Lo[CH + 8];
+  __shared__ __attribute__((aligned(16))) float a[CH + 32], d[CH + 32], So[CH + 32], Lo[CH + 32];
   __shared__ __attribute__((aligned(16))) v2f ad[CH + 8], ls[CH + 8];
   const int tid = threadIdx.x;
-  for (int i = tid; i < CH + 8; i += 256) {
+  for (int i = tid; i < CH + 8; i += 256) {     // (what lies beyond is read ahead by (5), (6) and never used)
     const float x = src[(blockIdx.x * 131 + i) % 4096], y = src[(blockIdx.x * 17 + 3 * i) % 4096];
     a[i] = x; d[i] = y - x; ad[i] = (v2f){y - x, x};
   }
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(256) void k_walk(const float *src, float *dst, int 
       if (V == 2) walk_pairs(ad, ls, CH, S, L);
       if (V == 3) walk_sep_pipelined(a, d, So, Lo, CH, S, L);
       if (V == 4) walk_s_only(a, CH, S);
+      if (V == 5) S = dabx::acq_walk_S(a, So, CH / 16, S);
+      if (V == 6) { dabx::acq_walk_L(d, Lo, CH / 16, L); L = Lo[CH - 1]; }
       asm volatile("" ::: "memory");
     }
     dst[blockIdx.x * 4 + 0] = S; dst[blockIdx.x * 4 + 1] = L;
@@ -140,6 +143,8 @@ int main()
     run<2>("interleaved pairs, packed add", src, dst, blocks);
     run<3>("separate arrays, stores before loads, no packing", src, dst, blocks);
     run<4>("S only, no stores", src, dst, blocks);
+    run<5>("acq_walk_S (asm: 16 samples per iteration, counted waits)", src, dst, blocks);
+    run<6>("acq_walk_L (asm)", src, dst, blocks);
   }
   return 0;
 }
