@@ -403,6 +403,25 @@ class Engine:
         n = check(load().dabx_discover_subchannels(self._h, stream, out, max_out))
         return [out[i] for i in range(n)]
 
+    def follow_fic(self, stream):
+        out = Reconf()
+        check(load().dabx_follow_fic(self._h, stream, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in Reconf._fields_ if k != "reserved"}
+
+    def next_subchannels(self, stream, max_out=64):
+        out = (SubchDesc * max_out)()
+        n = check(load().dabx_next_subchannels(self._h, stream, out, max_out))
+        return [out[i] for i in range(n)]
+
+    def set_subchannels_at(self, subch, stream, at_cif, dab_plus=True):
+        arr = (SubchDesc * max(1, len(subch)))()
+        for i, c in enumerate(subch):
+            dp = getattr(c, "dab_plus", -1)
+            arr[i] = SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, int(dab_plus) if dp < 0 else dp, 0)
+        load().dabx_set_subchannels_at.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64]
+        check(load().dabx_set_subchannels_at(self._h, stream, arr, len(subch), at_cif))
+        self.subch = list(subch)
+
     def subch_stats(self, stream, j):
         st = SubchStats()
         check(load().dabx_get_subch_stats(self._h, stream, j, C.byref(st)))
@@ -540,6 +559,54 @@ def play_file(engine, stream, path, block_frames=4, on_block=None):
                 on_block(engine)
     feed.close()
     return frames
+
+
+class FibdecInfo(C.Structure):
+    _fields_ = [("fibs_processed", C.c_int64), ("fig00_fib", C.c_int64), ("last_change_fib", C.c_int64), ("cif_count", C.c_int32),
+                ("cif_count_hi", C.c_int32), ("cif_count_lo", C.c_int32), ("change_flags", C.c_int32), ("occurrence_change", C.c_int32),
+                ("n_changes", C.c_int32), ("n_restarts", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Reconf(C.Structure):
+    _fields_ = [("pending", C.c_int32), ("n_changes", C.c_int32), ("frames_missed", C.c_int32), ("reserved", C.c_int32),
+                ("at_cif", C.c_int64), ("last_change_cif", C.c_int64), ("frames_fed", C.c_int64)]
+
+
+class FibDecoder:
+    """dabx_fibdec_*: FibDecoder's FIG 0/0-0/2 walk with a current and a next configuration (host only)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(load().dabx_fibdec_create(C.byref(self._h)))
+
+    def process(self, fibs, crc_ok):
+        fibs = np.ascontiguousarray(fibs, np.uint8).reshape(-1, 32)
+        crc_ok = np.ascontiguousarray(crc_ok, np.uint8).reshape(-1)
+        return check(load().dabx_fibdec_process(self._h, _p(fibs), _p(crc_ok), fibs.shape[0]))
+
+    def info(self):
+        out = FibdecInfo()
+        check(load().dabx_fibdec_get_info(self._h, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in FibdecInfo._fields_ if k != "reserved"}
+
+    def subchannels(self, next=False, max_out=64):
+        out = (SubchDesc * max_out)()
+        n = check(load().dabx_fibdec_subchannels(self._h, int(next), out, max_out))
+        return [out[i] for i in range(n)]
+
+    def reset(self):
+        check(load().dabx_fibdec_reset(self._h))
+
+    def close(self):
+        if self._h and _LIB is not None:
+            _LIB.dabx_fibdec_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def parse_fibs(fibs, crc_ok, max_out=64):

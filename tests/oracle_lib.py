@@ -96,6 +96,11 @@ def oracle():
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.ora_parse_fibs.argtypes = [_u8p, _u8p, C.c_int, C.POINTER(SubchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    L.ora_fibdec_new.restype = C.c_void_p
+    L.ora_fibdec_free.argtypes = [C.c_void_p]
+    L.ora_fibdec_process.argtypes = [C.c_void_p, _u8p, _u8p, C.c_int]
+    L.ora_fibdec_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.ora_fibdec_subchannels.argtypes = [C.c_void_p, C.c_int, C.POINTER(SubchDesc), C.POINTER(C.c_int), C.c_int]
     L.ora_eti_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(SubchDesc), C.c_int, _u8p, C.POINTER(C.c_void_p), _u8p]
     L.ora_iq_convert.restype = C.c_longlong
     L.ora_iq_convert.argtypes = [C.c_int] * 6 + [_u8p, C.c_longlong, C.c_void_p, C.c_longlong]
@@ -259,3 +264,33 @@ def backend_stats(rx, i):
 def make_descs(subch):
     return (SubchDesc * len(subch))(*[SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form)
                                       for c in subch])
+
+
+class OraFibDecoder:
+    """oracle/fib.c: the stateful restatement (current / next configuration, change-flag swap)."""
+    INFO = ("fibs_processed", "fig00_fib", "last_change_fib", "cif_count", "cif_count_hi", "cif_count_lo", "change_flags",
+            "occurrence_change", "n_changes", "n_restarts")
+
+    def __init__(self):
+        self._h = oracle().ora_fibdec_new()
+
+    def process(self, fibs, crc_ok):
+        fibs = np.ascontiguousarray(fibs, np.uint8).reshape(-1, 32)
+        crc_ok = np.ascontiguousarray(crc_ok, np.uint8).reshape(-1)
+        return oracle().ora_fibdec_process(self._h, fibs, crc_ok, fibs.shape[0])
+
+    def info(self):
+        v = (C.c_longlong * 10)()
+        oracle().ora_fibdec_info(self._h, v)
+        return dict(zip(self.INFO, list(v)))
+
+    def subchannels(self, next=False, max_out=64):
+        out = (SubchDesc * max_out)()
+        dp = (C.c_int * max_out)()
+        n = oracle().ora_fibdec_subchannels(self._h, int(next), out, dp, max_out)
+        return [(out[i].subch_id, out[i].cu_start, out[i].cu_size, out[i].kbps, out[i].prot_level, out[i].short_form, dp[i]) for i in range(n)]
+
+    def close(self):
+        if self._h:
+            oracle().ora_fibdec_free(self._h)
+        self._h = None

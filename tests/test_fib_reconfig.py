@@ -1,0 +1,123 @@
+"""FIG 0/0 change flags, current / next configuration and their swap (fib_decoder_fig0.cpp:89-112, :149, :240; fib_decoder.h:97):
+libdabx's running FIB decoder (dabx_fibdec_*) against the oracle restatement (oracle/fib.c, ora_fibdec_*) and against what the
+synthetic transmitter announced.  CPU only."""
+import os
+import sys
+
+import numpy as np
+
+import oracle_lib as ol
+from dabstar_amd import lib as dx
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tools import dab_synth as ds  # noqa: E402
+
+
+def _tab(descs):
+    return [(g.subch_id, g.cu_start, g.cu_size, g.kbps, g.prot_level, g.short_form, g.dab_plus) for g in descs]
+
+
+def _layouts():
+    a = [ds.SubCh(i, 48 * i, 48, 64, 2, 0) for i in range(6)]
+    b = a[:3] + [ds.SubCh(3, 400, 48, 64, 2, 0),            # moves
+                 ds.SubCh(4, 500, 72, 96, 2, 0),            # grows: 64 -> 96 kbit/s
+                 ds.SubCh(6, 192, 24, 32, 2, 0, dab_plus=0)]   # 5 ends, 6 begins
+    return a, b
+
+
+def _fib_stream(a, b, n_cif, switch, announce_from, cif_start=0):
+    out = []
+    for q in range(n_cif):
+        ann = announce_from <= q < switch
+        out.append(ds.build_fibs_reconf(a if q < switch else b, b if ann else None, cif_start + q, 3 if ann else 0,
+                                        (cif_start + switch) % 250).reshape(3, 32))
+    return np.concatenate(out)
+
+
+def _both(fibs, crc, step=3):
+    """feeds both decoders `step` FIBs at a time; yields (index of the first FIB of the chunk, libdabx decoder, oracle decoder)"""
+    d, o = dx.FibDecoder(), ol.OraFibDecoder()
+    for i in range(0, len(fibs), step):
+        nd, no = d.process(fibs[i:i + step], crc[i:i + step]), o.process(fibs[i:i + step], crc[i:i + step])
+        assert nd == no
+        yield i, d, o
+    d.close(); o.close()
+
+
+def test_announced_reconfiguration_swaps_at_the_first_fig00_with_cleared_flags():
+    a, b = _layouts()
+    switch, ann = 60, 28
+    fibs = _fib_stream(a, b, 100, switch, ann, cif_start=4990)          # the CIF counter wraps 4999 -> 0 on the way
+    crc = np.ones(len(fibs), np.uint8)
+    want_a = [(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, 0, 1) for c in a]
+    want_b = [(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, 0, int(c.dab_plus)) for c in b]
+    for i, d, o in _both(fibs, crc):
+        q = i // 3                                                       # the CIF whose FIC group was just fed
+        inf = d.info()
+        assert inf == o.info(), (q, inf, o.info())
+        cur, nxt = _tab(d.subchannels()), _tab(d.subchannels(next=True))
+        assert cur == o.subchannels() and nxt == o.subchannels(next=True), q
+        assert inf["cif_count"] == (4990 + q) % 5000 and inf["fig00_fib"] == 3 * q
+        if q >= 1:
+            assert sorted(cur) == sorted(want_a if q < switch else want_b), q      # complete after two CIFs, swapped AT the switch
+        assert inf["change_flags"] == (3 if ann <= q < switch else 0)
+        if ann <= q < switch:
+            assert inf["occurrence_change"] == (4990 + switch) % 250
+            assert ((inf["occurrence_change"] - inf["cif_count_lo"]) % 250) == switch - q    # CIFs to go
+        if ann + 3 <= q < switch:
+            assert sorted(nxt) == sorted(want_b), q                      # FIG 0/1 and 0/2 with C/N = 1 both seen
+        assert inf["n_changes"] == (1 if q >= switch else 0)
+        assert inf["last_change_fib"] == (3 * switch if q >= switch else -1)
+        if q >= switch:
+            assert nxt == []                                             # next->reset(), fib_decoder_fig0.cpp:107
+        assert inf["n_restarts"] == 0
+
+
+def test_without_the_swap_the_new_table_would_collide_with_the_old_one():
+    """What round 3 did (current configuration only, change flags ignored): after the switch the new FIG 0/1 entries overlap the
+    remembered ones and the whole collection restarts (fib_decoder_fig0.cpp:204-209) -- the table is found again, but late, and
+    the announced switch CIF is never seen.  With change flags stuck at 1 (not 3) the reference does not swap either."""
+    a, b = _layouts()
+    fibs = _fib_stream(a, b, 80, 40, 40)                                 # no announcement at all: flags stay 0
+    crc = np.ones(len(fibs), np.uint8)
+    restarts = 0
+    for i, d, o in _both(fibs, crc):
+        assert d.info() == o.info() and _tab(d.subchannels()) == o.subchannels()
+        restarts = d.info()["n_restarts"]
+        assert d.info()["n_changes"] == 0
+    assert restarts >= 1
+
+
+def test_crc_failures_damaged_figs_and_garbage_follow_the_oracle():
+    a, b = _layouts()
+    rng = np.random.default_rng(3)
+    fibs = _fib_stream(a, b, 120, 70, 40).copy()
+    crc = (rng.random(len(fibs)) > 0.25).astype(np.uint8)                # a quarter of the FIBs fail their CRC
+    for k in rng.choice(len(fibs), 40, replace=False):                   # ... and some that "pass" are damaged (as after a false CRC match)
+        fibs[k, rng.integers(0, 30)] ^= 1 << rng.integers(0, 8)
+    junk = rng.integers(0, 256, (30, 32)).astype(np.uint8)               # pure noise that passed its CRC
+    fibs = np.concatenate([fibs[:150], junk, fibs[150:]])
+    crc = np.concatenate([crc[:150], np.ones(30, np.uint8), crc[150:]])
+    for step in (1, 3, 12):
+        last = None
+        for i, d, o in _both(fibs, crc, step):
+            assert d.info() == o.info(), (step, i)
+            assert _tab(d.subchannels()) == o.subchannels() and _tab(d.subchannels(next=True)) == o.subchannels(next=True), (step, i)
+            last = (d.info(), _tab(d.subchannels()))
+        if step == 1:
+            first = last
+        assert last == first                                             # chunking of the calls changes nothing
+
+
+def test_one_shot_parse_is_the_running_decoder_on_a_fresh_state():
+    a, b = _layouts()
+    fibs = _fib_stream(a, b, 30, 20, 8)
+    crc = np.ones(len(fibs), np.uint8)
+    got, cif = dx.parse_fibs(fibs, crc)
+    d = dx.FibDecoder()
+    d.process(fibs, crc)
+    assert _tab(got) == _tab(d.subchannels()) and cif == d.info()["cif_count"] == 29
+    assert sorted(g.subch_id for g in got) == [0, 1, 2, 3, 4, 6]          # the configuration after the switch
+    d.reset()
+    assert d.info()["fibs_processed"] == 0 and d.subchannels() == []
+    d.close()

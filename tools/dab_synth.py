@@ -308,6 +308,39 @@ class Ensemble:
     tx_bits: np.ndarray        # [n_frames, 75, 3072] uint8 transmitted (interleaved) bits per OFDM symbol
 
 
+def _ofdm_frames(tx_bits: np.ndarray, n_frames: int, cyclic: bool, cif_start: int, tii: list | None) -> np.ndarray:
+    """[n_frames, 75, 3072] transmitted bits -> [n_frames, TF] complex64 frames (null symbol + PRS + 75 D-QPSK symbols)."""
+    # ---- QPSK, frequency interleaving, D-QPSK, OFDM
+    perm = freq_perm() % TU
+    prs = prs_spectrum()
+    q = ((1 - 2.0 * tx_bits[:, :, :K]) + 1j * (1 - 2.0 * tx_bits[:, :, K:])) / np.sqrt(2)
+    iq = np.zeros((n_frames, TF), np.complex64)
+    scale = 1.0 / np.sqrt(K)          # unit mean power in the useful part
+    tii_z = None
+    if tii:                               # [(main_id, sub_id, amplitude, etsi)]: sum of the transmitters' TII signals
+        tii_z = sum(tii_null_spectrum(m, c, a, e) for (m, c, a, e) in tii)
+    for f in range(n_frames):
+        # the null symbol that opens frame f closes frame f-1: it carries TII when the CIF counter of the last FIG 0/0
+        # of that frame has (count & 7) >= 4 (the receiver's rule, dab_processor.cpp:274)
+        if tii_z is not None and ((cif_start + 4 * ((f - 1) % n_frames if cyclic else f - 1) + 3) & 7) >= 4 and (cyclic or f > 0):
+            t = np.fft.ifft(tii_z) * TU * scale
+            iq[f, 0:TG] = t[-TG:]
+            iq[f, TG:TG + TU] = t
+            iq[f, TG + TU:TN] = t[:TN - TG - TU]
+        z = prs.copy()
+        pos = TN
+        for l in range(L):
+            if l > 0:
+                y = np.zeros(TU, np.complex128)
+                y[perm] = q[f, l - 1]
+                z = np.where(np.abs(prs) > 0, z * np.where(y == 0, 1, y), 0)
+            t = np.fft.ifft(z) * TU * scale
+            iq[f, pos: pos + TG] = t[-TG:]
+            iq[f, pos + TG: pos + TS] = t
+            pos += TS
+    return iq
+
+
 def build_ensemble(n_frames: int = 10, subch: list | None = None, seed: int = 0, cyclic: bool = True,
                    cif_start: int = 0, tii: list | None = None) -> Ensemble:
     subch = default_subchannels() if subch is None else subch
@@ -357,35 +390,159 @@ def build_ensemble(n_frames: int = 10, subch: list | None = None, seed: int = 0,
             fic.append(conv_encode(np.unpackbits(fb) ^ fdisp)[fmask])
         tx_bits[f, :3] = np.concatenate(fic).reshape(3, 3072)
         tx_bits[f, 3:] = tx_cif[4 * f: 4 * f + 4].reshape(72, 3072)
-    # ---- QPSK, frequency interleaving, D-QPSK, OFDM
-    perm = freq_perm() % TU
-    prs = prs_spectrum()
-    q = ((1 - 2.0 * tx_bits[:, :, :K]) + 1j * (1 - 2.0 * tx_bits[:, :, K:])) / np.sqrt(2)
-    iq = np.zeros((n_frames, TF), np.complex64)
-    scale = 1.0 / np.sqrt(K)          # unit mean power in the useful part
-    tii_z = None
-    if tii:                               # [(main_id, sub_id, amplitude, etsi)]: sum of the transmitters' TII signals
-        tii_z = sum(tii_null_spectrum(m, c, a, e) for (m, c, a, e) in tii)
-    for f in range(n_frames):
-        # the null symbol that opens frame f closes frame f-1: it carries TII when the CIF counter of the last FIG 0/0
-        # of that frame has (count & 7) >= 4 (the receiver's rule, dab_processor.cpp:274)
-        if tii_z is not None and ((cif_start + 4 * ((f - 1) % n_frames if cyclic else f - 1) + 3) & 7) >= 4 and (cyclic or f > 0):
-            t = np.fft.ifft(tii_z) * TU * scale
-            iq[f, 0:TG] = t[-TG:]
-            iq[f, TG:TG + TU] = t
-            iq[f, TG + TU:TN] = t[:TN - TG - TU]
-        z = prs.copy()
-        pos = TN
-        for l in range(L):
-            if l > 0:
-                y = np.zeros(TU, np.complex128)
-                y[perm] = q[f, l - 1]
-                z = np.where(np.abs(prs) > 0, z * np.where(y == 0, 1, y), 0)
-            t = np.fft.ifft(z) * TU * scale
-            iq[f, pos: pos + TG] = t[-TG:]
-            iq[f, pos + TG: pos + TS] = t
-            pos += TS
+    iq = _ofdm_frames(tx_bits, n_frames, cyclic, cif_start, tii)
     return Ensemble(n_frames, subch, iq.reshape(-1), fibs, msc_bytes, superframes, tx_bits)
+
+
+# ---------------------------------------------------------------------------------------------- multiplex reconfiguration
+def fig00_bytes(cif_count: int, eid: int = 0x10F2, change_flags: int = 0, occurrence: int = 0) -> bytes:
+    """FIG 0/0 (EN 300 401 6.4.1): EId, change flags, CIF count and -- while a change is announced -- OccurrenceChange."""
+    hi, lo = (cif_count // 250) % 20, cif_count % 250
+    body = bytes([0x00, eid >> 8, eid & 0xFF, ((change_flags & 3) << 6) | (hi & 0x1F), lo]) + (bytes([occurrence]) if change_flags else b"")
+    return bytes([len(body)]) + body
+
+
+def fig01_bytes(chs, cn: int = 0) -> bytes:
+    body = bytearray([(cn << 7) | 0x01])
+    for c in chs:
+        if c.short_form:
+            idx = UEP_ROWS.index((c.kbps, c.prot_level))
+            body += bytes([(c.subch_id << 2) | (c.cu_start >> 8), c.cu_start & 0xFF, idx])
+            continue
+        opt, lvl = (c.prot_level >> 2) & 1, c.prot_level & 3
+        w = (c.subch_id << 26) | (c.cu_start << 16) | (1 << 15) | (opt << 12) | (lvl << 10) | c.cu_size
+        body += w.to_bytes(4, "big")
+    return bytes([len(body)]) + bytes(body)
+
+
+def fig02_bytes(chs, cn: int = 0) -> bytes:
+    body = bytearray([(cn << 7) | 0x02])
+    for c in chs:
+        sid = 0x1000 + c.subch_id
+        comp = (0 << 14) | ((63 if c.dab_plus else 0) << 8) | (c.subch_id << 2) | (1 << 1)
+        body += bytes([sid >> 8, sid & 0xFF, 0x01, comp >> 8, comp & 0xFF])
+    return bytes([len(body)]) + bytes(body)
+
+
+def pack_fibs(figs: list) -> np.ndarray:
+    """FIGs (header included, in order) into the three FIBs of one CIF: end marker, padding, CRC.  96 bytes."""
+    fibs, cur = [], b""
+    for g in figs:
+        assert len(g) <= 30
+        if len(cur) + len(g) > 30:
+            fibs.append(cur); cur = b""
+        cur += g
+    fibs.append(cur)
+    assert len(fibs) <= 3, "the FIGs of this CIF do not fit into three FIBs"
+    out = []
+    for data in fibs + [b""] * (3 - len(fibs)):
+        if len(data) < 30:
+            data += b"\xFF" + b"\x00" * (29 - len(data))
+        c = crc16(data)
+        out.append(data + bytes([c >> 8, c & 0xFF]))
+    return np.frombuffer(b"".join(out), np.uint8).copy()
+
+
+def build_fibs_reconf(cur: list, nxt: list | None, cif_count: int, change_flags: int = 0, occurrence: int = 0) -> np.ndarray:
+    """One CIF's FIC group while a reconfiguration may be announced: FIG 0/0 in every CIF; the current configuration's FIG 0/1 and
+    0/2 (C/N = 0) on CIFs 0 and 1 of four, the next one's (C/N = 1) on CIFs 2 and 3 while it is announced (else the current again)."""
+    def chunks(chs, first, rest):
+        out, k = [], first
+        while chs:
+            out.append(chs[:k]); chs = chs[k:]; k = rest
+        return out
+    figs = [fig00_bytes(cif_count, change_flags=change_flags, occurrence=occurrence)]
+    phase = cif_count % 4
+    which, cn = (nxt, 1) if (nxt is not None and phase >= 2) else (cur, 0)
+    if phase % 2 == 0:
+        figs += [fig01_bytes(ch, cn) for ch in chunks(list(which), 5, 7)]
+    else:
+        figs += [fig02_bytes(ch, cn) for ch in chunks(list(which), 4, 5)]
+    return pack_fibs(figs)
+
+
+@dataclasses.dataclass
+class ReconfEnsemble:
+    n_frames: int
+    subch_a: list              # the configuration before the switch ...
+    subch_b: list              # ... and from CIF switch_cif on
+    switch_cif: int
+    iq: np.ndarray
+    fibs: np.ndarray           # [n_frames, 12, 32]
+    payload: dict              # (layout "a" / "b", subch_id) -> (first CIF, [n, 3*kbps] logical frames from there on); a sub-channel
+                               # with the same description in both layouts runs through and appears under "a" only
+
+
+def _same_desc(x, y):
+    return (x.subch_id, x.cu_start, x.cu_size, x.kbps, x.prot_level, x.short_form, x.dab_plus) == \
+           (y.subch_id, y.cu_start, y.cu_size, y.kbps, y.prot_level, y.short_form, y.dab_plus)
+
+
+def build_reconfigured_ensemble(n_frames: int, subch_a: list, subch_b: list, switch_frame: int, announce_frames: int = 8,
+                                seed: int = 0, cif_start: int = 0) -> ReconfEnsemble:
+    """A multiplex reconfiguration (EN 300 401 6.5) at the first CIF of frame switch_frame: layout A before, layout B from then on,
+    announced for announce_frames frames in advance (FIG 0/0 change flags 3 + OccurrenceChange, the next configuration's FIG 0/1
+    and 0/2 with C/N = 1); afterwards the flags are 0 and B is the current configuration.  Sub-channels described identically in
+    A and B run through (same convolutional interleaver, no gap); one that ends has its last 15 logical frames cut off in
+    the air (their later interleaver branches fall on CUs that belong to B); one that begins starts its interleaver at the switch."""
+    rng = np.random.default_rng(seed)
+    n_cif, N = 4 * n_frames, 4 * switch_frame
+    through = [c for c in subch_a if any(_same_desc(c, d) for d in subch_b)]
+    only_b = [d for d in subch_b if not any(_same_desc(c, d) for c in subch_a)]
+    pos = np.arange(55296)
+    delay = INTERLEAVE_MAP[pos & 15]
+
+    def code(c, first, last):
+        """coded bits of the sub-channel's logical frames first..last-1: [n_cif, 64 * cu_size] (zero outside), payload"""
+        nb = 3 * c.kbps
+        n = last - first
+        n_sf = (n + 4) // 5
+        sfs = [build_superframe(c.kbps, rng) if c.dab_plus else rng.integers(0, 256, 15 * c.kbps).astype(np.uint8) for _ in range(n_sf)]
+        stream = np.concatenate(sfs)[: n * nb].reshape(n, nb)
+        mask = (eep_mask(c.kbps, c.prot_level) if c.mask is None else np.asarray(c.mask)).astype(bool)
+        disp = prbs(24 * c.kbps)
+        out = rng.integers(0, 2, (n_cif, 64 * c.cu_size), dtype=np.uint8)          # what is not payload is random
+        for q in range(first, last):
+            cw = conv_encode(np.unpackbits(stream[q - first]) ^ disp)[mask]
+            out[q, : len(cw)] = cw
+        return out, stream
+
+    tx_cif = rng.integers(0, 2, (n_cif, 55296), dtype=np.uint8)                  # padding / the cut-off branches: random
+    payload = {}
+    for layout, chs, first, last, t0, t1 in (("a", subch_a, 0, None, 0, None), ("b", only_b, N, n_cif, N, n_cif)):
+        for c in chs:
+            runs_through = layout == "a" and c in through
+            lf_last = n_cif if (layout == "b" or runs_through) else N                # logical frames it carries
+            cif_last = n_cif if (layout == "b" or runs_through) else N               # CIFs in which its CUs are its own
+            coded, stream = code(c, first, lf_last)
+            payload[(layout, c.subch_id)] = (first, stream)
+            sl = slice(c.cu_start * 64, (c.cu_start + c.cu_size) * 64)
+            d = delay[sl]
+            cols = np.arange(64 * c.cu_size)
+            for t in range(t0, cif_last):
+                src = t - d
+                ok = (src >= first) & (src < lf_last)
+                row = tx_cif[t, sl]
+                row[ok] = coded[src[ok], cols[ok]]
+    # ---- FIC
+    fmask = fic_mask().astype(bool)
+    fdisp = prbs(768)
+    fibs = np.zeros((n_frames, 12, 32), np.uint8)
+    tx_bits = np.zeros((n_frames, 75, 3072), np.uint8)
+    occurrence = (cif_start + N) % 250
+    for f in range(n_frames):
+        fic = []
+        for g in range(4):
+            q = 4 * f + g
+            announced = N - 4 * announce_frames <= q < N
+            fb = build_fibs_reconf(subch_a if q < N else subch_b, subch_b if announced else None, cif_start + q,
+                                   change_flags=3 if announced else 0, occurrence=occurrence)
+            fibs[f, 3 * g: 3 * g + 3] = fb.reshape(3, 32)
+            fic.append(conv_encode(np.unpackbits(fb) ^ fdisp)[fmask])
+        tx_bits[f, :3] = np.concatenate(fic).reshape(3, 3072)
+        tx_bits[f, 3:] = tx_cif[4 * f: 4 * f + 4].reshape(72, 3072)
+    iq = _ofdm_frames(tx_bits, n_frames, False, cif_start, None)
+    return ReconfEnsemble(n_frames, list(subch_a), list(subch_b), N, iq.reshape(-1), fibs, payload)
 
 
 def channel(iq: np.ndarray, snr_db: float = 20.0, cfo_hz: float = 0.0, timing_offset: int = 0, gain: float = 0.25,
