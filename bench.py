@@ -69,6 +69,8 @@ def parse():
                          "symbol all the time; shows what streams in a drop-out cost the streams in lock")
     ap.add_argument("--unlocked-kind", choices=["silence", "floor"], default="silence",
                     help="silence: all-zero samples; floor: the ensemble 60 dB down under its (unchanged) noise")
+    ap.add_argument("--exact-level", action="store_true",
+                    help="not the headline: dabx_config.exact_level_tracker = 1 (SampleReader's level IIR sample by sample in lock too)")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
                     help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
                          "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
@@ -522,7 +524,7 @@ def main():
         from dabstar_amd import lib as dx
         dx.check(dx.load().dabx_set_device(local_rank))
         eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, fic_only=args.fic_only,
-                        viterbi_tie_mode=args.viterbi_tie_mode)
+                        viterbi_tie_mode=args.viterbi_tie_mode, exact_level_tracker=args.exact_level)
         if not args.fic_only:
             if args.layout == "mixed":
                 for s_ in range(args.streams):
@@ -688,6 +690,9 @@ def main():
                 args.unlocked, "silence" if args.unlocked_kind == "silence" else "the ensemble 60 dB down under its noise")
             out["unlocked_streams_per_gpu"] = args.unlocked
             out["frames_per_s_per_locked_stream"] = round(value / (n_joined * n_lock), 3)
+        if args.exact_level:
+            out["config"]["workload"] += "; exact_level_tracker = 1"
+            out["exact_level_tracker"] = 1
         if args.layout == "mixed":       # the byte model above is the uniform layout's: no roofline claim for this variant
             out["config"]["workload"] = out["config"]["workload"].replace("18x64 kbit/s EEP 3-A DAB+ each", "alternating 18x64 kbit/s EEP 3-A and a 16-service multiplex of 7 profiles (32..128 kbit/s, EEP 2-A/3-A/3-B)")
             out["roofline"] = None

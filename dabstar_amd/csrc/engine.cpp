@@ -1,8 +1,12 @@
 // engine.cpp -- host side of the stream-batched receiver and the engine-level C ABI (include/dabx.h).
 #include "pipeline.h"
 #include "viterbi_core.h"
+#ifndef DABX_CU_SPLIT_DEMAP_FRONT
+#define DABX_CU_SPLIT_DEMAP_FRONT 0
+#endif
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +18,7 @@ namespace dabx {
 int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool async_acquire);
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk);
 int launch_dciq(const EngineDev &e, int mode, hipStream_t st);
+int launch_level_exact(const EngineDev &e, hipStream_t st);
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
 extern const char *const kStepKernelNames[11];
 int launch_commit(const EngineDev &e, int stream, unsigned long long n, hipStream_t st);
@@ -65,6 +70,7 @@ struct dabx_engine {
 
   std::vector<void *> fast_allocs;             // buffers of the current MSC classes (replaced on reconfiguration)
   bool classes_dirty = false;
+  bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
   int build_msc_classes();
 
   template <class T> int alloc(T **p, size_t count, bool zero = true)
@@ -183,6 +189,13 @@ static int sync_all(dabx_engine *e)
   if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
   if (e->ss.q) DABX_HIP(hipStreamSynchronize(e->ss.q));
   e->ss.acq_in_flight = false;
+  // cfg.exact_level_tracker: the level tracker follows the frame chain on its own; behind the last frame it is run once more, so
+  // that what the host reads next (dabx_get_stats, the ring's read cursor) includes every sample the receiver has read
+  if (e->dev.exact_level && e->dev.level_pos && e->level_dirty) {
+    if (int rc = launch_level_exact(e->dev, e->stream)) return rc;
+    DABX_HIP(hipStreamSynchronize(e->stream));
+    e->level_dirty = false;
+  }
   return 0;
 }
 
@@ -225,14 +238,31 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   // front end (frame-to-frame feedback = critical path) above the batched MSC decode
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // lo = least urgent (numerically greatest)
+#ifdef DABX_CU_SPLIT
+  // Experiment builds only (tools/build_variant.sh -DDABX_CU_SPLIT=n; DESIGN.md 6 "spatial partitioning"): the front-end stream gets
+  // n of the 256 CUs, the decoder and the MSC symbols' demapper the other 256 - n.  The KFD deals the bits of a queue's CU mask
+  // round-robin to the 8 XCDs, so the first n bits are n / 8 CUs on every XCD.
+  uint32_t mask_front[8], mask_back[8];
+  for (int w = 0; w < 8; w++) {
+    mask_front[w] = mask_back[w] = 0;
+    for (int b = 0; b < 32; b++) { if (32 * w + b < DABX_CU_SPLIT) mask_front[w] |= 1u << b; else mask_back[w] |= 1u << b; }
+  }
+  H(hipExtStreamCreateWithCUMask(&e->stream, 8, mask_front));
+#else
   H(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi));
+#endif
   e->ss.a = e->stream;
   if (cfg->schedule == 0) {
     // overlapped schedule (default): MSC batches on b, the MSC symbols' demapper on d (pipeline.hip, launch_front_step /
     // launch_msc_batch).  All streams live on this device: a device-scope release is all a dependency needs (the default
     // system-scope release writes the caches back for host visibility on every record)
+#ifdef DABX_CU_SPLIT
+    H(hipExtStreamCreateWithCUMask(&e->ss.b, 8, mask_back));
+    H(hipExtStreamCreateWithCUMask(&e->ss.d, 8, DABX_CU_SPLIT_DEMAP_FRONT ? mask_front : mask_back));
+#else
     H(hipStreamCreateWithPriority(&e->ss.b, hipStreamNonBlocking, prio_lo));
     H(hipStreamCreateWithPriority(&e->ss.d, hipStreamNonBlocking, prio_hi));
+#endif
     H(hipEventCreateWithFlags(&e->ss.prep_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.msc_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -264,6 +294,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.demap_busy, S));
   A(e->alloc(&d.dciq_state, (size_t)S * 8));
   A(e->alloc(&d.dciq_done, S));
+  if (d.exact_level) A(e->alloc(&d.level_pos, S));
   {
     std::vector<float> st8((size_t)S * 8, 0.0f);                  // sample_reader.h:102-106: meanII = meanQQ = 1
     for (int s_ = 0; s_ < S; s_++) { st8[(size_t)s_ * 8 + 2] = 1.0f; st8[(size_t)s_ * 8 + 3] = 1.0f; }
@@ -490,6 +521,11 @@ static int push_room(dabx_engine *e, int stream, size_t n, const char *who)
     if (attempt == 1) { if (int rc0 = sync_all(e)) return rc0; }
     e->ctl_peek.resize(e->dev.n_streams);
     DABX_HIP(hipMemcpy(e->ctl_peek.data(), e->dev.ctl, sizeof(StreamCtl) * e->dev.n_streams, hipMemcpyDeviceToHost));
+    if (e->dev.exact_level && e->dev.level_pos) {          // the exact level tracker still has to read what lies behind ITS cursor
+      std::vector<unsigned long long> lp(e->dev.n_streams);
+      DABX_HIP(hipMemcpy(lp.data(), e->dev.level_pos, sizeof(unsigned long long) * lp.size(), hipMemcpyDeviceToHost));
+      for (int s = 0; s < e->dev.n_streams; s++) e->ctl_peek[s].rd = std::min(e->ctl_peek[s].rd, lp[s]);
+    }
     for (int s = 0; s < e->dev.n_streams; s++) e->rd_seen[s] = std::max(e->rd_seen[s], e->ctl_peek[s].rd);
   }
   return 0;
@@ -633,6 +669,7 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     }
     int rc = launch_front_step(e->dev, e->ss, e->mk, async_acquire);
     if (rc) return rc;
+    e->level_dirty = true;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
       e->dev.snap = e->snap_buf[e->ss.batch_parity];
       rc = launch_msc_batch(e->dev, 4 * e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk);
@@ -892,13 +929,32 @@ int dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int 
   return dabx_fibdec_subchannels(fd, 1, out, max_out);
 }
 
+#undef dabx_get_stats
+static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out);
+// The entry point binaries built against ABI 3 call: writes exactly the ABI-3 record (up to and including peak_level), so a
+// caller whose dabx_stats is the old, shorter one is not overrun.  Sources compiled against this header reach
+// dabx_get_stats_sized through the macro of the same name and get everything their record has room for.
 int dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out)
+{
+  return dabx_get_stats_sized(e, stream, out, offsetof(dabx_stats, peak_level) + sizeof(float));
+}
+int dabx_get_stats_sized(dabx_engine *e, int stream, void *out, size_t size)
+{
+  if (!out || size < sizeof(int64_t)) return DABX_E_ARG;
+  dabx_stats full;
+  if (int rc = get_stats_full(e, stream, &full)) return rc;
+  memcpy(out, &full, std::min(size, sizeof(full)));
+  if (size > sizeof(full)) memset((char *)out + sizeof(full), 0, size - sizeof(full));
+  return 0;
+}
+static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out)
 {
   if (!e || stream < 0 || stream >= e->dev.n_streams || !out) return DABX_E_ARG;
   StreamCtl c;
   int rc = fetch_ctl(e, stream, &c);
   if (rc) return rc;
   memset(out, 0, sizeof(*out));
+  out->level_margin_events = c.level_margin;
   out->frames = c.frames; out->samples_consumed = (int64_t)c.rd; out->state = c.state;
   out->fic_ratio_percent = c.fic_ratio * 10; out->freq_offs_bb_hz = c.f_bb; out->clock_err_hz = c.clock_err;
   out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;

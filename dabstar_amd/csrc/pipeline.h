@@ -45,7 +45,8 @@ struct StreamCtl {
   float head_abs_a, head_abs_b;   // sum |x| over the T_u correlation window / the start_index samples read after it (level tracker)
   int32_t np_sel;                 // which noise-power buffer (DemapDev::null_power / null_power2) is current; k_frame_tail flips it
   int32_t pad_;
-  unsigned long long step_rd0;    // rd when the current step began: a step consumes at most about one frame of samples per stream
+  unsigned long long step_rd0;    // (unused since round 4)
+  long long level_margin;         // null-dip comparisons that fell within 1e-4 (relative) of their threshold (dabx_stats.level_margin_events)
 };
 
 struct SubchDev {
@@ -75,6 +76,7 @@ struct EngineDev {
   float threshold;
   int32_t strongest, fic_only, capture_soft;
   int32_t exact_level;            // 1: in lock, SampleReader's level IIR is run sample by sample too (cfg.exact_level_tracker)
+  unsigned long long *level_pos;  // [S] exact_level only: index of the first sample the level tracker has not seen yet (<= ctl.rd)
   int32_t tie_mode;               // 1: Viterbi arithmetic of the reference's AVX2 / SSE2 builds (viterbi_core.h, vit_step_simd)
   int32_t msc_stride;             // bytes per logical-frame slot (3 * max kbps)
   int32_t sf_stride;              // bytes per super-frame slot (110 * max kbps / 8)
@@ -142,7 +144,6 @@ struct EngineStreams {
   hipStream_t q = nullptr;                             // k_acquire of dabx_process(sync == 0): streams out of lock are searched next to the steps of the others
   hipEvent_t acq_done = nullptr;
   bool acq_in_flight = false;                          // a pass on q may still be running
-  int acq_credit = 0;                                  // steps since the last pass was launched (its budget in frames)
   hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
   unsigned step_count = 0;

@@ -204,7 +204,7 @@ struct AcqLds {
   __attribute__((aligned(16))) float L[ACQ_CH + 8];           // level after sample i at L[4 + i]
   unsigned long long consumed;                                // results of the pass (wave 1 -> everyone)
   float s_final, pk;
-  int done, ok;
+  int done, ok, margin;
   float red[8];
   int flag[4];
 };
@@ -299,6 +299,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   int nb = 0;                            // samples of the seed / of the attempt evaluated so far
   int n2 = 0;                            // attempt-relative index at which the dip began
   float L = 0.f, pk = 0.f;
+  int margin = 0;                        // comparisons within 1e-4 of their threshold
 #ifdef DABX_ACQ_TIMING                   // experiment builds only (tools/build_variant.sh): where a block's time goes, per wave role
   long long tm[6] = {0, 0, 0, 0, 0, 0}, t_loop = clock64();
 #define ACQ_T0 const long long t0_ = clock64();
@@ -352,15 +353,27 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
               const int p = p0 + lane;
               const float Lp = w.L[3 + p], Sp = Sb[3 + p];                   // the state BEFORE sample p is read (:58, :74)
               const bool valid = p < q + m && nb + (p - q) >= 50;
-              const float mean = Lp / 50.f;
-              const unsigned long long mb = __ballot(valid && !(mean > 0.55f * Sp));
-              unsigned long long me = __ballot(valid && !(mean < 0.75f * Sp));
-              if (phase != 3 && mb) {
-                const int i2 = __builtin_ctzll(mb);
-                phase = 3; n2 = nb + (p0 + i2 - q);
-                me &= ~0ull << i2;                                           // the dip's end is looked for from the same sample on (:74)
+              const float mean = Lp / 50.f, tb = 0.55f * Sp, te = 0.75f * Sp;
+              const unsigned long long mb = __ballot(valid && !(mean > tb));
+              unsigned long long me = __ballot(valid && !(mean < te));
+              // comparisons that a relative error of 1e-4 in sLevel could have turned (the chunk-wise in-lock tracker is good to ~1e-5)
+              unsigned long long nearb = __ballot(valid && fabsf(mean - tb) <= 1e-4f * tb), neare = __ballot(valid && fabsf(mean - te) <= 1e-4f * te);
+              if (phase != 3) {
+                if (mb) {
+                  const int i2 = __builtin_ctzll(mb);
+                  phase = 3; n2 = nb + (p0 + i2 - q);
+                  me &= ~0ull << i2;                                         // the dip's end is looked for from the same sample on (:74)
+                  nearb &= ~(~1ull << i2);                                   // begin comparisons up to and including i2, end comparisons from it
+                  neare &= ~0ull << i2;
+                } else neare = 0;
+              } else nearb = 0;
+              if (phase == 3 && me) {
+                const int i3 = __builtin_ctzll(me);
+                margin += __builtin_popcountll(nearb) + __builtin_popcountll(neare & ~(~1ull << i3));
+                lim = p0 + i3 - q; ok = 1; stop = 1;
+                break;
               }
-              if (phase == 3 && me) { lim = p0 + __builtin_ctzll(me) - q; ok = 1; stop = 1; break; }
+              margin += __builtin_popcountll(nearb) + __builtin_popcountll(neare);
             }
             ACQ_T(3)
           }
@@ -387,7 +400,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
         ACQ_T(4) }
         if (stop) {
           const float pkw = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, pk), [](unsigned x, unsigned y) { return x > y ? x : y; }));
-          if (lane == 0) { w.consumed = P + (unsigned)q; w.s_final = Sb[3 + q]; w.pk = pkw; w.ok = ok; w.done = 1; }
+          if (lane == 0) { w.consumed = P + (unsigned)q; w.s_final = Sb[3 + q]; w.pk = pkw; w.ok = ok; w.margin = margin; w.done = 1; }
         }
       }
     } else {
@@ -407,6 +420,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   if (tid == 0) {
     c.rd = rd0 + w.consumed;           // frequency offset is 0 while searching: NCO phase unchanged
     c.s_level = w.s_final; c.peak_level = fmaxf(c.peak_level, w.pk);
+    c.level_margin += w.margin;
     c.sample_count = 0;
     c.sync_thr = e.threshold;
     c.clock_err = 0.0f;
@@ -421,21 +435,25 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
 // start-up the level is still far from settled (it starts at 0.1) and the null-dip detector of the next attempt compares
 // against it.  buf: >= T_u floats of LDS (16-byte aligned), red: >= 8.  The caller changes c.state.
 __device__ __forceinline__ void sync_failed(EngineDev &e, int s, int tid, const RingView &rv, unsigned long long rd, int phase0, int f,
-                                            float *buf, float *red)
+                                            float *buf, float *red, bool track_level)
 {
   StreamCtl &c = e.ctl[s];
   float pk = 0.f;
+  if (track_level) {                                       // (not the frame chain with cfg.exact_level_tracker: k_level_exact walks everything it reads)
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
-    const float2 x = rv.at(tid + 256 * u);
-    const float a = sqrtf(x.x * x.x + x.y * x.y);
-    buf[tid + 256 * u] = a;
-    pk = fmaxf(pk, a);
+    for (int u = 0; u < 8; u++) {
+      const float2 x = rv.at(tid + 256 * u);
+      const float a = sqrtf(x.x * x.x + x.y * x.y);
+      buf[tid + 256 * u] = a;
+      pk = fmaxf(pk, a);
+    }
+    pk = block_max_nonneg(pk, red, tid);                   // (its barriers also publish buf)
   }
-  pk = block_max_nonneg(pk, red, tid);                     // (its barriers also publish buf)
   if (tid == 0) {
-    c.s_level = level_walk(buf, TU, c.s_level);
-    c.peak_level = fmaxf(c.peak_level, pk);
+    if (track_level) {
+      c.s_level = level_walk(buf, TU, c.s_level);
+      c.peak_level = fmaxf(c.peak_level, pk);
+    }
     c.rd = rd + TU;
     c.nco_phase = nco_advance(phase0, f, TU);
     c.sync_lost++;
@@ -468,7 +486,10 @@ __global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, in
     // The search resets the demapper (dab_processor.cpp:146-153).  The MSC symbols of the stream's last frame may still be going
     // through it on their own HIP stream: then this pass is skipped (no new launch for the stream can start while it is out of lock)
     const int busy = e.demap_busy ? __hip_atomic_load(&e.demap_busy[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    w.flag[0] = (st0 != ST_EVAL_SYNC && !busy) ? 1 : 0;
+    // cfg.exact_level_tracker: the search continues the level where k_level_exact (in front of this kernel on the same HIP stream)
+    // left it -- which must be where the stream stands (a correlation that failed in between has moved rd: next pass)
+    const int behind = e.exact_level ? (e.level_pos[s] != c.rd) : 0;
+    w.flag[0] = (st0 != ST_EVAL_SYNC && !busy && !behind) ? 1 : 0;
     w.flag[1] = st0;
     s_wr = e.wr[s];
   }
@@ -498,11 +519,12 @@ __global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, in
     const int start = prs_correlate_block(v, c.sync_thr, e.strongest, t, lds, peak, red, tid);   // dab_processor.cpp:394
     __syncthreads();
     if (start >= 0) break;
-    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red);
+    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red, true);
     new_state = ST_WAIT_SYNC;
     if (wr - c.rd < (unsigned long long)(ACQ_NEED + FRAME_NEED)) break;
   }
   if (new_state < 0) return;
+  if (tid == 0 && e.exact_level) e.level_pos[s] = c.rd;    // every sample read here went through the level tracker
   __threadfence();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(&c.state, new_state, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, 
   __syncthreads();
   if (start < 0) {
     // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER: the stream goes over to k_acquire
-    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red);
+    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red, !e.exact_level);
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&c.state, (int)ST_WAIT_SYNC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1136,20 +1158,26 @@ __global__ __launch_bounds__(64) void k_level_exact(EngineDev e)
 {
   const int s = blockIdx.x, lane = threadIdx.x;
   StreamCtl &c = e.ctl[s];
-  if (!c.frame_ok) return;
   constexpr int CH = 1024;
   __shared__ __attribute__((aligned(16))) float chunk[2][CH];
-  const unsigned long long rd0 = c.sym0_pos - (unsigned long long)c.start_index;   // k_frame_tail has moved c.rd to the frame's end
-  const unsigned n = (unsigned)(c.rd - rd0);
+  // Everything the receiver has read that the tracker has not seen: [level_pos, rd) -- in lock the frame chain moves rd (k_frame_tail;
+  // k_frame_head by T_u on a failed correlation), out of lock k_acquire tracks the level itself and moves level_pos along.  The
+  // kernel runs next to the frame chain (its own HIP stream, or in front of k_acquire in step): whatever value of rd it sees is a
+  // point the receiver has reached; dabx_synchronize and every read-out run it once more behind the last frame.
+  const unsigned long long rd0 = e.level_pos[s];
+  const unsigned long long rd1 = __hip_atomic_load(&c.rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (rd1 <= rd0) return;
+  const unsigned long long n = rd1 - rd0;
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
-  const unsigned len = (unsigned)e.ring_len, base = (unsigned)(rd0 % (unsigned long long)e.ring_len);
-  auto mags = [&](unsigned p0, float *dst) {               // |x| of samples [p0, p0 + CH) (0 beyond n)
+  const unsigned len = (unsigned)e.ring_len;
+  auto mags = [&](unsigned long long p0, float *dst) {      // |x| of samples [p0, p0 + CH) (0 beyond n)
+    const unsigned o0 = (unsigned)((rd0 + p0) % len);
 #pragma unroll
     for (int q = 0; q < CH / 64; q++) {
-      const unsigned i = p0 + lane + 64 * q;
+      const unsigned i = lane + 64 * q;
       float a = 0.f;
-      if (i < n) {
-        unsigned o = base + i; if (o >= len) o -= len;
+      if (p0 + i < n) {
+        unsigned o = o0 + i; if (o >= len) o -= len;
         const float2 v = ring[o];
         a = sqrtf(v.x * v.x + v.y * v.y);
       }
@@ -1159,9 +1187,10 @@ __global__ __launch_bounds__(64) void k_level_exact(EngineDev e)
   float lv = c.s_level, pk = c.peak_level;
   mags(0, chunk[0]);
   __syncthreads();
-  for (unsigned p0 = 0, b = 0; p0 < n; p0 += CH, b ^= 1) {
+  unsigned b = 0;
+  for (unsigned long long p0 = 0; p0 < n; p0 += CH, b ^= 1) {
     if (p0 + CH < n) mags(p0 + CH, chunk[b ^ 1]);          // the next chunk's loads and square roots are issued ahead of the walk
-    const unsigned m = n - p0 < CH ? n - p0 : CH;
+    const unsigned m = n - p0 < CH ? (unsigned)(n - p0) : CH;
     const float4 *src = reinterpret_cast<const float4 *>(chunk[b]);
     unsigned i = 0;
     for (; i + 4 <= m; i += 4) {
@@ -1182,7 +1211,13 @@ __global__ __launch_bounds__(64) void k_level_exact(EngineDev e)
     }
     __syncthreads();
   }
-  if (lane == 0) { c.s_level = lv; c.peak_level = pk; }
+  if (lane == 0) { c.s_level = lv; c.peak_level = pk; e.level_pos[s] = rd1; }
+}
+int launch_level_exact(const EngineDev &e, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, st, e);
+  DABX_HIP(hipGetLastError());
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------- MSC
@@ -1468,18 +1503,23 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   hipStream_t st = ss.a;
   // Streams out of lock (k_acquire).  In step: on the front-end stream, before the frame head -- every step then offers every
   // stream a frame's worth of search.  Asynchronous: on HIP stream q; a pass is launched when the previous one has finished
-  // (hipEventQuery, no wait), with the steps that went by meanwhile as its budget (at most two frames of samples per pass).
+  // (hipEventQuery, no wait); a pass is a frame's worth of samples.
+  // cfg.exact_level_tracker: k_level_exact in front of every pass (same HIP stream); then the passes are never skipped -- the frame
+  // chain lets the tracker fall one step behind at most (the samples it still has to see must stay in the ring), so the exact
+  // tracker costs max(0, its 1.6 ms per frame - the step) of the step instead of adding to it.
   if (async_acquire && ss.q) {
-    ss.acq_credit = ss.acq_credit < 2 ? ss.acq_credit + 1 : 2;
-    if (!ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess) {
-      mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, ss.acq_credit); mk.end(0, ss.q);
+    bool go = true;
+    if (e.exact_level) { if (ss.acq_in_flight) DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); }
+    else go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
+    if (go) {
+      if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, ss.q, e);
+      mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, 1); mk.end(0, ss.q);
       DABX_HIP(hipEventRecord(ss.acq_done, ss.q));
       ss.acq_in_flight = true;
-      ss.acq_credit = 0;
     }
   } else {
     if (ss.acq_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); ss.acq_in_flight = false; }   // a pass of an earlier, asynchronous call
-    ss.acq_credit = 0;
+    if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, st, e);
     mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, st, e, *t, 1); mk.end(0, st);
   }
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
@@ -1516,7 +1556,6 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   }
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
-  if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, st, e);
   DABX_HIP(hipGetLastError());
   return 0;
 }

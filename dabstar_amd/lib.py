@@ -295,7 +295,8 @@ class Stats(C.Structure):
                 ("last_start_index", C.c_int32), ("cif_count", C.c_int32),
                 ("fib_ok", C.c_int64), ("fib_total", C.c_int64), ("sf_ok", C.c_int64), ("sf_fail", C.c_int64),
                 ("rs_corrected", C.c_int64), ("rs_failed", C.c_int64), ("au_ok", C.c_int64), ("au_bad", C.c_int64),
-                ("cifs_decoded", C.c_int64), ("signal_level", C.c_float), ("peak_level", C.c_float)]
+                ("cifs_decoded", C.c_int64), ("signal_level", C.c_float), ("peak_level", C.c_float),
+                ("level_margin_events", C.c_int64), ("reserved", C.c_int64 * 7)]
 
 
 COUNTER_NAMES = ["frames", "samples", "fib_ok", "fib_total", "sync_lost", "streams_locked", "cifs_decoded", "sf_ok", "sf_fail",
@@ -459,8 +460,8 @@ class Engine:
 
     def stats(self, stream):
         st = Stats()
-        check(load().dabx_get_stats(self._h, stream, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in Stats._fields_}
+        check(load().dabx_get_stats_sized(self._h, stream, C.byref(st), C.c_size_t(C.sizeof(st))))
+        return {k: getattr(st, k) for k, _ in Stats._fields_ if k != "reserved"}
 
     def counters(self):
         out = (C.c_int64 * 16)()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DABX_ABI_VERSION 3
+#define DABX_ABI_VERSION 4
 
 typedef enum {
   DABX_OK = 0,
@@ -258,6 +258,11 @@ typedef struct {
   int64_t fib_ok, fib_total, sf_ok, sf_fail, rs_corrected, rs_failed, au_ok, au_bad, cifs_decoded;
   float   signal_level;      /* SampleReader::sLevel (sample_reader.h:70,95; .cpp:245-248) after the newest frame */
   float   peak_level;        /* SampleReader::peakLevel (.cpp:247); tracked out of lock and, with exact_level_tracker, in lock */
+  /* -- ABI 4 (everything above is the ABI-3 record) -- */
+  int64_t level_margin_events; /* null-symbol search: comparisons level/50 <> 0.55 / 0.75 sLevel (timesyncer.cpp:58, 74) that fell within
+                                1e-4 (relative) of their threshold, i.e. that the default (chunk-wise, ~1e-5) in-lock level tracker
+                                could conceivably have decided differently from the sample-serial one; 0 = the approximation never mattered */
+  int64_t reserved[7];       /* zero; later fields go here without changing the record's size */
 } dabx_stats;
 
 void dabx_default_config(dabx_config *cfg);
@@ -337,7 +342,13 @@ int  dabx_read_msc(dabx_engine *e, int stream, int subch_idx, int n_cifs, uint8_
 /* RS-corrected DAB+ super frames (110*kbps/8 bytes each), newest last; returns count copied. */
 int  dabx_read_superframes(dabx_engine *e, int stream, int subch_idx, int n, uint8_t *bytes);
 int  dabx_read_soft(dabx_engine *e, int stream, int16_t *soft /* 75*3072 */);
+/* dabx_get_stats_sized fills the first `size` bytes of a dabx_stats.  dabx_get_stats is that call with the caller's own
+ * sizeof -- as a macro, so that a binary and the library never disagree about how much is written; the exported function of the
+ * same name is what binaries built against ABI 3 call and writes the ABI-3 record only.  Hosts that load the library at run time
+ * compare dabx_abi_version() with the DABX_ABI_VERSION they were built against (shim/dabx_shim_env.h does). */
+int  dabx_get_stats_sized(dabx_engine *e, int stream, void *out, size_t size);
 int  dabx_get_stats(dabx_engine *e, int stream, dabx_stats *out);
+#define dabx_get_stats(e, stream, out) dabx_get_stats_sized((e), (stream), (out), sizeof(*(out)))
 /* Per-slot counters (Backend / Mp4Processor members: backend.cpp:146-150 warm-up, mp4processor.h:106-112 signals). */
 typedef struct dabx_subch_stats_s {
   int64_t start_cif;         /* CIF index (since open) at which the slot was configured */

@@ -38,3 +38,16 @@ inline void dabx_shim_check(int rc, const char * what)
   std::fprintf(stderr, "dabx shim: %s failed (%d): %s\n", what, rc, dabx_last_error());
   std::abort();
 }
+
+/* The shims are compiled against include/dabx.h; the library is found at run time.  Records such as dabx_stats and dabx_config
+ * grow with the ABI version: a library of another version than the header is refused before the first object is created. */
+inline void dabx_shim_check_abi()
+{
+  static const bool ok = [] {
+    if (dabx_abi_version() == DABX_ABI_VERSION) return true;
+    std::fprintf(stderr, "dabx shim: built against libdabx ABI %d, the library loaded is ABI %d\n", DABX_ABI_VERSION, dabx_abi_version());
+    std::abort();
+    return false;
+  }();
+  (void)ok;
+}

@@ -18,6 +18,7 @@ class FicDecoder : public QObject
 public:
   explicit FicDecoder(DabRadio * iMr) : mpFibDecoder(FibDecoderFactory::create(iMr))
   {
+    dabx_shim_check_abi();
     dabx_shim_check(dabx_fic_create(&mpFic), "dabx_fic_create");
     dabx_shim_check(dabx_fic_stop(mpFic), "dabx_fic_stop");        // mIsRunning{false} until restart(), fic_decoder.h:77
     dabx_shim_connect_gui(iMr);                                    // fic_decoder.cpp:126

@@ -13,6 +13,7 @@ class MscHandler
 public:
   MscHandler(DabRadio * ipRadio, RingBuffer<u8> * ipFrameBuffer) : mpRadioInterface(ipRadio), mpFrameBuffer(ipFrameBuffer)
   {
+    dabx_shim_check_abi();
     dabx_shim_check(dabx_msc_create(cMaxServices, &mpMsc), "dabx_msc_create");
   }
   ~MscHandler() { dabx_msc_destroy(mpMsc); }

@@ -20,6 +20,7 @@ public:
   OfdmDecoder(DabRadio * ipRadio, RingBuffer<cf32> * ipIqBuffer, RingBuffer<f32> * ipCarrBuffer)
     : mpRadioInterface(ipRadio), mpIqBuffer(ipIqBuffer), mpCarrBuffer(ipCarrBuffer)
   {
+    dabx_shim_check_abi();
     dabx_shim_check(dabx_demap_create(1, &mpDemap), "dabx_demap_create");
     dabx_shim_connect_gui();      // ofdm_decoder.cpp:60-61 (defined in shim/dab_hip_gui.cpp in the reference tree)
   }

@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.dabx_abi_version() == 3
+    assert L.dabx_abi_version() == 4
 
 
 def test_fails_loudly_without_device():

@@ -29,6 +29,7 @@ for what in "$@"; do
              python3 bench.py $cfg --no-cpu-baseline 2>/dev/null | line "$cfg ->"; done > $OUT/variants.txt 2>&1; cat $OUT/variants.txt ;;
     # streams out of lock next to streams in lock: interleaved pairs, the driver's form
     unlocked) for r in 1 2 3; do for u in 0 8 64; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --unlocked $u 2>/dev/null | tee $OUT/unlocked_${u}_$r.json | line "unlocked $u"; done; done > $OUT/unlocked.txt 2>&1; cat $OUT/unlocked.txt ;;
+    exactlevel) for r in 1 2 3; do for x in "" "--exact-level"; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $x 2>/dev/null | tee $OUT/exact_level_${x:2:5}_$r.json | line "exact_level[$x]"; done; done > $OUT/exact_level.txt 2>&1; cat $OUT/exact_level.txt ;;
     acqtime) python3 tools/acq_time.py 8 > $OUT/acq_time_8.jsonl 2>&1; python3 tools/acq_time.py 512 > $OUT/acq_time_512.jsonl 2>&1; cat $OUT/acq_time_8.jsonl $OUT/acq_time_512.jsonl ;;
     acqphases) DABX_LIB=$(realpath dabstar_amd/_ab/libdabx_acqtime.so) python3 tools/acq_time.py 8 2>&1 | grep -E "^acq wave|case" | head -40 > $OUT/acq_phases.txt; cat $OUT/acq_phases.txt ;;
     walkbench) tools/_build/acq_walk_bench > $OUT/acq_walk_bench.jsonl 2>&1; cat $OUT/acq_walk_bench.jsonl ;;
