@@ -269,8 +269,12 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
     // streams out of lock are searched on q next to the steps of the others (dabx_process with sync == 0)
-    H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, prio_lo));
+    // With the exact level tracker every stream has a block on q in every step (two lone waves for 1.6 ms): at the lowest queue
+    // priority those blocks were dispatched only into the gaps the frame chain's kernels left (5 ms per step); at the chain's own
+    // priority they are resident from the start of the step.
+    H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, cfg->exact_level_tracker ? prio_hi : prio_lo));
     H(hipEventCreateWithFlags(&e->ss.acq_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.tail_done, hipEventDisableTiming | hipEventReleaseToDevice));
   }
   H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
   H(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
@@ -361,6 +365,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.demap_done) (void)hipEventDestroy(e->ss.demap_done);
   if (e->ss.q) { (void)hipStreamSynchronize(e->ss.q); (void)hipStreamDestroy(e->ss.q); }
   if (e->ss.acq_done) (void)hipEventDestroy(e->ss.acq_done);
+  if (e->ss.tail_done) (void)hipEventDestroy(e->ss.tail_done);
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);

@@ -142,7 +142,8 @@ struct MscLaunch { int n, groups; MscLaunchCls c[MSC_MAX_CLASSES]; };
 struct EngineStreams {
   hipStream_t a = nullptr, b = nullptr, d = nullptr;   // d: demapper of the MSC symbols of the frame in flight; b, d null = serial schedule
   hipStream_t q = nullptr;                             // k_acquire of dabx_process(sync == 0): streams out of lock are searched next to the steps of the others
-  hipEvent_t acq_done = nullptr;
+  hipEvent_t acq_done = nullptr, tail_done = nullptr;  // tail_done: the frame chain of the last step has moved the read cursors (exact level tracker)
+  bool tail_recorded = false;
   bool acq_in_flight = false;                          // a pass on q may still be running
   hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step

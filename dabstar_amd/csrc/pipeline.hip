@@ -181,7 +181,7 @@ int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
 // and tests  level / 50 > 0.55 sLevel  (dip begins)  /  level / 50 < 0.75 sLevel  (dip ends)  BEFORE it reads the next sample.
 // Only the two recurrences are serial, and sLevel -- three dependent float operations per sample -- depends on nothing but
 // the samples.  So the four waves of the block form a pipeline over blocks of 1024 samples, one barrier per block:
-//   wave 0, one lane: sLevel over block i, operands and results as 16-byte LDS accesses -- it never waits for anything else
+//   wave 0:           sLevel over block i (every lane the same walk), operands and results as 16-byte LDS accesses -- it never waits for anything else
 //                     and sets the pace (acq_walk_S: ~24 cycles per sample for a lone wave, tools/acq_walk_bench.hip);
 //   wave 1:           everything else about block i - 1: the moving sum's increments d[n] = |x[n]| - |x[n - 50]| (64 lanes, the
 //                     same float subtraction), level (one lane, one add per sample), then the two comparisons of all 1024
@@ -209,16 +209,17 @@ struct AcqLds {
   int flag[4];
 };
 
-// sLevel alone over m samples (the T_u window of a failed correlation): loads only, the compiler's loop is as fast as the chain
+// sLevel alone over m samples, m a multiple of 16 (the T_u window of a failed correlation; k_frame_head has no room for acq_walk_S's
+// registers): sixteen operands are requested before the first is used, so that one LDS latency is paid per 16 samples, not per 4
 __device__ __forceinline__ float level_walk(const float *__restrict__ a, int m, float S)
 {
   const float4 *a4 = reinterpret_cast<const float4 *>(a);
-  for (int i = 0; i < (m >> 2); i++) {
-    const float4 av = a4[i];
-    S += 0.00001f * (av.x - S);
-    S += 0.00001f * (av.y - S);
-    S += 0.00001f * (av.z - S);
-    S += 0.00001f * (av.w - S);
+  for (int i = 0; i < (m >> 2); i += 4) {
+    const float4 v0 = a4[i], v1 = a4[i + 1], v2 = a4[i + 2], v3 = a4[i + 3];
+    asm volatile("" ::: "memory");
+#define DABX_LV4(v) S += 0.00001f * (v.x - S); S += 0.00001f * (v.y - S); S += 0.00001f * (v.z - S); S += 0.00001f * (v.w - S);
+    DABX_LV4(v0) DABX_LV4(v1) DABX_LV4(v2) DABX_LV4(v3)
+#undef DABX_LV4
   }
   return S;
 }
@@ -311,12 +312,12 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   int i = 0;
   for (;; i++) {
     if (wave == 0) {
-      if (lane == 0) {
-        ACQ_T0
-        w.S[i & 1][3] = S;
-        S = acq_walk_S(w.a[i % 3] + 64, w.S[i & 1] + 4, ACQ_CH / 16, S);
-        ACQ_T(0)
-      }
+      // every lane walks (same addresses, same values): with a single lane active, two such waves on one CU -- two streams
+      // searching -- slow each other down to half speed; with the full wave they do not (tools/acq_walk_bench.hip, 512 blocks)
+      ACQ_T0
+      w.S[i & 1][3] = S;
+      S = acq_walk_S(w.a[i % 3] + 64, w.S[i & 1] + 4, ACQ_CH / 16, S);
+      ACQ_T(0)
     } else if (wave == 1) {
       if (i > 0) {
         const int jb = i - 1;
@@ -342,10 +343,9 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
               }
             ACQ_T(1) }
             { ACQ_T0
-            if (lane == 0) {
-              w.L[3 + q] = L;
-              acq_walk_L(db + q16, w.L + 4 + q16, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L);
-            }
+            __builtin_amdgcn_wave_barrier();
+            w.L[3 + q] = L;
+            acq_walk_L(db + q16, w.L + 4 + q16, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L);
             __builtin_amdgcn_wave_barrier();
             ACQ_T(2) }
             ACQ_T0
@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, in
   __shared__ unsigned long long s_wr;
   const int s = blockIdx.x, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
+  front_prio();                                            // four lone waves per stream: almost no issue slots, but the ones they need, at once
   if (tid == 0) {                                          // one thread looks, everyone follows (a flag that flips meanwhile must not split the block)
     const int st0 = __hip_atomic_load(&c.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     // The search resets the demapper (dab_processor.cpp:146-153).  The MSC symbols of the stream's last frame may still be going
@@ -1154,68 +1155,74 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
 // per sample, 196 104 + start_index samples per frame: one wave per stream computes |x| for 1024 samples at a time into LDS
 // (all lanes) and then walks them (every lane redundantly: LDS broadcast reads, no divergence).  About 1.5 ms per frame,
 // more than the rest of the receiver together -- which is why the default advances the tracker chunk-wise (k_frame_tail).
-__global__ __launch_bounds__(64) void k_level_exact(EngineDev e)
+__global__ __launch_bounds__(128) void k_level_exact(EngineDev e)
 {
-  const int s = blockIdx.x, lane = threadIdx.x;
+  front_prio();                          // two lone waves per stream that issue an instruction every few cycles: they must not queue behind the decoder's
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   StreamCtl &c = e.ctl[s];
   constexpr int CH = 1024;
-  __shared__ __attribute__((aligned(16))) float chunk[2][CH];
+  __shared__ __attribute__((aligned(16))) float chunk[2][CH + 32];   // (+ what acq_walk_S reads ahead)
   // Everything the receiver has read that the tracker has not seen: [level_pos, rd) -- in lock the frame chain moves rd (k_frame_tail;
   // k_frame_head by T_u on a failed correlation), out of lock k_acquire tracks the level itself and moves level_pos along.  The
   // kernel runs next to the frame chain (its own HIP stream, or in front of k_acquire in step): whatever value of rd it sees is a
   // point the receiver has reached; dabx_synchronize and every read-out run it once more behind the last frame.
+  // Wave 0 walks chunk k out of LDS; wave 1 meanwhile turns the samples of chunk k + 1 -- requested a whole chunk
+  // earlier, so that their HBM latency next to the frame chain's traffic (several microseconds) stays behind the walk -- into
+  // magnitudes and requests chunk k + 2.  (With one wave doing both, every chunk began by waiting for its own loads: 5.5 ms per
+  // frame next to the frame chain instead of 1.6.)
   const unsigned long long rd0 = e.level_pos[s];
   const unsigned long long rd1 = __hip_atomic_load(&c.rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (rd1 <= rd0) return;
   const unsigned long long n = rd1 - rd0;
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
   const unsigned len = (unsigned)e.ring_len;
-  auto mags = [&](unsigned long long p0, float *dst) {      // |x| of samples [p0, p0 + CH) (0 beyond n)
+  float2 raw[CH / 64];
+  __shared__ float s_pk;
+  auto request = [&](unsigned long long p0) {               // samples [p0, p0 + CH) into registers (zeros beyond n)
     const unsigned o0 = (unsigned)((rd0 + p0) % len);
 #pragma unroll
     for (int q = 0; q < CH / 64; q++) {
       const unsigned i = lane + 64 * q;
-      float a = 0.f;
-      if (p0 + i < n) {
-        unsigned o = o0 + i; if (o >= len) o -= len;
-        const float2 v = ring[o];
-        a = sqrtf(v.x * v.x + v.y * v.y);
-      }
-      dst[lane + 64 * q] = a;
+      unsigned o = o0 + i; if (o >= len) o -= len;
+      raw[q] = p0 + i < n ? ring[o] : make_float2(0.f, 0.f);
     }
   };
-  float lv = c.s_level, pk = c.peak_level;
-  mags(0, chunk[0]);
+  float pk = 0.f;                                            // peakLevel is a maximum: taken by the wave that makes the magnitudes
+  auto publish = [&](float *dst) {
+#pragma unroll
+    for (int q = 0; q < CH / 64; q++) {
+      const float a = sqrtf(raw[q].x * raw[q].x + raw[q].y * raw[q].y);
+      dst[lane + 64 * q] = a;
+      pk = fmaxf(pk, a);
+    }
+  };
+  float lv = c.s_level;
+  if (wave == 1) { request(0); publish(chunk[0]); request(CH); }
   __syncthreads();
   unsigned b = 0;
   for (unsigned long long p0 = 0; p0 < n; p0 += CH, b ^= 1) {
-    if (p0 + CH < n) mags(p0 + CH, chunk[b ^ 1]);          // the next chunk's loads and square roots are issued ahead of the walk
-    const unsigned m = n - p0 < CH ? (unsigned)(n - p0) : CH;
-    const float4 *src = reinterpret_cast<const float4 *>(chunk[b]);
-    unsigned i = 0;
-    for (; i + 4 <= m; i += 4) {
-      const float4 a = src[i >> 2];
-      if (a.x > pk) pk = a.x;
-      lv += 0.00001f * (a.x - lv);
-      if (a.y > pk) pk = a.y;
-      lv += 0.00001f * (a.y - lv);
-      if (a.z > pk) pk = a.z;
-      lv += 0.00001f * (a.z - lv);
-      if (a.w > pk) pk = a.w;
-      lv += 0.00001f * (a.w - lv);
-    }
-    for (; i < m; i++) {
-      const float a = chunk[b][i];
-      if (a > pk) pk = a;
-      lv += 0.00001f * (a - lv);
+    if (wave == 1) {
+      publish(chunk[b ^ 1]);                               // chunk k + 1: requested one walk ago
+      request(p0 + 2 * CH);
+    } else {                                                 // every lane of the wave walks: see acquire_stream
+      const unsigned m = n - p0 < CH ? (unsigned)(n - p0) : CH;
+      const int n16 = __builtin_amdgcn_readfirstlane((int)(m >> 4));
+      if (n16 > 0) lv = acq_walk_S_only(chunk[b], n16, lv);
+      for (unsigned i = 16u * (unsigned)n16; i < m; i++) lv += 0.00001f * (chunk[b][i] - lv);
     }
     __syncthreads();
   }
-  if (lane == 0) { c.s_level = lv; c.peak_level = pk; e.level_pos[s] = rd1; }
+  if (wave == 1) {
+    pk = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, pk), [](unsigned x, unsigned y) { return x > y ? x : y; }));
+    if (lane == 0) s_pk = pk;
+  }
+  __syncthreads();
+  if (tid == 0) { c.s_level = lv; c.peak_level = fmaxf(c.peak_level, s_pk); e.level_pos[s] = rd1; }
 }
 int launch_level_exact(const EngineDev &e, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, st, e);
+  hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, st, e);
   DABX_HIP(hipGetLastError());
   return 0;
 }
@@ -1512,14 +1519,18 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
     if (e.exact_level) { if (ss.acq_in_flight) DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); }
     else go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
     if (go) {
-      if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, ss.q, e);
+      if (e.exact_level) {
+        // the tracker of step n walks the frame of step n - 1 while the chain demodulates frame n: behind that chain's tail, not before
+        if (ss.tail_recorded) DABX_HIP(hipStreamWaitEvent(ss.q, ss.tail_done, 0));
+        hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, ss.q, e);
+      }
       mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, 1); mk.end(0, ss.q);
       DABX_HIP(hipEventRecord(ss.acq_done, ss.q));
       ss.acq_in_flight = true;
     }
   } else {
     if (ss.acq_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); ss.acq_in_flight = false; }   // a pass of an earlier, asynchronous call
-    if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(64), 0, st, e);
+    if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, st, e);
     mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, st, e, *t, 1); mk.end(0, st);
   }
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
@@ -1556,6 +1567,7 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   }
   mk.begin(4, st); hipLaunchKernelGGL(k_fic_frame, dim3(e.n_streams), dim3(256), 0, st, e, *t, 0, 4); mk.end(4, st);
   mk.begin(5, st); hipLaunchKernelGGL(k_frame_tail, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(5, st);
+  if (e.exact_level && ss.tail_done) { DABX_HIP(hipEventRecord(ss.tail_done, st)); ss.tail_recorded = true; }
   DABX_HIP(hipGetLastError());
   return 0;
 }

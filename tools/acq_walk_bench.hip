@@ -94,19 +94,24 @@ __global__ __launch_bounds__(256) void k_walk(const float *src, float *dst, int 
   }
   __syncthreads();
   float S = 0.1f, L = 0.f;
-  if (tid == 0) {
+  // variants 7..9: the same loops with ALL 64 lanes of the wave active (every lane redundantly; same-address LDS accesses)
+  if (V >= 7 ? tid < 64 : tid == 0) {
     for (int r = 0; r < reps; r++) {
       if (V == 1) walk_sep(a, d, So, Lo, CH, S, L);
       if (V == 2) walk_pairs(ad, ls, CH, S, L);
       if (V == 3) walk_sep_pipelined(a, d, So, Lo, CH, S, L);
       if (V == 4) walk_s_only(a, CH, S);
-      if (V == 5) S = dabx::acq_walk_S(a, So, CH / 16, S);
+      if (V == 5 || V == 8) S = dabx::acq_walk_S(a, So, CH / 16, S);
+      if (V == 7) walk_s_only(a, CH, S);
+      if (V == 10) S = dabx::acq_walk_S_only(a, CH / 16, S);
+      if (V == 9) { dabx::acq_walk_L(d, Lo, CH / 16, L); L = Lo[CH - 1]; }
       if (V == 6) { dabx::acq_walk_L(d, Lo, CH / 16, L); L = Lo[CH - 1]; }
       asm volatile("" ::: "memory");
     }
-    dst[blockIdx.x * 4 + 0] = S; dst[blockIdx.x * 4 + 1] = L;
-    dst[blockIdx.x * 4 + 2] = (V == 2) ? ls[CH - 1].y : So[CH - 1];
-    dst[blockIdx.x * 4 + 3] = (V == 2) ? ls[CH - 1].x : Lo[CH - 1];
+    if (tid == 0) { dst[blockIdx.x * 4 + 0] = S; dst[blockIdx.x * 4 + 1] = L; }
+    if (tid == 0)
+    { dst[blockIdx.x * 4 + 2] = (V == 2) ? ls[CH - 1].y : So[CH - 1];
+      dst[blockIdx.x * 4 + 3] = (V == 2) ? ls[CH - 1].x : Lo[CH - 1]; }
   }
 }
 
@@ -145,6 +150,10 @@ int main()
     run<4>("S only, no stores", src, dst, blocks);
     run<5>("acq_walk_S (asm: 16 samples per iteration, counted waits)", src, dst, blocks);
     run<6>("acq_walk_L (asm)", src, dst, blocks);
+    run<7>("S only, no stores, all 64 lanes active", src, dst, blocks);
+    run<8>("acq_walk_S (asm), all 64 lanes active", src, dst, blocks);
+    run<9>("acq_walk_L (asm), all 64 lanes active", src, dst, blocks);
+    run<10>("acq_walk_S_only (asm, no stores), all 64 lanes active", src, dst, blocks);
   }
   return 0;
 }
