@@ -29,6 +29,10 @@ extern "C" {
 
 const char *dabx_last_error(void) { return dabx::last_error(); }
 int dabx_abi_version(void) { return DABX_ABI_VERSION; }
+#ifndef DABX_HIPMODULE
+// 0: the kernels are in this library's fat binary (default build); 1 in the hipModule form (csrc/hipmodule/hipmodule_rt.cpp)
+int dabx_internal_hipmodule(void) { return 0; }
+#endif
 int dabx_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 int dabx_set_device(int device)
 {

@@ -16,7 +16,7 @@ for what in "$@"; do
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     bench20) python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; cat $OUT/bench20.json ;;
     ab)    bash tools/ab.sh $OUT/ab ${AB_REPS:-3} ${AB_CFGS} > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
-    prof)  bash tools/prof_round.sh $TAG > $OUT/prof_round.log 2>&1; tail -3 $OUT/prof_round.log ;;
+    prof)  bash tools/prof_round.sh $TAG ${PROF_COMMIT:-unknown} > $OUT/prof_round.log 2>&1; tail -3 $OUT/prof_round.log ;;
     pmc)   bash tools/prof_pmc2.sh $OUT/pmc "${PMC_KERNELS:-k_demap_frame6|k_symbols_persistent|k_demap_fic}" > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
     ingest) python3 tools/bench_ingest.py > $OUT/ingest.json 2> $OUT/ingest.err; tail -5 $OUT/ingest.json ;;
     fuzz)  python3 tools/fuzz_hunt.py --seeds ${FUZZ_SEEDS:-4000:4030} > $OUT/fuzz_log.jsonl 2> $OUT/fuzz.err; tail -2 $OUT/fuzz_log.jsonl ;;

@@ -4,14 +4,16 @@
 # FETCH_SIZE correction per kernel from the calibration of tools/fetch_calib.hip (profiles/r02_fetch_calib.json): the counter
 # reads 0.5 of the bytes for coalesced 4 / 8 / 16-byte-per-lane streams and 256-B rows (x2) but 1.0 for k_msc_prep's
 # 64-byte runs, one HBM line each (x1); WRITE_SIZE is exact for the coalesced patterns.
-# Usage: tools/prof_round.sh <tag>      -> gpurun_out/<tag>/...
-TAG=${1:-r03}
+# Usage: tools/prof_round.sh <tag> [commit]      -> gpurun_out/<tag>/...   (commit: `git rev-parse --short HEAD` of what is measured --
+#        .git does not travel to the GPU box; it is written into traffic.json and printed by bench.py as roofline.traffic_commit)
+TAG=${1:-r04}
+export DABX_PROF_COMMIT=${2:-unknown}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/stats_bench.log 2>&1
-FILT="k_msc_vitT|k_msc_prep|k_demap_frame|k_demap_fic|k_symbols|k_dabplus|k_fic_frame|k_frame_head|k_frame_tail"
+FILT="k_msc_vitT|k_msc_prep|k_demap_frame|k_demap_fic|k_symbols|k_dabplus|k_fic_frame|k_frame_head|k_frame_tail|k_acquire"
 ARGS="--steps 14 --warmup 7 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
   --kernel-include-regex "$FILT" -d $OUT/p1 --output-format csv -- python3 bench.py $ARGS > $OUT/p1.log 2>&1
@@ -21,7 +23,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$FILT" -d $OUT
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$FILT" -d $OUT/p4 --output-format csv -- python3 bench.py $ARGS > $OUT/p4.log 2>&1
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, json, collections, re
+import csv, glob, sys, json, collections, re, os
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p[134]/**/*counter_collection.csv", recursive=True):
@@ -41,6 +43,7 @@ for k, v in acc.items():
 tot = sum(v["hbm_bytes_per_launch"] / (7 if (k.startswith("k_msc") or k == "k_dabplus") else 1) for k, v in res.items())
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, mean over full-size launches; FETCH_SIZE x fetch_correction "
                    "(profiles/r02_fetch_calib.json: 0.5 counted for coalesced streams -> x2, exact for k_msc_prep's 64-B runs -> x1); SQ_INSTS_VALU = wave-level VALU instructions",
+           "commit": os.environ.get("DABX_PROF_COMMIT", "unknown"),
            "streams": 512, "chain_hbm_bytes_per_step": tot, "kernels": res}, open(out + "/traffic.json", "w"), indent=1)
 PY
 cat $OUT/bench.json
