@@ -31,6 +31,10 @@ def test_bench_line_keeps_its_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
     assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes_per_launch"] > 0          # measured bytes incl. the decision round trip
     assert 0.2 < r["valu"]["util"] < 1.0 and 0.5 < r["standalone"]["valu_util"] < 1.0 and r["standalone"]["avg_launch_ms"] < r["avg_launch_ms"]
+    # host time inside dabx_commit_iq + dabx_process per step (launches and event traffic, sync = 0: no device wait): what one of N rank
+    # processes asks of its host core; far below the step itself (measured 23-36 us)
+    assert 1.0 < j["host_us_per_step"] < 300.0 and j["host_us_per_step"] < 0.3 * 1e3 * j["ms_per_step"]
+    assert r["traffic_commit"] and r["frac_of_limiting"] == r["valu"]["util"]
     c = j["chain"]
     assert c["algorithmic_bytes_per_frame"] == 2115456 and abs(c["frac_of_hbm_peak"] - j["value"] * 2115456 / 8e12) < 1e-4
     assert set(c["kernel_ms_per_step_standalone"]) >= {"k_symbols", "k_demap_frame", "k_fic_frame", "k_msc_prep", "k_msc_vitT", "k_dabplus"}
