@@ -78,6 +78,44 @@ __device__ __forceinline__ float acq_walk_S(const float *a, float *out, int n16,
   "s_cmp_lg_u32 %[n], 0\n\t"                                                                                                   \
   "s_cbranch_scc1 1b\n\t"                                                                                                      \
   "s_waitcnt lgkmcnt(0)\n\t"
+// The recurrence with a CHECKPOINT per 16 samples instead of every value (k_acquire): ck[k] = the state after sample 16 k + 15.
+// The values in between are recomputed where they are needed, 64 groups of 16 in parallel (acquire_stream, wave 1): one 4-byte
+// LDS write per 16 samples instead of four 16-byte ones -- sLevel walks at ~17 instead of 23.5 cycles per sample, level at ~9
+// instead of 15.5.
+#define DABX_ACQ_SKELETON_CKPT(STEP)                                                                                            \
+  "ds_read_b128 v[200:203], %[ap]\n\t"                                                                                         \
+  "ds_read_b128 v[204:207], %[ap] offset:16\n\t"                                                                               \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                      \
+  "1:\n\t"                                                                                                                      \
+  "ds_read_b128 v[208:211], %[ap] offset:32\n\t"                                                                               \
+  "ds_read_b128 v[212:215], %[ap] offset:48\n\t"                                                                               \
+  "s_waitcnt lgkmcnt(3)\n\t"                                                                                                    \
+  STEP("v200", "v216", "%[x]") STEP("v201", "v217", "v216") STEP("v202", "v218", "v217") STEP("v203", "v219", "v218")           \
+  STEP("v204", "v220", "v219") STEP("v205", "v221", "v220") STEP("v206", "v222", "v221") STEP("v207", "v223", "v222")           \
+  "ds_read_b128 v[200:203], %[ap] offset:64\n\t"                                                                               \
+  "ds_read_b128 v[204:207], %[ap] offset:80\n\t"                                                                               \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
+  STEP("v208", "v226", "v223") STEP("v209", "v227", "v226") STEP("v210", "v228", "v227") STEP("v211", "v229", "v228")           \
+  STEP("v212", "v230", "v229") STEP("v213", "v231", "v230") STEP("v214", "v232", "v231") STEP("v215", "%[x]", "v232")           \
+  "ds_write_b32 %[op], %[x]\n\t"                                                                                               \
+  "v_add_u32 %[ap], 64, %[ap]\n\t"                                                                                             \
+  "v_add_u32 %[op], 4, %[op]\n\t"                                                                                              \
+  "s_sub_u32 %[n], %[n], 1\n\t"                                                                                                \
+  "s_cmp_lg_u32 %[n], 0\n\t"                                                                                                   \
+  "s_cbranch_scc1 1b\n\t"                                                                                                      \
+  "s_waitcnt lgkmcnt(0)\n\t"
+__device__ __forceinline__ float acq_walk_S_ckpt(const float *a, float *ck, int n16, float S)
+{
+  unsigned ap = lds_addr(a), op = lds_addr(ck);
+  asm volatile(DABX_ACQ_SKELETON_CKPT(DABX_ACQ_STEP_S) : [ap] "+v"(ap), [op] "+v"(op), [n] "+s"(n16), [x] "+v"(S) : [c] "s"(0.00001f) : DABX_ACQ_CLOBBERS);
+  return S;
+}
+__device__ __forceinline__ float acq_walk_L_ckpt(const float *d, float *ck, int n16, float L)
+{
+  unsigned ap = lds_addr(d), op = lds_addr(ck);
+  asm volatile(DABX_ACQ_SKELETON_CKPT(DABX_ACQ_STEP_L) : [ap] "+v"(ap), [op] "+v"(op), [n] "+s"(n16), [x] "+v"(L) : : DABX_ACQ_CLOBBERS);
+  return L;
+}
 __device__ __forceinline__ float acq_walk_S_only(const float *a, int n16, float S)
 {
   unsigned ap = lds_addr(a);

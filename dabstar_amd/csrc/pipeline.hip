@@ -198,10 +198,10 @@ int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
 constexpr int ACQ_CH = 1024;
 struct AcqLds {
   __attribute__((aligned(16))) float a[3][64 + ACQ_CH + 32];  // |x| of three consecutive blocks: a[j % 3][64 + i] = sample i of block j, [0..63] = the 64 samples before it
-  __attribute__((aligned(16))) float S[2][ACQ_CH + 8];        // sLevel after sample i of block j at S[j & 1][4 + i]; [3] = before the block
   __attribute__((aligned(16))) float d[2][ACQ_CH + 32];       // increments of the moving sum |x[n]| - |x[n - 50]| of block j in d[j & 1]
   float bmax[3][4];                                           // maximum of a[j % 3] in four parts
-  __attribute__((aligned(16))) float L[ACQ_CH + 8];           // level after sample i at L[4 + i]
+  float Sc[2][ACQ_CH / 16 + 8];                               // sLevel CHECKPOINTS of block j: Sc[j & 1][1 + k] after sample 16 k + 15, [0] before the block
+  float Lc[ACQ_CH / 16 + 8];                                  // level checkpoints of the block being evaluated: Lc[1 + k] after sample 16 k + 15
   unsigned long long consumed;                                // results of the pass (wave 1 -> everyone)
   float s_final, pk;
   int done, ok, margin;
@@ -315,14 +315,26 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
       // every lane walks (same addresses, same values): with a single lane active, two such waves on one CU -- two streams
       // searching -- slow each other down to half speed; with the full wave they do not (tools/acq_walk_bench.hip, 512 blocks)
       ACQ_T0
-      w.S[i & 1][3] = S;
-      S = acq_walk_S(w.a[i % 3] + 64, w.S[i & 1] + 4, ACQ_CH / 16, S);
+      w.Sc[i & 1][0] = S;
+      S = acq_walk_S_ckpt(w.a[i % 3] + 64, w.Sc[i & 1] + 1, ACQ_CH / 16, S);
       ACQ_T(0)
     } else if (wave == 1) {
       if (i > 0) {
         const int jb = i - 1;
-        const float *ab = w.a[jb % 3] + 64, *Sb = w.S[jb & 1];
+        const float *ab = w.a[jb % 3] + 64, *Scb = w.Sc[jb & 1];
         const unsigned long long P = (unsigned long long)jb * ACQ_CH;
+        // sLevel BEFORE sample pos of this block (pos <= ACQ_CH), from the checkpoint of its group: a 16-step walk by the lane that owns it
+        auto s_before = [&](int pos) {
+          if (pos == ACQ_CH) return Scb[ACQ_CH / 16];
+          float Sx = Scb[lane];                                             // before sample 16 * lane
+          float cap = 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            if (16 * lane + k == pos) cap = Sx;
+            Sx += 0.00001f * (ab[16 * lane + k] - Sx);
+          }
+          return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cap), pos >> 4));
+        };
         int q = 0, stop = 0, ok = 0;
         while (q < ACQ_CH && !stop) {
           // the segment ends where the attempt would time out: NO_DIP_FOUND after reading sample T_F + 50 of the attempt (counter > T_F,
@@ -333,7 +345,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
           if (phase != 0) {
             // An attempt that starts mid-block starts its level at zero: the walk begins at the 16-sample boundary below q with
             // zero increments up to q (what it writes there belongs to positions already evaluated)
-            const int q16 = q & ~15;
+            const int q16 = q & ~15, g0 = q16 >> 4;
             float *db = w.d[jb & 1];
             { ACQ_T0
             if (nb < 50 || q16 < q)                                          // the attempt's first 50 samples: level += |x| (:64-66)
@@ -344,43 +356,65 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
             ACQ_T(1) }
             { ACQ_T0
             __builtin_amdgcn_wave_barrier();
-            w.L[3 + q] = L;
-            acq_walk_L(db + q16, w.L + 4 + q16, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L);
+            w.Lc[g0] = L;                                                    // level before sample q16 (= before q: zero increments in between)
+            acq_walk_L_ckpt(db + q16, w.Lc + 1 + g0, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L);
             __builtin_amdgcn_wave_barrier();
             ACQ_T(2) }
             ACQ_T0
-            for (int p0 = q; p0 < q + m; p0 += 64) {
-              const int p = p0 + lane;
-              const float Lp = w.L[3 + p], Sp = Sb[3 + p];                   // the state BEFORE sample p is read (:58, :74)
-              const bool valid = p < q + m && nb + (p - q) >= 50;
-              const float mean = Lp / 50.f, tb = 0.55f * Sp, te = 0.75f * Sp;
-              const unsigned long long mb = __ballot(valid && !(mean > tb));
-              unsigned long long me = __ballot(valid && !(mean < te));
-              // comparisons that a relative error of 1e-4 in sLevel could have turned (the chunk-wise in-lock tracker is good to ~1e-5)
-              unsigned long long nearb = __ballot(valid && fabsf(mean - tb) <= 1e-4f * tb), neare = __ballot(valid && fabsf(mean - te) <= 1e-4f * te);
-              if (phase != 3) {
-                if (mb) {
-                  const int i2 = __builtin_ctzll(mb);
-                  phase = 3; n2 = nb + (p0 + i2 - q);
-                  me &= ~0ull << i2;                                         // the dip's end is looked for from the same sample on (:74)
-                  nearb &= ~(~1ull << i2);                                   // begin comparisons up to and including i2, end comparisons from it
-                  neare &= ~0ull << i2;
-                } else neare = 0;
-              } else nearb = 0;
-              if (phase == 3 && me) {
-                const int i3 = __builtin_ctzll(me);
-                margin += __builtin_popcountll(nearb) + __builtin_popcountll(neare & ~(~1ull << i3));
-                lim = p0 + i3 - q; ok = 1; stop = 1;
-                break;
+            // Lane t owns samples 16 t .. 16 t + 15: from the two checkpoints in front of its group it re-walks both recurrences in
+            // registers and evaluates, BEFORE each sample, the two comparisons of timesyncer.cpp:58, 74 -- 16 bits per lane each
+            unsigned bm = 0, em = 0, nbm = 0, nem = 0;                       // dip begins / ends here; the comparison came within 1e-4 of its threshold
+            const int p_last = q + m - 1;
+            float L_end = 0.f;
+            {
+              float Sx = Scb[lane], Lx = w.Lc[lane];
+              const bool mine = lane >= g0 && 16 * lane < q + m;
+#pragma unroll
+              for (int k = 0; k < 16; k++) {
+                const int p = 16 * lane + k;
+                const bool valid = mine && p >= q && p < q + m && nb + (p - q) >= 50;
+                const float mean = Lx / 50.f, tb = 0.55f * Sx, te = 0.75f * Sx;
+                if (valid && !(mean > tb)) bm |= 1u << k;
+                if (valid && !(mean < te)) em |= 1u << k;
+                if (valid && fabsf(mean - tb) <= 1e-4f * tb) nbm |= 1u << k;
+                if (valid && fabsf(mean - te) <= 1e-4f * te) nem |= 1u << k;
+                Sx += 0.00001f * (ab[p] - Sx);
+                Lx += db[p];
+                if (p == p_last) L_end = Lx;
               }
-              margin += __builtin_popcountll(nearb) + __builtin_popcountll(neare);
             }
+            int p2 = -1, p3 = -1;                                            // block positions of the dip's begin / end in this segment
+            if (phase != 3) {
+              const unsigned long long any = __ballot(bm != 0);
+              if (any) {
+                const int t2 = __builtin_ctzll(any);
+                p2 = 16 * t2 + __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)bm, t2));
+                phase = 3; n2 = nb + (p2 - q);
+              }
+            }
+            if (phase == 3) {
+              // the dip's end is looked for from the same sample on (:74)
+              const unsigned em2 = p2 < 0 ? em : (lane < (p2 >> 4) ? 0u : (lane == (p2 >> 4) ? em & (~0u << (p2 & 15)) : em));
+              const unsigned long long any = __ballot(em2 != 0);
+              if (any) {
+                const int t3 = __builtin_ctzll(any);
+                p3 = 16 * t3 + __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)em2, t3));
+              }
+              // comparisons a relative error of 1e-4 in sLevel could have turned: begin comparisons up to the begin, end comparisons from it to the end
+              const int lo = p2 < 0 ? 0 : p2, hi = p3 < 0 ? ACQ_CH : p3;
+              unsigned ne = nem, nbq = (p2 < 0) ? 0u : nbm;                    // (p2 < 0: the segment began in phase 3: no begin comparisons at all)
+              if (p2 >= 0) { if (lane > (p2 >> 4)) nbq = 0; else if (lane == (p2 >> 4)) nbq &= ~(~1u << (p2 & 15)); }
+              if (lane < (lo >> 4)) ne = 0; else if (lane == (lo >> 4)) ne &= ~0u << (lo & 15);
+              if (hi != ACQ_CH) { if (lane > (hi >> 4)) ne = 0; else if (lane == (hi >> 4)) ne &= ~(~1u << (hi & 15)); }
+              margin += wave_sum_int(__builtin_popcount(nbq) + __builtin_popcount(ne));
+              if (p3 >= 0) { lim = p3 - q; ok = 1; stop = 1; }
+            } else margin += wave_sum_int(__builtin_popcount(nbm));
             ACQ_T(3)
+            L = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L_end), p_last >> 4));   // level after the segment's last sample
           }
           q += lim;
           if (ok) break;
           nb += m;
-          L = w.L[3 + q];
           if (nb == last) {
             if (phase == 0) { phase = 1; nb = 0; L = 0.f; }
             else {
@@ -400,7 +434,8 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
         ACQ_T(4) }
         if (stop) {
           const float pkw = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, pk), [](unsigned x, unsigned y) { return x > y ? x : y; }));
-          if (lane == 0) { w.consumed = P + (unsigned)q; w.s_final = Sb[3 + q]; w.pk = pkw; w.ok = ok; w.margin = margin; w.done = 1; }
+          const float s_fin = s_before(q);
+          if (lane == 0) { w.consumed = P + (unsigned)q; w.s_final = s_fin; w.pk = pkw; w.ok = ok; w.margin = margin; w.done = 1; }
         }
       }
     } else {

@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void k_walk(const float *src, float *dst, int 
       if (V == 5 || V == 8) S = dabx::acq_walk_S(a, So, CH / 16, S);
       if (V == 7) walk_s_only(a, CH, S);
       if (V == 10) S = dabx::acq_walk_S_only(a, CH / 16, S);
+      if (V == 11) S = dabx::acq_walk_S_ckpt(a, So, CH / 16, S);
+      if (V == 12) L = dabx::acq_walk_L_ckpt(d, Lo, CH / 16, L);
       if (V == 9) { dabx::acq_walk_L(d, Lo, CH / 16, L); L = Lo[CH - 1]; }
       if (V == 6) { dabx::acq_walk_L(d, Lo, CH / 16, L); L = Lo[CH - 1]; }
       asm volatile("" ::: "memory");
@@ -154,6 +156,8 @@ int main()
     run<8>("acq_walk_S (asm), all 64 lanes active", src, dst, blocks);
     run<9>("acq_walk_L (asm), all 64 lanes active", src, dst, blocks);
     run<10>("acq_walk_S_only (asm, no stores), all 64 lanes active", src, dst, blocks);
+    run<11>("acq_walk_S_ckpt (asm, one checkpoint per 16 samples), all 64 lanes active", src, dst, blocks);
+    run<12>("acq_walk_L_ckpt (asm, one checkpoint per 16 samples), all 64 lanes active", src, dst, blocks);
   }
   return 0;
 }
