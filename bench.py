@@ -359,12 +359,6 @@ def step_chunks(n, chunk=7):
     overlap with (2.3 ms for 6-7 frames against a 21-ms timed region of 20 steps).  Issuing the final frames as (4, 2) to
     shorten that tail was measured and is SLOWER (-3 %, profiles/r03_ab/ab2_tapered_tail_steps20.txt): small batches run the
     lane-per-trellis decoder at one or two waves per SIMD."""
-    if os.environ.get("DABX_BENCH_CHUNKS"):                        # experiments only: an explicit list, e.g. "3,3,7,7"
-        ch = [int(v) for v in os.environ["DABX_BENCH_CHUNKS"].split(",")]
-        if sum(ch) == n and max(ch) <= chunk:
-            return ch
-    if os.environ.get("DABX_BENCH_SHORT_CHUNK_LAST") == "1":       # A/B of the order only (tools/gpu_round.sh chunkorder)
-        return [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
     # The short chunk goes FIRST: its batch (6 frames = 3.4 decoder waves per SIMD, as long a launch as 7 frames = 3.9) then
     # runs next to the following chunk's front end, which moves into the SIMDs it leaves idle, and the last, un-overlapped
     # batch is a full one.

@@ -45,3 +45,28 @@ def test_product_path_does_not_touch_the_oracle():
     assert not bad, bad
     needed = subprocess.run(["readelf", "-d", dx.lib_path()], capture_output=True, text=True).stdout
     assert "NEEDED" in needed and "oracle" not in needed and "dabref" not in needed
+
+
+def test_hipmodule_form_exports_the_same_abi_and_carries_no_device_code():
+    """dabstar_amd/hipmodule/libdabx.so (north_star's "hipModule shim": host code only, kernels in dabx_gfx950_*.hsaco loaded at run
+    time): the same exported C ABI as the default library, no fat binary inside, the runtime entry points it defines kept private."""
+    import os
+    import shutil
+    import subprocess
+    from dabstar_amd import build as b
+    mod = os.path.join(os.path.dirname(dx.lib_path()) if "DABX_LIB" not in os.environ else os.path.dirname(os.path.abspath(b.__file__)), "hipmodule")
+    so = os.path.join(mod, "libdabx.so")
+    if not os.path.exists(so):
+        if not shutil.which(b.HIPCC):
+            pytest.skip("no hipcc and no prebuilt hipmodule/libdabx.so")
+        b.build_hipmodule()
+    L = C.CDLL(so)
+    missing = [n for n in dx.declared_symbols() if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.dabx_abi_version() == 4 and L.dabx_internal_hipmodule() == 1 and dx.load().dabx_internal_hipmodule() == 0
+    sections = subprocess.run(["readelf", "-S", "-W", so], capture_output=True, text=True, check=True).stdout
+    assert ".hip_fatbin" not in sections
+    assert ".hip_fatbin" in subprocess.run(["readelf", "-S", "-W", dx.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout.split()
+    assert not [n for n in exported if n.startswith(("hipLaunchKernel", "__hipRegister", "__hipPush", "__hipPop", "hipMemcpyToSymbol"))]
+    assert len([f for f in os.listdir(mod) if f.startswith("dabx_gfx950_") and f.endswith(".hsaco")]) == 6
