@@ -665,7 +665,9 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
   }
   // Streams out of lock: searched in step (every step waits for them) when the caller waits for the call's result anyway, next to
   // the steps on their own HIP stream when it does not (pipelined use); cfg.acquire_mode 1 / 2 fixes either form.
-  const bool async_acquire = e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync);
+  // (With cfg.dc_iq_correction the committed samples are corrected in place on the front-end stream before anything reads them:
+  // a search running next to that stream could read them uncorrected, so it stays in step.)
+  const bool async_acquire = !e->cfg.dc_iq_correction && (e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync));
   for (int i = 0; i < max_frames; i++) {
     // the 5th frame after a batch starts rewriting time-de-interleaver slots the previous batch's k_msc_prep (stream b) reads
     if (e->ss.prep_pending && e->pending_frames >= 4) {

@@ -237,7 +237,9 @@ typedef struct {
                                  frame's worth of search, exactly DabProcessor's order of events per stream), sync == 0 searches on
                                  a HIP stream of its own next to the steps of the streams in lock, which never wait for it (a
                                  stream joins the first step after its search has finished); 1: always in step; 2: always
-                                 asynchronous.  Same samples, same decisions, same frames either way -- only WHEN differs. */
+                                 asynchronous.  Same samples, same decisions, same frames either way -- only WHEN differs.  (With
+                                 dc_iq_correction the search always runs in step: the correction of newly committed samples is ordered
+                                 on the front-end stream.) */
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */
