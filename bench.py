@@ -582,8 +582,7 @@ def main():
 
     # priming (untimed, not part of warmup): acquisition, CFO pull-in, 16-CIF de-interleaver fill, super-frame sync
     eng.commit(ring_frames * TF - TF)
-    step(14, sync=True)                # in step: all streams acquire together
-    step(26)
+    step(40)
     eng.synchronize()
     # Still priming: one whole MSC batch (7 steps) with every kernel instrumented and the host waiting for each one
     # (dabx_set_profiling -1: one kernel on the chip at a time) -- the per-kernel STAND-ALONE breakdown, whose largest entry is

@@ -70,6 +70,7 @@ struct dabx_engine {
 
   std::vector<void *> fast_allocs;             // buffers of the current MSC classes (replaced on reconfiguration)
   bool classes_dirty = false;
+  int32_t *locked_host = nullptr;              // hipHostMalloc'ed: number of streams in lock, kept by the device (EngineDev::locked_count)
   bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
   int build_msc_classes();
 
@@ -275,6 +276,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, cfg->exact_level_tracker ? prio_hi : prio_lo));
     H(hipEventCreateWithFlags(&e->ss.acq_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.tail_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.acq_a_done, hipEventDisableTiming | hipEventReleaseToDevice));
   }
   H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
   H(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
@@ -299,6 +301,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.dciq_state, (size_t)S * 8));
   A(e->alloc(&d.dciq_done, S));
   if (d.exact_level) A(e->alloc(&d.level_pos, S));
+  H(hipHostMalloc((void **)&e->locked_host, sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+  *e->locked_host = 0;
+  H(hipHostGetDevicePointer((void **)&d.locked_count, e->locked_host, 0));
   {
     std::vector<float> st8((size_t)S * 8, 0.0f);                  // sample_reader.h:102-106: meanII = meanQQ = 1
     for (int s_ = 0; s_ < S; s_++) { st8[(size_t)s_ * 8 + 2] = 1.0f; st8[(size_t)s_ * 8 + 3] = 1.0f; }
@@ -366,6 +371,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.q) { (void)hipStreamSynchronize(e->ss.q); (void)hipStreamDestroy(e->ss.q); }
   if (e->ss.acq_done) (void)hipEventDestroy(e->ss.acq_done);
   if (e->ss.tail_done) (void)hipEventDestroy(e->ss.tail_done);
+  if (e->ss.acq_a_done) (void)hipEventDestroy(e->ss.acq_a_done);
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
@@ -379,6 +385,7 @@ void dabx_destroy(dabx_engine *e)
     if (e->aslot_done[i]) (void)hipEventDestroy(e->aslot_done[i]);
   }
   for (void *p : e->allocs) (void)hipFree(p);
+  if (e->locked_host) (void)hipHostFree(e->locked_host);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -667,7 +674,12 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
   // the steps on their own HIP stream when it does not (pipelined use); cfg.acquire_mode 1 / 2 fixes either form.
   // (With cfg.dc_iq_correction the committed samples are corrected in place on the front-end stream before anything reads them:
   // a search running next to that stream could read them uncorrected, so it stays in step.)
-  const bool async_acquire = !e->cfg.dc_iq_correction && (e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync));
+  // And while fewer than half of the streams are in lock (start-up of a whole engine; the device keeps the count in host memory, read
+  // here without a wait) the search runs in step: there is little to hold up, and streams that start together lock together instead of
+  // falling behind their producers while nearly empty steps go by.  (A stream that joins late stays late: a step never advances a
+  // stream by more than one frame.)
+  const bool some_locked = !e->locked_host || 2 * __atomic_load_n(e->locked_host, __ATOMIC_RELAXED) >= e->dev.n_streams;
+  const bool async_acquire = !e->cfg.dc_iq_correction && (e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync && some_locked));
   for (int i = 0; i < max_frames; i++) {
     // the 5th frame after a batch starts rewriting time-de-interleaver slots the previous batch's k_msc_prep (stream b) reads
     if (e->ss.prep_pending && e->pending_frames >= 4) {

@@ -77,6 +77,8 @@ struct EngineDev {
   int32_t strongest, fic_only, capture_soft;
   int32_t exact_level;            // 1: in lock, SampleReader's level IIR is run sample by sample too (cfg.exact_level_tracker)
   unsigned long long *level_pos;  // [S] exact_level only: index of the first sample the level tracker has not seen yet (<= ctl.rd)
+  int32_t *locked_count;          // streams in ST_EVAL_SYNC, in host memory the device updates (system-scope atomics on hand-over): dabx_process
+                                  // looks at it without waiting for anything -- while NO stream is in lock there is nobody the search could hold up
   int32_t tie_mode;               // 1: Viterbi arithmetic of the reference's AVX2 / SSE2 builds (viterbi_core.h, vit_step_simd)
   int32_t msc_stride;             // bytes per logical-frame slot (3 * max kbps)
   int32_t sf_stride;              // bytes per super-frame slot (110 * max kbps / 8)
@@ -144,6 +146,8 @@ struct EngineStreams {
   hipStream_t q = nullptr;                             // k_acquire of dabx_process(sync == 0): streams out of lock are searched next to the steps of the others
   hipEvent_t acq_done = nullptr, tail_done = nullptr;  // tail_done: the frame chain of the last step has moved the read cursors (exact level tracker)
   bool tail_recorded = false;
+  hipEvent_t acq_a_done = nullptr;                     // the last pass that ran IN STEP on stream a: a pass on q must not start before it has finished
+  bool acq_a_pending = false;
   bool acq_in_flight = false;                          // a pass on q may still be running
   hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step

@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, in
   }
   if (new_state < 0) return;
   if (tid == 0 && e.exact_level) e.level_pos[s] = c.rd;    // every sample read here went through the level tracker
+  if (tid == 0 && new_state == ST_EVAL_SYNC && e.locked_count) __hip_atomic_fetch_add(e.locked_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(&c.state, new_state, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -609,7 +610,10 @@ __global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, 
     sync_failed(e, s, tid, rv, rd, phase0, f, peak, red, !e.exact_level);
     __threadfence();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&c.state, (int)ST_WAIT_SYNC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __hip_atomic_store(&c.state, (int)ST_WAIT_SYNC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (e.locked_count) __hip_atomic_fetch_add(e.locked_count, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   // symbol 0 = samples [start, start + Tu) of the same (mixed) stream, :402-411
@@ -1554,6 +1558,9 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
     if (e.exact_level) { if (ss.acq_in_flight) DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); }
     else go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
     if (go) {
+      // two passes must never work on a stream at the same time: one that ran in step (an earlier call, or the start-up rule of
+      // dabx_process) has to be through before the first one on q starts
+      if (ss.acq_a_pending) { DABX_HIP(hipStreamWaitEvent(ss.q, ss.acq_a_done, 0)); ss.acq_a_pending = false; }
       if (e.exact_level) {
         // the tracker of step n walks the frame of step n - 1 while the chain demodulates frame n: behind that chain's tail, not before
         if (ss.tail_recorded) DABX_HIP(hipStreamWaitEvent(ss.q, ss.tail_done, 0));
@@ -1567,6 +1574,7 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
     if (ss.acq_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); ss.acq_in_flight = false; }   // a pass of an earlier, asynchronous call
     if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, st, e);
     mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, st, e, *t, 1); mk.end(0, st);
+    if (ss.q && ss.acq_a_done) { DABX_HIP(hipEventRecord(ss.acq_a_done, st)); ss.acq_a_pending = true; }
   }
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
   mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);

@@ -236,7 +236,8 @@ typedef struct {
                                  way dabx_process is called: sync != 0 searches in step (every step first gives every such stream a
                                  frame's worth of search, exactly DabProcessor's order of events per stream), sync == 0 searches on
                                  a HIP stream of its own next to the steps of the streams in lock, which never wait for it (a
-                                 stream joins the first step after its search has finished); 1: always in step; 2: always
+                                 stream joins the first step after its search has finished; while fewer than half of the streams are
+                                 in lock -- start-up -- the search runs in step even then); 1: always in step; 2: always
                                  asynchronous.  Same samples, same decisions, same frames either way -- only WHEN differs.  (With
                                  dc_iq_correction the search always runs in step: the correction of newly committed samples is ordered
                                  on the front-end stream.) */

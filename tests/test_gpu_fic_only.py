@@ -91,7 +91,7 @@ def test_512_stream_fic_only_engine_sampled_streams_match_the_oracle():
     while done < n_steps:
         m = min(7, n_steps - done)
         eng.commit(m * ds.TF)
-        eng.process(m, sync=(done == 0))           # the first call in step: all streams start together (dabx.h, acquire_mode)
+        eng.process(m, sync=False)
         done += m
         if done == 14:
             eng.synchronize()

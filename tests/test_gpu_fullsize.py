@@ -40,7 +40,7 @@ def test_512_streams_round_trip_and_sampled_oracle_parity():
     while done < N_STEPS:                          # as bench.py: 7 frames per MSC launch
         m = min(7, N_STEPS - done)
         eng.commit(m * ds.TF)
-        eng.process(m, sync=(done == 0))           # the first call in step (every stream is searched before its step goes on): all 512 start together
+        eng.process(m, sync=False)
         done += m
         if done == N_PRIME:                        # acquisition, CFO pull-in, de-interleaver fill and super-frame sync are over
             eng.synchronize()

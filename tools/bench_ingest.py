@@ -45,7 +45,9 @@ def main():
         for mode in args.modes.split(","):
             if mode == "pinned":
                 dx.host_register(host[fmt])
-            eng = dx.Engine(n_streams=args.streams, ring_frames=2 * CHUNK + 2, max_subch=18, out_frames=8)
+            # three chunks of ring: two in flight + the few frames a stream stays behind after it had to search for its lock next to the
+            # steps of the others (dabx_process(sync = 0); a step never advances a stream by more than one frame, so a late joiner stays late)
+            eng = dx.Engine(n_streams=args.streams, ring_frames=3 * CHUNK, max_subch=18, out_frames=8)
             eng.set_subchannels(subch)
             n = CHUNK * ds.TF
             per = n * (2 if fmt != "cf32" else 1)
