@@ -269,6 +269,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    // the ingest stream BEFORE q: the runtime deals streams to its hardware queues in order of creation, and as the fifth stream the
+    // ingest stream shared one (every synchronous push 20 us = 20 % dearer at 512 streams, tools/bench_ingest.py)
+    H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
     // streams out of lock are searched on q next to the steps of the others (dabx_process with sync == 0)
     // With the exact level tracker every stream has a block on q in every step (two lone waves for 1.6 ms): at the lowest queue
     // priority those blocks were dispatched only into the gaps the frame chain's kernels left (5 ms per step); at the chain's own
@@ -278,8 +281,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipEventCreateWithFlags(&e->ss.tail_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.acq_a_done, hipEventDisableTiming | hipEventReleaseToDevice));
   }
-  H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
-  H(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
+  if (!e->ingest) H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
+  // (ingest2 is created by the first dabx_push_iq_async: every HIP stream that exists makes each synchronous push -- a pageable
+  // hipMemcpyAsync, an event, a stream wait and a stream synchronisation -- about 20 us dearer, 20 % of a push at 512 streams)
   H(hipEventCreateWithFlags(&e->ingest_done, hipEventDisableTiming | hipEventReleaseToDevice));
   e->rd_seen.assign(cfg->n_streams, 0);
   const int S = cfg->n_streams;
@@ -596,6 +600,7 @@ int dabx_push_iq_async(dabx_engine *e, int stream, const void *iq, int fmt, size
     DABX_HIP(hipMalloc(&e->aslot[k], bytes));
     e->aslot_cap[k] = bytes;
   }
+  if (!e->ingest2) DABX_HIP(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
   hipStream_t ing = (k & 1) ? e->ingest2 : e->ingest;
   DABX_HIP(hipMemcpyAsync(e->aslot[k], iq, bytes, hipMemcpyHostToDevice, ing));
   int rc = launch_convert_iq(e->aslot[k], fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, ing);
@@ -610,7 +615,7 @@ int dabx_push_wait(dabx_engine *e)
   if (!e) return DABX_E_ARG;
   if (int rc = use_device(e)) return rc;
   DABX_HIP(hipStreamSynchronize(e->ingest));
-  DABX_HIP(hipStreamSynchronize(e->ingest2));
+  if (e->ingest2) DABX_HIP(hipStreamSynchronize(e->ingest2));
   return 0;
 }
 
