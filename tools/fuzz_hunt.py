@@ -26,16 +26,21 @@ def main():
     for seed in seeds:
         cfg = CFGS[seed % len(CFGS)]
         fast = seed % 4 == 3                     # every fourth run through the lane-per-trellis classes
+        if seed % 4 == 1:
+            fast = 2                             # ... and every fourth with the search for the null symbol on its own HIP stream (acquire_mode 2)
+        tie = (seed // 4) % 3 if seed % 8 == 5 else 0   # a few with the SIMD builds' Viterbi arithmetic
         which = "test_random_service_start_stop_schedules" if seed % 7 == 6 else "test_random_channels_and_layouts_follow_the_oracle"
         env = dict(os.environ, DABX_FUZZ_SEED=str(seed), DABX_FUZZ_CFG=cfg, DABX_FUZZ_VERBOSE="1")
         if fast:
-            env.update(DABX_FUZZ_FAST="1")
+            env.update(DABX_FUZZ_FAST=str(int(fast)))
+        if tie:
+            env.update(DABX_FUZZ_TIE=str(tie))
         t0 = time.time()
         p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "tests/test_gpu_fuzz.py", "-k", which],
                            cwd=ROOT, env=env, capture_output=True, text=True)
         ok = p.returncode == 0
         n_pass += ok; n_fail += (not ok)
-        rec = {"seed": seed, "test": which, "cfg_threshold_strongest_softtype": cfg, "lane_per_trellis_classes": bool(fast),
+        rec = {"seed": seed, "test": which, "cfg_threshold_strongest_softtype": cfg, "lane_per_trellis_classes": fast == 1 or fast is True, "acquire_mode": 2 if fast == 2 else 0, "viterbi_tie_mode": tie,
                "passed": ok, "seconds": round(time.time() - t0, 1)}
         # streams whose walk needed the exact level tracker to follow the oracle (tests/test_gpu_fuzz.py)
         lv = [l for l in p.stdout.splitlines() if l.startswith("walk differs with the chunk-wise level tracker")]
