@@ -121,3 +121,67 @@ def test_one_shot_parse_is_the_running_decoder_on_a_fresh_state():
     d.reset()
     assert d.info()["fibs_processed"] == 0 and d.subchannels() == []
     d.close()
+
+
+def test_random_fig_streams_with_both_configurations_follow_the_oracle():
+    """Differential run on random FIG streams: FIG 0/0 with random change flags (every transition, not only 3 -> 0), FIG 0/1 and 0/2 with
+    random C/N flags, random sub-channel ids / start addresses / sizes (collisions and out-of-range entries restart the collection),
+    short and long form, P/D = 1 services, truncated FIGs, unknown extensions and types.  After every FIB both decoders agree on
+    every scalar and on both tables."""
+    rng = np.random.default_rng(11)
+
+    def rand_fig():
+        kind = rng.integers(0, 10)
+        cn = int(rng.integers(0, 2)) << 7
+        if kind == 0:
+            flags = int(rng.choice([0, 0, 3, 3, 1, 2]))
+            body = bytes([0x00, 0x10, 0xF2, (flags << 6) | int(rng.integers(0, 20)), int(rng.integers(0, 250))]) + \
+                (bytes([int(rng.integers(0, 250))]) if flags and rng.random() < 0.9 else b"")
+        elif kind <= 4:
+            body = bytearray([cn | 0x01])
+            for _ in range(int(rng.integers(1, 5))):
+                sid, start = int(rng.integers(0, 12)), int(rng.integers(0, 900))
+                if rng.random() < 0.3:
+                    body += bytes([(sid << 2) | (start >> 8), start & 0xFF, int(rng.integers(0, 64))])
+                else:
+                    w = (sid << 26) | (start << 16) | (1 << 15) | (int(rng.integers(0, 3)) << 12) | (int(rng.integers(0, 4)) << 10) | int(rng.integers(1, 120))
+                    body += w.to_bytes(4, "big")
+            body = bytes(body[: len(body) - (1 if rng.random() < 0.1 else 0)])       # sometimes truncated
+        elif kind <= 7:
+            pd = int(rng.random() < 0.2)
+            body = bytearray([cn | (pd << 5) | 0x02])
+            for _ in range(int(rng.integers(1, 3))):
+                body += bytes(rng.integers(0, 256, 4 if pd else 2).tolist())
+                ncomp = int(rng.integers(0, 3))
+                body += bytes([ncomp])
+                for _c in range(ncomp):
+                    tmid = int(rng.choice([0, 0, 0, 1, 3]))
+                    body += bytes([(tmid << 6) | int(rng.choice([63, 0, 5])), (int(rng.integers(0, 12)) << 2) | 2])
+            body = bytes(body)
+        elif kind == 8:
+            body = bytes([cn | int(rng.integers(3, 32))]) + bytes(rng.integers(0, 256, int(rng.integers(0, 8))).tolist())
+        else:
+            return bytes([(int(rng.integers(1, 7)) << 5) | 3]) + bytes(rng.integers(0, 256, 3).tolist())   # another FIG type
+        return bytes([len(body) & 0x1F]) + body
+
+    fibs = []
+    for _ in range(1500):
+        data = b""
+        while True:
+            g = rand_fig()
+            if len(data) + len(g) > 30:
+                break
+            data += g
+        if len(data) < 30:
+            data += b"\xFF" + b"\x00" * (29 - len(data))
+        c = ds.crc16(data)
+        fibs.append(np.frombuffer(data + bytes([c >> 8, c & 0xFF]), np.uint8))
+    fibs = np.stack(fibs)
+    crc = (rng.random(len(fibs)) > 0.1).astype(np.uint8)
+    swaps = restarts = 0
+    for i, d, o in _both(fibs, crc, 1):
+        a, b = d.info(), o.info()
+        assert a == b, (i, a, b)
+        assert _tab(d.subchannels()) == o.subchannels() and _tab(d.subchannels(next=True)) == o.subchannels(next=True), i
+        swaps, restarts = a["n_changes"], a["n_restarts"]
+    assert swaps >= 5 and restarts >= 5                                   # the stream did exercise both mechanisms
