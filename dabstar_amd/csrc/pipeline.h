@@ -45,7 +45,6 @@ struct StreamCtl {
   float head_abs_a, head_abs_b;   // sum |x| over the T_u correlation window / the start_index samples read after it (level tracker)
   int32_t np_sel;                 // which noise-power buffer (DemapDev::null_power / null_power2) is current; k_frame_tail flips it
   int32_t pad_;
-  unsigned long long step_rd0;    // (unused since round 4)
   long long level_margin;         // null-dip comparisons that fell within 1e-4 (relative) of their threshold (dabx_stats.level_margin_events)
 };
 

@@ -2,7 +2,9 @@
 // stream that is in lock (and has a frame of samples) by one DAB frame; this file is the device-side
 // equivalent of DabProcessor::run (base/main/dab_processor.cpp:110-442).
 //
-//   k_acquire      ST_INIT / ST_WAIT_SYNC: level seeding + null-dip detector (timesyncer.cpp:40-90)
+//   k_acquire      streams out of lock (ST_INIT / ST_WAIT_SYNC): level seeding + null-dip detector (timesyncer.cpp:40-90) + correlation of
+//                  every candidate; in step on the frame chain's HIP stream or next to it on its own (launch_front_step)
+//   k_level_exact  cfg.exact_level_tracker: SampleReader's level IIR sample by sample in lock too (sample_reader.cpp:245-248)
 //   k_frame_head   PRS correlation -> start index, symbol-0 FFT, optional coarse CFO (dab_processor.cpp:389-414, 191-224)
 //   k_symbols      symbols 1..75: NCO mix, cyclic-prefix correlation, FFT (dab_processor.cpp:304-341)
 //   k_demap_frame  75 x decode_symbol, soft bits -> Viterbi symbols -> FIC buffer / time-deinterleaver ring
@@ -1556,8 +1558,8 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   if (async_acquire && ss.q) {
     // every step grants the streams that are searching a frame's worth of samples; steps whose pass could not be launched (the one
     // before was still running, or the host has simply queued several steps at once) add their frame to the next pass's budget, so a
-    // stream that needs many attempts (fuzz seeds 5001, 10001) keeps the pace of a frame per step on average
-    ss.acq_credit = ss.acq_credit < 16 ? ss.acq_credit + 1 : 16;
+    // stream that needs many attempts (fuzz seed 5001) keeps a pace of up to four frames per pass
+    ss.acq_credit = ss.acq_credit < 4 ? ss.acq_credit + 1 : 4;     // (at most four frames, 7-8 ms, per pass: a dabx_synchronize waits for the one that is running)
     bool go = true;
     if (e.exact_level) { if (ss.acq_in_flight) DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); }
     else go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
