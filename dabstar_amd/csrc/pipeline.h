@@ -148,7 +148,6 @@ struct EngineStreams {
   hipEvent_t acq_a_done = nullptr;                     // the last pass that ran IN STEP on stream a: a pass on q must not start before it has finished
   bool acq_a_pending = false;
   bool acq_in_flight = false;                          // a pass on q may still be running
-  int acq_credit = 0;                                  // steps that went by without a pass being launched (the previous one was still running): the next pass's budget in frames
   hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
   unsigned step_count = 0;

@@ -1551,15 +1551,11 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   hipStream_t st = ss.a;
   // Streams out of lock (k_acquire).  In step: on the front-end stream, before the frame head -- every step then offers every
   // stream a frame's worth of search.  Asynchronous: on HIP stream q; a pass is launched when the previous one has finished
-  // (hipEventQuery, no wait).
+  // (hipEventQuery, no wait); a pass is a frame's worth of samples (< 2 ms: what a dabx_synchronize may have to wait for).
   // cfg.exact_level_tracker: k_level_exact in front of every pass (same HIP stream); then the passes are never skipped -- the frame
   // chain lets the tracker fall one step behind at most (the samples it still has to see must stay in the ring), so the exact
   // tracker costs max(0, its 1.6 ms per frame - the step) of the step instead of adding to it.
   if (async_acquire && ss.q) {
-    // every step grants the streams that are searching a frame's worth of samples; steps whose pass could not be launched (the one
-    // before was still running, or the host has simply queued several steps at once) add their frame to the next pass's budget, so a
-    // stream that needs many attempts (fuzz seed 5001) keeps a pace of up to four frames per pass
-    ss.acq_credit = ss.acq_credit < 4 ? ss.acq_credit + 1 : 4;     // (at most four frames, 7-8 ms, per pass: a dabx_synchronize waits for the one that is running)
     bool go = true;
     if (e.exact_level) { if (ss.acq_in_flight) DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); }
     else go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
@@ -1572,14 +1568,12 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
         if (ss.tail_recorded) DABX_HIP(hipStreamWaitEvent(ss.q, ss.tail_done, 0));
         hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, ss.q, e);
       }
-      mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, ss.acq_credit); mk.end(0, ss.q);
+      mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, 1); mk.end(0, ss.q);
       DABX_HIP(hipEventRecord(ss.acq_done, ss.q));
       ss.acq_in_flight = true;
-      ss.acq_credit = 0;
     }
   } else {
     if (ss.acq_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); ss.acq_in_flight = false; }   // a pass of an earlier, asynchronous call
-    ss.acq_credit = 0;
     if (e.exact_level) hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, st, e);
     mk.begin(0, st); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, st, e, *t, 1); mk.end(0, st);
     if (ss.q && ss.acq_a_done) { DABX_HIP(hipEventRecord(ss.acq_a_done, st)); ss.acq_a_pending = true; }
