@@ -32,13 +32,19 @@ def _oracle(x, subch):
     return res
 
 
-def test_reconfiguration_is_followed_at_the_announced_cif():
+@pytest.mark.parametrize("cif_in_frame", [0, 2])
+def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame):
+    """cif_in_frame = 2: the configuration changes in the MIDDLE of a transmission frame (its third CIF).  dabx_set_subchannels_at is
+    called at the frame boundary in front of it with the announced CIF: the new services' de-interleavers start exactly there (their
+    first logical frame is delivered complete); the services that end are cut at the frame boundary -- the two logical frames numbered
+    at_cif - 2 and at_cif - 1, which a receiver that switches inside a frame would still deliver, are the price of switching between
+    two steps (include/dabx.h)."""
     a = [ds.SubCh(i, 48 * i, 48, 64, 2, 0) for i in range(6)]
     b = a[:3] + [ds.SubCh(3, 400, 48, 64, 2, 0),               # moves
                  ds.SubCh(4, 500, 72, 96, 2, 0),               # grows
                  ds.SubCh(6, 192, 24, 32, 2, 0, dab_plus=0)]   # sub-channel 5 ends, 6 begins (not DAB+)
     n_frames, switch_frame = 27, 12
-    ens = ds.build_reconfigured_ensemble(n_frames, a, b, switch_frame, announce_frames=7, seed=5)
+    ens = ds.build_reconfigured_ensemble(n_frames, a, b, switch_frame, announce_frames=7, seed=5, switch_cif_in_frame=cif_in_frame)
     x = ds.channel(ens.iq, snr_db=20.0, cfo_hz=310.0, timing_offset=3000, seed=5, cyclic=False)
     ora_a, ora_b = _oracle(x, a), _oracle(x, b)
     assert ora_a["n"] == ora_b["n"] >= n_frames - 2 and ora_a["crc"][2:].all()      # (the first two frames: start-up of the CFO loop)
@@ -57,7 +63,7 @@ def test_reconfiguration_is_followed_at_the_announced_cif():
             at_cif = rc["at_cif"]
             nxt = eng.next_subchannels(0)
         before = eng.stats(0)["frames"]
-        if at_cif is not None and not applied and 4 * before == at_cif:    # the coming frame is the first of the new configuration
+        if at_cif is not None and not applied and before == at_cif // 4:   # the coming frame holds the first CIF of the new configuration
             assert sorted((g.subch_id, g.cu_start, g.cu_size, g.kbps, g.prot_level, g.dab_plus) for g in nxt) == \
                 sorted((c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, int(c.dab_plus)) for c in b)
             by_id = {g.subch_id: g for g in nxt}
@@ -99,8 +105,9 @@ def test_reconfiguration_is_followed_at_the_announced_cif():
     for j in range(3):                                                     # run through: no gap, nothing lost
         merged = dict(got[0][j]); merged.update(got[1][j])
         check("through %d" % j, merged, ora_a["msc"][j], ("a", j), 16, end)
-    for j, sid in ((3, 3), (4, 4), (5, 5)):                                # end at the switch: every frame numbered below at_cif
-        check("ends %d" % sid, got[0][j], ora_a["msc"][j], ("a", sid), 16, at_cif)
+    assert at_cif % 4 == cif_in_frame
+    for j, sid in ((3, 3), (4, 4), (5, 5)):                                # end at the switch: every frame numbered below at_cif (mid-frame: below its frame's first CIF)
+        check("ends %d" % sid, got[0][j], ora_a["msc"][j], ("a", sid), 16, at_cif - cif_in_frame)
     for j, sid in ((3, 3), (4, 4), (5, 6)):                                # begin at the switch: from frame at_cif + 16, the service's first one
         check("begins %d" % sid, got[1][j], ora_b["msc"][j], ("b", sid), at_cif + 16, end)
     s4 = eng.subch_stats(0, 4)

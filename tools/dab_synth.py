@@ -479,14 +479,14 @@ def _same_desc(x, y):
 
 
 def build_reconfigured_ensemble(n_frames: int, subch_a: list, subch_b: list, switch_frame: int, announce_frames: int = 8,
-                                seed: int = 0, cif_start: int = 0) -> ReconfEnsemble:
-    """A multiplex reconfiguration (EN 300 401 6.5) at the first CIF of frame switch_frame: layout A before, layout B from then on,
+                                seed: int = 0, cif_start: int = 0, switch_cif_in_frame: int = 0) -> ReconfEnsemble:
+    """A multiplex reconfiguration (EN 300 401 6.5) at CIF switch_cif_in_frame (0..3) of frame switch_frame: layout A before, layout B from then on,
     announced for announce_frames frames in advance (FIG 0/0 change flags 3 + OccurrenceChange, the next configuration's FIG 0/1
     and 0/2 with C/N = 1); afterwards the flags are 0 and B is the current configuration.  Sub-channels described identically in
     A and B run through (same convolutional interleaver, no gap); one that ends has its last 15 logical frames cut off in
     the air (their later interleaver branches fall on CUs that belong to B); one that begins starts its interleaver at the switch."""
     rng = np.random.default_rng(seed)
-    n_cif, N = 4 * n_frames, 4 * switch_frame
+    n_cif, N = 4 * n_frames, 4 * switch_frame + switch_cif_in_frame
     through = [c for c in subch_a if any(_same_desc(c, d) for d in subch_b)]
     only_b = [d for d in subch_b if not any(_same_desc(c, d) for c in subch_a)]
     pos = np.arange(55296)
