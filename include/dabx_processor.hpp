@@ -7,6 +7,7 @@
 // whenever samples have been handed over.  One Processor = one ensemble = one stream of a one-stream engine; the
 // stream-batched engine API (dabx_create with n_streams > 1) is the one to use for many ensembles at once.
 #pragma once
+#include <algorithm>
 #include <complex>
 #include <cstdio>
 #include <cstring>
@@ -39,6 +40,12 @@ public:
   std::function<void(int ficPercent, float freqOffsBbHz, float clockErrHz, float snrDb)> on_status;   // slot_show_fic_status, ..._freq_corr_bb_Hz, ..._clock_error
 
   std::function<void(const std::vector<dabx_tii_result> &)> on_tii;                                 // signal_show_tii
+  // IFibDecoder::signal_change_in_configuration (fib_decoder_fig0.cpp:109) -- which the reference answers with "not supported yet"
+  // (dabradio.cpp:271-274).  Here the running services are carried over to the announced configuration at its first CIF before the
+  // callback fires: a service described as before runs through, one whose sub-channel changes restarts its de-interleaver there,
+  // one that is no longer announced stops.  first_cif counts the CIFs this processor has demodulated (4 per frame).
+  std::function<void(long long first_cif)> on_configuration_change;
+  bool follow_reconfigurations = true;
 
   explicit Processor(const Params &p = Params()) : params_(p)
   {
@@ -91,6 +98,18 @@ public:
     if (!running_) return 0;
     dabx_stats before, after;
     check(dabx_get_stats(eng_, 0, &before), "dabx_get_stats");
+    if (follow_reconfigurations) {
+      // FIG 0/0 announces a change seconds ahead (change flags, OccurrenceChange): never demodulate past the frame boundary in front of
+      // its first CIF without having switched the tables there
+      dabx_reconf rc;
+      check(dabx_follow_fic(eng_, 0, &rc), "dabx_follow_fic");
+      if (rc.pending && rc.at_cif != applied_cif_) {
+        const long long frame = rc.at_cif / 4;
+        if (before.frames < frame) max_frames = (int)std::min<long long>(max_frames, frame - before.frames);
+        else apply_next_configuration(before.frames == frame ? rc.at_cif : -1);     // (-1: the announcement was seen too late: switch now)
+        if (before.frames >= frame) applied_cif_ = rc.at_cif;
+      }
+    }
     check(dabx_process(eng_, max_frames, 1), "dabx_process");
     check(dabx_get_stats(eng_, 0, &after), "dabx_get_stats");
     const int frames = (int)(after.frames - before.frames);
@@ -199,6 +218,32 @@ private:
   long long eti_frames_ = 0;
   bool tii_on_ = false, tii_collisions_ = false;
   int tii_threshold_ = 6, tii_sub_id_ = 0;
+  long long applied_cif_ = -1;                  // first CIF of the newest configuration that has been switched to
+
+  // carries the running services over to the NEXT configuration (FIG 0/1 and 0/2 with C/N = 1) from CIF at_cif on
+  void apply_next_configuration(long long at_cif)
+  {
+    std::vector<dabx_subch_desc> next(64);
+    const int n_next = dabx_next_subchannels(eng_, 0, next.data(), 64);
+    if (n_next <= 0) return;                     // nothing announced (yet): keep what runs
+    int n = 0;
+    for (size_t j = 0; j < slots_.size(); j++) {
+      if (!slots_[j].kbps) continue;
+      const dabx_subch_desc old = slots_[j];
+      dabx_subch_desc now{};
+      for (int k = 0; k < n_next; k++) if (next[(size_t)k].subch_id == old.subch_id) now = next[(size_t)k];
+      if (now.kbps && now.dab_plus < 0) now.dab_plus = old.dab_plus;
+      const bool same = now.kbps == old.kbps && now.cu_start == old.cu_start && now.cu_size == old.cu_size &&
+                        now.prot_level == old.prot_level && now.short_form == old.short_form && now.dab_plus == old.dab_plus;
+      slots_[j] = now;
+      if (!same) { delivered_[j] = 0; sf_delivered_[j] = 0; }      // a changed slot counts its logical frames from zero again
+      if (now.kbps) n = (int)j + 1;
+    }
+    for (size_t j = 0; j < slots_.size(); j++) if (slots_[j].kbps) n = (int)j + 1;
+    if (at_cif >= 0) check(dabx_set_subchannels_at(eng_, 0, slots_.data(), n, at_cif), "dabx_set_subchannels_at");
+    else check(dabx_set_subchannels(eng_, 0, slots_.data(), n), "dabx_set_subchannels");
+    if (on_configuration_change) on_configuration_change(at_cif);
+  }
 
   bool any_service() const
   {

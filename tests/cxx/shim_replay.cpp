@@ -24,6 +24,8 @@ int main(int argc, char **argv)
     rx.on_fib = [&](const uint8_t *, bool ok, int) { fibs++; fibs_ok += ok; };
     rx.on_logical_frame = [&](int id, const uint8_t *, int) { lf++; lf_per_service[id]++; lf_this_run[id]++; };
     rx.on_super_frame = [&](int, const uint8_t *, int) { sf++; };
+    long long config_changes = 0, change_cif = -1;
+    rx.on_configuration_change = [&](long long cif) { config_changes++; change_cif = cif; };
     const dabx_iq_format fmt = rx.open_recording(argv[1]);
     rx.start();
     if (!rx.start_eti_generator(argv[2])) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 2; }
@@ -63,8 +65,8 @@ int main(int argc, char **argv)
     for (const auto &kv : lf_per_service) per += (per.size() > 1 ? ", \"" : "\"") + std::to_string(kv.first) + "\": " + std::to_string(kv.second);
     per += "}";
     std::printf("{\"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"services\": %zu, "
-                "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"lf_per_service\": %s}\n", frames, fibs, fibs_ok, lf, sf,
-                lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, per.c_str());
+                "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"config_changes\": %lld, \"change_cif\": %lld, \"lf_per_service\": %s}\n",
+                frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, config_changes, change_cif, per.c_str());
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "shim_replay: %s\n", e.what());

@@ -109,6 +109,36 @@ def test_adapter_adds_a_higher_rate_service_without_silencing_the_running_ones(t
     assert 0 < lf[5] == 4 * (res["frames"] - res["late_added_at"]) - 16        # the late one: 16-CIF fill from where it was added
 
 
+@pytest.mark.gpu
+def test_adapter_follows_an_announced_reconfiguration(tmp_path):
+    """Processor::run with follow_reconfigurations (default): a recording in which the multiplex is reconfigured (FIG 0/0 change flags +
+    OccurrenceChange, next configuration with C/N = 1; tools/dab_synth.py::build_reconfigured_ensemble).  The adapter never steps past
+    the frame boundary in front of the announced CIF without switching: the service that runs through delivers four logical frames with
+    every frame, before and after; the ones whose sub-channel moves / grows restart their 16-CIF fill at the switch; the one that is
+    no longer announced stops there; on_configuration_change fires once, with the announced CIF."""
+    from tools import dab_synth as ds
+    from tools import iq_files as iqf
+    exe = _build()
+    a = [ds.SubCh(i, 48 * i, 48, 64, 2, 0) for i in range(6)]
+    b = a[:3] + [ds.SubCh(3, 400, 48, 64, 2, 0), ds.SubCh(4, 500, 72, 96, 2, 0), ds.SubCh(6, 192, 24, 32, 2, 0, dab_plus=0)]
+    n_frames, switch_frame = 36, 18
+    ens = ds.build_reconfigured_ensemble(n_frames, a, b, switch_frame, announce_frames=8, seed=6)
+    x = ds.channel(ens.iq, snr_db=22.0, cfo_hz=250.0, timing_offset=5000, seed=6, cyclic=False)
+    rec = str(tmp_path / "rec.sdr")
+    iqf.write_sdr(rec, x, 2048000, 0.25 / np.sqrt(np.mean(np.abs(x) ** 2)))
+    p = subprocess.run([exe, rec, str(tmp_path / "o.eti"), "0", "3", "4", "5"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    lf = {int(k): v for k, v in res["lf_per_service"].items()}
+    frames, at = res["frames"], res["change_cif"]
+    assert res["config_changes"] == 1 and at > 0 and at % 4 == 0 and frames >= n_frames - 3
+    t0 = 4 * frames - lf[0] - 16                       # CIF at which the services were selected (FIC ratio >= 90 %): service 0 has run through since
+    assert 0 <= t0 <= 24 and t0 % 4 == 0
+    assert lf[5] == at - t0 - 16                       # ended at the switch: every logical frame numbered below it
+    assert lf[3] == lf[4] == (at - t0 - 16) + (4 * frames - at - 16)      # moved / grown: the old sub-channel up to the switch, the new one from its 16-CIF fill on
+    assert 6 not in lf                                 # (a service that BEGINS with the new configuration is not selected by anybody)
+
+
 def test_host_parsers_are_clean_under_asan_and_ubsan():
     """tests/cxx/san_host.cpp: FIB walk, ETI assembly, container probing on mutated headers and the TII detector, built with
     g++ -fsanitize=address,undefined from the library's own host sources (GPU sanitizers are not available on the pool)."""
