@@ -484,6 +484,18 @@ static int set_subchannels_impl(dabx_engine *e, int stream, const dabx_subch_des
                         old.kbps == sc.kbps && old.prot_level == sc.prot_level && old.short_form == sc.short_form &&
                         old.dab_plus == sc.dab_plus && e->subch_id_host[(size_t)s * d.max_subch + j] == desc[j].subch_id;
       if (same) continue;
+      // A sub-channel that only MOVES (same SubChId, size, bit rate, protection; other capacity units -- a multiplex reconfiguration):
+      // the slot keeps running, its de-interleaver reads the CIFs before the change at the old address (what a Backend that is handed
+      // its slice from another place does, msc_handler.cpp:161-166).  One move per 16 CIFs; anything faster restarts the slot.
+      const bool moved = old.active && sc.active && old.cu_start != sc.cu_start && old.cu_size == sc.cu_size && old.kbps == sc.kbps &&
+                         old.prot_level == sc.prot_level && old.short_form == sc.short_form && old.dab_plus == sc.dab_plus &&
+                         e->subch_id_host[(size_t)s * d.max_subch + j] == desc[j].subch_id && sc.start_cif >= old.move_cif + 16;
+      if (moved) {
+        SubchDev keep = old;
+        keep.prev_cu_start = old.cu_start; keep.cu_start = sc.cu_start; keep.move_cif = sc.start_cif;
+        e->subch_host[(size_t)s * d.max_subch + j] = keep;
+        continue;
+      }
       e->subch_host[(size_t)s * d.max_subch + j] = sc;
       e->subch_id_host[(size_t)s * d.max_subch + j] = (j < n && sc.active) ? desc[j].subch_id : -1;
       e->eti[s] = dabx_engine::EtiCursor{};
@@ -848,6 +860,7 @@ int dabx_read_eti(dabx_engine *e, int stream, int max_frames, uint8_t *out, int3
     if (cur.hi < 0 || cur.lo < 0) continue;              // eti_generator.cpp:156-160: no FIG 0/0 yet
     for (size_t a = 0; a < act.size(); a++) {
       const SubchDev &sc = row[act[a]];
+      desc[a].cu_start = r < sc.move_cif ? sc.prev_cu_start : sc.cu_start;     // a sub-channel that moved: the address the FIC of CIF r gave it
       const long long lf = r - sc.start_cif - 16;
       DABX_HIP(hipMemcpy(msc.data() + a * (size_t)d.msc_stride,
                          d.msc_out + (((size_t)stream * d.max_subch + act[a]) * MSC_SLOTS + (size_t)(lf % MSC_SLOTS)) * d.msc_stride,

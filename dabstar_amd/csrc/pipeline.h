@@ -60,7 +60,19 @@ struct SubchDev {
   int32_t blocks_in_buf, sf_sync;
   long long sf_count;
   long long sf_ok, sf_fail, rs_corr, rs_fail, fc_corr, au_ok, au_bad;
+  // A sub-channel that only MOVED to other capacity units (multiplex reconfiguration): it keeps running, and its time de-interleaver
+  // reads the CIFs before move_cif at the old address.  Zero = never moved (logical frame r >= 16 reads CIFs >= 0).
+  long long move_cif;
+  int32_t prev_cu_start, pad2_;
 };
+#ifdef __HIPCC__
+// of the 16 CIFs r - 16 + m (m = 0..15) that logical frame r is de-interleaved from, those with m < msc_move_thr lie before the move
+__device__ __forceinline__ int msc_move_thr(const SubchDev &sc, long long r)
+{
+  const long long t = sc.move_cif - r + 16;
+  return t <= 0 ? 0 : (t >= 16 ? 16 : (int)t);
+}
+#endif
 
 // Per-batch snapshot of the CIF counters: the MSC kernels of a batch run on their own HIP stream while the front
 // end already advances cif_no for the next frames.

@@ -1274,6 +1274,7 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
   const uint16_t *map;
   long long r;                         // CIF being output
   int base;                            // cu_start * 64
+  int base_prev, thr;                  // a sub-channel that moved: CIFs r - 16 + m with m < thr are read at its old address (msc_move_thr)
   typedef ushort4 Key;
   struct Raw { uint8_t a, b, c, d; };
   __device__ Key key(int t) const { return *reinterpret_cast<const ushort4 *>(map + 4 * t); }
@@ -1284,7 +1285,7 @@ struct SrcMsc {                        // time de-interleaver read + depuncture 
     const int i4 = idx & 15;
     const int m = ((i4 & 1) << 3) | ((i4 & 2) << 1) | ((i4 & 4) >> 1) | ((i4 & 8) >> 3);
     const long long q = r - 16 + m;
-    return tdi[tdi_off(q, base + idx)];
+    return tdi[tdi_off(q, (m < thr ? base_prev : base) + idx)];
   }
   __device__ Raw raw(Key m) const { return {ld(m.x), ld(m.y), ld(m.z), ld(m.w)}; }
   __device__ static int cv(uint8_t v, uint16_t idx) { return vit_sym_from_u8(idx == PUNCT ? (uint8_t)127 : v); }
@@ -1304,7 +1305,7 @@ __global__ __launch_bounds__(256, 8) void k_msc_frame(EngineDev e, DevTables t, 
   const SubchDev &sc = e.subch[(size_t)s * e.max_subch + j];
   if (sc.fast_class && ((fast_mask >> (sc.fast_class - 1)) & 1u)) return;
   const long long r = q.r, out_idx = q.out_idx;
-  SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64};
+  SrcMsc src{e.tdi + (size_t)s * TDI_SLOTS * CIF_BITS, sc.map, r, sc.cu_start * 64, sc.prev_cu_start * 64, msc_move_thr(sc, r)};
   uint32_t *dec = e.vit_scratch + ((size_t)e.n_streams * 4 + (size_t)job) * (size_t)e.vit_stride;
   const VitLaneConst k = vit_lane_const(lane);
   if (e.tie_mode == 2) vit_forward<2>(src, sc.nbits + 6, wtab[wave], dec, lane, k);

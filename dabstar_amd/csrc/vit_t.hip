@@ -46,7 +46,8 @@ __device__ __forceinline__ void prep_item(int it, int cw, bool full, int &d, int
   pl = jp & 15; job = jp >> 4;
 }
 // requests this thread's items of the chunk at ring position p0 (cw dwords per run) into registers
-__device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int tid, int p0, int cw, const uint8_t *const *s_base, const long long *s_r)
+__device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int tid, int p0, int cw, const uint8_t *const *s_base, const long long *s_r,
+                                             const int2 *s_mv /* per job: {CIFs m < x lie before the sub-channel's move, byte offset of its old address} */)
 {
   const bool full = cw == PCH / 4;
   if (full) {
@@ -61,7 +62,8 @@ __device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int ti
       uint32_t v = 0x7F7F7F7Fu;
       if (base) {
         const unsigned slot = (unsigned)(s_r[r] - 16 + brev) & (TDI_SLOTS - 1);      // out_r[idx] = in_{r-16+map[idx&15]}[idx], backend.cpp:129
-        v = *reinterpret_cast<const uint32_t *>(base + (size_t)slot * CIF_BITS + in_plane);
+        const int2 mv = s_mv[r];
+        v = *reinterpret_cast<const uint32_t *>(base + (brev < mv.x ? mv.y : 0) + (size_t)slot * CIF_BITS + in_plane);
       }
       stage[r] = v;
     }
@@ -78,7 +80,8 @@ __device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int ti
       if (base) {
         // out_r[idx] = in_{r-16+map[idx&15]}[idx], map = 4-bit reversal (backend.cpp:129); planar ring: plane = idx & 15
         const long long cif = s_r[job] - 16 + bitrev4(pl);
-        v = *reinterpret_cast<const uint32_t *>(base + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d);
+        const int2 mv = s_mv[job];
+        v = *reinterpret_cast<const uint32_t *>(base + (bitrev4(pl) < mv.x ? mv.y : 0) + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d);
       }
     }
     stage[r] = v;
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
   __shared__ __attribute__((aligned(16))) uint8_t tile[PJB * PJS];
   __shared__ const uint8_t *s_base[PJB];     // per job: stream ring + cu_start*4 (nullptr = invalid job)
   __shared__ long long s_r[PJB];
+  __shared__ int2 s_mv[PJB];
   const int ci = msc_class_of_group(L, blockIdx.x / (64 / PJB));
   const MscLaunchCls &cl = L.c[ci];
   const int n_in = cl.n_in;
@@ -98,8 +102,10 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
   const int tid = threadIdx.x, job0 = (blockIdx.x - cl.g0 * (64 / PJB)) * PJB;      // job within the class
   if (tid < PJB) {
     const MscJob q = msc_class_job(e, cl, job0 + tid, cifs);
-    s_base[tid] = q.valid ? e.tdi + (size_t)q.s * TDI_SLOTS * CIF_BITS + e.subch[(size_t)q.s * e.max_subch + q.j].cu_start * 4 : nullptr;
+    const SubchDev &sc = e.subch[(size_t)q.s * e.max_subch + q.j];
+    s_base[tid] = q.valid ? e.tdi + (size_t)q.s * TDI_SLOTS * CIF_BITS + sc.cu_start * 4 : nullptr;
     s_r[tid] = q.r;
+    s_mv[tid] = make_int2(q.valid ? msc_move_thr(sc, q.r) : 0, (sc.prev_cu_start - sc.cu_start) * 4);
   }
   const int rows = n_in / 4 + 1;
   const int jl = tid & (PJB - 1), pg = (tid >> 5) & 3, qd = tid >> 7;      // job in block, plane group, half of the chunk
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
   // coalesce) are in flight behind the LDS reads, permutes and stores of the chunk before instead of in front of a barrier.
   uint32_t stage[PREP_STG];
   auto chunk_dwords = [&](int p0) { return (npos - p0 < PCH ? npos - p0 : PCH) / 4; };     // npos % 4 == 0
-  if (npos > 0) prep_request(stage, tid, 0, chunk_dwords(0), s_base, s_r);
+  if (npos > 0) prep_request(stage, tid, 0, chunk_dwords(0), s_base, s_r, s_mv);
   for (int p0 = 0; p0 < npos; p0 += PCH) {
     const int cw = chunk_dwords(p0);                               // dwords per run in this chunk
     const bool full = cw == PCH / 4;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
       }
     }
     __syncthreads();
-    if (p0 + PCH < npos) prep_request(stage, tid, p0 + PCH, chunk_dwords(p0 + PCH), s_base, s_r);
+    if (p0 + PCH < npos) prep_request(stage, tid, p0 + PCH, chunk_dwords(p0 + PCH), s_base, s_r, s_mv);
     // (2) transpose 4 planes x 4 positions, write idx-ordered dwords
     const uint8_t *mine = tile + jl * PJS + (4 * pg) * PCH;
     for (int d = qd; d < cw; d += 2) {

@@ -272,7 +272,9 @@ void dabx_default_config(dabx_config *cfg);
 int  dabx_create(const dabx_config *cfg, dabx_engine **out);
 void dabx_destroy(dabx_engine *e);
 /* MscHandler::set_channel / stop_service equivalent for stream (or all streams when stream < 0): d[j] describes slot j
- * (kbps == 0: empty slot).  A slot whose description is unchanged keeps decoding without interruption; new or changed
+ * (kbps == 0: empty slot).  A slot whose description is unchanged keeps decoding without interruption, and so does one whose
+ * sub-channel only moves to other capacity units (same SubChId, size, bit rate, protection: a multiplex reconfiguration; its
+ * de-interleaver reads the CIFs before the change at the old address); new or otherwise changed
  * slots start their 16-CIF de-interleaver fill at the current CIF; a new largest bit rate re-strides the output rings in
  * place, running services are not disturbed.
  * Streams may carry different layouts: the decoder groups the slots of all streams by protection profile (rebuilt by the

@@ -42,8 +42,8 @@ public:
   std::function<void(const std::vector<dabx_tii_result> &)> on_tii;                                 // signal_show_tii
   // IFibDecoder::signal_change_in_configuration (fib_decoder_fig0.cpp:109) -- which the reference answers with "not supported yet"
   // (dabradio.cpp:271-274).  Here the running services are carried over to the announced configuration at its first CIF before the
-  // callback fires: a service described as before runs through, one whose sub-channel changes restarts its de-interleaver there,
-  // one that is no longer announced stops.  first_cif counts the CIFs this processor has demodulated (4 per frame).
+  // callback fires: a service described as before runs through, also at other capacity units; one whose sub-channel changes size or
+  // protection restarts its de-interleaver there; one that is no longer announced stops.  first_cif counts the CIFs this processor has demodulated (4 per frame).
   std::function<void(long long first_cif)> on_configuration_change;
   bool follow_reconfigurations = true;
 
@@ -233,7 +233,8 @@ private:
       dabx_subch_desc now{};
       for (int k = 0; k < n_next; k++) if (next[(size_t)k].subch_id == old.subch_id) now = next[(size_t)k];
       if (now.kbps && now.dab_plus < 0) now.dab_plus = old.dab_plus;
-      const bool same = now.kbps == old.kbps && now.cu_start == old.cu_start && now.cu_size == old.cu_size &&
+      // (a sub-channel that only moves to other capacity units keeps running in the engine: same counters)
+      const bool same = now.kbps == old.kbps && now.cu_size == old.cu_size &&
                         now.prot_level == old.prot_level && now.short_form == old.short_form && now.dab_plus == old.dab_plus;
       slots_[j] = now;
       if (!same) { delivered_[j] = 0; sf_delivered_[j] = 0; }      // a changed slot counts its logical frames from zero again

@@ -214,6 +214,7 @@ void ora_phaseref_set_strongest(ora_phaseref *p, int on);
 typedef struct ora_receiver ora_receiver;
 ora_receiver *ora_rx_create(const ora_subch_desc *subch, int n_subch);
 void ora_rx_destroy(ora_receiver *r);
+void ora_rx_move_subch(ora_receiver *r, int i, int new_cu_start, long at_cif);   /* back end i reads its slice at new_cu_start from CIF at_cif on */
 void ora_rx_set_dc_iq(ora_receiver *r, int mode);   /* SampleReader::set_dc_and_iq_correction: 0 off, 1 DC, 2 DC + IQ */
 void ora_dciq_sample(ora_cf32 *v, int mode, float *st5);
 void ora_dciq_buffer(ora_cf32 *iq, size_t n, int mode, float *st5);

@@ -20,6 +20,8 @@ struct ora_receiver {
   float threshold; int sync_strongest;
   ora_phaseref pr; ora_demap dm; ora_fic fic;
   int n_back; ora_backend *back;
+  long cifs_done;                    /* CIFs handed to the back ends so far */
+  long *move_cif; int *move_to;      /* per back end: from CIF move_cif on its capacity units start at move_to (ora_rx_move_subch) */
   int16_t cif[ORA_CIF_BITS];
   ora_cf32 buf[ORA_TN];
   int16_t bits[ORA_2K];
@@ -171,6 +173,7 @@ void ora_rx_destroy(ora_receiver *r)
 {
   if (!r) return;
   for (int i = 0; i < r->n_back; i++) ora_backend_free(&r->back[i]);
+  free(r->move_cif); free(r->move_to);
   free(r->back);
   free(r->cap.fibs); free(r->cap.fib_crc); free(r->cap.soft); free(r->cap.start_idx); free(r->cap.fbb); free(r->cap.sym0_pos);
   free(r->cap.fbb_end); free(r->cap.clock_err); free(r->cap.fic_ratio); free(r->cap.snr_db); free(r->cap.fic_overflow); free(r->cap.msc_overflow);
@@ -213,7 +216,23 @@ static void msc_process_block(ora_receiver *r, const int16_t *bits, int blk)
   const int cur = (blk - 4) % 18;
   memcpy(&r->cif[cur * ORA_2K], bits, sizeof(int16_t) * ORA_2K);
   if (cur < 17) return;
-  for (int i = 0; i < r->n_back; i++) ora_backend_process(&r->back[i], &r->cif[r->back[i].d.cu_start * 64]);
+  for (int i = 0; i < r->n_back; i++) {
+    /* A sub-channel that only moves to other capacity units at a reconfiguration: the Backend object keeps running (its
+     * de-interleaver history is its own, backend.cpp:131-139), MscHandler hands it its slice from the new address on */
+    if (r->move_cif && r->move_cif[i] >= 0 && r->cifs_done >= r->move_cif[i]) { r->back[i].d.cu_start = r->move_to[i]; r->move_cif[i] = -1; }
+    ora_backend_process(&r->back[i], &r->cif[r->back[i].d.cu_start * 64]);
+  }
+  r->cifs_done++;
+}
+void ora_rx_move_subch(ora_receiver *r, int i, int new_cu_start, long at_cif)
+{
+  if (i < 0 || i >= r->n_back) return;
+  if (!r->move_cif) {
+    r->move_cif = (long *)malloc(sizeof(long) * (size_t)r->n_back);
+    r->move_to = (int *)calloc((size_t)r->n_back, sizeof(int));
+    for (int k = 0; k < r->n_back; k++) r->move_cif[k] = -1;
+  }
+  r->move_cif[i] = at_cif; r->move_to[i] = new_cu_start;
 }
 
 /* dab_processor.cpp:191-265 + :304-367 + :267-302 ; returns 0 at end of input */

@@ -96,6 +96,7 @@ def oracle():
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.ora_parse_fibs.argtypes = [_u8p, _u8p, C.c_int, C.POINTER(SubchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    L.ora_rx_move_subch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long]
     L.ora_fibdec_new.restype = C.c_void_p
     L.ora_fibdec_free.argtypes = [C.c_void_p]
     L.ora_fibdec_process.argtypes = [C.c_void_p, _u8p, _u8p, C.c_int]

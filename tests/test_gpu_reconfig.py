@@ -1,8 +1,9 @@
 """Multiplex reconfiguration, followed at the announced CIF (VERDICT r3 "Next round" 3; EN 300 401 6.4.1 / 6.5).
 
 The transmitter (tools/dab_synth.py::build_reconfigured_ensemble) announces the next configuration for seven frames -- FIG 0/0 with
-change flags 3 and OccurrenceChange, FIG 0/1 and 0/2 with C/N = 1 -- and switches at a frame boundary: three services run
-through, one moves to other capacity units, one grows from 64 to 96 kbit/s, one ends, one begins.  The host follows with
+change flags 3 and OccurrenceChange, FIG 0/1 and 0/2 with C/N = 1 -- and switches: three services run through, one moves to other
+capacity units (and runs through as well: its de-interleaver reads the CIFs before the switch at the old address), one grows from
+64 to 96 kbit/s, one ends, one begins.  The host follows with
 dabx_follow_fic / dabx_next_subchannels / dabx_set_subchannels_at.  Every logical frame either side of the switch must equal the
 oracle receiver's (run once with the old and once with the new table over the whole stream) and what was transmitted."""
 import os
@@ -20,9 +21,12 @@ from tools import dab_synth as ds  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(x, subch):
+def _oracle(x, subch, move=None):
+    """move = (back end, new first capacity unit, CIF): that sub-channel is handed its slice from the new address from that CIF on"""
     L = ol.oracle()
     rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+    if move:
+        L.ora_rx_move_subch(rx, *move)
     n = L.ora_rx_run(rx, x, len(x), 10000)
     cap = L.ora_rx_get_capture(rx).contents
     res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy(), crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy(),
@@ -48,6 +52,10 @@ def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame):
     x = ds.channel(ens.iq, snr_db=20.0, cfo_hz=310.0, timing_offset=3000, seed=5, cyclic=False)
     ora_a, ora_b = _oracle(x, a), _oracle(x, b)
     assert ora_a["n"] == ora_b["n"] >= n_frames - 2 and ora_a["crc"][2:].all()      # (the first two frames: start-up of the CFO loop)
+    # the sub-channel that only moves: one Backend that is handed its slice from the new address from the switch CIF on (the receivers
+    # count CIFs from their first frame: transmitted CIF = counted CIF + the counter of the first FIG 0/0 - its position)
+    c0_ora = dx.parse_fibs(ora_a["fibs"][2][:1], np.ones(1, np.uint8))[1] - 8
+    ora_m = _oracle(x, a, move=(3, 400, ens.switch_cif - c0_ora))
 
     eng = dx.Engine(n_streams=1, ring_frames=n_frames + 2, max_subch=6, out_frames=4)
     eng.set_subchannels(a)
@@ -67,7 +75,7 @@ def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame):
             assert sorted((g.subch_id, g.cu_start, g.cu_size, g.kbps, g.prot_level, g.dab_plus) for g in nxt) == \
                 sorted((c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, int(c.dab_plus)) for c in b)
             by_id = {g.subch_id: g for g in nxt}
-            eng.set_subchannels_at([by_id[c.subch_id] for c in b], 0, at_cif)   # slot order: 0 1 2 | 3 moved | 4 grown | 6 new
+            eng.set_subchannels_at([by_id[c.subch_id] for c in b], 0, at_cif)   # slot order: 0 1 2 | 3 moves | 4 grows | 6 begins
             applied = True
         eng.process(1)
         st = eng.stats(0)
@@ -102,13 +110,16 @@ def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame):
                 assert np.array_equal(frames_by_cif[r], payload[r + c0 - 16 - first]), (tag, r, "transmitted")
 
     end = 4 * frames
-    for j in range(3):                                                     # run through: no gap, nothing lost
+    for j in range(4):                                                     # run through, 3 at another address from the switch on: no gap, nothing lost
         merged = dict(got[0][j]); merged.update(got[1][j])
-        check("through %d" % j, merged, ora_a["msc"][j], ("a", j), 16, end)
-    assert at_cif % 4 == cif_in_frame
-    for j, sid in ((3, 3), (4, 4), (5, 5)):                                # end at the switch: every frame numbered below at_cif (mid-frame: below its frame's first CIF)
+        check("through %d" % j, merged, (ora_m if j == 3 else ora_a)["msc"][j], ("a", j), 16, end)
+    assert at_cif % 4 == cif_in_frame and c0 == c0_ora
+    if cif_in_frame:
+        # (in the middle of a frame the engine moves the sub-channel's address at the announced CIF exactly: start_cif of a moved slot stays)
+        assert eng.subch_stats(0, 3)["start_cif"] == 0
+    for j, sid in ((4, 4), (5, 5)):                                        # end at the switch: every frame numbered below at_cif (mid-frame: below its frame's first CIF)
         check("ends %d" % sid, got[0][j], ora_a["msc"][j], ("a", sid), 16, at_cif - cif_in_frame)
-    for j, sid in ((3, 3), (4, 4), (5, 6)):                                # begin at the switch: from frame at_cif + 16, the service's first one
+    for j, sid in ((4, 4), (5, 6)):                                        # begin at the switch: from frame at_cif + 16, the service's first one
         check("begins %d" % sid, got[1][j], ora_b["msc"][j], ("b", sid), at_cif + 16, end)
     s4 = eng.subch_stats(0, 4)
     assert s4["start_cif"] == at_cif and s4["sf_ok"] >= 5 and s4["sf_fail"] == 0       # the grown service: DAB+ super frames again

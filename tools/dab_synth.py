@@ -483,12 +483,22 @@ def build_reconfigured_ensemble(n_frames: int, subch_a: list, subch_b: list, swi
     """A multiplex reconfiguration (EN 300 401 6.5) at CIF switch_cif_in_frame (0..3) of frame switch_frame: layout A before, layout B from then on,
     announced for announce_frames frames in advance (FIG 0/0 change flags 3 + OccurrenceChange, the next configuration's FIG 0/1
     and 0/2 with C/N = 1); afterwards the flags are 0 and B is the current configuration.  Sub-channels described identically in
-    A and B run through (same convolutional interleaver, no gap); one that ends has its last 15 logical frames cut off in
+    A and B run through (same convolutional interleaver, no gap), and so does one that only moves to other capacity units (its bits are
+    sent at the new address from the switch on); one that ends has its last 15 logical frames cut off in
     the air (their later interleaver branches fall on CUs that belong to B); one that begins starts its interleaver at the switch."""
     rng = np.random.default_rng(seed)
     n_cif, N = 4 * n_frames, 4 * switch_frame + switch_cif_in_frame
     through = [c for c in subch_a if any(_same_desc(c, d) for d in subch_b)]
-    only_b = [d for d in subch_b if not any(_same_desc(c, d) for c in subch_a)]
+    # a sub-channel that only MOVES (same id, size, bit rate, protection; other capacity units) keeps its interleaver running: from the
+    # switch on its bits are sent at the new address
+    def _moved_to(c):
+        for d in subch_b:
+            if (d.subch_id, d.cu_size, d.kbps, d.prot_level, d.short_form, d.dab_plus) == (c.subch_id, c.cu_size, c.kbps, c.prot_level, c.short_form, c.dab_plus) \
+                    and d.cu_start != c.cu_start:
+                return d
+        return None
+    moved = {c.subch_id: _moved_to(c) for c in subch_a if _moved_to(c) is not None}
+    only_b = [d for d in subch_b if not any(_same_desc(c, d) for c in subch_a) and d.subch_id not in moved]
     pos = np.arange(55296)
     delay = INTERLEAVE_MAP[pos & 15]
 
@@ -511,15 +521,16 @@ def build_reconfigured_ensemble(n_frames: int, subch_a: list, subch_b: list, swi
     payload = {}
     for layout, chs, first, last, t0, t1 in (("a", subch_a, 0, None, 0, None), ("b", only_b, N, n_cif, N, n_cif)):
         for c in chs:
-            runs_through = layout == "a" and c in through
+            runs_through = layout == "a" and (c in through or c.subch_id in moved)
             lf_last = n_cif if (layout == "b" or runs_through) else N                # logical frames it carries
             cif_last = n_cif if (layout == "b" or runs_through) else N               # CIFs in which its CUs are its own
             coded, stream = code(c, first, lf_last)
             payload[(layout, c.subch_id)] = (first, stream)
-            sl = slice(c.cu_start * 64, (c.cu_start + c.cu_size) * 64)
-            d = delay[sl]
             cols = np.arange(64 * c.cu_size)
             for t in range(t0, cif_last):
+                start = moved[c.subch_id].cu_start if (layout == "a" and c.subch_id in moved and t >= N) else c.cu_start
+                sl = slice(start * 64, (start + c.cu_size) * 64)
+                d = delay[sl]                                                         # (the branch a bit takes depends on its position in the CIF)
                 src = t - d
                 ok = (src >= first) & (src < lf_last)
                 row = tx_cif[t, sl]
