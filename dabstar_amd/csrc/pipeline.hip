@@ -200,7 +200,9 @@ int launch_dciq(const EngineDev &e, int mode, hipStream_t st)
 constexpr int ACQ_CH = 1024;
 struct AcqLds {
   __attribute__((aligned(16))) float a[3][64 + ACQ_CH + 32];  // |x| of three consecutive blocks: a[j % 3][64 + i] = sample i of block j, [0..63] = the 64 samples before it
-  __attribute__((aligned(16))) float d[2][ACQ_CH + 32];       // increments of the moving sum |x[n]| - |x[n - 50]| of block j in d[j & 1]
+  __attribute__((aligned(16))) float r[3][64 + ACQ_CH + 32];  // |x * osc| of the same blocks: what the time syncer sees (the sample reader hands it the sample times
+                                                              // oscillatorTable[currentPhase], sample_reader.cpp:274-281 -- a constant phasor while searching, but the rounding of the product is in the magnitude)
+  __attribute__((aligned(16))) float d[2][ACQ_CH + 32];       // increments of the moving sum |x osc|[n] - |x osc|[n - 50] of block j in d[j & 1]
   float bmax[3][4];                                           // maximum of a[j % 3] in four parts
   float Sc[2][ACQ_CH / 16 + 8];                               // sLevel CHECKPOINTS of block j: Sc[j & 1][1 + k] after sample 16 k + 15, [0] before the block
   float Lc[ACQ_CH / 16 + 8];                                  // level checkpoints of the block being evaluated: Lc[1 + k] after sample 16 k + 15
@@ -260,35 +262,46 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
   const unsigned len = (unsigned)e.ring_len, base = (unsigned)(rd0 % (unsigned long long)e.ring_len);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform: the roles below branch on the scalar unit
+  // The search reads with frequency offset 0: currentPhase stays where the last frame left it and every sample is multiplied by the
+  // same table entry (sample_reader.cpp:274-281).  sLevel and peakLevel are taken before that product (:245-248), the time syncer's
+  // envelope after it (timesyncer.cpp:52, 64, 78): two magnitudes per sample, equal only while the phase is still 0.
+  float2 osc;
+  {
+    double si, co;
+    sincospi(2.0 * (double)c.nco_phase / (double)INPUT_RATE, &si, &co);
+    osc = make_float2((float)co, (float)si);
+  }
   // |x| of block j of this pass (and, in front of it, the last 64 magnitudes of block j - 1) by threads t0, t0 + nt, ...; nothing
   // beyond the committed samples is touched (a line fetched before its samples were committed would stay in this CU's cache
   // for the rest of the kernel)
   auto mags = [&](int j, int t0, int nt) {
-    float *dst = w.a[j % 3];
+    float *dst = w.a[j % 3], *dsr = w.r[j % 3];
     const unsigned long long p0 = (unsigned long long)j * ACQ_CH;
     const unsigned o0 = (unsigned)((base + p0) % len);     // one 64-bit modulo per block, then add + conditional subtract
     float mx = 0.f;
     for (int q = t0; q < ACQ_CH; q += nt) {
-      float a = 0.f;
+      float a = 0.f, ar = 0.f;
       if (p0 + (unsigned)q < avail) {
         unsigned o = o0 + (unsigned)q;
         if (o >= len) o -= len;
         const float2 v = ring[o];
         a = sqrtf(v.x * v.x + v.y * v.y);
+        const float2 m = cmul(v, osc);
+        ar = sqrtf(m.x * m.x + m.y * m.y);
       }
-      dst[64 + q] = a;
+      dst[64 + q] = a; dsr[64 + q] = ar;
       mx = fmaxf(mx, a);
     }
-    if (j > 0) for (int q = t0; q < 64; q += nt) dst[q] = w.a[(j - 1) % 3][ACQ_CH + q];
+    if (j > 0) for (int q = t0; q < 64; q += nt) dsr[q] = w.r[(j - 1) % 3][ACQ_CH + q];
     mx = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, mx), [](unsigned x, unsigned y) { return x > y ? x : y; }));
     if (lane == 0) w.bmax[j % 3][wave] = mx;               // (order of non-negative floats = order of their bits)
     if (nt < T && tid < 128 + 2) w.bmax[j % 3][tid - 128] = 0.f;   // two waves fill the block: the other two parts are empty
   };
   // the increments of block j as they are in the middle of an attempt (its first 50 samples are patched by the search, below)
   auto incs = [&](int j, int t0, int nt) {
-    const float *ab = w.a[j % 3] + 64;
+    const float *rb = w.r[j % 3] + 64;
     float *dst = w.d[j & 1];
-    for (int q = t0; q < ACQ_CH; q += nt) dst[q] = ab[q] - ab[q - 50];       // timesyncer.cpp:78-80
+    for (int q = t0; q < ACQ_CH; q += nt) dst[q] = rb[q] - rb[q - 50];       // timesyncer.cpp:78-80
   };
   if (tid == 0) { w.done = 0; w.ok = 0; }
   mags(0, tid, T);
@@ -323,7 +336,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
     } else if (wave == 1) {
       if (i > 0) {
         const int jb = i - 1;
-        const float *ab = w.a[jb % 3] + 64, *Scb = w.Sc[jb & 1];
+        const float *ab = w.a[jb % 3] + 64, *rb = w.r[jb % 3] + 64, *Scb = w.Sc[jb & 1];
         const unsigned long long P = (unsigned long long)jb * ACQ_CH;
         // sLevel BEFORE sample pos of this block (pos <= ACQ_CH), from the checkpoint of its group: a 16-step walk by the lane that owns it
         auto s_before = [&](int pos) {
@@ -353,7 +366,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
             if (nb < 50 || q16 < q)                                          // the attempt's first 50 samples: level += |x| (:64-66)
               for (int p = q16 + lane; p < q16 + 128; p += 64) {
                 if (p < q) db[p] = 0.f;
-                else if (p < q + m && nb + (p - q) < 50) db[p] = ab[p];
+                else if (p < q + m && nb + (p - q) < 50) db[p] = rb[p];
               }
             ACQ_T(1) }
             { ACQ_T0

@@ -120,6 +120,26 @@ def _rerun_exact_level(x, subch, cfg, tie=0):
     return fibs, crcs, walk
 
 
+def test_the_search_sees_the_samples_behind_the_oscillator():
+    """The time syncer gets its samples from the sample reader, i.e. multiplied by oscillatorTable[currentPhase] also while the frequency
+    offset handed in is 0 (sample_reader.cpp:274-281): after a frame that was read with a carrier offset the phase stands somewhere, and
+    the magnitude of the product differs from the magnitude of the sample in its last bit now and then.  Hunt 11000-11059 found the stream
+    on which that decides where a null symbol ends (seed 11033, stream 20: lock on a false peak, loss, second search one sample late,
+    start index 458 instead of 459): with the exact level tracker the walk must be the oracle's, frame by frame."""
+    layouts, cases, xs, _rng = draw_streams(11033, only=20)
+    li = cases[20][0]
+    cfg = (3.0, 1, 1)
+    ora = _oracle(xs[20], layouts[li], cfg)
+    fibs, crcs, walk = _rerun_exact_level(xs[20], layouts[li], cfg)
+    n = min(len(fibs), ora["n"])
+    assert n >= 20 and abs(len(fibs) - ora["n"]) <= 1
+    assert ora["start"][:3].tolist() == [295, 459, 504]                    # the case is the one described above
+    assert [w[0] for w in walk[:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[:n]] == ora["start"][:n].tolist()
+    assert np.array_equal(np.array(crcs)[:n], ora["crc"][:n])
+    ok = ora["crc"][:n].astype(bool)
+    assert ok.sum() >= 12 * 18 and np.array_equal(np.array(fibs)[:n][ok], ora["fibs"][:n][ok])
+
+
 # The committed draws: three seeds, each with its own receiver options, all under the strict rules (no stream may need the exact
 # level tracker, no logical frame may differ where the oracle delivers the transmitted one).  DABX_FUZZ_SEED (tools/fuzz_hunt.py)
 # replaces them by one hunting draw under the tolerant rules.
