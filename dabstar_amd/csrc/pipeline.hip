@@ -18,6 +18,7 @@
 #include "viterbi_core.h"
 #include "fec_core.h"
 #include "acq_walk.h"
+#include "level_par.h"
 
 namespace dabx {
 
@@ -310,6 +311,8 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   __syncthreads();
   // wave 0: sLevel
   float S = c.s_level;
+  LevelPar lp;
+  if (wave == 0) lp.init(lane);
   // wave 1: the search proper (all of it wave-uniform)
   int phase = (st == ST_INIT) ? 0 : 1;   // 0: seeding the level (20 T_u samples, dab_processor.cpp:130-139); 1: looking for the begin of a dip; 3: for its end
   int nb = 0;                            // samples of the seed / of the attempt evaluated so far
@@ -327,11 +330,10 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   int i = 0;
   for (;; i++) {
     if (wave == 0) {
-      // every lane walks (same addresses, same values): with a single lane active, two such waves on one CU -- two streams
-      // searching -- slow each other down to half speed; with the full wave they do not (tools/acq_walk_bench.hip, 512 blocks)
+      // the block's 64 groups of 16 samples in parallel, one per lane (level_par.h): Sc[g] = sLevel before group g, bit for bit what
+      // the sample-serial walk gives (round 4 began with that walk here: 17.6 cycles per sample, 20 000 per block, the pace of the search)
       ACQ_T0
-      w.Sc[i & 1][0] = S;
-      S = acq_walk_S_ckpt(w.a[i % 3] + 64, w.Sc[i & 1] + 1, ACQ_CH / 16, S);
+      S = lp.block(w.a[i % 3] + 64, ACQ_CH / 16, S, w.Sc[i & 1], lane);
       ACQ_T(0)
     } else if (wave == 1) {
       if (i > 0) {
@@ -1252,6 +1254,8 @@ __global__ __launch_bounds__(128) void k_level_exact(EngineDev e)
     }
   };
   float lv = c.s_level;
+  LevelPar lp;
+  if (wave == 0) lp.init(lane);
   if (wave == 1) { request(0); publish(chunk[0]); request(CH); }
   __syncthreads();
   unsigned b = 0;
@@ -1262,7 +1266,7 @@ __global__ __launch_bounds__(128) void k_level_exact(EngineDev e)
     } else {                                                 // every lane of the wave walks: see acquire_stream
       const unsigned m = n - p0 < CH ? (unsigned)(n - p0) : CH;
       const int n16 = __builtin_amdgcn_readfirstlane((int)(m >> 4));
-      if (n16 > 0) lv = acq_walk_S_only(chunk[b], n16, lv);
+      if (n16 > 0) lv = lp.block(chunk[b], n16, lv, nullptr, lane);
       for (unsigned i = 16u * (unsigned)n16; i < m; i++) lv += 0.00001f * (chunk[b][i] - lv);
     }
     __syncthreads();

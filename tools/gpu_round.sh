@@ -35,6 +35,7 @@ for what in "$@"; do
            for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -14 $f | cut -c1-200; done > $OUT/profvariants.txt; cat $OUT/profvariants.txt ;;
     acqtime) python3 tools/acq_time.py 8 > $OUT/acq_time_8.jsonl 2>&1; python3 tools/acq_time.py 512 > $OUT/acq_time_512.jsonl 2>&1; cat $OUT/acq_time_8.jsonl $OUT/acq_time_512.jsonl ;;
     acqphases) DABX_LIB=$(realpath dabstar_amd/_ab/libdabx_acqtime.so) python3 tools/acq_time.py 8 2>&1 | grep -E "^acq wave|case" | head -40 > $OUT/acq_phases.txt; cat $OUT/acq_phases.txt ;;
+    levelpar) tools/_build/level_par_check ${LEVELPAR_N:-8000000} > $OUT/level_par_check.jsonl 2>&1; echo "rc=$?" >> $OUT/level_par_check.jsonl; cat $OUT/level_par_check.jsonl ;;
     walkbench) tools/_build/acq_walk_bench > $OUT/acq_walk_bench.jsonl 2>&1; cat $OUT/acq_walk_bench.jsonl ;;
   esac
 done
