@@ -32,23 +32,16 @@
 // this code on the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "acq_walk.h"
 
 namespace dabx {
 
 constexpr int LVL_K = 32;
+constexpr int LVL_MAX_WALKED = 6;          // groups settled one by one before the rest of a block is handed to the serial walker
 
-#define DABX_LV_OP2(name, ins) \
-  __device__ __forceinline__ float name(float a, float b) { float r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// (opaque to the optimiser: the two walks of a lane must not be fused into v_pk_*_f32, whose latency is four times v_*_f32's
-//  for a lone wave, nor contracted or re-associated -- they ARE the reference's three roundings)
-DABX_LV_OP2(lv_sub, "v_sub_f32")
-DABX_LV_OP2(lv_add, "v_add_f32")
-DABX_LV_OP2(lv_min, "v_min_f32")
-DABX_LV_OP2(lv_max, "v_max_f32")
-__device__ __forceinline__ float lv_mulc(float a) { float r; asm("v_mul_f32 %0, 0x3727c5ac, %1" : "=v"(r) : "v"(a)); return r; }   // 0.00001f *
-__device__ __forceinline__ float lv_max3abs(float m, float a, float b) { float r; asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float lv_step(float S, float a) { return lv_add(S, lv_mulc(lv_sub(a, S))); }
-
+#ifdef DABX_LV_DEBUG
+__device__ unsigned *dabx_lv_debug;
+#endif
 struct LevelPar {
   float q, p1, p2;                       // per lane: alpha^lane - 1, alpha^(lane % 16 + 1), alpha^(lane % 32 + 1); alpha = (1 - c)^16: a group's slope
   static constexpr double C = (double)0.00001f;
@@ -139,22 +132,39 @@ struct LevelPar {
     const bool safe = Gb > (25u << 23) + K && Gb < 0x7f000000u && dacc == 0 && tmax != half_ulp &&
                       (__builtin_bit_cast(unsigned, mn) >> 23) == (__builtin_bit_cast(unsigned, mx) >> 23) && amax <= 1024.f * lo0;
     const unsigned E = __builtin_bit_cast(unsigned, lo) + K;           // where the walk from G itself would have ended, if the group is safe
-    // 3. offsets from the guesses: exclusive prefix sum of D_g = E_g - G_{g+1} (mod 2^32 throughout: unsafe groups put garbage in)
-    unsigned D = E - dppu<0x130, 0xF>(Gb);                               // wave_shl:1: the next lane's guess
-    D += dppu<0x111, 0xF>(D);
-    D += dppu<0x112, 0xF>(D);
-    D += dppu<0x114, 0xF>(D);
-    D += dppu<0x118, 0xF>(D);
-    D += dppu<0x142, 0xA>(D);
-    D += dppu<0x143, 0xC>(D);
-    unsigned k = dppu<0x138, 0xF>(D);
+    // 3. offsets from the guesses: k_g = sum over the groups before g of (E_j - G_{j+1}), i.e. the inclusive prefix sum of
+    //    D_g = E_{g-1} - G_g, D_0 = 0 (mod 2^32 throughout: unsafe groups put garbage in, step 4 takes it out again)
+    unsigned Eprev;                                                      // wave_shr:1 as an instruction of its own: folded into the subtraction
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(Eprev) : "v"(E));   // (v_subrev_u32_dpp) it shifted the wrong operand
+    unsigned k = lane == 0 ? 0u : Eprev - Gb;
+    k += dppu<0x111, 0xF>(k);
+    k += dppu<0x112, 0xF>(k);
+    k += dppu<0x114, 0xF>(k);
+    k += dppu<0x118, 0xF>(k);
+    k += dppu<0x142, 0xA>(k);
+    k += dppu<0x143, 0xC>(k);
+#ifdef DABX_LV_DEBUG
+    if (dabx_lv_debug) { unsigned *o = dabx_lv_debug + 8 * lane; o[0] = Gb; o[1] = __builtin_bit_cast(unsigned, lo); o[2] = __builtin_bit_cast(unsigned, hi); o[3] = E; o[4] = k; o[5] = safe; o[6] = __builtin_bit_cast(unsigned, B); o[7] = __builtin_bit_cast(unsigned, x[0]); }
+#endif
     // 4. settle the groups in order
     const unsigned long long valid = ng >= 64 ? ~0ull : ((1ull << ng) - 1ull);
     bool walked = false;
     unsigned tend = 0;
+    int n_walked = 0, serial_from = 64;
+    float S_serial = 0.f;
     unsigned long long todo = __ballot(!(safe && k + K <= 2u * K)) & valid;
     while (todo) {
       const int gs = __builtin_ctzll(todo);
+      if (++n_walked > LVL_MAX_WALKED) {
+        // an input that defeats the guess (a constant envelope parks the float recurrence in its dead zone, away from the real one; a
+        // NaN): the rest of the block sample by sample, from the true start of group gs -- the block then costs about what it always did
+        S_serial = __builtin_bit_cast(float, rl(Gb + k, gs));
+        const int rest = __builtin_amdgcn_readfirstlane(ng - gs);
+        S_serial = ck ? acq_walk_S_ckpt(a + 16 * gs, ck + gs + 1, rest, S_serial) : acq_walk_S_only(a + 16 * gs, rest, S_serial);
+        serial_from = gs;
+        if (fallbacks && lane == 0) *fallbacks += rest;
+        break;
+      }
       // every lane walks its own group from where it believes it starts; only lane gs is known to be right (and is the one that is used)
       float S = __builtin_bit_cast(float, Gb + k);
 #pragma unroll
@@ -174,7 +184,8 @@ struct LevelPar {
       if (lane > gs) k += delta;
       todo = __ballot(!(safe && k + K <= 2u * K)) & valid & (~0ull << (gs + 1));
     }
-    if (ck && lane < ng) ck[lane] = __builtin_bit_cast(float, Gb + k);
+    if (ck && lane < ng && lane <= serial_from) ck[lane] = __builtin_bit_cast(float, Gb + k);
+    if (serial_from < 64) return S_serial;                              // (ck[serial_from + 1 .. ng] are the walker's)
     const float S_end = __builtin_bit_cast(float, rl(walked ? tend : E + k, ng - 1));
     if (ck && lane == 0) ck[ng] = S_end;
     return S_end;

@@ -1213,7 +1213,10 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
 // more than the rest of the receiver together -- which is why the default advances the tracker chunk-wise (k_frame_tail).
 __global__ __launch_bounds__(128) void k_level_exact(EngineDev e)
 {
-  front_prio();                          // two lone waves per stream that issue an instruction every few cycles: they must not queue behind the decoder's
+#ifndef DABX_LEVEL_PRIO
+#define DABX_LEVEL_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(DABX_LEVEL_PRIO);
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   StreamCtl &c = e.ctl[s];
@@ -1570,14 +1573,14 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   // Streams out of lock (k_acquire).  In step: on the front-end stream, before the frame head -- every step then offers every
   // stream a frame's worth of search.  Asynchronous: on HIP stream q; a pass is launched when the previous one has finished
   // (hipEventQuery, no wait); a pass is a frame's worth of samples (< 2 ms: what a dabx_synchronize may have to wait for).
-  // cfg.exact_level_tracker: k_level_exact in front of every pass (same HIP stream); then the passes are never skipped -- the frame
-  // chain lets the tracker fall one step behind at most (the samples it still has to see must stay in the ring), so the exact
-  // tracker costs max(0, its 1.6 ms per frame - the step) of the step instead of adding to it.
+  // cfg.exact_level_tracker: k_level_exact in front of every pass (same HIP stream).  The frame chain never waits for it: the level is
+  // read nowhere in lock, the tracker walks whatever the receiver has read since its last pass ([level_pos, rd): 0.2 ms per frame
+  // and stream since level_par.h, a fifth of a step), and the samples it still has to see stay in the ring (push_room, engine.cpp).
   if (async_acquire && ss.q) {
-    bool go = true;
-    if (e.exact_level) { if (ss.acq_in_flight) DABX_HIP(hipStreamWaitEvent(st, ss.acq_done, 0)); }
-    else go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
-    if (go) {
+    // a search pass only when q has nothing left to do (a host that queues twenty steps in a millisecond starts one, not twenty: a pass can
+    // take 2 ms); the level tracker with EVERY step -- it is short, and what it leaves undone the next one has to do
+    const bool go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
+    if (go || e.exact_level) {
       // two passes must never work on a stream at the same time: one that ran in step (an earlier call, or the start-up rule of
       // dabx_process) has to be through before the first one on q starts
       if (ss.acq_a_pending) { DABX_HIP(hipStreamWaitEvent(ss.q, ss.acq_a_done, 0)); ss.acq_a_pending = false; }
@@ -1586,7 +1589,7 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
         if (ss.tail_recorded) DABX_HIP(hipStreamWaitEvent(ss.q, ss.tail_done, 0));
         hipLaunchKernelGGL(k_level_exact, dim3(e.n_streams), dim3(128), 0, ss.q, e);
       }
-      mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, 1); mk.end(0, ss.q);
+      if (go) { mk.begin(0, ss.q); hipLaunchKernelGGL(k_acquire, dim3(e.n_streams), dim3(256), 0, ss.q, e, *t, 1); mk.end(0, ss.q); }
       DABX_HIP(hipEventRecord(ss.acq_done, ss.q));
       ss.acq_in_flight = true;
     }

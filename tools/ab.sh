@@ -2,15 +2,15 @@
 # Same-box A/B of engine builds / toggles (run on the GPU box through gpurun): every configuration is one bench.py run,
 # configurations are interleaved and repeated so that box-to-box and minute-to-minute drift cancels.  A variant library is
 # selected through DABX_LIB (read by dabstar_amd/lib.py, the ctypes binding): the product libdabx.so is never overwritten.
-#   tools/ab.sh <out-dir> <reps> "<name>|<lib or ->|<ENV=.. ENV=..>" ...        BENCH_ARGS="--steps 20 --warmup 5" overrides the run
+#   tools/ab.sh <out-dir> <reps> "<name>|<lib or ->|<ENV=.. ENV=..>|<extra bench.py arguments>" ...        BENCH_ARGS="--steps 20 --warmup 5" overrides the run
 OUT=$1; REPS=$2; shift 2
 mkdir -p $OUT
 for r in $(seq 1 $REPS); do
   for cfg in "$@"; do
-    IFS='|' read -r name lib envs <<< "$cfg"
+    IFS='|' read -r name lib envs extra <<< "$cfg"
     libenv=""
     if [ "$lib" != "-" ]; then libenv="DABX_LIB=$(realpath $lib)"; fi
-    env $libenv $envs python3 bench.py ${BENCH_ARGS:---steps 49 --warmup 14} --no-cpu-baseline > $OUT/${name}_$r.json 2> $OUT/${name}_$r.err
+    env $libenv $envs python3 bench.py ${BENCH_ARGS:---steps 49 --warmup 14} --no-cpu-baseline $extra > $OUT/${name}_$r.json 2> $OUT/${name}_$r.err
     python3 - "$OUT/${name}_$r.json" "$name" <<'PY'
 import json, sys
 try:

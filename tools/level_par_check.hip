@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#define DABX_LV_DEBUG
 #include "level_par.h"
 #include "acq_walk.h"
 
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(64) void k_par(const float *a, long n_per_case, flo
   for (long p = 0; p + BLOCK <= n_per_case; p += BLOCK) {
     for (int i = lane; i < BLOCK; i += 64) buf[i] = src[p + i];
     __syncthreads();
+    dabx_lv_debug = (p == 0 && c == 1) ? (unsigned *)(ck_out + (size_t)gridDim.x * (n_per_case / 16)) : nullptr;
     const long long t0 = clock64();
     S = lp.block(buf, 64, S, ck, lane, &fb);
     cyc += clock64() - t0;
@@ -92,7 +94,7 @@ int main(int argc, char **argv)
     }
   // case 7: the NaN arrives at N / 4; to see the infinity as well the level would have to recover, which it does not (NaN stays): keep both
   float *d_a, *d_ck, *d_s, *d_s2; int *d_fb; long long *d_cy, *d_cy2;
-  CK(hipMalloc(&d_a, a.size() * 4)); CK(hipMalloc(&d_ck, (size_t)NC * (N / 16) * 4)); CK(hipMalloc(&d_s, NC * 4)); CK(hipMalloc(&d_s2, NC * 4));
+  CK(hipMalloc(&d_a, a.size() * 4)); CK(hipMalloc(&d_ck, (size_t)NC * (N / 16) * 4 + 64 * 8 * 4)); CK(hipMalloc(&d_s, NC * 4)); CK(hipMalloc(&d_s2, NC * 4));
   CK(hipMalloc(&d_fb, NC * 4)); CK(hipMalloc(&d_cy, NC * 8)); CK(hipMalloc(&d_cy2, NC * 8));
   CK(hipMemcpy(d_a, a.data(), a.size() * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_par, dim3(NC), dim3(64), 0, 0, d_a, N, d_ck, d_s, d_fb, d_cy);
@@ -102,12 +104,21 @@ int main(int argc, char **argv)
   CK(hipMemcpy(ck.data(), d_ck, ck.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(s.data(), d_s, NC * 4, hipMemcpyDeviceToHost));
   CK(hipMemcpy(s2.data(), d_s2, NC * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fb.data(), d_fb, NC * 4, hipMemcpyDeviceToHost));
   CK(hipMemcpy(cy.data(), d_cy, NC * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(cy2.data(), d_cy2, NC * 8, hipMemcpyDeviceToHost));
+  if (getenv("LEVELPAR_VERBOSE")) {
+    unsigned dbg[64 * 8];
+    CK(hipMemcpy(dbg, d_ck + (size_t)NC * (N / 16), sizeof(dbg), hipMemcpyDeviceToHost));
+    for (int l = 0; l < 8; l++) printf("  lane %d: G %08x lo_end %08x hi_end %08x E %08x k %d safe %u B %a x0 %a\n", l, dbg[8*l], dbg[8*l+1], dbg[8*l+2], dbg[8*l+3], (int)dbg[8*l+4], dbg[8*l+5], *(float*)&dbg[8*l+6], *(float*)&dbg[8*l+7]);
+  }
   long bad_total = 0;
   for (int c = 0; c < NC; c++) {
     float S = 0.1f;
     long bad = 0;
     for (long i = 0; i < N; i++) {
-      if ((i & 15) == 0 && f2u(ck[(size_t)c * (N / 16) + i / 16]) != f2u(S)) bad++;
+      if ((i & 15) == 0 && f2u(ck[(size_t)c * (N / 16) + i / 16]) != f2u(S)) {
+        if (bad < 6 && getenv("LEVELPAR_VERBOSE")) printf("  case %d checkpoint %ld (group %ld of its block): got %a (%08x) want %a (%08x)\n", c, i / 16, (i / 16) % 64,
+                                                          ck[(size_t)c * (N / 16) + i / 16], f2u(ck[(size_t)c * (N / 16) + i / 16]), S, f2u(S));
+        bad++;
+      }
       S = step(S, a[(size_t)c * N + i]);
     }
     if (f2u(S) != f2u(s[c])) bad++;
