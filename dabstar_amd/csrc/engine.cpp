@@ -70,6 +70,7 @@ struct dabx_engine {
 
   std::vector<void *> fast_allocs;             // buffers of the current MSC classes (replaced on reconfiguration)
   bool classes_dirty = false;
+  unsigned long long *horizon_host = nullptr;  // hipHostMalloc'ed, EngineDev::wr_horizon: what pushes may have overwritten (written BEFORE a copy is issued)
   int32_t *locked_host = nullptr;              // hipHostMalloc'ed: number of streams in lock, kept by the device (EngineDev::locked_count)
   bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
   int build_msc_classes();
@@ -224,7 +225,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   if (!cfg || !out || cfg->n_streams <= 0 || cfg->ring_frames < 2 || cfg->max_subch < 0 || cfg->max_subch > MAX_SUBCH ||
       cfg->out_frames < 1 || cfg->soft_bit_type < 1 || cfg->soft_bit_type > 3 || cfg->dc_iq_correction < 0 || cfg->dc_iq_correction > 2 ||
       cfg->viterbi_tie_mode < 0 || cfg->viterbi_tie_mode > 2 || cfg->schedule < 0 || cfg->schedule > 1 ||
-      cfg->msc_fast_min_jobs < 0 || cfg->msc_class_min_jobs < 0 || cfg->exact_level_tracker < 0 || cfg->exact_level_tracker > 1 ||
+      cfg->msc_fast_min_jobs < 0 || cfg->msc_class_min_jobs < 0 || cfg->exact_level_tracker < 0 || cfg->exact_level_tracker > 2 ||
       cfg->acquire_mode < 0 || cfg->acquire_mode > 2) {
     set_error("dabx_create: bad configuration");
     return DABX_E_ARG;
@@ -279,7 +280,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     #ifndef DABX_LEVEL_STREAM_HI
 #define DABX_LEVEL_STREAM_HI 1
 #endif
-    H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, (cfg->exact_level_tracker && DABX_LEVEL_STREAM_HI) ? prio_hi : prio_lo));
+    H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, (cfg->exact_level_tracker == 1 && DABX_LEVEL_STREAM_HI) ? prio_hi : prio_lo));
     H(hipEventCreateWithFlags(&e->ss.acq_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.tail_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.acq_a_done, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -295,7 +296,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   d.ring_len = cfg->ring_frames * TF;
   d.threshold = cfg->sync_threshold; d.strongest = cfg->sync_strongest;
   d.fic_only = cfg->fic_only; d.capture_soft = cfg->capture_soft; d.tie_mode = cfg->viterbi_tie_mode;
-  d.exact_level = cfg->exact_level_tracker;
+  d.exact_level = cfg->exact_level_tracker == 1;
+  d.anchor_level = cfg->exact_level_tracker == 0;
   const DevTables *t;
   if ((rc = get_tables(&t))) { dabx_destroy(e); return rc; }
 #define A(x) if ((rc = (x))) { dabx_destroy(e); return rc; }
@@ -310,6 +312,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   if (d.exact_level) A(e->alloc(&d.level_pos, S));
   H(hipHostMalloc((void **)&e->locked_host, sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
   *e->locked_host = 0;
+  H(hipHostMalloc((void **)&e->horizon_host, sizeof(unsigned long long) * S, hipHostMallocMapped | hipHostMallocCoherent));
+  for (int s = 0; s < S; s++) e->horizon_host[s] = 0;
+  H(hipHostGetDevicePointer((void **)&d.wr_horizon, e->horizon_host, 0));
   H(hipHostGetDevicePointer((void **)&d.locked_count, e->locked_host, 0));
   {
     std::vector<float> st8((size_t)S * 8, 0.0f);                  // sample_reader.h:102-106: meanII = meanQQ = 1
@@ -348,6 +353,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   for (auto &c : ctl) {
     memset(&c, 0, sizeof(c));
     c.state = ST_INIT; c.s_level = 0.1f; c.peak_level = -1.0e6f; c.sync_thr = cfg->sync_threshold;
+    c.lvl_anchor_S = 0.1f;
   }
   H(hipMemcpyAsync(d.ctl, ctl.data(), sizeof(StreamCtl) * S, hipMemcpyHostToDevice, e->stream));
   H(hipStreamSynchronize(e->stream));
@@ -393,6 +399,7 @@ void dabx_destroy(dabx_engine *e)
   }
   for (void *p : e->allocs) (void)hipFree(p);
   if (e->locked_host) (void)hipHostFree(e->locked_host);
+  if (e->horizon_host) (void)hipHostFree(e->horizon_host);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -525,7 +532,30 @@ int dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *cap)
   return 0;
 }
 
+// What a push may overwrite is announced BEFORE its copy is issued (EngineDev::wr_horizon, host memory the device reads): the level
+// tracker's re-walk from its anchor (k_acquire) only trusts samples at or above horizon - ring_len, and looks again after the walk.
+static void announce_write(dabx_engine *e, int stream, unsigned long long upto)
+{
+  if (!e->horizon_host) return;
+  for (int s = 0; s < e->dev.n_streams; s++)
+    if ((stream < 0 || s == stream) && e->horizon_host[s] < upto) __atomic_store_n(&e->horizon_host[s], upto, __ATOMIC_RELEASE);
+}
+static int commit_impl(dabx_engine *e, int stream, size_t n);
 int dabx_commit_iq(dabx_engine *e, int stream, size_t n)
+{
+  if (!e || stream >= e->dev.n_streams) return DABX_E_ARG;
+  // a zero-copy producer writes into the ring on its own: from here on nothing behind the read cursor can be taken for intact
+  announce_write(e, stream, ~0ull);
+  return commit_impl(e, stream, n);
+}
+// iqfile.cpp: samples it converted into the ring itself, while nothing was running (dabx_internal_ring_info drains the engine)
+int dabx_internal_commit(dabx_engine *e, int stream, size_t n)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams) return DABX_E_ARG;
+  announce_write(e, stream, e->wr_host[stream] + n);
+  return commit_impl(e, stream, n);
+}
+static int commit_impl(dabx_engine *e, int stream, size_t n)
 {
   if (!e || stream >= e->dev.n_streams) return DABX_E_ARG;
   if (int rc = use_device(e)) return rc;
@@ -581,12 +611,13 @@ int dabx_push_iq(dabx_engine *e, int stream, const void *iq, int fmt, size_t n)
   }
   // copy + conversion on the ingest stream, next to whatever the receiver streams are computing: the samples land
   // beyond the committed write index, which no queued kernel reads; only the commit is ordered into the front-end stream
+  announce_write(e, stream, e->wr_host[stream] + n);
   DABX_HIP(hipMemcpyAsync(e->stage, iq, bytes, hipMemcpyHostToDevice, e->ingest));
   int rc = launch_convert_iq(e->stage, fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, e->ingest);
   if (rc) return rc;
   DABX_HIP(hipEventRecord(e->ingest_done, e->ingest));
   DABX_HIP(hipStreamWaitEvent(e->stream, e->ingest_done, 0));
-  rc = dabx_commit_iq(e, stream, n);
+  rc = commit_impl(e, stream, n);
   DABX_HIP(hipStreamSynchronize(e->ingest));   // the caller's buffer and the staging buffer are free again
   return rc;
 }
@@ -617,12 +648,13 @@ int dabx_push_iq_async(dabx_engine *e, int stream, const void *iq, int fmt, size
   }
   if (!e->ingest2) DABX_HIP(hipStreamCreateWithFlags(&e->ingest2, hipStreamNonBlocking));
   hipStream_t ing = (k & 1) ? e->ingest2 : e->ingest;
+  announce_write(e, stream, e->wr_host[stream] + n);
   DABX_HIP(hipMemcpyAsync(e->aslot[k], iq, bytes, hipMemcpyHostToDevice, ing));
   int rc = launch_convert_iq(e->aslot[k], fmt, e->dev.iq + (size_t)stream * e->dev.ring_len, e->dev.ring_len, e->wr_host[stream], n, ing);
   if (rc) return rc;
   DABX_HIP(hipEventRecord(e->aslot_done[k], ing));
   DABX_HIP(hipStreamWaitEvent(e->stream, e->aslot_done[k], 0));      // the commit (and every frame after it) sees the samples
-  return dabx_commit_iq(e, stream, n);
+  return commit_impl(e, stream, n);
 }
 
 int dabx_push_wait(dabx_engine *e)
@@ -995,6 +1027,7 @@ static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out)
   if (rc) return rc;
   memset(out, 0, sizeof(*out));
   out->level_margin_events = c.level_margin;
+  out->level_rewalk_events = c.lvl_rewalks; out->level_unanchored_events = c.lvl_unanchored;
   out->frames = c.frames; out->samples_consumed = (int64_t)c.rd; out->state = c.state;
   out->fic_ratio_percent = c.fic_ratio * 10; out->freq_offs_bb_hz = c.f_bb; out->clock_err_hz = c.clock_err;
   out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;

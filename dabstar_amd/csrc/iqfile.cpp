@@ -464,7 +464,7 @@ static long long feed_push(dabx_feed *f, const uint8_t *bytes, size_t n_bytes)
     f->carry_n = (int)keep;
   }
   if (f->eng) {
-    if (produced && (rc = dabx_commit_iq(f->eng, f->stream, (size_t)produced))) return rc;
+    if (produced && (rc = dabx_internal_commit(f->eng, f->stream, (size_t)produced))) return rc;
   } else f->lin_n += (size_t)produced;
   DABX_HIP(hipStreamSynchronize(f->st));     // `src` (caller memory / joined) and the stage buffer are free again
   return produced;

@@ -19,5 +19,6 @@ int launch_resample_1ms(const float2 *V, int M, const int16_t *tab_int, const fl
 // engine.cpp: ring of a stream, its write position (host mirror), the read position (device, synchronises) and stream
 }  // namespace dabx
 
+extern "C" int dabx_internal_commit(dabx_engine *e, int stream, size_t n);   // commit of samples iqfile.cpp wrote itself (announces them first)
 extern "C" int dabx_internal_ring_info(dabx_engine *e, int stream, float2 **ring, int *ring_len, unsigned long long *wr,
                                         unsigned long long *rd, hipStream_t *st);

@@ -46,6 +46,14 @@ struct StreamCtl {
   int32_t np_sel;                 // which noise-power buffer (DemapDev::null_power / null_power2) is current; k_frame_tail flips it
   int32_t pad_;
   long long level_margin;         // null-dip comparisons that fell within 1e-4 (relative) of their threshold (dabx_stats.level_margin_events)
+  // The level tracker's ANCHOR (EngineDev::anchor_level, the default): s_level was exact -- lvl_anchor_S, the value the sample-serial
+  // recurrence has -- before sample lvl_anchor_pos.  The search (k_acquire) keeps it at rd; the frame chain moves rd on and advances
+  // s_level chunk-wise (k_frame_tail: valid before sample lvl_approx_pos).  When the stream comes back to the search, the samples
+  // since the anchor are walked exactly, if they are all still in the ring (EngineDev::wr_horizon).
+  unsigned long long lvl_anchor_pos, lvl_approx_pos;
+  float lvl_anchor_S;
+  int32_t pad3_;
+  long long lvl_rewalks, lvl_unanchored;   // returns to the search that re-walked from the anchor / that had to start from the approximation
 };
 
 struct SubchDev {
@@ -86,7 +94,10 @@ struct EngineDev {
   int32_t ring_len;               // IQ ring capacity per stream in samples
   float threshold;
   int32_t strongest, fic_only, capture_soft;
-  int32_t exact_level;            // 1: in lock, SampleReader's level IIR is run sample by sample too (cfg.exact_level_tracker)
+  int32_t exact_level;            // 1: in lock, SampleReader's level IIR is run sample by sample too (cfg.exact_level_tracker = 1)
+  int32_t anchor_level;           // 1 (cfg.exact_level_tracker = 0, default): chunk-wise in lock, re-walked exactly from the anchor when the search needs it
+  unsigned long long *wr_horizon; // [S] host memory: one past the highest sample index a push has been ISSUED for (written before the copy
+                                  //     starts); ~0 after a zero-copy commit (writes the library does not see).  Samples >= horizon - ring_len are intact
   unsigned long long *level_pos;  // [S] exact_level only: index of the first sample the level tracker has not seen yet (<= ctl.rd)
   int32_t *locked_count;          // streams in ST_EVAL_SYNC, in host memory the device updates (system-scope atomics on hand-over): dabx_process
                                   // looks at it without waiting for anything -- while NO stream is in lock there is nobody the search could hold up

@@ -513,6 +513,88 @@ __device__ __forceinline__ void sync_failed(EngineDev &e, int s, int tid, const 
   __syncthreads();
 }
 
+// cfg.exact_level_tracker = 0 (EngineDev::anchor_level, the default).  In lock nobody reads sLevel, so the frame chain only advances it
+// chunk-wise (k_frame_tail: ~1e-5 relative).  The search reads it -- and decides where a null symbol begins and ends by comparing
+// against it -- so before a stream that the frame chain had goes back into the search, the level is brought to where the sample-serial
+// recurrence has it: walked (level_par.h, 1024 samples at a time) from the ANCHOR -- the position and value at which the search last
+// handed the stream over -- over everything the receiver has read since.  That needs those samples to be in the ring still: a push
+// announces what it may overwrite before it starts (EngineDev::wr_horizon, host memory), the walk looks before and after.  If they are
+// not (a long time in lock with a short ring, or a zero-copy producer whose writes the library does not see), the level continues from
+// the chunk-wise value over the samples read since (the T_u window of the failed correlation), as it did before round 4, and the
+// event is counted (dabx_stats.level_unanchored_events; level_rewalk_events counts the exact ones).
+__device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, AcqLds &w)
+{
+  constexpr int T = 256;
+  StreamCtl &c = e.ctl[s];
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const unsigned long long p1 = c.rd, len64 = (unsigned long long)e.ring_len;
+  const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  const unsigned len = (unsigned)e.ring_len;
+  LevelPar lp;
+  if (wave == 0) lp.init(lane);
+  float S = 0.f, pk = 0.f;
+  bool anchored = false;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (tid == 0) {                                          // one thread looks, everyone follows
+      const unsigned long long hz = __hip_atomic_load(&e.wr_horizon[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      w.flag[2] = (attempt == 0 && hz <= c.lvl_anchor_pos + len64) ? 1 : 0;
+    }
+    __syncthreads();
+    anchored = w.flag[2] != 0;
+    const unsigned long long p0 = anchored ? c.lvl_anchor_pos : c.lvl_approx_pos;
+    S = anchored ? c.lvl_anchor_S : c.s_level;
+    const unsigned long long n = p1 - p0;
+    const int nblk = (int)((n + ACQ_CH - 1) / ACQ_CH);
+    float mx = 0.f;
+    auto mags = [&](int j, int t0, int nt) {                 // |x| of block j into w.a[j & 1] (zeros beyond the last sample)
+      float *dst = w.a[j & 1] + 64;
+      const unsigned long long b0 = (unsigned long long)j * ACQ_CH;
+      const unsigned o0 = (unsigned)((p0 + b0) % len64);
+      for (int q = t0; q < ACQ_CH; q += nt) {
+        float a = 0.f;
+        if (b0 + (unsigned)q < n) {
+          unsigned o = o0 + (unsigned)q;
+          if (o >= len) o -= len;
+          const float2 v = ring[o];
+          a = sqrtf(v.x * v.x + v.y * v.y);
+        }
+        dst[q] = a;
+        mx = fmaxf(mx, a);
+      }
+    };
+    if (nblk > 0) mags(0, tid, T);
+    __syncthreads();
+    for (int i = 0; i < nblk; i++) {
+      if (wave == 0) {
+        const float *ab = w.a[i & 1] + 64;
+        const unsigned long long left = n - (unsigned long long)i * ACQ_CH;
+        const int m = left < (unsigned long long)ACQ_CH ? (int)left : ACQ_CH;
+        const int n16 = __builtin_amdgcn_readfirstlane(m >> 4);
+        if (n16 > 0) S = lp.block(ab, n16, S, nullptr, lane);
+        for (int r = 16 * n16; r < m; r++) S += 0.00001f * (ab[r] - S);
+      } else if (i + 1 < nblk) mags(i + 1, tid - 64, T - 64);
+      __syncthreads();
+    }
+    pk = block_max_nonneg(mx, w.red, tid);
+    if (!anchored) break;
+    if (tid == 0) {                                          // nothing of it was overwritten while it was read?
+      const unsigned long long hz = __hip_atomic_load(&e.wr_horizon[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      w.flag[2] = hz <= c.lvl_anchor_pos + len64 ? 1 : 0;
+    }
+    __syncthreads();
+    const bool still = w.flag[2] != 0;
+    __syncthreads();
+    if (still) break;
+  }
+  // (wave 0 holds the level; S is the same in all its lanes)
+  if (tid == 0) {
+    if (c.lvl_approx_pos != c.lvl_anchor_pos) { if (anchored) c.lvl_rewalks++; else c.lvl_unanchored++; }
+    c.s_level = S; c.peak_level = fmaxf(c.peak_level, pk);
+    c.lvl_anchor_pos = c.lvl_approx_pos = p1; c.lvl_anchor_S = S;
+  }
+  __syncthreads();
+}
+
 // Acquisition kernel: one block per stream, does something only for streams that are NOT in lock.  Ownership of a stream's
 // control record follows c.state: ST_EVAL_SYNC = the frame chain (k_frame_head ... k_frame_tail on HIP stream a), anything
 // else = this kernel.  It therefore runs either in step (on stream a, before k_frame_head: every step waits for the streams
@@ -552,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, in
   int st = w.flag[1], new_state = -1;
   const unsigned long long wr = s_wr, rd_start = c.rd, budget = (unsigned long long)budget_frames * TF;
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
+  if (e.anchor_level && c.lvl_anchor_pos != c.rd) level_from_anchor(e, s, tid, w);
   for (;;) {
     const unsigned long long used = c.rd - rd_start;
     if (used >= budget) break;
@@ -578,6 +661,7 @@ __global__ __launch_bounds__(256, 2) void k_acquire(EngineDev e, DevTables t, in
   }
   if (new_state < 0) return;
   if (tid == 0 && e.exact_level) e.level_pos[s] = c.rd;    // every sample read here went through the level tracker
+  if (tid == 0 && e.anchor_level) { c.lvl_anchor_pos = c.lvl_approx_pos = c.rd; c.lvl_anchor_S = c.s_level; }   // ... sample by sample: exact up to here
   if (tid == 0 && new_state == ST_EVAL_SYNC && e.locked_count) __hip_atomic_fetch_add(e.locked_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence();
   __syncthreads();
@@ -624,7 +708,9 @@ __global__ __launch_bounds__(256, DABX_HEAD_OCC) void k_frame_head(EngineDev e, 
   __syncthreads();
   if (start < 0) {
     // :396-400 -> WAIT_FOR_TIME_SYNC_MARKER: the stream goes over to k_acquire
-    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red, !e.exact_level);
+    // (the level over the T_u samples just read: here from the chunk-wise value in the round-3 mode only; k_level_exact or k_acquire's
+    //  re-walk from the anchor see to it otherwise)
+    sync_failed(e, s, tid, rv, rd, phase0, f, peak, red, !e.exact_level && !e.anchor_level);
     __threadfence();
     __syncthreads();
     if (tid == 0) {
@@ -1186,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
       // symbols 1..75: lv <- lv q^75 + (1 - q) sum_l q^(74-l) mean_l, the weighted sum taken in parallel above
       lv = lv * __expf((float)(75 * TS) * LNQ) + (1.0f - __expf((float)TS * LNQ)) * sym_w;
       upd(an * (1.0f / (float)TN), __expf((float)TN * LNQ));
-      if (!e.exact_level) c.s_level = lv;                  // cfg.exact_level_tracker: k_level_exact walks the frame's samples instead
+      if (!e.exact_level) c.s_level = lv;                  // cfg.exact_level_tracker = 1: k_level_exact walks the frame's samples instead
     }
     if (e.frame_pos) {                                      // per-frame record next to the FIBs (dabx_read_frame_info)
       const size_t slot = (size_t)s * e.out_frames + (size_t)(c.frames % e.out_frames);
@@ -1194,6 +1280,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     }
     c.sample_count = sample_count;
     c.rd = base + TN;
+    c.lvl_approx_pos = c.rd;                               // (anchor_level: s_level is the chunk-wise value up to here; the anchor stays where the search left it)
     c.nco_phase = nco_advance(phase_null, f2, TN);
     c.cif_no += 4;
     c.frames += 1;

@@ -228,10 +228,19 @@ typedef struct {
                                  20480 (measured break-even, about 41 streams x 18 sub-channels) */
   int32_t msc_class_min_jobs; /* smallest protection-profile class (trellises per batch, all streams together) that gets its own
                                  lane-per-trellis class; smaller ones stay on the wave-per-trellis kernel.  0 = default 256 */
-  int32_t exact_level_tracker;/* SampleReader's signal-level IIR (sample_reader.cpp:246-248) in lock: 0 (default) advanced chunk by
-                                 chunk (exact decay between chunks, equal weights within one: relative error ~1e-5);
-                                 1: run sample by sample exactly as the reference does, on one lane per stream (slower: +196 608
-                                 dependent updates per frame and stream).  Out of lock it is always exact. */
+  int32_t exact_level_tracker;/* SampleReader's signal-level IIR (sample_reader.cpp:246-248).  Out of lock -- where the null-symbol
+                                 search compares against it -- it is always the reference's recurrence, sample by sample.  In lock,
+                                 where nothing reads it:
+                                 0 (default): advanced chunk by chunk (relative error ~1e-5: what dabx_stats.signal_level shows in
+                                   lock), and when a stream falls out of lock, walked exactly from the point and value at which the
+                                   search had handed it over -- so the search continues from the reference's value, provided the
+                                   samples read since then are still in the ring (pushes through dabx_push_iq* and the file
+                                   readers are tracked; after a zero-copy dabx_commit_iq they cannot be, and a lock that outlasts
+                                   the ring has lost them).  Otherwise it continues from the chunk-wise value: counted in
+                                   dabx_stats.level_unanchored_events, the exact returns in level_rewalk_events;
+                                 1: exact in lock too (a second pass over every sample on a HIP stream of its own: -27 % throughput
+                                   at 512 streams);
+                                 2: chunk-wise only, the search continues from that value (the behaviour before round 4). */
   int32_t acquire_mode;       /* streams OUT of lock (null-symbol search + candidate correlations, k_acquire): 0 (default) -- by the
                                  way dabx_process is called: sync != 0 searches in step (every step first gives every such stream a
                                  frame's worth of search, exactly DabProcessor's order of events per stream), sync == 0 searches on
@@ -265,7 +274,9 @@ typedef struct {
   int64_t level_margin_events; /* null-symbol search: comparisons level/50 <> 0.55 / 0.75 sLevel (timesyncer.cpp:58, 74) that fell within
                                 1e-4 (relative) of their threshold, i.e. that the default (chunk-wise, ~1e-5) in-lock level tracker
                                 could conceivably have decided differently from the sample-serial one; 0 = the approximation never mattered */
-  int64_t reserved[7];       /* zero; later fields go here without changing the record's size */
+  int64_t level_rewalk_events;     /* losses of lock after which the level was re-walked exactly from its anchor (exact_level_tracker 0) */
+  int64_t level_unanchored_events; /* ... after which it had to continue from the chunk-wise value (samples no longer in the ring) */
+  int64_t reserved[5];       /* zero; later fields go here without changing the record's size */
 } dabx_stats;
 
 void dabx_default_config(dabx_config *cfg);

@@ -217,6 +217,7 @@ void ora_rx_destroy(ora_receiver *r);
 void ora_rx_move_subch(ora_receiver *r, int i, int new_cu_start, long at_cif);   /* back end i reads its slice at new_cu_start from CIF at_cif on */
 void ora_rx_set_dc_iq(ora_receiver *r, int mode);   /* SampleReader::set_dc_and_iq_correction: 0 off, 1 DC, 2 DC + IQ */
 void ora_dciq_sample(ora_cf32 *v, int mode, float *st5);
+float ora_level_walk(const ora_cf32 *x, size_t n, float s0);   /* SampleReader's sLevel after reading x[0..n) from s0 (sample_reader.cpp:245-248) */
 void ora_dciq_buffer(ora_cf32 *iq, size_t n, int mode, float *st5);
 void ora_dciq_buffer_f64(ora_cf32 *iq, size_t n, int mode, double *st5);
 void ora_rx_configure(ora_receiver *r, float threshold, int sync_strongest, int soft_bit_type);   /* defaults 3.0, 0, 1 */

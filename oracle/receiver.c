@@ -109,6 +109,17 @@ static int get_samples(ora_receiver *r, ora_cf32 *dst, int n, float freq_bb)
   return n;
 }
 
+/* sample_reader.cpp:245-248 alone: the level after n samples read in order, from s0 (the operations of get_samples above) */
+float ora_level_walk(const ora_cf32 *x, size_t n, float s0)
+{
+  float s = s0;
+  for (size_t i = 0; i < n; i++) {
+    const float a = sqrtf(x[i].re * x[i].re + x[i].im * x[i].im);
+    s += 0.00001f * (a - s);
+  }
+  return s;
+}
+
 /* timesyncer.cpp:40-90 ; returns 1 established, 0 otherwise, -1 eof */
 static int time_sync(ora_receiver *r)
 {

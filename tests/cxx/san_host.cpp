@@ -24,6 +24,7 @@ int prs_quarter_turns(int k) { return (k * 7 + 3) & 3; }      // any table will 
 }  // namespace dabx
 extern "C" int dabx_internal_ring_info(dabx_engine *, int, float2 **, int *, unsigned long long *, unsigned long long *, hipStream_t *) { abort(); }
 extern "C" int dabx_commit_iq(dabx_engine *, int, size_t) { abort(); }
+extern "C" int dabx_internal_commit(dabx_engine *, int, size_t) { abort(); }
 extern "C" const char *dabx_last_error(void) { return dabx::g_err.c_str(); }
 
 static std::mt19937 rng(12345);

@@ -97,6 +97,8 @@ def oracle():
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.ora_parse_fibs.argtypes = [_u8p, _u8p, C.c_int, C.POINTER(SubchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
     L.ora_rx_move_subch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long]
+    L.ora_level_walk.argtypes = [_c64p, C.c_size_t, C.c_float]
+    L.ora_level_walk.restype = C.c_float
     L.ora_fibdec_new.restype = C.c_void_p
     L.ora_fibdec_free.argtypes = [C.c_void_p]
     L.ora_fibdec_process.argtypes = [C.c_void_p, _u8p, _u8p, C.c_int]

@@ -828,6 +828,95 @@ def test_exact_level_tracker_is_bit_identical_to_the_oracle(gain):
     assert 0 <= margin[0] <= 20 and abs(margin[1] - margin[0]) <= 2, margin
 
 
+def _level_after(x, n):
+    """SampleReader's sLevel after reading x[0..n) from its start value (sample_reader.cpp:245-248): every sample goes through
+    get_samples exactly once, in order, whatever the state machine does with it -- so the level at a read position is a function of the
+    samples alone."""
+    return np.float32(ol.oracle().ora_level_walk(np.ascontiguousarray(x[:n], np.complex64), n, 0.1))
+
+
+@pytest.mark.parametrize("gain", [0.25, 3e-4])
+def test_search_after_a_lost_lock_starts_from_the_references_level(gain):
+    """The default level tracker (cfg.exact_level_tracker = 0): chunk-wise in lock, where nothing reads it, and when the lock is lost
+    the samples read since the search handed the stream over are walked exactly (level_from_anchor in k_acquire).  The null-symbol
+    search then runs with the level the sample-serial recurrence has: after every step that leaves the stream searching, sLevel
+    is BIT-IDENTICAL to the recurrence over all samples read so far -- before the first lock, and after 10 frames in lock and a
+    drop-out.  Mode 2 (chunk-wise only, the behaviour before round 4) is close but not equal there."""
+    subch = ds.default_subchannels(4, 64)
+    ens = ds.build_ensemble(10, subch, seed=171)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=911.0, timing_offset=77777, gain=gain, seed=17, n_out=30 * ds.TF).copy()
+    a, b = int(10.6 * ds.TF), int(14.4 * ds.TF)                   # a drop-out long enough for steps that search and find nothing
+    x[a:b] = 0
+    ora = _oracle_run(x, subch)
+
+    def run(mode):
+        eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=4, out_frames=4, exact_level_tracker=mode)
+        eng.set_subchannels(subch)
+        eng.push_iq(0, x)
+        searching, starts, idle, steps = [], [], 0, 0
+        while idle < 4 and steps < 400:
+            before = eng.stats(0)
+            eng.process(1)
+            st = eng.stats(0)
+            steps += 1
+            idle = idle + 1 if st["samples_consumed"] == before["samples_consumed"] else 0
+            if st["frames"] > before["frames"]:
+                starts.append(st["last_start_index"])
+            elif before["state"] == 1 and st["state"] == 1 and st["samples_consumed"] > before["samples_consumed"]:      # searched, still searching
+                # (a step that BEGAN out of lock: in the step in which the correlation fails the search has not seen the stream yet)
+                searching.append((st["samples_consumed"], np.float32(st["signal_level"]), st["frames"]))
+        st = eng.stats(0)
+        eng.close()
+        return searching, np.array(starts), st
+
+    searching, starts, st = run(0)
+    n = min(len(starts), ora["n"])
+    assert n >= ora["n"] - 1 and n >= 20 and np.array_equal(starts[:n], ora["start"][:n])
+    after_lock = [t for t in searching if t[2] >= 5]
+    assert len(searching) >= 2 and len(after_lock) >= 1, searching
+    for pos, lv, _frames in searching:
+        want = _level_after(x, pos)
+        assert lv.view(np.uint32) == want.view(np.uint32), (pos, lv, want)
+    assert st["level_rewalk_events"] >= 1 and st["level_unanchored_events"] == 0, st
+    searching2, starts2, st2 = run(2)
+    assert np.array_equal(starts2[:n], ora["start"][:n]) and st2["level_rewalk_events"] == 0
+    diffs = [abs(float(lv) - float(_level_after(x, pos))) / float(lv) for pos, lv, frames in searching2 if frames >= 5]
+    assert diffs and 0 < max(diffs) < 1e-4, diffs
+
+
+def test_level_anchor_that_has_left_the_ring_is_counted():
+    """Same stream, fed frame by frame through a ring of four frames: when the lock is lost after ten frames, the samples read since
+    the search handed the stream over are long overwritten -- the level continues from the chunk-wise value (as before round 4: same
+    walk here), and dabx_stats.level_unanchored_events says so."""
+    subch = ds.default_subchannels(4, 64)
+    ens = ds.build_ensemble(10, subch, seed=171)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=911.0, timing_offset=77777, gain=0.25, seed=17, n_out=30 * ds.TF).copy()
+    x[int(10.6 * ds.TF):int(12.2 * ds.TF)] = 0
+    ora = _oracle_run(x, subch)
+    eng = dx.Engine(n_streams=1, ring_frames=4, max_subch=4, out_frames=4)
+    eng.set_subchannels(subch)
+    starts, pushed = [], 0
+    for _ in range(200):
+        st = eng.stats(0)
+        room = 4 * ds.TF - (pushed - st["samples_consumed"])
+        m = min(room, ds.TF, len(x) - pushed)
+        if m > 0:
+            eng.push_iq(0, x[pushed:pushed + m]); pushed += m
+        before = st
+        eng.process(1)
+        st = eng.stats(0)
+        if st["frames"] > before["frames"]:
+            starts.append(st["last_start_index"])
+        elif m <= 0 and st["samples_consumed"] == before["samples_consumed"]:
+            break
+    st = eng.stats(0)
+    eng.close()
+    n = min(len(starts), ora["n"])
+    assert n >= 20 and np.array_equal(np.array(starts[:n]), ora["start"][:n])
+    # (the stream re-locks for one frame on its way through the drop-out: that second loss finds its anchor in the ring)
+    assert st["level_unanchored_events"] == 1 and st["level_rewalk_events"] <= 1, st
+
+
 def test_failed_sync_attempts_do_not_starve_a_stream():
     """A stream whose candidates keep failing the PRS correlation (fuzz seed 5001, stream 18: a fading channel 25 carriers off
     frequency, strongest-peak sync with threshold 4 -- false null dips every few thousand samples; the oracle needs 7.7 frames of

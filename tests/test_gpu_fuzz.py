@@ -99,11 +99,11 @@ def draw_streams(seed, only=None):
     return layouts, cases, xs, rng
 
 
-def _rerun_exact_level(x, subch, cfg, tie=0):
-    """One stream alone on an engine with cfg.exact_level_tracker: FIBs, CRC flags and the walk of all its frames."""
+def _rerun_exact_level(x, subch, cfg, tie=0, level_mode=1):
+    """One stream alone on an engine with cfg.exact_level_tracker = level_mode: FIBs, CRC flags and the walk of all its frames."""
     thr, strongest, soft_type = cfg
     eng = dx.Engine(n_streams=1, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr, sync_strongest=bool(strongest),
-                    soft_bit_type=soft_type, exact_level_tracker=1, viterbi_tie_mode=tie)
+                    soft_bit_type=soft_type, exact_level_tracker=level_mode, viterbi_tie_mode=tie)
     eng.set_subchannels(subch)
     eng.push_iq(0, x)
     fibs, crcs, walk = [], [], []
@@ -138,6 +138,23 @@ def test_the_search_sees_the_samples_behind_the_oscillator():
     assert np.array_equal(np.array(crcs)[:n], ora["crc"][:n])
     ok = ora["crc"][:n].astype(bool)
     assert ok.sum() >= 12 * 18 and np.array_equal(np.array(fibs)[:n][ok], ora["fibs"][:n][ok])
+
+
+@pytest.mark.parametrize("seed,stream", [(11036, 18), (11054, 18)])
+def test_streams_that_needed_the_exact_tracker_follow_the_oracle_by_default(seed, stream):
+    """Hunt 11000-11059 (round 4, before the level anchor): two streams of 1 440 re-locked on a different sample than the oracle because the
+    level the search resumed with was the chunk-wise one, and followed it only with cfg.exact_level_tracker = 1.  With the default mode
+    re-walking the level from its anchor when a lock is lost, they follow it as they are; mode 2 (chunk-wise only) still shows the difference."""
+    layouts, cases, xs, _rng = draw_streams(seed, only=stream)
+    subch, cfg = layouts[cases[stream][0]], (3.0, 0, 1)
+    ora = _oracle(xs[stream], subch, cfg)
+    fibs, crcs, walk = _rerun_exact_level(xs[stream], subch, cfg, level_mode=0)
+    n = min(len(fibs), ora["n"])
+    assert n >= 3 and abs(len(fibs) - ora["n"]) <= 1
+    assert [w[0] for w in walk[:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[:n]] == ora["start"][:n].tolist()
+    _f2, _c2, walk2 = _rerun_exact_level(xs[stream], subch, cfg, level_mode=2)
+    m = min(len(walk2), ora["n"])
+    assert [w[1] for w in walk2[:m]] != ora["start"][:m].tolist() or [w[0] for w in walk2[:m]] != ora["sym0"][:m].tolist() or len(walk2) != len(walk)
 
 
 # The committed draws: three seeds, each with its own receiver options, all under the strict rules (no stream may need the exact
