@@ -1027,7 +1027,7 @@ static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out)
   if (rc) return rc;
   memset(out, 0, sizeof(*out));
   out->level_margin_events = c.level_margin;
-  out->level_rewalk_events = c.lvl_rewalks; out->level_unanchored_events = c.lvl_unanchored;
+  out->level_rewalk_events = c.lvl_rewalks; out->level_unanchored_events = c.lvl_unanchored; out->level_healed_events = c.lvl_healed;
   out->frames = c.frames; out->samples_consumed = (int64_t)c.rd; out->state = c.state;
   out->fic_ratio_percent = c.fic_ratio * 10; out->freq_offs_bb_hz = c.f_bb; out->clock_err_hz = c.clock_err;
   out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;

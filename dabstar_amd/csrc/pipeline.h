@@ -54,7 +54,11 @@ struct StreamCtl {
   float lvl_anchor_S;
   int32_t pad3_;
   long long lvl_rewalks, lvl_unanchored;   // returns to the search that re-walked from the anchor / that had to start from the approximation
+  long long lvl_healed;                    // ... that started two walks around a frame boundary's chunk-wise value and saw them merge (exact all the same)
+  unsigned long long lvl_hist_pos[16];     // read position after each of the last 16 frames ...
+  float lvl_hist_S[16];                    // ... and the chunk-wise level there (k_frame_tail)
 };
+constexpr int LVL_HIST = 16;
 
 struct SubchDev {
   int32_t cu_start, cu_size, kbps, prot_level, short_form, dab_plus;

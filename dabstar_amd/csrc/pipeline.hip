@@ -531,18 +531,41 @@ __device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, 
   const float2 *ring = e.iq + (size_t)s * e.ring_len;
   const unsigned len = (unsigned)e.ring_len;
   LevelPar lp;
-  if (wave == 0) lp.init(lane);
+  if (wave <= 1) lp.init(lane);
+  // How the level gets to rd, best first:
+  //   1  from the anchor, exactly (everything read since the hand-over is still in the ring);
+  //   2  from the oldest frame boundary still in the ring whose chunk-wise value the frame tail has kept (lvl_hist_*): TWO walks, from
+  //      that value -/+ 2^-11 (fifty times the chunk-wise tracker's observed error).  The recurrence forgets: two trajectories close in
+  //      on each other by 1e-5 of their distance per sample and, one float apart, merge for good within ~1e5 samples -- after four to
+  //      eight frames they are the SAME float, and then so is every trajectory that started in between (the step is monotone in the
+  //      level while no sample is thousands of times larger than it: checked): the exact value, with a certificate;
+  //   0  from the chunk-wise value over the samples read since (the T_u window of the failed correlation) -- as before round 4; counted.
+  int mode = 0;
   float S = 0.f, pk = 0.f;
-  bool anchored = false;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (tid == 0) {                                          // one thread looks, everyone follows
       const unsigned long long hz = __hip_atomic_load(&e.wr_horizon[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      w.flag[2] = (attempt == 0 && hz <= c.lvl_anchor_pos + len64) ? 1 : 0;
+      int m = 0, pick = -1;
+      if (attempt == 0) {
+        if (hz <= c.lvl_anchor_pos + len64) m = 1;
+        else {
+          unsigned long long best = ~0ull;
+          for (int h = 0; h < LVL_HIST; h++) {
+            const unsigned long long hp = c.lvl_hist_pos[h];
+            if (hp > c.lvl_anchor_pos && hp <= c.lvl_approx_pos && hz <= hp + len64 && p1 - hp >= 4ull * TF && hp < best) { best = hp; pick = h; }
+          }
+          if (pick >= 0) m = 2;
+        }
+      }
+      w.flag[2] = m; w.flag[3] = pick;
     }
     __syncthreads();
-    anchored = w.flag[2] != 0;
-    const unsigned long long p0 = anchored ? c.lvl_anchor_pos : c.lvl_approx_pos;
-    S = anchored ? c.lvl_anchor_S : c.s_level;
+    mode = w.flag[2];
+    const int pick = w.flag[3];
+    const unsigned long long p0 = mode == 1 ? c.lvl_anchor_pos : (mode == 2 ? c.lvl_hist_pos[pick] : c.lvl_approx_pos);
+    const float Sh = mode == 2 ? c.lvl_hist_S[pick] : 0.f;
+    S = mode == 1 ? c.lvl_anchor_S : (mode == 2 ? (wave == 0 ? Sh - Sh * 0x1p-11f : Sh + Sh * 0x1p-11f) : c.s_level);
+    float s_min = S;
     const unsigned long long n = p1 - p0;
     const int nblk = (int)((n + ACQ_CH - 1) / ACQ_CH);
     float mx = 0.f;
@@ -565,21 +588,30 @@ __device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, 
     if (nblk > 0) mags(0, tid, T);
     __syncthreads();
     for (int i = 0; i < nblk; i++) {
-      if (wave == 0) {
+      if (wave == 0 || (wave == 1 && mode == 2)) {           // wave 0: the walk (mode 2: the lower one); wave 1: the upper one
         const float *ab = w.a[i & 1] + 64;
         const unsigned long long left = n - (unsigned long long)i * ACQ_CH;
         const int m = left < (unsigned long long)ACQ_CH ? (int)left : ACQ_CH;
         const int n16 = __builtin_amdgcn_readfirstlane(m >> 4);
         if (n16 > 0) S = lp.block(ab, n16, S, nullptr, lane);
         for (int r = 16 * n16; r < m; r++) S += 0.00001f * (ab[r] - S);
-      } else if (i + 1 < nblk) mags(i + 1, tid - 64, T - 64);
+        s_min = fminf(s_min, S);
+      } else if (wave >= 2 && i + 1 < nblk) mags(i + 1, tid - 128, T - 128);
       __syncthreads();
     }
     pk = block_max_nonneg(mx, w.red, tid);
-    if (!anchored) break;
+    if (mode == 0) break;
+    if (mode == 2) {                                         // merged?  (and monotone all the way: no sample beyond 512 x the lowest level seen)
+      if (lane == 0 && wave <= 1) { w.Lc[wave] = S; w.Lc[2 + wave] = s_min; }
+      __syncthreads();
+      const bool same = __builtin_bit_cast(unsigned, w.Lc[0]) == __builtin_bit_cast(unsigned, w.Lc[1]) && pk <= 512.f * fminf(w.Lc[2], w.Lc[3]) && w.Lc[2] > 0.f;
+      S = w.Lc[0];
+      __syncthreads();
+      if (!same) continue;                                   // not yet (a short window, a level that rose a thousandfold): mode 0
+    }
     if (tid == 0) {                                          // nothing of it was overwritten while it was read?
       const unsigned long long hz = __hip_atomic_load(&e.wr_horizon[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      w.flag[2] = hz <= c.lvl_anchor_pos + len64 ? 1 : 0;
+      w.flag[2] = hz <= p0 + len64 ? 1 : 0;
     }
     __syncthreads();
     const bool still = w.flag[2] != 0;
@@ -588,7 +620,7 @@ __device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, 
   }
   // (wave 0 holds the level; S is the same in all its lanes)
   if (tid == 0) {
-    if (c.lvl_approx_pos != c.lvl_anchor_pos) { if (anchored) c.lvl_rewalks++; else c.lvl_unanchored++; }
+    if (c.lvl_approx_pos != c.lvl_anchor_pos) { if (mode == 1) c.lvl_rewalks++; else if (mode == 2) c.lvl_healed++; else c.lvl_unanchored++; }
     c.s_level = S; c.peak_level = fmaxf(c.peak_level, pk);
     c.lvl_anchor_pos = c.lvl_approx_pos = p1; c.lvl_anchor_S = S;
   }
@@ -1281,6 +1313,7 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
     c.sample_count = sample_count;
     c.rd = base + TN;
     c.lvl_approx_pos = c.rd;                               // (anchor_level: s_level is the chunk-wise value up to here; the anchor stays where the search left it)
+    { const int h = (int)(c.frames % LVL_HIST); c.lvl_hist_pos[h] = c.rd; c.lvl_hist_S[h] = c.s_level; }   // ... and kept per frame for level_from_anchor's second resort
     c.nco_phase = nco_advance(phase_null, f2, TN);
     c.cif_no += 4;
     c.frames += 1;

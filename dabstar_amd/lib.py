@@ -297,7 +297,7 @@ class Stats(C.Structure):
                 ("rs_corrected", C.c_int64), ("rs_failed", C.c_int64), ("au_ok", C.c_int64), ("au_bad", C.c_int64),
                 ("cifs_decoded", C.c_int64), ("signal_level", C.c_float), ("peak_level", C.c_float),
                 ("level_margin_events", C.c_int64), ("level_rewalk_events", C.c_int64), ("level_unanchored_events", C.c_int64),
-                ("reserved", C.c_int64 * 5)]
+                ("level_healed_events", C.c_int64), ("reserved", C.c_int64 * 4)]
 
 
 COUNTER_NAMES = ["frames", "samples", "fib_ok", "fib_total", "sync_lost", "streams_locked", "cifs_decoded", "sf_ok", "sf_fail",

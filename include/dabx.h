@@ -236,8 +236,11 @@ typedef struct {
                                    search had handed it over -- so the search continues from the reference's value, provided the
                                    samples read since then are still in the ring (pushes through dabx_push_iq* and the file
                                    readers are tracked; after a zero-copy dabx_commit_iq they cannot be, and a lock that outlasts
-                                   the ring has lost them).  Otherwise it continues from the chunk-wise value: counted in
-                                   dabx_stats.level_unanchored_events, the exact returns in level_rewalk_events;
+                                   the ring has lost them).  Then two walks are started a little below and above the chunk-wise
+                                   value of the oldest frame boundary still in the ring; the recurrence forgets, and once they have
+                                   merged into the same float (4 - 8 frames) that float is the exact value (level_healed_events).
+                                   Failing that too, the level continues from the chunk-wise value: level_unanchored_events; the
+                                   returns walked from the anchor itself are counted in level_rewalk_events;
                                  1: exact in lock too (a second pass over every sample on a HIP stream of its own: -27 % throughput
                                    at 512 streams);
                                  2: chunk-wise only, the search continues from that value (the behaviour before round 4). */
@@ -276,7 +279,9 @@ typedef struct {
                                 could conceivably have decided differently from the sample-serial one; 0 = the approximation never mattered */
   int64_t level_rewalk_events;     /* losses of lock after which the level was re-walked exactly from its anchor (exact_level_tracker 0) */
   int64_t level_unanchored_events; /* ... after which it had to continue from the chunk-wise value (samples no longer in the ring) */
-  int64_t reserved[5];       /* zero; later fields go here without changing the record's size */
+  int64_t level_healed_events;     /* ... after which the anchor was gone but two walks started 2^-11 either side of a frame boundary's
+                                      chunk-wise value, four or more frames back in the ring, had merged into one float: exact all the same */
+  int64_t reserved[4];       /* zero; later fields go here without changing the record's size */
 } dabx_stats;
 
 void dabx_default_config(dabx_config *cfg);

@@ -917,6 +917,41 @@ def test_level_anchor_that_has_left_the_ring_is_counted():
     assert st["level_unanchored_events"] == 1 and st["level_rewalk_events"] <= 1, st
 
 
+def test_level_is_exact_again_when_two_walks_around_the_chunk_wise_value_have_merged():
+    """A stream fed frame by frame through a ring of 13 frames loses its lock after 24 frames in lock: the anchor (where the search handed
+    the stream over) left the ring long ago.  level_from_anchor then starts two walks 2^-11 below and above the chunk-wise level of the
+    oldest frame boundary still in the ring; the recurrence forgets its start value, the two merge into one float after a few frames, and
+    that float is the exact level: in every step that leaves the stream searching sLevel is bit-identical to the recurrence over all samples
+    read (level_healed_events = 1, nothing unanchored)."""
+    subch = ds.default_subchannels(4, 64)
+    ens = ds.build_ensemble(10, subch, seed=171)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=911.0, timing_offset=77777, gain=0.25, seed=17, n_out=34 * ds.TF).copy()
+    x[int(26.6 * ds.TF):int(30.4 * ds.TF)] = 0
+    ring = 13
+    eng = dx.Engine(n_streams=1, ring_frames=ring, max_subch=4, out_frames=4)
+    eng.set_subchannels(subch)
+    searching, pushed, frames_at_loss = [], 0, None
+    for _ in range(300):
+        st = eng.stats(0)
+        m = min(ring * ds.TF - (pushed - st["samples_consumed"]), ds.TF, len(x) - pushed)
+        if m > 0:
+            eng.push_iq(0, x[pushed:pushed + m]); pushed += m
+        before = st
+        eng.process(1)
+        st = eng.stats(0)
+        if before["state"] == 1 and st["state"] == 1 and st["samples_consumed"] > before["samples_consumed"] and st["frames"] >= 20:
+            searching.append((st["samples_consumed"], np.float32(st["signal_level"])))
+        if m <= 0 and st["samples_consumed"] == before["samples_consumed"]:
+            break
+    st = eng.stats(0)
+    eng.close()
+    assert st["frames"] >= 26 and len(searching) >= 2, (st["frames"], searching)
+    for pos, lv in searching:
+        want = _level_after(x, pos)
+        assert lv.view(np.uint32) == want.view(np.uint32), (pos, lv, want)
+    assert st["level_healed_events"] == 1 and st["level_unanchored_events"] == 0, st
+
+
 def test_failed_sync_attempts_do_not_starve_a_stream():
     """A stream whose candidates keep failing the PRS correlation (fuzz seed 5001, stream 18: a fading channel 25 carriers off
     frequency, strongest-peak sync with threshold 4 -- false null dips every few thousand samples; the oracle needs 7.7 frames of
