@@ -33,16 +33,19 @@ def _layouts():
     return [full, mixed, [full[1], full[8], full[17]]]
 
 
-def _oracle(x, subch, cfg, tie=0):
-    """tie = 1 / 2: the oracle receiver decodes with its restatement of the VITERBI_AVX2 / VITERBI_SSE2 build's arithmetic"""
+def _oracle(x, subch, cfg, tie=0, set_mode=True):
+    """tie = 1 / 2: the oracle receiver decodes with its restatement of the VITERBI_AVX2 / VITERBI_SSE2 build's arithmetic
+    (a process-wide switch: set_mode = False when the caller has set it for a pool of threads, one receiver each)"""
     L = ol.oracle()
     rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
     L.ora_rx_configure(rx, *cfg)
-    L.ora_set_viterbi_mode(tie)
+    if set_mode:
+        L.ora_set_viterbi_mode(tie)
     try:
         n = L.ora_rx_run(rx, x, len(x), 10000)
     finally:
-        L.ora_set_viterbi_mode(0)
+        if set_mode:
+            L.ora_set_viterbi_mode(0)
     cap = L.ora_rx_get_capture(rx).contents
     res = dict(n=n, fibs=np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy() if n else np.zeros((0, 12, 32), np.uint8),
                crc=np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy() if n else np.zeros((0, 12), np.uint8),
@@ -230,10 +233,21 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
     msc_frames = msc_oracle_wrong = msc_wrong_differ = msc_engine_wrong = 0
     msc_events = []
     level_approx_streams = []
+    # the 24 oracle receivers, each on a thread of its own (ctypes releases the GIL; the oracle keeps no state outside a receiver except
+    # the Viterbi arithmetic switch, set once here)
+    from concurrent.futures import ThreadPoolExecutor
+    ol.oracle().ora_set_viterbi_mode(tie)
+    try:
+        run = lambda q: _oracle(xs[q], layouts[cases[q][0]], (thr, strongest, soft_type), tie, set_mode=False)   # noqa: E731
+        first = run(0)                                     # (its lazily built tables are complete before the pool starts)
+        with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
+            oras = [first] + list(pool.map(run, range(1, N_CASES)))
+    finally:
+        ol.oracle().ora_set_viterbi_mode(0)
     for s, (li, snr, cfo, toff, gain) in enumerate(cases):
         tag = (s, li, round(snr, 1), round(cfo), toff, gain)
         subch = layouts[li]
-        ora = _oracle(xs[s], subch, (thr, strongest, soft_type), tie)
+        ora = oras[s]
         n = len(fibs[s])
         assert abs(n - ora["n"]) <= 1, (tag, n, ora["n"])           # the oracle also counts a last, partially read frame
         n = min(n, ora["n"])
