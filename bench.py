@@ -139,6 +139,9 @@ def fill_rings(eng, torch, dev, args, rank, subch):
         rc = H.hipMemcpy(ptr, y.data_ptr(), n * 8, 3)                  # device to device
         assert rc == 0, rc
     torch.cuda.synchronize()
+    # the rings are filled once and only read again (periodic signals, committed frame by frame): said once, so that a stream that loses
+    # its lock still finds the samples it read in lock where the level tracker's anchor expects them (dabx_announce_write)
+    eng.announce_write(n)
     return n_frames
 
 

@@ -70,6 +70,7 @@ struct dabx_engine {
 
   std::vector<void *> fast_allocs;             // buffers of the current MSC classes (replaced on reconfiguration)
   bool classes_dirty = false;
+  std::vector<char> announcing;                // per stream: the zero-copy producer uses dabx_announce_write
   unsigned long long *horizon_host = nullptr;  // hipHostMalloc'ed, EngineDev::wr_horizon: what pushes may have overwritten (written BEFORE a copy is issued)
   int32_t *locked_host = nullptr;              // hipHostMalloc'ed: number of streams in lock, kept by the device (EngineDev::locked_count)
   bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
@@ -314,6 +315,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   *e->locked_host = 0;
   H(hipHostMalloc((void **)&e->horizon_host, sizeof(unsigned long long) * S, hipHostMallocMapped | hipHostMallocCoherent));
   for (int s = 0; s < S; s++) e->horizon_host[s] = 0;
+  e->announcing.assign(S, 0);
   H(hipHostGetDevicePointer((void **)&d.wr_horizon, e->horizon_host, 0));
   H(hipHostGetDevicePointer((void **)&d.locked_count, e->locked_host, 0));
   {
@@ -544,9 +546,26 @@ static int commit_impl(dabx_engine *e, int stream, size_t n);
 int dabx_commit_iq(dabx_engine *e, int stream, size_t n)
 {
   if (!e || stream >= e->dev.n_streams) return DABX_E_ARG;
-  // a zero-copy producer writes into the ring on its own: from here on nothing behind the read cursor can be taken for intact
-  announce_write(e, stream, ~0ull);
+  // a zero-copy producer writes into the ring on its own: unless it has said how far (dabx_announce_write), nothing behind the read
+  // cursor can be taken for intact from here on
+  if (e->horizon_host)
+    for (int s = 0; s < e->dev.n_streams; s++)
+      if ((stream < 0 || s == stream) && !e->announcing[s]) __atomic_store_n(&e->horizon_host[s], ~0ull, __ATOMIC_RELEASE);
   return commit_impl(e, stream, n);
+}
+int dabx_announce_write(dabx_engine *e, int stream, size_t n)
+{
+  if (!e || stream >= e->dev.n_streams) { set_error("dabx_announce_write: bad argument"); return DABX_E_ARG; }
+  if (!e->horizon_host) return 0;
+  for (int s = 0; s < e->dev.n_streams; s++)
+    if (stream < 0 || s == stream) {
+      // from its first announcement on the producer is taken at its word: commits no longer mean "unknown writes" (a ring that is
+      // filled once and only read again -- periodic test signals -- is announced once)
+      const unsigned long long prev = e->announcing[s] ? e->horizon_host[s] : 0ull;
+      e->announcing[s] = 1;
+      __atomic_store_n(&e->horizon_host[s], std::max(prev, e->wr_host[s] + (unsigned long long)n), __ATOMIC_RELEASE);
+    }
+  return 0;
 }
 // iqfile.cpp: samples it converted into the ring itself, while nothing was running (dabx_internal_ring_info drains the engine)
 int dabx_internal_commit(dabx_engine *e, int stream, size_t n)

@@ -52,6 +52,7 @@ def load(build_if_missing=True):
     L.dabx_host_register.argtypes = [C.c_void_p, C.c_size_t]
     L.dabx_host_unregister.argtypes = [C.c_void_p]
     L.dabx_commit_iq.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.dabx_announce_write.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     _LIB = L
     return L
 
@@ -376,6 +377,9 @@ class Engine:
 
     def commit(self, n_samples, stream=-1):
         check(load().dabx_commit_iq(self._h, stream, n_samples))
+
+    def announce_write(self, n_samples, stream=-1):
+        check(load().dabx_announce_write(self._h, stream, n_samples))
 
     def process(self, max_frames, sync=True):
         return check(load().dabx_process(self._h, max_frames, int(sync)))

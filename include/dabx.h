@@ -235,7 +235,7 @@ typedef struct {
                                    lock), and when a stream falls out of lock, walked exactly from the point and value at which the
                                    search had handed it over -- so the search continues from the reference's value, provided the
                                    samples read since then are still in the ring (pushes through dabx_push_iq* and the file
-                                   readers are tracked; after a zero-copy dabx_commit_iq they cannot be, and a lock that outlasts
+                                   readers are tracked; a zero-copy producer's are if it uses dabx_announce_write; a lock that outlasts
                                    the ring has lost them).  Then two walks are started a little below and above the chunk-wise
                                    value of the oldest frame boundary still in the ring; the recurrence forgets, and once they have
                                    merged into the same float (4 - 8 frames) that float is the exact value (level_healed_events).
@@ -317,6 +317,13 @@ int  dabx_host_unregister(void *p);
 /* Device-resident producers: ring base (cf32, capacity ring_frames*T_F) and commit of n new samples. */
 int  dabx_iq_ring_dev(dabx_engine *e, int stream, void **ring, size_t *capacity_samples);
 int  dabx_commit_iq(dabx_engine *e, int stream /* <0: all */, size_t n_samples);
+/* Optional, for device-resident producers that want the level tracker's anchor kept (dabx_config.exact_level_tracker = 0): the library
+ * cannot see their writes, so after a plain dabx_commit_iq it must assume that anything behind the read cursor may have been
+ * overwritten.  dabx_announce_write says, BEFORE the producer writes: "everything I have written so far, and everything I am going to
+ * write until my next announcement, lies below committed + n_samples".  From its first announcement on the producer is taken at
+ * its word (a commit no longer means "unknown writes"): announce before every write -- or once, with the ring's capacity, for a ring that
+ * is filled once and only read again (periodic test signals). */
+int  dabx_announce_write(dabx_engine *e, int stream /* <0: all */, size_t n_samples);
 /* Host copy of ring samples [first, first + n) counted from the first sample ever committed (scopes, tests);
  * they must still be in the ring. */
 int  dabx_read_iq(dabx_engine *e, int stream, uint64_t first, size_t n, float *iq_out);

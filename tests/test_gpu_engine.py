@@ -952,6 +952,50 @@ def test_level_is_exact_again_when_two_walks_around_the_chunk_wise_value_have_me
     assert st["level_healed_events"] == 1 and st["level_unanchored_events"] == 0, st
 
 
+@pytest.mark.parametrize("announce", [False, True])
+def test_zero_copy_producers_keep_the_level_anchor_by_announcing_their_writes(announce):
+    """A device-resident producer (dabx_iq_ring_dev + dabx_commit_iq) writes where the library cannot see: after a plain commit a lost lock
+    finds no trustworthy anchor (level_unanchored_events), the walk is the oracle's all the same here.  A producer that says how far it
+    writes before it does (dabx_announce_write) keeps the anchor: the search resumes from the exact level."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    subch = ds.default_subchannels(4, 64)
+    ens = ds.build_ensemble(10, subch, seed=171)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=911.0, timing_offset=77777, gain=0.25, seed=17, n_out=30 * ds.TF).copy()
+    x[int(10.6 * ds.TF):int(14.4 * ds.TF)] = 0
+    x = np.ascontiguousarray(x, np.complex64)
+    ora = _oracle_run(x, subch)
+    eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=4, out_frames=4)
+    eng.set_subchannels(subch)
+    ptr, cap = eng.ring_ptr(0)
+    assert cap >= len(x)
+    if announce:
+        eng.announce_write(len(x))
+    assert hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(x.ctypes.data), C.c_size_t(8 * len(x)), 1) == 0          # host to device
+    eng.commit(len(x))
+    searching, starts, idle = [], [], 0
+    for _ in range(400):
+        before = eng.stats(0)
+        eng.process(1)
+        st = eng.stats(0)
+        idle = idle + 1 if st["samples_consumed"] == before["samples_consumed"] else 0
+        if st["frames"] > before["frames"]:
+            starts.append(st["last_start_index"])
+        elif before["state"] == 1 and st["state"] == 1 and st["samples_consumed"] > before["samples_consumed"] and st["frames"] >= 5:
+            searching.append((st["samples_consumed"], np.float32(st["signal_level"])))
+        if idle >= 4:
+            break
+    st = eng.stats(0)
+    eng.close()
+    n = min(len(starts), ora["n"])
+    assert n >= 20 and np.array_equal(np.array(starts[:n]), ora["start"][:n]) and len(searching) >= 1
+    exact = [lv.view(np.uint32) == _level_after(x, pos).view(np.uint32) for pos, lv in searching]
+    if announce:
+        assert all(exact) and st["level_rewalk_events"] >= 1 and st["level_unanchored_events"] == 0, (exact, st)
+    else:
+        assert not any(exact) and st["level_unanchored_events"] >= 1 and st["level_rewalk_events"] == 0, (exact, st)
+
+
 def test_failed_sync_attempts_do_not_starve_a_stream():
     """A stream whose candidates keep failing the PRS correlation (fuzz seed 5001, stream 18: a fading channel 25 carriers off
     frequency, strongest-peak sync with threshold 4 -- false null dips every few thousand samples; the oracle needs 7.7 frames of
