@@ -278,10 +278,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     // With the exact level tracker every stream has a block on q in every step (two lone waves for 1.6 ms): at the lowest queue
     // priority those blocks were dispatched only into the gaps the frame chain's kernels left (5 ms per step); at the chain's own
     // priority they are resident from the start of the step.
-    #ifndef DABX_LEVEL_STREAM_HI
-#define DABX_LEVEL_STREAM_HI 1
-#endif
-    H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, (cfg->exact_level_tracker == 1 && DABX_LEVEL_STREAM_HI) ? prio_hi : prio_lo));
+        H(hipStreamCreateWithPriority(&e->ss.q, hipStreamNonBlocking, cfg->exact_level_tracker == 1 ? prio_hi : prio_lo));
     H(hipEventCreateWithFlags(&e->ss.acq_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.tail_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.acq_a_done, hipEventDisableTiming | hipEventReleaseToDevice));

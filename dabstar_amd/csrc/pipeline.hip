@@ -1333,10 +1333,8 @@ __global__ __launch_bounds__(256) void k_frame_tail(EngineDev e, DevTables t)
 // more than the rest of the receiver together -- which is why the default advances the tracker chunk-wise (k_frame_tail).
 __global__ __launch_bounds__(128) void k_level_exact(EngineDev e)
 {
-#ifndef DABX_LEVEL_PRIO
-#define DABX_LEVEL_PRIO 3
-#endif
-  __builtin_amdgcn_s_setprio(DABX_LEVEL_PRIO);
+  front_prio();                          // (wave priority 0 / 1 / 3 and the HIP stream's priority make no difference to what the tracker costs
+                                         //  the frame chain: profiles/r04_ab/ab27_exact_level_priorities.txt)
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   StreamCtl &c = e.ctl[s];
