@@ -36,7 +36,8 @@
 
 namespace dabx {
 
-constexpr int LVL_K = 32;
+constexpr int LVL_K = 32, LVL_K_WIDE = 128;
+constexpr int LVL_MAX_WALKED_WIDE = 12;
 constexpr int LVL_MAX_WALKED = 6;          // groups settled one by one before the rest of a block is handed to the serial walker
 
 #ifdef DABX_LV_DEBUG
@@ -68,7 +69,6 @@ struct LevelPar {
   // group g, ck[ng] = after the last.  Every lane of the wave must be active.  fallbacks (if given) += groups walked in step 4.
   __device__ __forceinline__ float block(const float *a, int ng, float S0, float *ck, int lane, int *fallbacks = nullptr) const
   {
-    constexpr unsigned K = LVL_K;
     float x[16];
     {
       const float4 *p = reinterpret_cast<const float4 *>(a + 16 * (lane < ng ? lane : 0));
@@ -96,6 +96,15 @@ struct LevelPar {
     const float Bex = dpp<0x138, 0xF>(B);                 // wave_shr:1: everything before this lane's group
     const float G = S0 + __builtin_fmaf(q, S0, Bex);      // (lane 0: S0 itself)
     const unsigned Gb = __builtin_bit_cast(unsigned, G);
+    const unsigned long long valid = ng >= 64 ? ~0ull : ((1ull << ng) - 1ull);
+    // Two tiers: brackets of +-32 floats first; if more groups than can be walked singly end up outside theirs -- an input whose float
+    // trajectory runs away from the real one faster than the roundings' random walk: exact zeros, where the error of successive steps is
+    // correlated over a thousand samples -- once more with +-128 (merges are four times as frequent then: 2-3 groups per block) before
+    // the rest of the block goes to the serial walker.
+#pragma nounroll
+    for (int tier = 0;; tier++) {
+    const unsigned K = tier ? LVL_K_WIDE : LVL_K;
+    const int max_walked = tier ? LVL_MAX_WALKED_WIDE : LVL_MAX_WALKED;
     // 2. the two walks
     float lo = __builtin_bit_cast(float, Gb - K), hi = __builtin_bit_cast(float, Gb + K);
     const float lo0 = lo;
@@ -147,15 +156,15 @@ struct LevelPar {
     if (dabx_lv_debug) { unsigned *o = dabx_lv_debug + 8 * lane; o[0] = Gb; o[1] = __builtin_bit_cast(unsigned, lo); o[2] = __builtin_bit_cast(unsigned, hi); o[3] = E; o[4] = k; o[5] = safe; o[6] = __builtin_bit_cast(unsigned, B); o[7] = __builtin_bit_cast(unsigned, x[0]); }
 #endif
     // 4. settle the groups in order
-    const unsigned long long valid = ng >= 64 ? ~0ull : ((1ull << ng) - 1ull);
     bool walked = false;
     unsigned tend = 0;
     int n_walked = 0, serial_from = 64;
     float S_serial = 0.f;
     unsigned long long todo = __ballot(!(safe && k + K <= 2u * K)) & valid;
+    if (tier == 0 && __builtin_popcountll(todo) > max_walked) continue;
     while (todo) {
       const int gs = __builtin_ctzll(todo);
-      if (++n_walked > LVL_MAX_WALKED) {
+      if (++n_walked > max_walked) {
         // an input that defeats the guess (a constant envelope parks the float recurrence in its dead zone, away from the real one; a
         // NaN): the rest of the block sample by sample, from the true start of group gs -- the block then costs about what it always did
         S_serial = __builtin_bit_cast(float, rl(Gb + k, gs));
@@ -189,7 +198,34 @@ struct LevelPar {
     const float S_end = __builtin_bit_cast(float, rl(walked ? tend : E + k, ng - 1));
     if (ck && lane == 0) ck[ng] = S_end;
     return S_end;
+    }
   }
 };
+
+// The other recurrence of the null-symbol search, the 50-tap moving sum as the reference keeps it (timesyncer.cpp:64-66, 78-80):
+//     level += d            one float addition per sample, d = |x[n]| - |x[n - 50]| (or |x[n]| while the window fills)
+// stays sample-serial (acq_walk_L_ckpt).  The same scheme was built for it and measured (round 4): d does not depend on the level, so
+// one walk per group suffices -- but d is a difference of two magnitudes and has only six or seven bits below the level's last place, so
+// one addition in a hundred is an exact tie (round-to-even then sends odd and even neighbours different ways: one group in six), and a
+// level near a power of two (the moving sum of noise wanders +-7 %) crosses the binade every few groups: 13 000 - 17 000 cycles per block
+// against the serial walk's 9 000 - 11 000.  What is kept is the one case that is free: a segment of exact zeros at level zero (a
+// drop-out, a squelched input) needs no walk at all.
+// d: the increments in LDS (16-byte aligned, ng * 16 of them, readable 16 floats further); ng: 1..64, wave-uniform; L0: the level before them;
+// ck: ck[g] = the level before group g, ck[ng] = after the last.  Every lane of the wave must be active.
+__device__ __forceinline__ void level_sum_block(const float *d, int ng, float L0, float *ck, int lane)
+{
+  const float4 *p = reinterpret_cast<const float4 *>(d + 16 * (lane < ng ? lane : 0));
+  const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+  const float amax = fmaxf(fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))), fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))),
+                           fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))), fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
+  const unsigned long long valid = ng >= 64 ? ~0ull : ((1ull << ng) - 1ull);
+  if (L0 == 0.f && (__ballot(amax != 0.f) & valid) == 0) {              // 0 + 0 = 0
+    if (lane <= ng) ck[lane] = 0.f;
+    if (ng == 64 && lane == 0) ck[64] = 0.f;
+    return;
+  }
+  if (lane == 0) ck[0] = L0;
+  acq_walk_L_ckpt(d, ck + 1, ng, L0);
+}
 
 }  // namespace dabx

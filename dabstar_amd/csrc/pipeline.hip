@@ -275,10 +275,42 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   // |x| of block j of this pass (and, in front of it, the last 64 magnitudes of block j - 1) by threads t0, t0 + nt, ...; nothing
   // beyond the committed samples is touched (a line fetched before its samples were committed would stay in this CU's cache
   // for the rest of the kernel)
-  auto mags = [&](int j, int t0, int nt) {
-    float *dst = w.a[j % 3], *dsr = w.r[j % 3];
+  // ... in two halves for the waves that fetch while the others walk: request(j) puts the samples of block j into registers (8 per
+  // thread of waves 2-3), publish(j) turns them into the two magnitudes -- a whole block later, so that the HBM latency of the loads
+  // (several microseconds next to the frame chain's traffic) lies behind a block's walk instead of in front of every eight samples
+  float2 raw[ACQ_CH / 128];
+  auto request = [&](int j) {
     const unsigned long long p0 = (unsigned long long)j * ACQ_CH;
     const unsigned o0 = (unsigned)((base + p0) % len);     // one 64-bit modulo per block, then add + conditional subtract
+#pragma unroll
+    for (int u = 0; u < ACQ_CH / 128; u++) {
+      const int q = (tid - 128) + 128 * u;
+      unsigned o = o0 + (unsigned)q;
+      if (o >= len) o -= len;
+      raw[u] = p0 + (unsigned)q < avail ? ring[o] : make_float2(0.f, 0.f);
+    }
+  };
+  auto publish = [&](int j) {
+    float *dst = w.a[j % 3], *dsr = w.r[j % 3];
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < ACQ_CH / 128; u++) {
+      const int q = (tid - 128) + 128 * u;
+      const float2 v = raw[u];
+      const float a = sqrtf(v.x * v.x + v.y * v.y);
+      const float2 m = cmul(v, osc);
+      dst[64 + q] = a; dsr[64 + q] = sqrtf(m.x * m.x + m.y * m.y);
+      mx = fmaxf(mx, a);
+    }
+    if (tid - 128 < 64) dsr[tid - 128] = w.r[(j - 1) % 3][ACQ_CH + (tid - 128)];       // (j >= 1)
+    mx = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, mx), [](unsigned x, unsigned y) { return x > y ? x : y; }));
+    if (lane == 0) w.bmax[j % 3][wave] = mx;
+    if (tid < 128 + 2) w.bmax[j % 3][tid - 128] = 0.f;     // two waves fill the block: the other two parts are empty
+  };
+  auto mags = [&](int j, int t0, int nt) {                 // block 0, by everyone, before the pipeline runs
+    float *dst = w.a[j % 3], *dsr = w.r[j % 3];
+    const unsigned long long p0 = (unsigned long long)j * ACQ_CH;
+    const unsigned o0 = (unsigned)((base + p0) % len);
     float mx = 0.f;
     for (int q = t0; q < ACQ_CH; q += nt) {
       float a = 0.f, ar = 0.f;
@@ -293,10 +325,8 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
       dst[64 + q] = a; dsr[64 + q] = ar;
       mx = fmaxf(mx, a);
     }
-    if (j > 0) for (int q = t0; q < 64; q += nt) dsr[q] = w.r[(j - 1) % 3][ACQ_CH + q];
     mx = __builtin_bit_cast(float, wave_butterfly_u32(__builtin_bit_cast(unsigned, mx), [](unsigned x, unsigned y) { return x > y ? x : y; }));
     if (lane == 0) w.bmax[j % 3][wave] = mx;               // (order of non-negative floats = order of their bits)
-    if (nt < T && tid < 128 + 2) w.bmax[j % 3][tid - 128] = 0.f;   // two waves fill the block: the other two parts are empty
   };
   // the increments of block j as they are in the middle of an attempt (its first 50 samples are patched by the search, below)
   auto incs = [&](int j, int t0, int nt) {
@@ -305,6 +335,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
     for (int q = t0; q < ACQ_CH; q += nt) dst[q] = rb[q] - rb[q - 50];       // timesyncer.cpp:78-80
   };
   if (tid == 0) { w.done = 0; w.ok = 0; }
+  if (wave >= 2) request(1);
   mags(0, tid, T);
   __syncthreads();
   incs(0, tid, T);                       // (block 0 has no samples in front of it: its first 50 increments are never used as they are)
@@ -373,8 +404,8 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
             ACQ_T(1) }
             { ACQ_T0
             __builtin_amdgcn_wave_barrier();
-            w.Lc[g0] = L;                                                    // level before sample q16 (= before q: zero increments in between)
-            acq_walk_L_ckpt(db + q16, w.Lc + 1 + g0, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L);
+            // level before sample q16 (= before q: zero increments in between) -> w.Lc[g0], then checkpoint by checkpoint
+            level_sum_block(db + q16, __builtin_amdgcn_readfirstlane((q + m - q16 + 15) >> 4), L, w.Lc + g0, lane);
             __builtin_amdgcn_wave_barrier();
             ACQ_T(2) }
             ACQ_T0
@@ -385,20 +416,34 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
             float L_end = 0.f;
             {
               float Sx = Scb[lane], Lx = w.Lc[lane];
-              const bool mine = lane >= g0 && 16 * lane < q + m;
+              // the group's 16 samples and 16 increments as eight 16-byte LDS reads, four samples at a time (one read per use, each waited
+              // for, and a branch per comparison, was 7 500 - 9 500 of the block's cycles), and the comparisons straight-line: bits for all 16
+              // positions, masked afterwards with the positions that count -- inside the segment, 50 samples or more into the attempt
+              const float4 *pa = reinterpret_cast<const float4 *>(ab + 16 * lane), *pd = reinterpret_cast<const float4 *>(db + 16 * lane);
+              const int k_last = p_last - 16 * lane;
 #pragma unroll
-              for (int k = 0; k < 16; k++) {
-                const int p = 16 * lane + k;
-                const bool valid = mine && p >= q && p < q + m && nb + (p - q) >= 50;
-                const float mean = Lx / 50.f, tb = 0.55f * Sx, te = 0.75f * Sx;
-                if (valid && !(mean > tb)) bm |= 1u << k;
-                if (valid && !(mean < te)) em |= 1u << k;
-                if (valid && fabsf(mean - tb) <= 1e-4f * tb) nbm |= 1u << k;
-                if (valid && fabsf(mean - te) <= 1e-4f * te) nem |= 1u << k;
-                Sx += 0.00001f * (ab[p] - Sx);
-                Lx += db[p];
-                if (p == p_last) L_end = Lx;
+              for (int v = 0; v < 4; v++) {
+                const float4 fa = pa[v], fd = pd[v];
+                const float xa[4] = {fa.x, fa.y, fa.z, fa.w}, xd[4] = {fd.x, fd.y, fd.z, fd.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  const int k = 4 * v + u;
+                  const float mean = Lx / 50.f, tb = 0.55f * Sx, te = 0.75f * Sx;
+                  bm |= (unsigned)(!(mean > tb)) << k;
+                  em |= (unsigned)(!(mean < te)) << k;
+                  nbm |= (unsigned)(fabsf(mean - tb) <= 1e-4f * tb) << k;
+                  nem |= (unsigned)(fabsf(mean - te) <= 1e-4f * te) << k;
+                  Sx += 0.00001f * (xa[u] - Sx);
+                  Lx += xd[u];
+                  L_end = k == k_last ? Lx : L_end;
+                }
               }
+              // positions p = 16 lane + k with q' <= p < q + m, q' = q + (what is missing to 50 samples of the attempt), in groups g0 and up
+              const int lo = q + (nb < 50 ? 50 - nb : 0) - 16 * lane, hi = q + m - 16 * lane;
+              const unsigned below_hi = hi >= 16 ? 0xFFFFu : (hi <= 0 ? 0u : (1u << hi) - 1u);
+              const unsigned from_lo = lo <= 0 ? 0xFFFFu : (lo >= 16 ? 0u : (0xFFFFu << lo) & 0xFFFFu);
+              const unsigned vm = lane >= g0 ? (below_hi & from_lo) : 0u;
+              bm &= vm; em &= vm; nbm &= vm; nem &= vm;
             }
             int p2 = -1, p3 = -1;                                            // block positions of the dip's begin / end in this segment
             if (phase != 3) {
@@ -457,7 +502,8 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
       }
     } else {
       ACQ_T0
-      mags(i + 1, tid - 128, T - 128);
+      publish(i + 1);                                      // requested a block ago
+      request(i + 2);
       if (i > 0) incs(i, tid - 128, T - 128);             // block i's magnitudes are complete since the last barrier
       ACQ_T(5)
     }
