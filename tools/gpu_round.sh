@@ -30,8 +30,8 @@ for what in "$@"; do
     # streams out of lock next to streams in lock: interleaved pairs, the driver's form
     unlocked) for r in 1 2 3; do for u in 0 8 64; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --unlocked $u 2>/dev/null | tee $OUT/unlocked_${u}_$r.json | line "unlocked $u"; done; done > $OUT/unlocked.txt 2>&1; cat $OUT/unlocked.txt ;;
     exactlevel) for r in 1 2 3; do for x in "" "--exact-level"; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $x 2>/dev/null | tee $OUT/exact_level_${x:2:5}_$r.json | line "exact_level[$x]"; done; done > $OUT/exact_level.txt 2>&1; cat $OUT/exact_level.txt ;;
-    # rocprofv3 kernel statistics of the variants (program directly behind --, never a shell)
-    profvariants) cd /tmp; for v in ${PROF_VARIANTS:-"--unlocked 8" "--exact-level"}; do tag=$(echo $v | tr -d ' -'); rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats_$tag --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline $v > $GRAFT_REPO_ROOT/$OUT/stats_$tag.log 2>&1; done; cd $GRAFT_REPO_ROOT;
+    # rocprofv3 kernel statistics of the variants (program directly behind --, never a shell); PROF_VARIANTS="--unlocked 8|--exact-level"
+    profvariants) cd /tmp; IFS='|' read -ra PV <<< "${PROF_VARIANTS:---unlocked 8|--exact-level}"; for v in "${PV[@]}"; do tag=$(echo $v | tr -d ' -'); rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats_$tag --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline $v > $GRAFT_REPO_ROOT/$OUT/stats_$tag.log 2>&1; done; cd $GRAFT_REPO_ROOT;
            for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -14 $f | cut -c1-200; done > $OUT/profvariants.txt; cat $OUT/profvariants.txt ;;
     acqtime) python3 tools/acq_time.py 8 > $OUT/acq_time_8.jsonl 2>&1; python3 tools/acq_time.py 512 > $OUT/acq_time_512.jsonl 2>&1; cat $OUT/acq_time_8.jsonl $OUT/acq_time_512.jsonl ;;
     acqphases) DABX_LIB=$(realpath dabstar_amd/_ab/libdabx_acqtime.so) python3 tools/acq_time.py 8 2>&1 | grep -E "^acq wave|case" | head -40 > $OUT/acq_phases.txt; cat $OUT/acq_phases.txt ;;
