@@ -267,6 +267,9 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
             # of a later attempt can then fall on the other side of its threshold (hunt 5000-5047: seed 5030, stream 18 of
             # 1 152, a carrier offset outside the +-35 kHz range, no FIB ever decoded).  Such a stream must follow the oracle
             # with cfg.exact_level_tracker -- the approximation is then the proven cause -- and stays the exception.
+            # Since the end of round 4 the default re-walks the level from its anchor when a lock is lost (every sample of a stream is
+            # pushed at once here, so the anchor is always in the ring): no stream of 156 hunting draws has come this way since, and
+            # none may -- the re-run only serves to say WHY, should one ever do.
             level_approx_streams.append(tag)
             fibs[s], crcs[s], walk[s] = _rerun_exact_level(xs[s], subch, (thr, strongest, soft_type), tie)
             n = min(len(fibs[s]), ora["n"])
@@ -346,9 +349,9 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
                 want, _ = te._ora_frame(hi, lo, q, descs, fib[96 * q:96 * q + 96], msc_r)
                 assert np.array_equal(frames_eti[i], want), (tag, i, r)
             eti_checked += 1
-    assert len(level_approx_streams) <= (0 if "DABX_FUZZ_SEED" not in os.environ else 1), level_approx_streams
     if level_approx_streams and os.environ.get("DABX_FUZZ_VERBOSE"):
         print("walk differs with the chunk-wise level tracker, equal with the exact one:", level_approx_streams)
+    assert not level_approx_streams, level_approx_streams
     # logical frames the oracle got right and the engine did not (see above): none with the committed seed, one stream below 10 dB in a hunting draw
     if os.environ.get("DABX_FUZZ_VERBOSE"):
         print("logical frames compared:", msc_frames, "of which the oracle got wrong:", msc_oracle_wrong, "(the engine:", msc_engine_wrong, ") of which differ:", msc_wrong_differ, "events:", msc_events)
