@@ -33,6 +33,7 @@ def _oracle_run(x, subch, want_soft=False, config=None):
                fbb_end=np.ctypeslib.as_array(cap.fbb_end, (n,)).copy(), clock_err=np.ctypeslib.as_array(cap.clock_err, (n,)).copy(),
                fic_ratio=np.ctypeslib.as_array(cap.fic_ratio, (n,)).copy(), snr_db=np.ctypeslib.as_array(cap.snr_db, (n,)).copy(),
                s_level=np.ctypeslib.as_array(cap.s_level, (n,)).copy(), peak_level=np.ctypeslib.as_array(cap.peak_level, (n,)).copy(),
+               sym0=np.ctypeslib.as_array(cap.sym0_pos, (n,)).copy(),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
                sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
                stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
@@ -1455,6 +1456,50 @@ def test_async_pushes_from_page_locked_buffers_decode_like_synchronous_ones(fmt)
             assert np.array_equal(ref.read_msc(0, j, 16), eng.read_msc(s, j, 16)), (s, j)
     assert a["frames"] >= 17 and a["sf_ok"] > 0
     eng.close(); ref.close()
+
+
+def test_repeated_drop_outs_under_asynchronous_pushes_follow_the_oracle():
+    """The level anchor's bookkeeping next to a producer that keeps overwriting the ring: a stream with a drop-out every nine frames, fed
+    one frame at a time with dabx_push_iq_async through a ring of six frames while the steps (and the search, on its own HIP stream) run
+    asynchronously.  Some returns to the search find their anchor in the ring, some find it overwritten and use two walks or the
+    chunk-wise value -- whichever, every frame is found where the oracle finds it, and every return is accounted for."""
+    subch = ds.default_subchannels(4, 64)
+    ens = ds.build_ensemble(10, subch, seed=171)
+    x = ds.channel(ens.iq, snr_db=16.0, cfo_hz=911.0, timing_offset=77777, gain=0.25, seed=17, n_out=44 * ds.TF).copy()
+    for k in (9.6, 18.6, 27.6, 36.6):
+        x[int(k * ds.TF):int((k + 1.7) * ds.TF)] = 0
+    x = np.ascontiguousarray(x, np.complex64)
+    ora = _oracle_run(x, subch)
+    ring = 6
+    eng = dx.Engine(n_streams=1, ring_frames=ring, max_subch=4, out_frames=8)
+    eng.set_subchannels(subch)
+    dx.host_register(x)
+    walk, seen, pushed, idle = [], 0, 0, 0
+    try:
+        for _ in range(600):
+            st = eng.stats(0)
+            m = min(ring * ds.TF - (pushed - st["samples_consumed"]), ds.TF, len(x) - pushed)
+            if m > 0:
+                eng.push_iq_async(0, x[pushed:pushed + m]); pushed += m
+            eng.process(1, sync=False)
+            st2 = eng.stats(0)
+            if st2["frames"] > seen:
+                pos, sti = eng.read_frame_info(0, st2["frames"] - seen)
+                walk.extend(zip(pos.tolist(), sti.tolist())); seen = st2["frames"]
+            idle = idle + 1 if (m <= 0 and st2["samples_consumed"] == st["samples_consumed"]) else 0
+            if idle >= 6:
+                break
+        eng.push_wait()
+    finally:
+        dx.host_unregister(x)
+    st = eng.stats(0)
+    lost = eng.counters()["sync_lost"]
+    eng.close()
+    n = min(len(walk), ora["n"])
+    assert n >= 30 and abs(len(walk) - ora["n"]) <= 1, (len(walk), ora["n"])
+    assert [w[0] for w in walk[:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[:n]] == ora["start"][:n].tolist()
+    events = st["level_rewalk_events"] + st["level_healed_events"] + st["level_unanchored_events"]
+    assert lost >= 4 and 4 <= events <= lost, (st, lost)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
