@@ -19,9 +19,11 @@
 //      gives every group its offset k_g from its guess;
 //   4. the first group whose checks failed or whose k_g lies outside [-K, K] is walked from its true start (known: everything
 //      before it is settled), the offsets behind it are corrected by what that changed; repeat until no group is left.
-//      About one group per block for receiver input (tools/level_bracket_sim.c: 0.65 - 1.3; a constant envelope, which parks
-//      the float recurrence in its dead zone away from the real one, or exact zeros need it for most groups -- then the
-//      block costs what the serial walk costs).
+//      About one group per block for receiver input (tools/level_bracket_sim.c: 0.65 - 1.3).  If more than six groups need it,
+//      steps 2 - 4 are repeated with K = 128 (exact zeros: the rounding errors of successive steps are correlated over a thousand
+//      samples there and the trajectory leaves a +-32 bracket; merges are four times as frequent with the wide one, 2 - 3 groups
+//      per block); and if more than twelve still do -- a constant envelope, which parks the float recurrence in its dead zone
+//      away from the real one; a NaN -- the rest of the block goes to the serial walker and costs what it always did.
 // Why 2 holds.  One step maps S to fl(S + d(S)), d(S) = fl(c fl(a - S)) non-increasing in S (rounding is monotone).  For the
 // 2 K + 1 lattice points S_j between the two walked ones, inside one binade with spacing u: S_j + d_j = S_j + m u + e_j where
 // m u = r_lo - S_lo is what the low walk added after rounding and e_j = d_j - m u its residual.  e_hi <= e_j <= e_lo, and the
@@ -36,9 +38,8 @@
 
 namespace dabx {
 
-constexpr int LVL_K = 32, LVL_K_WIDE = 128;
-constexpr int LVL_MAX_WALKED_WIDE = 12;
-constexpr int LVL_MAX_WALKED = 6;          // groups settled one by one before the rest of a block is handed to the serial walker
+constexpr int LVL_K = 32, LVL_K_WIDE = 128;                // half-width of the brackets, first and second tier
+constexpr int LVL_MAX_WALKED = 6, LVL_MAX_WALKED_WIDE = 12; // groups settled one by one per tier before the next tier / the serial walker takes over
 
 #ifdef DABX_LV_DEBUG
 __device__ unsigned *dabx_lv_debug;
