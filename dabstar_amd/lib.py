@@ -52,7 +52,8 @@ def load(build_if_missing=True):
     L.dabx_host_register.argtypes = [C.c_void_p, C.c_size_t]
     L.dabx_host_unregister.argtypes = [C.c_void_p]
     L.dabx_commit_iq.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-    L.dabx_announce_write.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    if hasattr(L, "dabx_announce_write"):            # (absent from libraries older than the level anchor: tools/ab.sh runs those through this binding too)
+        L.dabx_announce_write.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     _LIB = L
     return L
 
@@ -379,7 +380,8 @@ class Engine:
         check(load().dabx_commit_iq(self._h, stream, n_samples))
 
     def announce_write(self, n_samples, stream=-1):
-        check(load().dabx_announce_write(self._h, stream, n_samples))
+        if hasattr(load(), "dabx_announce_write"):
+            check(load().dabx_announce_write(self._h, stream, n_samples))
 
     def process(self, max_frames, sync=True):
         return check(load().dabx_process(self._h, max_frames, int(sync)))
