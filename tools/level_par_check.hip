@@ -124,8 +124,10 @@ int main(int argc, char **argv)
     if (f2u(S) != f2u(s[c])) bad++;
     if (f2u(S) != f2u(s2[c])) bad += 1000000000;       // (the serial walker itself)
     const double nb = (double)(N / BLOCK);
+    char lvl[32];
+    if (std::isfinite(s[c])) snprintf(lvl, sizeof(lvl), "%.8g", (double)s[c]); else snprintf(lvl, sizeof(lvl), "null");     // (the NaN case: JSON has no NaN)
     printf("{\"case\": \"%s\", \"samples\": %ld, \"checkpoints_differing\": %ld, \"fallbacks_per_block\": %.3f, \"cycles_per_block\": %.0f, "
-           "\"serial_walker_cycles_per_block\": %.0f, \"level\": %.8g}\n", names[c], N, bad, fb[c] / nb, cy[c] / nb, cy2[c] / nb, (double)s[c]);
+           "\"serial_walker_cycles_per_block\": %.0f, \"level\": %s}\n", names[c], N, bad, fb[c] / nb, cy[c] / nb, cy2[c] / nb, lvl);
     bad_total += bad;
   }
   return bad_total != 0;
