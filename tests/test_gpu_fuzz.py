@@ -182,8 +182,10 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
     layouts, cases, xs, rng = draw_streams(seed)
 
     fast = dict(acquire_mode=2) if fast == 2 else (dict(msc_fast_min_jobs=64, msc_class_min_jobs=1) if fast else {})
+    # DABX_FUZZ_LEVEL (hunting runs): cfg.exact_level_tracker of the engine under test -- 1: the exact tracker in lock (k_level_exact), 2: chunk-wise only
     eng = dx.Engine(n_streams=N_CASES, ring_frames=N_FRAMES + 3, max_subch=18, out_frames=12, sync_threshold=thr,
-                    sync_strongest=bool(strongest), soft_bit_type=soft_type, viterbi_tie_mode=tie, **fast)
+                    sync_strongest=bool(strongest), soft_bit_type=soft_type, viterbi_tie_mode=tie,
+                    exact_level_tracker=int(os.environ.get("DABX_FUZZ_LEVEL", "0")), **fast)
     for s, (li, *_rest) in enumerate(cases):
         eng.set_subchannels(layouts[li], stream=s)
         eng.push_iq(s, xs[s])

@@ -19,6 +19,7 @@ CFGS = ["3.0,0,1", "3.0,0,1", "3.0,0,1", "4.0,1,2", "2.5,0,3", "3.0,1,1"]      #
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="1000:1030")
+    ap.add_argument("--level-mode", type=int, default=0, help="cfg.exact_level_tracker of the engine under test (1: exact in lock, k_level_exact)")
     a = ap.parse_args()
     # "lo:hi" or a comma-separated list of seeds
     seeds = [int(v) for v in a.seeds.split(",")] if "," in a.seeds or ":" not in a.seeds else list(range(*[int(v) for v in a.seeds.split(":")]))
@@ -35,13 +36,15 @@ def main():
             env.update(DABX_FUZZ_FAST=str(int(fast)))
         if tie:
             env.update(DABX_FUZZ_TIE=str(tie))
+        if a.level_mode:
+            env.update(DABX_FUZZ_LEVEL=str(a.level_mode))
         t0 = time.time()
         p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "tests/test_gpu_fuzz.py", "-k", which],
                            cwd=ROOT, env=env, capture_output=True, text=True)
         ok = p.returncode == 0
         n_pass += ok; n_fail += (not ok)
         rec = {"seed": seed, "test": which, "cfg_threshold_strongest_softtype": cfg, "lane_per_trellis_classes": fast == 1 or fast is True, "acquire_mode": 2 if fast == 2 else 0, "viterbi_tie_mode": tie,
-               "passed": ok, "seconds": round(time.time() - t0, 1)}
+               "passed": ok, "seconds": round(time.time() - t0, 1), "exact_level_tracker": a.level_mode}
         # streams whose walk needed the exact level tracker to follow the oracle (tests/test_gpu_fuzz.py)
         lv = [l for l in p.stdout.splitlines() if l.startswith("walk differs with the chunk-wise level tracker")]
         if lv:
