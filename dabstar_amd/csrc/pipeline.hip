@@ -581,7 +581,7 @@ __device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, 
   // How the level gets to rd, best first:
   //   1  from the anchor, exactly (everything read since the hand-over is still in the ring);
   //   2  from the oldest frame boundary still in the ring whose chunk-wise value the frame tail has kept (lvl_hist_*): TWO walks, from
-  //      that value -/+ 2^-11 (fifty times the chunk-wise tracker's observed error).  The recurrence forgets: two trajectories close in
+  //      that value -/+ 2^-9 (two hundred times the chunk-wise tracker's observed error, six times what one symbol with a 100 % level step in it can contribute).  The recurrence forgets: two trajectories close in
   //      on each other by 1e-5 of their distance per sample and, one float apart, merge for good within ~1e5 samples -- after four to
   //      eight frames they are the SAME float, and then so is every trajectory that started in between (the step is monotone in the
   //      level while no sample is thousands of times larger than it: checked): the exact value, with a certificate;
@@ -610,7 +610,7 @@ __device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, 
     const int pick = w.flag[3];
     const unsigned long long p0 = mode == 1 ? c.lvl_anchor_pos : (mode == 2 ? c.lvl_hist_pos[pick] : c.lvl_approx_pos);
     const float Sh = mode == 2 ? c.lvl_hist_S[pick] : 0.f;
-    S = mode == 1 ? c.lvl_anchor_S : (mode == 2 ? (wave == 0 ? Sh - Sh * 0x1p-11f : Sh + Sh * 0x1p-11f) : c.s_level);
+    S = mode == 1 ? c.lvl_anchor_S : (mode == 2 ? (wave == 0 ? Sh - Sh * 0x1p-9f : Sh + Sh * 0x1p-9f) : c.s_level);
     float s_min = S;
     const unsigned long long n = p1 - p0;
     const int nblk = (int)((n + ACQ_CH - 1) / ACQ_CH);

@@ -238,7 +238,7 @@ typedef struct {
                                    readers are tracked; a zero-copy producer's are if it uses dabx_announce_write; a lock that outlasts
                                    the ring has lost them).  Then two walks are started a little below and above the chunk-wise
                                    value of the oldest frame boundary still in the ring; the recurrence forgets, and once they have
-                                   merged into the same float (4 - 8 frames) that float is the exact value (level_healed_events).
+                                   merged into the same float (5 - 9 frames) that float is the exact value (level_healed_events).
                                    Failing that too, the level continues from the chunk-wise value: level_unanchored_events; the
                                    returns walked from the anchor itself are counted in level_rewalk_events;
                                  1: exact in lock too (a second pass over every sample on a HIP stream of its own: -27 % throughput
@@ -279,7 +279,7 @@ typedef struct {
                                 could conceivably have decided differently from the sample-serial one; 0 = the approximation never mattered */
   int64_t level_rewalk_events;     /* losses of lock after which the level was re-walked exactly from its anchor (exact_level_tracker 0) */
   int64_t level_unanchored_events; /* ... after which it had to continue from the chunk-wise value (samples no longer in the ring) */
-  int64_t level_healed_events;     /* ... after which the anchor was gone but two walks started 2^-11 either side of a frame boundary's
+  int64_t level_healed_events;     /* ... after which the anchor was gone but two walks started 2^-9 either side of a frame boundary's
                                       chunk-wise value, four or more frames back in the ring, had merged into one float: exact all the same */
   int64_t reserved[4];       /* zero; later fields go here without changing the record's size */
 } dabx_stats;

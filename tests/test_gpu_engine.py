@@ -920,7 +920,7 @@ def test_level_anchor_that_has_left_the_ring_is_counted():
 
 def test_level_is_exact_again_when_two_walks_around_the_chunk_wise_value_have_merged():
     """A stream fed frame by frame through a ring of 13 frames loses its lock after 24 frames in lock: the anchor (where the search handed
-    the stream over) left the ring long ago.  level_from_anchor then starts two walks 2^-11 below and above the chunk-wise level of the
+    the stream over) left the ring long ago.  level_from_anchor then starts two walks 2^-9 below and above the chunk-wise level of the
     oldest frame boundary still in the ring; the recurrence forgets its start value, the two merge into one float after a few frames, and
     that float is the exact level: in every step that leaves the stream searching sLevel is bit-identical to the recurrence over all samples
     read (level_healed_events = 1, nothing unanchored)."""
