@@ -71,6 +71,13 @@ def parse():
                     help="silence: all-zero samples; floor: the ensemble 60 dB down under its (unchanged) noise")
     ap.add_argument("--exact-level", action="store_true",
                     help="not the headline: dabx_config.exact_level_tracker = 1 (SampleReader's level IIR sample by sample in lock too)")
+    ap.add_argument("--deliver", action="store_true",
+                    help="the timed region itself runs with the bulk delivery open: every FIB, logical frame and super frame of every "
+                         "stream lands in page-locked host memory (one DMA per 7-frame chunk) inside the timed region; without the flag "
+                         "the same is measured in a second, equally long leg and reported as config.delivered_to_host")
+    ap.add_argument("--no-deliver-leg", action="store_true", help="skip the delivered_to_host leg")
+    ap.add_argument("--deliver-copy-engine", type=int, default=0, choices=[0, 1], help="experiments: dabx_delivery_config.copy_engine (1 = hipMemcpyAsync)")
+    ap.add_argument("--deliver-what", type=int, default=0, help="experiments: DABX_DELIVER_* mask (1 FIBs, 2 logical frames, 4 super frames; 0 = all)")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
                     help="mixed (not the headline): every second ensemble carries a 16-service multiplex of 7 different "
                          "protection profiles instead of 18 x 64 kbit/s EEP 3-A")
@@ -442,6 +449,106 @@ class DryEngine:
         pass
 
 
+class DeliverySink:
+    """The host consumer of the bulk delivery (dabx_delivery_next / _release) on its own thread: takes every chunk as it lands,
+    adds up what it carries from the slab's records and gives the slab back.  For `sample` streams it keeps the FIBs + CRC flags of
+    every frame (a few KB per chunk) for the oracle comparison after the run."""
+
+    def __init__(self, eng, sample=()):
+        import threading
+        self.eng, self.sample = eng, list(sample)
+        self.chunks = self.frames = self.cifs = self.sfs = self.slab_bytes = self.payload_bytes = self.lost = 0
+        self.fibs = {s: [] for s in self.sample}
+        self.stop = threading.Event()
+        self.error = None
+        self.th = threading.Thread(target=self.run, daemon=True)
+        self.th.start()
+
+    def run(self):
+        try:
+            while True:
+                ch = self.eng.delivery_next(wait=True)
+                if ch is None:
+                    if self.stop.is_set():
+                        return
+                    time.sleep(0.0002)
+                    continue
+                st, sc = ch.streams, ch.subch
+                nf = int(st["n_frames"].sum())
+                self.frames += nf
+                self.cifs += int(sc["n_cifs"].sum())
+                self.sfs += int(sc["n_sf"].sum())
+                self.lost += int(st["frames_lost"].sum()) + int(sc["cifs_lost"].sum()) + int(sc["sf_lost"].sum())
+                self.slab_bytes += ch.nbytes
+                self.payload_bytes += nf * 396 + int((sc["n_cifs"].astype(np.int64) * 3 * sc["kbps"]).sum()) + \
+                    int((sc["n_sf"].astype(np.int64) * 110 * (sc["kbps"] // 8)).sum())
+                for s in self.sample:
+                    n = int(st[s]["n_frames"])
+                    if n and hasattr(ch, "fibs"):
+                        self.fibs[s].append((int(st[s]["first_frame"]), ch.fibs[s, :n].copy(), ch.crc[s, :n].copy()))
+                ch.release()
+                self.chunks += 1         # last: whoever sees the count sees the chunk's sums too
+        except Exception as ex:          # reported by finish()
+            self.error = ex
+
+    def totals(self):
+        return {"chunks": self.chunks, "frames": self.frames, "logical_frames": self.cifs, "superframes": self.sfs,
+                "slab_bytes": self.slab_bytes, "payload_bytes": self.payload_bytes, "lost": self.lost}
+
+    def finish(self):
+        """Call after eng.synchronize(): every chunk has landed; waits until the thread has taken them all."""
+        self.stop.set()
+        self.th.join(timeout=60)
+        if self.error is not None:
+            raise self.error
+        if self.th.is_alive():
+            raise SystemExit("bench.py: the delivery consumer did not finish")
+
+
+def oracle_fib_check(eng, sink, subch, streams, ring_frames):
+    """SURVEY 8d metric (2): FIBs whose 32 bytes AND CRC flag equal the reference's.  The oracle receiver (the checker) decodes the very
+    IQ the device rings hold for `streams` from their first sample on, one thread per stream; every FIB the delivery brought to the
+    host for those streams is compared with the oracle's FIB of the same frame.  Outside every timed region."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    L = ol.oracle()
+    n_ring = ring_frames * TF
+    res = {}
+
+    def work(s, ring, n_frames):
+        x = np.tile(ring, (n_frames + 2) // ring_frames + 1)[: (n_frames + 2) * TF]      # periodic rings: sample a sits at a % n_ring
+        rx = L.ora_rx_create(ol.make_descs(subch), len(subch))
+        n = L.ora_rx_run(rx, x, len(x), n_frames + 2)
+        cap = L.ora_rx_get_capture(rx).contents
+        res[s] = (np.ctypeslib.as_array(cap.fibs, (n, 12, 32)).copy(), np.ctypeslib.as_array(cap.fib_crc, (n, 12)).copy())
+        L.ora_rx_destroy(rx)
+
+    th = []
+    for s in streams:
+        if not sink.fibs[s]:
+            continue
+        ptr, cap = eng.ring_ptr(s)
+        ring = np.zeros(n_ring, np.complex64)
+        rc = hip().hipMemcpy(ring.ctypes.data_as(C.c_void_p), ptr, n_ring * 8, 2)      # device to host
+        assert rc == 0 and cap == n_ring, (rc, cap)
+        last = max(first + len(f) for first, f, _ in sink.fibs[s])
+        th.append(threading.Thread(target=work, args=(s, ring, last)))
+    for i in range(0, len(th), 4):                      # four at a time: each holds its stream's whole IQ
+        for t in th[i:i + 4]:
+            t.start()
+        for t in th[i:i + 4]:
+            t.join()
+    tot = same = 0
+    for s in res:
+        o_f, o_c = res[s]
+        for first, f, c in sink.fibs[s]:
+            n = min(len(f), max(0, len(o_f) - first))
+            tot += 12 * len(f)                          # a frame the oracle did not produce counts as different
+            same += int(((f[:n] == o_f[first:first + n]).all(axis=2) & (c[:n] == o_c[first:first + n])).sum())
+    return {"fibs_compared": tot, "fibs_equal": same, "streams": sorted(res)}
+
+
 def load_traffic(dom):
     """HBM bytes and VALU instructions per FRAME of kernel `dom` from the committed rocprofv3 --pmc passes (tools/prof_round.sh)."""
     for name in ("r04_traffic.json", "r03_traffic_final.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -571,6 +678,14 @@ def main():
         sync_dev()
 
     host_time = [0.0]
+    delivering = [False]
+    closed = [0]                         # chunks closed so far with the delivery open
+
+    def sink_catch_up():
+        """After eng.synchronize() every chunk has landed; this waits until the consumer thread has taken and released them all."""
+        while sink is not None and sink.chunks < closed[0] and sink.error is None:
+            time.sleep(0.0001)
+    sample_streams = sorted({(i * (args.streams - 1)) // 7 for i in range(8)})
 
     def step(n=1, sync=False):
         # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch (a dabx_process call
@@ -579,6 +694,11 @@ def main():
         # stream of their own and never hold up a step of the others; sync=True (priming only) searches them in step.
         for m in step_chunks(n, args.chunk):
             h0 = time.perf_counter()
+            if delivering[0]:          # a chunk closes per 7 frames and call: wait until the consumer has given that many host slabs back
+                while eng.delivery_wait_free((m + 6) // 7, timeout_ms=2000) < (m + 6) // 7:
+                    if sink.error is not None or not sink.th.is_alive():
+                        raise SystemExit("bench.py: the delivery consumer died: %r" % (sink.error,))
+                closed[0] += (m + 6) // 7
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=sync)
             host_time[0] += time.perf_counter() - h0      # host time inside the two calls (launches, event traffic): no device wait when sync=False
@@ -605,21 +725,30 @@ def main():
         dom = max(share, key=share.get) if share else "k_symbols"
         dom_idx = [names[i].decode() for i in range(nk)].index(dom)
         dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+    sink = None
+    if args.deliver and not dry:
+        eng.delivery_open(slots=4, what=args.deliver_what, copy_engine=args.deliver_copy_engine)
+        sink = DeliverySink(eng, sample_streams)
+        delivering[0] = True
     step(args.warmup)
     eng.synchronize()
+    sink_catch_up()
     if not dry:
         dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
     c1 = eng.counters()
+    d1 = sink.totals() if sink else None
 
     barrier()
     host_time[0] = 0.0
     t0 = time.perf_counter()
     step(args.steps)
     host_s = host_time[0]
-    eng.synchronize()
+    eng.synchronize()                    # with a delivery open: every chunk has landed in host memory
+    sink_catch_up()                      # ... and the consumer has taken (and given back) every one of them
     barrier()
     dt = time.perf_counter() - t0
     c2 = eng.counters()
+    d2 = sink.totals() if sink else None
     if not dry:
         nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
         dx.check(dx.load().dabx_set_profiling(eng._h, 0))
@@ -642,6 +771,72 @@ def main():
     dt, (frames, fib_ok, fib_tot, sf_ok, sf_fail, msc_bytes, locked) = shard.reduce_results(
         dist, torch, dev, dt, [frames, fib_ok, fib_tot, c2["sf_ok"] - c1["sf_ok"], c2["sf_fail"] - c1["sf_fail"],
                                c2["msc_bytes"] - c1["msc_bytes"], c2["streams_locked"]])
+
+    # ---- delivered_to_host: the bulk delivery open -- every FIB + CRC flag, logical frame and super frame of every stream lands in
+    # page-locked host memory, one SDMA transfer per 7-frame chunk, taken and given back by a consumer thread -- measured live in this
+    # run, per rank (every GPU has its own link).  Two figures: a STEADY leg of >= 98 steps next to the same steps without delivery
+    # (like for like), and the timed region's own length (args.steps), where the last chunk's slab (100 MB for the measured
+    # configuration = 1.8 ms of link time that nothing can hide) weighs as it does in any short run.  With --deliver the timed region
+    # above WAS the second figure.
+    deliv = fibchk = None
+    if not dry and not args.no_deliver_leg:
+        def leg(n):
+            eng.synchronize()
+            sink_catch_up()
+            e1, q1 = eng.counters(), (sink.totals() if sink else None)
+            tq = time.perf_counter()
+            step(n)
+            eng.synchronize()
+            sink_catch_up()
+            dq = time.perf_counter() - tq
+            return e1, eng.counters(), q1, (sink.totals() if sink else None), dq
+
+        def figures(e1, e2, q1, q2, dq, n):
+            dfr = e2["frames"] - e1["frames"]
+            return {"steps": n, "frames_per_s": round(dfr / dq, 1), "host_GBps": round((q2["slab_bytes"] - q1["slab_bytes"]) / dq / 1e9, 3),
+                    "payload_GBps": round((q2["payload_bytes"] - q1["payload_bytes"]) / dq / 1e9, 3), "chunks": q2["chunks"] - q1["chunks"],
+                    "frames_delivered": q2["frames"] - q1["frames"], "frames_decoded": dfr,
+                    "logical_frames_delivered": q2["logical_frames"] - q1["logical_frames"], "logical_frames_decoded": e2["cifs_decoded"] - e1["cifs_decoded"],
+                    "superframes_delivered": q2["superframes"] - q1["superframes"], "superframes_decoded": e2["sf_ok"] - e1["sf_ok"]}
+        n_steady = max(98, args.steps)
+        if sink is None:
+            b1, b2, _, _, bdt = leg(n_steady)          # the same steps without delivery, right before
+            base_steady = (b2["frames"] - b1["frames"]) / bdt
+            eng.delivery_open(slots=4, what=args.deliver_what, copy_engine=args.deliver_copy_engine)
+            sink = DeliverySink(eng, sample_streams)
+            delivering[0] = True
+            step(7)                                    # first chunk: first touch of the slabs
+            steady = figures(*leg(n_steady), n_steady)
+            short = figures(*leg(args.steps), args.steps)
+        else:
+            short = figures(c1, c2, d1, d2, dt, args.steps)
+            steady = figures(*leg(n_steady), n_steady)
+            delivering[0] = False
+            sink.finish()
+            lost = sink.totals()["lost"]
+            if rank == 0 and args.layout == "uniform":
+                fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
+            slab_bytes = eng.delivery_slab_bytes()
+            eng.delivery_close()
+            sink = None
+            b1, b2, _, _, bdt = leg(n_steady)
+            base_steady = (b2["frames"] - b1["frames"]) / bdt
+        if sink is not None:
+            delivering[0] = False
+            sink.finish()
+            lost = sink.totals()["lost"]
+            if rank == 0 and args.layout == "uniform":
+                fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
+            slab_bytes = eng.delivery_slab_bytes()
+            eng.delivery_close()
+        steady["frames_per_s_without_delivery_same_steps"] = round(base_steady, 1)
+        steady["frac_of_that"] = round(steady["frames_per_s"] / base_steady, 4)
+        deliv = dict(steady, at_timed_region_length=short, lost=lost, slab_bytes_per_chunk=slab_bytes, host_slabs=4,
+                     in_timed_region=bool(args.deliver), copy_engine="sdma (hsa_amd_memory_async_copy)" if args.deliver_copy_engine == 0 else "hipMemcpyAsync",
+                     what="every FIB + CRC flag + frame record, logical frame and RS-corrected super frame of every stream and sub-channel: one "
+                          "slab and ONE SDMA transfer per 7-frame chunk into page-locked host slabs (dabx_delivery_*); consumer = a python "
+                          "thread: dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release",
+                     scope="this rank's GPU")
 
     if rank == 0:
         value = frames / dt
@@ -704,7 +899,12 @@ def main():
                        "step_chunks": step_chunks(args.steps, args.chunk) if args.steps <= 70 else "%d x %d + %d" % (args.steps // args.chunk, args.chunk, args.steps % args.chunk), "viterbi_tie_mode": args.viterbi_tie_mode,
                        "x_realtime_per_gpu": round(value / n_joined / (2048000.0 / TF), 1),
                        "msamples_per_s": round(value * TF / 1e6, 1)},
-            "fib_crc_match_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
+            # the engine's own count: FIBs whose CRC held / FIBs decoded in the timed region
+            "fib_crc_pass_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
+            # SURVEY 8d metric (2): FIBs whose 32 bytes AND CRC flag equal the oracle's, on sampled streams (see fib_match_vs_oracle)
+            "fib_match_vs_oracle_pct": round(100.0 * fibchk["fibs_equal"] / max(1, fibchk["fibs_compared"]), 4) if fibchk else None,
+            "fib_match_vs_oracle": dict(fibchk, note="every FIB the delivery brought to the host for these streams against the oracle receiver "
+                                        "(oracle/, the checker) run on the IQ read back from the same device rings; after the timed regions") if fibchk else None,
             "streams_locked": locked, "superframes_ok": sf_ok, "superframes_failed": sf_fail, "msc_bytes": msc_bytes,
             "roofline": roofline,
             "ranks_joined": n_joined, "per_rank": reports, "devices": sorted({r["pci_bus_id"] for r in reports}),
@@ -715,6 +915,9 @@ def main():
                       "frac_of_hbm_peak": round(value / n_joined * a_frame / HBM_PEAK, 6),
                       "kernel_ms_per_step_standalone": {k: round(v, 4) for k, v in share.items()}},
         }
+        if deliv is not None:
+            deliv["at_timed_region_length"]["frac_of_value"] = round(deliv["at_timed_region_length"]["frames_per_s"] / (value / n_joined), 4)
+            out["config"]["delivered_to_host"] = deliv
         if not dry and not args.fic_only and args.layout == "uniform" and args.streams == 512:
             out["config"]["pcie_inclusive"] = load_pcie_inclusive()
         if dry:

@@ -16,6 +16,7 @@ constexpr int TDI_SLOTS = 64;          // time-deinterleaver ring depth in CIFs 
 constexpr uint16_t PUNCT = 0xFFFF;     // depuncture map entry of a punctured mother-code bit
 
 void set_error(const char *fmt, ...);
+const char *last_error();
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define DABX_HIP(x)                                                                  \
   do {                                                                               \

@@ -1,6 +1,7 @@
 // engine.cpp -- host side of the stream-batched receiver and the engine-level C ABI (include/dabx.h).
 #include "pipeline.h"
 #include "viterbi_core.h"
+#include "sdma.h"
 #ifndef DABX_CU_SPLIT_DEMAP_FRONT
 #define DABX_CU_SPLIT_DEMAP_FRONT 0
 #endif
@@ -10,13 +11,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
 namespace dabx {
 int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool async_acquire);
-int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk);
+int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk, const DeliverDev *dv = nullptr,
+                     hipStream_t *tail = nullptr);
+int launch_deliver_front(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
 int launch_dciq(const EngineDev &e, int mode, hipStream_t st);
 int launch_level_exact(const EngineDev &e, hipStream_t st);
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
@@ -27,6 +36,38 @@ int launch_fic_only(const EngineDev &e, hipStream_t st, int first, int count);
 int launch_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n, hipStream_t st);
 }  // namespace dabx
 using namespace dabx;
+
+// Bulk delivery (include/dabx.h): host slabs (page-locked) the chunks land in, device slabs they are packed into, and the copier --
+// a thread of the library that waits (blocked, not spinning) for a chunk's gather kernels and then moves the slab with ONE SDMA
+// transfer (sdma.h: the HIP runtime's own device-to-host copy is a shader copy that stalls the receiver's kernels while it runs).
+struct Delivery {
+  bool open = false;
+  int what = 0;
+  int copy_engine = 0;                           // dabx_delivery_config.copy_engine: 0 SDMA through the HSA runtime, 1 hipMemcpyAsync
+  static constexpr int NDEV = 3;                 // device slabs: chunk n + 3 is packed into the slab of chunk n once its copy has left
+  uint8_t *dev[NDEV] = {nullptr, nullptr, nullptr};
+  hipEvent_t packed[NDEV] = {nullptr, nullptr, nullptr};    // the chunk's gather kernels have finished (blocking-sync events)
+  bool dev_busy[NDEV] = {false, false, false};   // packed into or being copied from (guarded by mu)
+  hipStream_t cs = nullptr;                      // copy_engine 1 only
+  Sdma sdma;
+  size_t capacity = 0, bytes = 0;                // bytes allocated per slab / bytes the current layout uses (= what is copied)
+  enum { FREE = 0, IN_FLIGHT = 1, LANDED = 2, HELD = 3 };
+  struct Slot { uint8_t *host = nullptr; uint64_t sig = 0; int state = FREE; uint64_t seq = 0; size_t bytes = 0; int devslab = 0; };
+  std::vector<Slot> slots;
+  std::deque<int> queue;                         // slots in flight or landed, oldest first (what dabx_delivery_next hands out)
+  std::deque<int> jobs;                          // slots whose copy the copier still has to make
+  std::mutex mu;                                 // everything above: the engine's thread, the copier and ONE consumer thread
+  std::condition_variable cv;                    // any state change
+  std::thread copier;
+  bool quit = false;
+  int device = 0;
+  std::string copier_error;
+  uint64_t next_seq = 0;
+  unsigned long long *layout_off = nullptr;      // device tables (DeliverDev)
+  int32_t *subch_id = nullptr;
+  long long *frames_done = nullptr, *cif_done = nullptr, *sf_done = nullptr;
+  dabx_chunk_header hdr{};
+};
 
 struct dabx_engine {
   dabx_config cfg{};
@@ -74,7 +115,11 @@ struct dabx_engine {
   unsigned long long *horizon_host = nullptr;  // hipHostMalloc'ed, EngineDev::wr_horizon: what pushes may have overwritten (written BEFORE a copy is issued)
   int32_t *locked_host = nullptr;              // hipHostMalloc'ed: number of streams in lock, kept by the device (EngineDev::locked_count)
   bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
+  Delivery dl;
   int build_msc_classes();
+  int delivery_layout();                       // offsets of every slot's bytes in a slab for the sub-channels configured now
+  int delivery_begin(DeliverDev *dv, int *slot, int *devslab);     // a chunk closes: host + device slab, front gather on stream a
+  int delivery_finish(int slot, int devslab, hipStream_t tail);    // ... its slot gather is queued on `tail`: the one copy
 
   template <class T> int alloc(T **p, size_t count, bool zero = true)
   {
@@ -184,6 +229,7 @@ static int use_device(const dabx_engine *e)
   return 0;
 }
 
+static int delivery_drain(dabx_engine *e);
 static int sync_all(dabx_engine *e)
 {
   if (int rc = use_device(e)) return rc;
@@ -191,6 +237,7 @@ static int sync_all(dabx_engine *e)
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
   if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
   if (e->ss.q) DABX_HIP(hipStreamSynchronize(e->ss.q));
+  if (int rc = delivery_drain(e)) return rc;                       // every chunk closed so far has landed
   e->ss.acq_in_flight = false;
   // cfg.exact_level_tracker: the level tracker follows the frame chain on its own; behind the last frame it is run once more, so
   // that what the host reads next (dabx_get_stats, the ring's read cursor) includes every sample the receiver has read
@@ -200,6 +247,183 @@ static int sync_all(dabx_engine *e)
     e->level_dirty = false;
   }
   return 0;
+}
+
+// ---- bulk delivery (include/dabx.h "Bulk delivery", deliver.hip) -------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static constexpr int DL_FRAMES = MSC_BATCH_FRAMES;                 // a chunk = what one MSC batch decodes
+static constexpr int DL_SF_CAP = (4 * DL_FRAMES + 4) / 5;          // super frames one chunk can complete (4 CIFs may be waiting from before)
+#if DABX_MSC_BATCH == 7
+static_assert(DL_FRAMES == DABX_CHUNK_FRAMES, "include/dabx.h: DABX_CHUNK_FRAMES is the library's MSC batch");
+#endif
+
+// Where every slot's bytes lie in a slab with the sub-channels configured now: table part (header, stream and slot records, FIBs,
+// CRC flags, frame records), then the logical frames of all slots, then the super frames of all slots.  Uploaded to the device;
+// called with the engine drained (dabx_delivery_open, dabx_set_subchannels*).
+int dabx_engine::delivery_layout()
+{
+  Delivery &D = dl;
+  const EngineDev &d = dev;
+  const size_t S = (size_t)d.n_streams, M = (size_t)d.max_subch, F = DL_FRAMES;
+  dabx_chunk_header h{};
+  h.magic = DABX_CHUNK_MAGIC; h.abi = DABX_ABI_VERSION;
+  h.n_streams = d.n_streams; h.max_subch = d.max_subch; h.max_frames = DL_FRAMES; h.what = D.what;
+  size_t off = sizeof(dabx_chunk_header);
+  h.off_stream = off; off = align_up(off + S * sizeof(dabx_chunk_stream), 16);
+  h.off_subch = off; off = align_up(off + S * M * sizeof(dabx_chunk_subch), 16);
+  const bool fib = (D.what & DABX_DELIVER_FIB) != 0;
+  h.off_fib = off; if (fib) off = align_up(off + S * F * 384, 16);
+  h.off_crc = off; if (fib) off = align_up(off + S * F * 12, 16);
+  h.off_frame = off; if (fib) off = align_up(off + S * F * sizeof(dabx_chunk_frame), 16);
+  std::vector<unsigned long long> lo(2 * S * M + 2, 0);
+  h.off_msc = off;
+  if ((D.what & DABX_DELIVER_MSC) && !d.fic_only)
+    for (size_t sj = 0; sj < S * M; sj++) {
+      const SubchDev &sc = subch_host[sj];
+      if (!sc.active) continue;
+      lo[2 * sj] = off;
+      off = align_up(off + (size_t)4 * F * 3 * sc.kbps, 16);
+    }
+  h.off_sf = off;
+  if ((D.what & DABX_DELIVER_SF) && !d.fic_only)
+    for (size_t sj = 0; sj < S * M; sj++) {
+      const SubchDev &sc = subch_host[sj];
+      if (!sc.active || !sc.dab_plus) continue;
+      lo[2 * sj + 1] = off;
+      off = align_up(off + (size_t)DL_SF_CAP * (size_t)((110 * (sc.kbps / 8) + 3) & ~3), 16);
+    }
+  h.bytes = off;
+  if (off > D.capacity) {
+    set_error("delivery: the configured sub-channels need %zu bytes per chunk, the slabs hold %zu (sub-channels of a stream that together "
+              "exceed a CIF's capacity?)", off, D.capacity);
+    return DABX_E_NOMEM;
+  }
+  D.hdr = h;
+  D.bytes = off;
+  if (S * M) {
+    DABX_HIP(hipMemcpy(D.layout_off, lo.data(), sizeof(unsigned long long) * 2 * S * M, hipMemcpyHostToDevice));
+    std::vector<int32_t> ids(subch_id_host.begin(), subch_id_host.begin() + S * M);
+    DABX_HIP(hipMemcpy(D.subch_id, ids.data(), sizeof(int32_t) * S * M, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// A chunk closes (dabx_process, before the MSC batch of its frames is launched): take a free host slab and the next device slab, and
+// gather the front end's results of the chunk's frames on the front-end stream.
+int dabx_engine::delivery_begin(DeliverDev *dv, int *slot, int *devslab)
+{
+  Delivery &D = dl;
+  int h = -1;
+  uint64_t seq;
+  {
+    std::unique_lock<std::mutex> lk(D.mu);
+    if (!D.copier_error.empty()) { set_error("delivery: %s", D.copier_error.c_str()); return DABX_E_HIP; }
+    for (size_t i = 0; i < D.slots.size() && h < 0; i++) if (D.slots[i].state == Delivery::FREE) h = (int)i;
+    if (h < 0) { set_error("delivery: no free host slab (dabx_delivery_release)"); return DABX_E_STATE; }
+    seq = D.next_seq++;
+    const int k = (int)(seq % Delivery::NDEV);
+    // the copy of chunk seq - NDEV has left the device slab (long ago, unless the link is the bottleneck: then the receiver waits here)
+    D.cv.wait(lk, [&]() { return !D.dev_busy[k] || !D.copier_error.empty(); });
+    if (!D.copier_error.empty()) { set_error("delivery: %s", D.copier_error.c_str()); return DABX_E_HIP; }
+    D.dev_busy[k] = true;
+    D.slots[(size_t)h].state = Delivery::IN_FLIGHT;
+    D.slots[(size_t)h].seq = seq;
+    D.slots[(size_t)h].devslab = k;
+    *devslab = k;
+  }
+  dv->slab = D.dev[*devslab]; dv->layout_off = D.layout_off; dv->subch_id = D.subch_id;
+  dv->frames_done = D.frames_done; dv->cif_done = D.cif_done; dv->sf_done = D.sf_done;
+  dv->hdr = D.hdr; dv->hdr.seq = seq;
+  *slot = h;
+  return launch_deliver_front(dev, *dv, stream);
+}
+
+// ... and once its slot gather is queued behind the DAB+ stage on `tail`: the copier takes over.
+int dabx_engine::delivery_finish(int slot, int devslab, hipStream_t tail)
+{
+  Delivery &D = dl;
+  DABX_HIP(hipEventRecord(D.packed[devslab], tail));
+  std::lock_guard<std::mutex> lk(D.mu);
+  D.slots[(size_t)slot].bytes = D.bytes;
+  D.queue.push_back(slot);
+  D.jobs.push_back(slot);
+  D.cv.notify_all();
+  return 0;
+}
+
+// The copier: one chunk at a time, in order -- wait for the gather kernels (hipEventSynchronize on a blocking-sync event), ONE transfer of
+// the slab, wait for it, hand the slab to the consumer.
+static void delivery_copier(Delivery *Dp)
+{
+  Delivery &D = *Dp;
+  (void)hipSetDevice(D.device);
+  for (;;) {
+    int h;
+    {
+      std::unique_lock<std::mutex> lk(D.mu);
+      D.cv.wait(lk, [&]() { return D.quit || !D.jobs.empty(); });
+      if (D.jobs.empty()) return;                // quit, nothing left to copy
+      h = D.jobs.front();
+    }
+    Delivery::Slot &sl = D.slots[(size_t)h];
+    std::string err;
+    hipError_t he = hipEventSynchronize(D.packed[sl.devslab]);
+    if (he != hipSuccess) err = std::string("hipEventSynchronize: ") + hipGetErrorString(he);
+#ifndef DABX_DELIVER_NOCOPY            // experiment builds only (tools/build_variant.sh): what the gather kernels alone cost
+    if (err.empty()) {
+      if (D.copy_engine == 0) {
+        if (sdma_copy(D.sdma, sl.host, D.dev[sl.devslab], sl.bytes, true, sl.sig) || sdma_wait(sl.sig)) err = dabx::last_error();
+      } else {
+        he = hipMemcpyAsync(sl.host, D.dev[sl.devslab], sl.bytes, hipMemcpyDeviceToHost, D.cs);
+        if (he == hipSuccess) he = hipStreamSynchronize(D.cs);
+        if (he != hipSuccess) err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he);
+      }
+    }
+#endif
+    std::lock_guard<std::mutex> lk(D.mu);
+    D.jobs.pop_front();
+    D.dev_busy[sl.devslab] = false;
+    sl.state = Delivery::LANDED;                 // (after an error too: nobody may wait for ever; the error is reported by the next call)
+    if (!err.empty() && D.copier_error.empty()) D.copier_error = err;
+    D.cv.notify_all();
+  }
+}
+
+// every chunk closed so far has landed in its host slab (dabx_synchronize and everything that drains the engine)
+static int delivery_drain(dabx_engine *e)
+{
+  Delivery &D = e->dl;
+  if (!D.open) return 0;
+  std::unique_lock<std::mutex> lk(D.mu);
+  D.cv.wait(lk, [&]() { return D.jobs.empty(); });
+  if (!D.copier_error.empty()) { set_error("delivery: %s", D.copier_error.c_str()); return DABX_E_HIP; }
+  return 0;
+}
+
+static void delivery_free(dabx_engine *e)
+{
+  Delivery &D = e->dl;
+  if (D.copier.joinable()) {
+    { std::lock_guard<std::mutex> lk(D.mu); D.quit = true; D.cv.notify_all(); }
+    D.copier.join();
+  }
+  D.quit = false;
+  if (D.cs) (void)hipStreamSynchronize(D.cs);
+  for (auto &sl : D.slots) { if (sl.host) (void)hipHostFree(sl.host); sdma_signal_destroy(sl.sig); }
+  D.slots.clear();
+  D.queue.clear();
+  D.jobs.clear();
+  for (int k = 0; k < Delivery::NDEV; k++) {
+    if (D.dev[k]) (void)hipFree(D.dev[k]);
+    if (D.packed[k]) (void)hipEventDestroy(D.packed[k]);
+    D.dev[k] = nullptr; D.packed[k] = nullptr; D.dev_busy[k] = false;
+  }
+  for (void *q : {(void *)D.layout_off, (void *)D.subch_id, (void *)D.frames_done, (void *)D.cif_done, (void *)D.sf_done}) if (q) (void)hipFree(q);
+  D.layout_off = nullptr; D.subch_id = nullptr; D.frames_done = D.cif_done = D.sf_done = nullptr;
+  if (D.cs) (void)hipStreamDestroy(D.cs);
+  D.cs = nullptr;
+  D.copier_error.clear();
+  D.open = false; D.capacity = D.bytes = 0; D.next_seq = 0;
 }
 
 static int need_device_e()
@@ -386,6 +610,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.acq_a_done) (void)hipEventDestroy(e->ss.acq_a_done);
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
+  delivery_free(e);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
   for (dabx_fibdec *f : e->fibdec) dabx_fibdec_destroy(f);
   if (e->ingest) { (void)hipStreamSynchronize(e->ingest); (void)hipStreamDestroy(e->ingest); }
@@ -481,6 +706,7 @@ static int set_subchannels_impl(dabx_engine *e, int stream, const dabx_subch_des
     d.msc_stride = new_msc; d.sf_stride = new_sf; d.vit_stride = new_vit;
     e->max_kbps = max_kbps;
   }
+  std::vector<size_t> restarted;
   for (int s = 0; s < d.n_streams; s++) {
     if (stream >= 0 && s != stream) continue;
     for (int j = 0; j < d.max_subch; j++) {
@@ -508,9 +734,19 @@ static int set_subchannels_impl(dabx_engine *e, int stream, const dabx_subch_des
       e->subch_host[(size_t)s * d.max_subch + j] = sc;
       e->subch_id_host[(size_t)s * d.max_subch + j] = (j < n && sc.active) ? desc[j].subch_id : -1;
       e->eti[s] = dabx_engine::EtiCursor{};
+      restarted.push_back((size_t)s * d.max_subch + j);
     }
   }
   DABX_HIP(hipMemcpy(d.subch, e->subch_host.data(), sizeof(SubchDev) * e->subch_host.size(), hipMemcpyHostToDevice));
+  if (e->dl.open) {
+    // slots that start anew count their frames from 0 again; the slab layout follows the new sub-channels (engine drained above)
+    const long long zero = 0;
+    for (size_t sj : restarted) {
+      DABX_HIP(hipMemcpy(e->dl.cif_done + sj, &zero, sizeof(zero), hipMemcpyHostToDevice));
+      DABX_HIP(hipMemcpy(e->dl.sf_done + sj, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    }
+    if ((rc = e->delivery_layout())) return rc;
+  }
   e->have_fast = false;
   e->classes_dirty = true;            // the decoder classes are rebuilt by the next dabx_process (one rebuild for a series of per-stream calls)
   return 0;
@@ -746,6 +982,19 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
   // here without a wait) the search runs in step: there is little to hold up, and streams that start together lock together instead of
   // falling behind their producers while nearly empty steps go by.  (A stream that joins late stays late: a step never advances a
   // stream by more than one frame.)
+  if (e->dl.open && max_frames > 0) {
+    // every chunk this call closes needs a free host slab; checked before anything is launched, so that a refused call changes nothing
+    const int need = (e->pending_frames + max_frames + MSC_BATCH_FRAMES - 1) / MSC_BATCH_FRAMES;
+    int free_slots = 0;
+    {
+      std::lock_guard<std::mutex> lk(e->dl.mu);
+      for (const auto &sl : e->dl.slots) free_slots += sl.state == Delivery::FREE;
+    }
+    if (free_slots < need) {
+      set_error("dabx_process: the call closes %d chunks, %d host slabs are free (dabx_delivery_next / dabx_delivery_release)", need, free_slots);
+      return DABX_E_STATE;
+    }
+  }
   const bool some_locked = !e->locked_host || 2 * __atomic_load_n(e->locked_host, __ATOMIC_RELAXED) >= e->dev.n_streams;
   const bool async_acquire = !e->cfg.dc_iq_correction && (e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync && some_locked));
   for (int i = 0; i < max_frames; i++) {
@@ -758,9 +1007,14 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     if (rc) return rc;
     e->level_dirty = true;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {
+      DeliverDev dv{};
+      int dl_slot = -1, dl_dev = -1;
+      if (e->dl.open && (rc = e->delivery_begin(&dv, &dl_slot, &dl_dev))) return rc;
       e->dev.snap = e->snap_buf[e->ss.batch_parity];
-      rc = launch_msc_batch(e->dev, 4 * e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk);
+      hipStream_t tail = e->stream;
+      rc = launch_msc_batch(e->dev, 4 * e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk, e->dl.open ? &dv : nullptr, &tail);
       if (rc) return rc;
+      if (e->dl.open && (rc = e->delivery_finish(dl_slot, dl_dev, tail))) return rc;
       e->pending_frames = 0;
     }
   }
@@ -1089,6 +1343,129 @@ int dabx_get_counters(dabx_engine *e, int64_t out[16])
     out[14] += (int64_t)q.cif_out * 3 * q.kbps;                 // MSC bytes out
   }
   return 0;
+}
+
+int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
+{
+  if (!e || (cfg && (cfg->host_slabs < 0 || cfg->host_slabs == 1 || cfg->host_slabs > 64 || (cfg->what & ~7) || cfg->copy_engine < 0 || cfg->copy_engine > 1))) {
+    set_error("dabx_delivery_open: bad argument");
+    return DABX_E_ARG;
+  }
+  if (e->dl.open) { set_error("dabx_delivery_open: already open"); return DABX_E_STATE; }
+  int rc = sync_all(e);
+  if (rc) return rc;
+  Delivery &D = e->dl;
+  const EngineDev &d = e->dev;
+  D.what = cfg && cfg->what ? cfg->what : (DABX_DELIVER_FIB | DABX_DELIVER_MSC | DABX_DELIVER_SF);
+  D.copy_engine = cfg ? cfg->copy_engine : 0;
+  D.device = e->device;
+  if (D.copy_engine == 0 && (rc = sdma_open(e->device, &D.sdma))) return rc;
+  const int n_slots = cfg && cfg->host_slabs ? cfg->host_slabs : 4;
+  const size_t S = (size_t)d.n_streams, M = (size_t)d.max_subch, F = DL_FRAMES;
+  // capacity: the tables + per stream what a full CIF can carry at the highest code rate of the standard (EEP 4-B, 4/5: 5530 B
+  // of logical frames per CIF) for 4 F CIFs, and the same again for the super frames of up to DL_SF_CAP x 5 CIFs
+  const size_t per_cif = 5632;
+  size_t cap = sizeof(dabx_chunk_header) + S * sizeof(dabx_chunk_stream) + S * M * sizeof(dabx_chunk_subch) + S * F * (384 + 12 + sizeof(dabx_chunk_frame)) + 6 * 16;
+  if (M && !d.fic_only) cap += S * ((size_t)4 * F * per_cif + (size_t)DL_SF_CAP * 5 * per_cif + 2 * 16 * M);
+  D.capacity = align_up(cap, 4096);
+#define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); delivery_free(e); return DABX_E_HIP; } } while (0)
+  if (D.copy_engine == 1) H(hipStreamCreateWithFlags(&D.cs, hipStreamNonBlocking));
+  for (int k = 0; k < Delivery::NDEV; k++) {
+    H(hipMalloc((void **)&D.dev[k], D.capacity));
+    H(hipMemset(D.dev[k], 0, D.capacity));
+    // system scope (the SDMA engine and the host read what the gather kernels wrote) and blocking: the copier sleeps until it fires
+    H(hipEventCreateWithFlags(&D.packed[k], hipEventDisableTiming | hipEventBlockingSync));
+  }
+  D.slots.resize((size_t)n_slots);
+  for (auto &sl : D.slots) {
+    H(hipHostMalloc((void **)&sl.host, D.capacity, hipHostMallocDefault));
+    if (D.copy_engine == 0 && (rc = sdma_signal_create(&sl.sig))) { delivery_free(e); return rc; }
+  }
+  H(hipMalloc((void **)&D.layout_off, sizeof(unsigned long long) * std::max<size_t>(2 * S * M, 2)));
+  H(hipMalloc((void **)&D.subch_id, sizeof(int32_t) * std::max<size_t>(S * M, 1)));
+  H(hipMalloc((void **)&D.frames_done, sizeof(long long) * S));
+  H(hipMalloc((void **)&D.cif_done, sizeof(long long) * std::max<size_t>(S * M, 1)));
+  H(hipMalloc((void **)&D.sf_done, sizeof(long long) * std::max<size_t>(S * M, 1)));
+  // delivery starts with what is decoded from now on
+  {
+    std::vector<StreamCtl> ctl(S);
+    H(hipMemcpy(ctl.data(), d.ctl, sizeof(StreamCtl) * S, hipMemcpyDeviceToHost));
+    std::vector<long long> fr(S), cd(std::max<size_t>(S * M, 1), 0), sd(std::max<size_t>(S * M, 1), 0);
+    for (size_t s_ = 0; s_ < S; s_++) fr[s_] = ctl[s_].frames;
+    if (S * M) {
+      H(hipMemcpy(e->subch_host.data(), d.subch, sizeof(SubchDev) * S * M, hipMemcpyDeviceToHost));
+      for (size_t sj = 0; sj < S * M; sj++) { cd[sj] = e->subch_host[sj].cif_out; sd[sj] = e->subch_host[sj].sf_count; }
+    }
+    H(hipMemcpy(D.frames_done, fr.data(), sizeof(long long) * S, hipMemcpyHostToDevice));
+    H(hipMemcpy(D.cif_done, cd.data(), sizeof(long long) * cd.size(), hipMemcpyHostToDevice));
+    H(hipMemcpy(D.sf_done, sd.data(), sizeof(long long) * sd.size(), hipMemcpyHostToDevice));
+  }
+#undef H
+  if ((rc = e->delivery_layout())) { delivery_free(e); return rc; }
+  D.quit = false;
+  D.copier = std::thread(delivery_copier, &D);
+  D.open = true;
+  return 0;
+}
+
+int dabx_delivery_close(dabx_engine *e)
+{
+  if (!e) return DABX_E_ARG;
+  if (!e->dl.open) return 0;
+  const int rc = sync_all(e);
+  delivery_free(e);
+  return rc;
+}
+
+long long dabx_delivery_slab_bytes(dabx_engine *e)
+{
+  if (!e) return DABX_E_ARG;
+  if (!e->dl.open) { set_error("dabx_delivery_slab_bytes: no delivery open"); return DABX_E_STATE; }
+  return (long long)e->dl.bytes;
+}
+
+// Consumer side (may run on a second thread): chunks in the order they were closed.
+int dabx_delivery_next(dabx_engine *e, int wait, dabx_chunk *out)
+{
+  if (!e || !out) return DABX_E_ARG;
+  Delivery &D = e->dl;
+  if (!D.open) { set_error("dabx_delivery_next: no delivery open"); return DABX_E_STATE; }
+  std::unique_lock<std::mutex> lk(D.mu);
+  if (D.queue.empty()) return 0;
+  Delivery::Slot &sl = D.slots[(size_t)D.queue.front()];      // only this thread pops: the front stays the front
+  if (sl.state != Delivery::LANDED) {
+    if (!wait) return 0;
+    D.cv.wait(lk, [&]() { return sl.state == Delivery::LANDED; });
+  }
+  if (!D.copier_error.empty()) { set_error("delivery: %s", D.copier_error.c_str()); return DABX_E_HIP; }
+  D.queue.pop_front();
+  sl.state = Delivery::HELD;
+  out->seq = sl.seq; out->data = sl.host; out->bytes = sl.bytes;
+  return 1;
+}
+
+int dabx_delivery_release(dabx_engine *e, uint64_t seq)
+{
+  if (!e) return DABX_E_ARG;
+  Delivery &D = e->dl;
+  if (!D.open) { set_error("dabx_delivery_release: no delivery open"); return DABX_E_STATE; }
+  std::lock_guard<std::mutex> lk(D.mu);
+  for (auto &sl : D.slots)
+    if (sl.state == Delivery::HELD && sl.seq == seq) { sl.state = Delivery::FREE; D.cv.notify_all(); return 0; }
+  set_error("dabx_delivery_release: chunk %llu is not held", (unsigned long long)seq);
+  return DABX_E_ARG;
+}
+
+int dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms)
+{
+  if (!e || n < 0) return DABX_E_ARG;
+  Delivery &D = e->dl;
+  if (!D.open) { set_error("dabx_delivery_wait_free: no delivery open"); return DABX_E_STATE; }
+  std::unique_lock<std::mutex> lk(D.mu);
+  auto free_now = [&D]() { int k = 0; for (const auto &sl : D.slots) k += sl.state == Delivery::FREE; return k; };
+  if (timeout_ms < 0) D.cv.wait(lk, [&]() { return free_now() >= n; });
+  else D.cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&]() { return free_now() >= n; });
+  return free_now();
 }
 
 int dabx_set_profiling(dabx_engine *e, int on)

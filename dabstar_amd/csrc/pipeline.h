@@ -10,7 +10,7 @@ constexpr int MSC_SLOTS = 32;     // ring of decoded logical frames per sub-chan
 #endif
 constexpr int MSC_BATCH_FRAMES = DABX_MSC_BATCH; // frames whose MSC CIFs are decoded together (the MSC has no feedback into the front end);
                                     // 7 x 4 CIFs x 18 sub-channels x 512 streams / 64 = 4032 waves = 3.94 per SIMD
-constexpr int SF_SLOTS = 4;       // ring of RS-corrected super frames per sub-channel
+constexpr int SF_SLOTS = 16;      // ring of RS-corrected super frames per sub-channel: two chunks' worth (a 7-frame MSC batch completes up to 6)
 constexpr int ACQ_NEED = 20 * TU + 50 + (TF + 1) + (TN + 50 + 21) + 64;   // worst-case samples one acquisition pass may read
 constexpr int FRAME_NEED = TF + 2 * TU;                                    // worst-case samples one in-lock frame may read
 
@@ -141,6 +141,16 @@ struct EngineDev {
   BatchSnap *snap;                // [S] counters of the MSC batch being decoded
   float2 *tii_acc;                // [S][2048] sum of the FFTs of the TII null symbols (TiiDetector::mNullSymbolBufferVec)
   int32_t *tii_cnt;               // [S][2] null symbols in the sum; detector-reset epoch (bumped on loss of lock)
+};
+
+// ---- bulk delivery (deliver.hip, include/dabx.h "Bulk delivery"): what the two gather kernels of a chunk are given, by value
+struct DeliverDev {
+  uint8_t *slab;                          // device slab of this chunk
+  const unsigned long long *layout_off;   // [S * max_subch][2] offset of the slot's logical frames / super frames in a slab
+  const int32_t *subch_id;                // [S * max_subch] SubChId (host knowledge: the device never needs it otherwise)
+  long long *frames_done;                 // [S] frames of the stream delivered so far
+  long long *cif_done, *sf_done;          // [S * max_subch] logical / super frames of the slot delivered so far
+  dabx_chunk_header hdr;                  // as it goes into the slab
 };
 
 // ---- lane-per-trellis path of the MSC decoder (vit_t.hip) ------------------------------------------------------

@@ -1807,12 +1807,19 @@ int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_
 
 // MSC decode of the newest `cifs` CIFs (4 per front-end step, <= 4 * MSC_BATCH_FRAMES; 1 for the per-symbol stage entry) + DAB+ stage.
 // `e.snap` must point at the snapshot buffer of this batch.
-int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk)
+int launch_deliver_msc(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
+// `dv` (optional): the chunk's slot gather (deliver.hip) goes behind the DAB+ stage on the stream that ran it, before the batch's
+// completion event; *tail (optional) = the stream whose work completes the batch.
+int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk, const DeliverDev *dv, hipStream_t *tail)
 {
   const DevTables *t;
   int rc = get_tables(&t);
   if (rc) return rc;
-  if (e.fic_only || e.max_subch <= 0 || !e.msc_out) return 0;
+  if (tail) *tail = ss.a;
+  if (e.fic_only || e.max_subch <= 0 || !e.msc_out) {
+    if (dv && (rc = launch_deliver_msc(e, *dv, ss.a))) return rc;          // the slot table says "nothing" for every slot
+    return 0;
+  }
   const int jobs = e.n_streams * cifs * e.max_subch;
   // the MSC symbols of the newest frame may still be on their way into the time-de-interleaver ring (stream d)
   if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.demap_done, 0)); ss.demap_in_flight = false; }
@@ -1866,6 +1873,8 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
     hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, sb, e, *t);
     hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, sb, e);
     mk.end(9, sb);
+    if (dv && (rc = launch_deliver_msc(e, *dv, sb))) return rc;
+    if (tail) *tail = sb;
     if (ss.b) {
       DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
       ss.msc_in_flight = true;
@@ -1878,6 +1887,7 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
     hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.a, e, *t);
     hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e);
     mk.end(9, ss.a);
+    if (dv && (rc = launch_deliver_msc(e, *dv, ss.a))) return rc;
   }
   ss.batch_parity ^= 1;
   DABX_HIP(hipGetLastError());

@@ -1,0 +1,104 @@
+// sdma.cpp -- see sdma.h.
+#include "sdma.h"
+#include "dabx_internal.h"
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace dabx {
+
+namespace {
+struct Find { uint32_t domain, bdf; hsa_agent_t gpu; bool found; hsa_agent_t cpu; bool have_cpu; };
+hsa_status_t agent_cb(hsa_agent_t a, void *p)
+{
+  Find *f = static_cast<Find *>(p);
+  hsa_device_type_t t;
+  if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+  if (t == HSA_DEVICE_TYPE_CPU && !f->have_cpu) { f->cpu = a; f->have_cpu = true; }
+  if (t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+  uint32_t bdf = 0, dom = 0;
+  (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+  (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
+  if ((bdf & 0xFFFFu) == f->bdf && dom == f->domain) { f->gpu = a; f->found = true; }
+  return HSA_STATUS_SUCCESS;
+}
+std::once_flag g_hsa_once;
+bool g_hsa_ok = false;
+hsa_agent_t g_cpu{};
+}  // namespace
+
+int sdma_open(int hip_device, Sdma *out)
+{
+  *out = Sdma{};
+  std::call_once(g_hsa_once, [] { g_hsa_ok = hsa_init() == HSA_STATUS_SUCCESS; });      // reference counted: the HIP runtime holds its own
+  if (!g_hsa_ok) { set_error("sdma: hsa_init failed"); return DABX_E_HIP; }
+  char bus[64] = {0};
+  DABX_HIP(hipDeviceGetPCIBusId(bus, sizeof(bus), hip_device));
+  unsigned dom = 0, b = 0, d = 0, fn = 0;
+  if (std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &fn) != 4) { set_error("sdma: cannot parse PCI bus id '%s'", bus); return DABX_E_HIP; }
+  Find f{};
+  f.domain = dom; f.bdf = ((b & 0xFFu) << 8) | ((d & 0x1Fu) << 3) | (fn & 7u);
+  if (hsa_iterate_agents(agent_cb, &f) != HSA_STATUS_SUCCESS || !f.found) {
+    set_error("sdma: no HSA agent for HIP device %d (%s)", hip_device, bus);
+    return DABX_E_HIP;
+  }
+  if (f.have_cpu) g_cpu = f.cpu;
+  out->gpu_agent = f.gpu.handle;
+  out->ok = true;
+  return 0;
+}
+
+int sdma_signal_create(uint64_t *sig)
+{
+  hsa_signal_t s{};
+  if (hsa_signal_create(0, 0, nullptr, &s) != HSA_STATUS_SUCCESS) { set_error("sdma: hsa_signal_create failed"); return DABX_E_HIP; }
+  *sig = s.handle;
+  return 0;
+}
+
+void sdma_signal_destroy(uint64_t sig)
+{
+  if (sig) (void)hsa_signal_destroy(hsa_signal_t{sig});
+}
+
+int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig)
+{
+  if (!s.ok) { set_error("sdma: not open"); return DABX_E_STATE; }
+  // the agent that owns the host allocation (the NUMA node hipHostMalloc took it from); any CPU agent would do for the engine choice
+  hsa_agent_t host = g_cpu;
+  hsa_amd_pointer_info_t info;
+  std::memset(&info, 0, sizeof(info));
+  info.size = sizeof(info);
+  const void *hp = to_host ? dst : src;
+  if (hsa_amd_pointer_info(hp, &info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS && info.type != HSA_EXT_POINTER_TYPE_UNKNOWN) {
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &t) == HSA_STATUS_SUCCESS && t == HSA_DEVICE_TYPE_CPU) host = info.agentOwner;
+  } else {
+    set_error("sdma: %p is not page-locked memory the runtime knows (hipHostMalloc / hipHostRegister)", hp);
+    return DABX_E_ARG;
+  }
+  const hsa_agent_t gpu{s.gpu_agent};
+  const hsa_signal_t done{sig};
+  hsa_signal_store_relaxed(done, 1);
+  const hsa_status_t st = to_host ? hsa_amd_memory_async_copy(dst, host, src, gpu, bytes, 0, nullptr, done)
+                                  : hsa_amd_memory_async_copy(dst, gpu, src, host, bytes, 0, nullptr, done);
+  if (st != HSA_STATUS_SUCCESS) {
+    const char *msg = nullptr;
+    (void)hsa_status_string(st, &msg);
+    set_error("sdma: hsa_amd_memory_async_copy failed: %s", msg ? msg : "?");
+    hsa_signal_store_relaxed(done, 0);
+    return DABX_E_HIP;
+  }
+  return 0;
+}
+
+int sdma_wait(uint64_t sig)
+{
+  const hsa_signal_t s{sig};
+  while (hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+  return 0;
+}
+
+}  // namespace dabx

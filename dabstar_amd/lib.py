@@ -52,6 +52,14 @@ def load(build_if_missing=True):
     L.dabx_host_register.argtypes = [C.c_void_p, C.c_size_t]
     L.dabx_host_unregister.argtypes = [C.c_void_p]
     L.dabx_commit_iq.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    if hasattr(L, "dabx_delivery_next"):
+        L.dabx_delivery_open.argtypes = [C.c_void_p, C.c_void_p]
+        L.dabx_delivery_close.argtypes = [C.c_void_p]
+        L.dabx_delivery_next.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.dabx_delivery_release.argtypes = [C.c_void_p, C.c_uint64]
+        L.dabx_delivery_slab_bytes.argtypes = [C.c_void_p]
+        L.dabx_delivery_wait_free.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.dabx_delivery_slab_bytes.restype = C.c_longlong
     if hasattr(L, "dabx_announce_write"):            # (absent from libraries older than the level anchor: tools/ab.sh runs those through this binding too)
         L.dabx_announce_write.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     _LIB = L
@@ -299,7 +307,74 @@ class Stats(C.Structure):
                 ("rs_corrected", C.c_int64), ("rs_failed", C.c_int64), ("au_ok", C.c_int64), ("au_bad", C.c_int64),
                 ("cifs_decoded", C.c_int64), ("signal_level", C.c_float), ("peak_level", C.c_float),
                 ("level_margin_events", C.c_int64), ("level_rewalk_events", C.c_int64), ("level_unanchored_events", C.c_int64),
-                ("level_healed_events", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("level_healed_events", C.c_int64), ("fic_ber_bits", C.c_int64), ("fic_ber_errors", C.c_int64),
+                ("reserved", C.c_int64 * 2)]
+
+
+# ---- bulk delivery (include/dabx.h "Bulk delivery"): the slab's records as numpy dtypes -----------------------------
+CHUNK_FRAMES = 7
+CHUNK_MAGIC = 0x43584244
+DELIVER_FIB, DELIVER_MSC, DELIVER_SF = 1, 2, 4
+CHUNK_HEADER = np.dtype([("magic", "<u4"), ("abi", "<u4"), ("seq", "<u8"), ("n_streams", "<i4"), ("max_subch", "<i4"),
+                         ("max_frames", "<i4"), ("what", "<i4"), ("bytes", "<u8"), ("off_stream", "<u8"), ("off_subch", "<u8"),
+                         ("off_fib", "<u8"), ("off_crc", "<u8"), ("off_frame", "<u8"), ("off_msc", "<u8"), ("off_sf", "<u8"),
+                         ("reserved", "<u8", 4)])
+CHUNK_STREAM = np.dtype([("first_frame", "<i8"), ("n_frames", "<i4"), ("frames_lost", "<i4"), ("state", "<i4"),
+                         ("fic_ratio_percent", "<i4"), ("cif_count", "<i4"), ("snr_db_est", "<f4"), ("freq_offs_bb_hz", "<f4"),
+                         ("clock_err_hz", "<f4"), ("signal_level", "<f4"), ("fic_ber_bits", "<i4"), ("fic_ber_errors", "<i4"),
+                         ("reserved", "<i4"), ("fib_ok", "<i8"), ("fib_total", "<i8")])
+CHUNK_FRAME = np.dtype([("sym0_pos", "<i8"), ("start_index", "<i4"), ("reserved", "<i4")])
+CHUNK_SUBCH = np.dtype([("active", "<i4"), ("subch_id", "<i4"), ("kbps", "<i4"), ("dab_plus", "<i4"), ("start_cif", "<i8"),
+                        ("first_cif", "<i8"), ("n_cifs", "<i4"), ("cifs_lost", "<i4"), ("first_sf", "<i8"), ("n_sf", "<i4"),
+                        ("sf_lost", "<i4"), ("msc_off", "<u8"), ("sf_off", "<u8"), ("sf_pitch", "<i4"), ("reserved", "<i4"),
+                        ("sf_ok", "<i8"), ("sf_fail", "<i8"), ("rs_corrected", "<i8"), ("rs_failed", "<i8"),
+                        ("fc_corrected", "<i8"), ("au_ok", "<i8"), ("au_bad", "<i8")])
+assert CHUNK_HEADER.itemsize == 128 and CHUNK_STREAM.itemsize == 72 and CHUNK_FRAME.itemsize == 16 and CHUNK_SUBCH.itemsize == 136
+
+
+class DeliveryConfig(C.Structure):
+    _fields_ = [("host_slabs", C.c_int32), ("what", C.c_int32), ("copy_engine", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class ChunkRef(C.Structure):
+    _fields_ = [("seq", C.c_uint64), ("data", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+class Chunk:
+    """One delivered slab, viewed in place (no copy): valid until release()."""
+
+    def __init__(self, engine, ref):
+        self._eng, self.seq, self.nbytes = engine, ref.seq, ref.bytes
+        self.raw = np.ctypeslib.as_array(C.cast(ref.data, C.POINTER(C.c_uint8)), shape=(ref.bytes,))
+        self.header = self.raw[:128].view(CHUNK_HEADER)[0]
+        h = self.header
+        assert h["magic"] == CHUNK_MAGIC and h["bytes"] == ref.bytes, (hex(int(h["magic"])), int(h["bytes"]), ref.bytes)
+        S, M, F = int(h["n_streams"]), int(h["max_subch"]), int(h["max_frames"])
+        self.S, self.M, self.F = S, M, F
+        self.streams = self.raw[int(h["off_stream"]):int(h["off_stream"]) + S * 72].view(CHUNK_STREAM)
+        self.subch = self.raw[int(h["off_subch"]):int(h["off_subch"]) + S * M * 136].view(CHUNK_SUBCH).reshape(S, M)
+        if h["what"] & DELIVER_FIB:
+            self.fibs = self.raw[int(h["off_fib"]):int(h["off_fib"]) + S * F * 384].reshape(S, F, 12, 32)
+            self.crc = self.raw[int(h["off_crc"]):int(h["off_crc"]) + S * F * 12].reshape(S, F, 12)
+            self.frames = self.raw[int(h["off_frame"]):int(h["off_frame"]) + S * F * 16].view(CHUNK_FRAME).reshape(S, F)
+
+    def msc(self, s, j):
+        """Logical frames of slot (s, j) in this chunk: [n_cifs, 3 * kbps] uint8 (a view)."""
+        r = self.subch[s, j]
+        nb = 3 * int(r["kbps"])
+        o = int(r["msc_off"])
+        return self.raw[o:o + int(r["n_cifs"]) * nb].reshape(int(r["n_cifs"]), nb)
+
+    def superframes(self, s, j):
+        """Super frames of slot (s, j) in this chunk: [n_sf, 110 * kbps / 8] uint8 (a view)."""
+        r = self.subch[s, j]
+        nb, pitch, o = 110 * int(r["kbps"]) // 8, int(r["sf_pitch"]), int(r["sf_off"])
+        return self.raw[o:o + int(r["n_sf"]) * pitch].reshape(int(r["n_sf"]), pitch)[:, :nb]
+
+    def release(self):
+        if self._eng is not None:
+            check(load().dabx_delivery_release(self._eng._h, C.c_uint64(self.seq)))
+            self._eng = None
 
 
 COUNTER_NAMES = ["frames", "samples", "fib_ok", "fib_total", "sync_lost", "streams_locked", "cifs_decoded", "sf_ok", "sf_fail",
@@ -464,6 +539,27 @@ class Engine:
         out = np.zeros((75, 3072), np.int16)
         check(load().dabx_read_soft(self._h, stream, _p(out)))
         return out
+
+    def delivery_open(self, slots=4, what=0, copy_engine=0):
+        cfg = DeliveryConfig(host_slabs=slots, what=what, copy_engine=copy_engine)
+        check(load().dabx_delivery_open(self._h, C.byref(cfg)))
+
+    def delivery_close(self):
+        check(load().dabx_delivery_close(self._h))
+
+    def delivery_slab_bytes(self):
+        load().dabx_delivery_slab_bytes.restype = C.c_longlong
+        return check(load().dabx_delivery_slab_bytes(self._h))
+
+    def delivery_wait_free(self, n=1, timeout_ms=-1):
+        return check(load().dabx_delivery_wait_free(self._h, int(n), int(timeout_ms)))
+
+    def delivery_next(self, wait=False):
+        """The oldest chunk not yet fetched as a Chunk (views into the page-locked host slab), or None."""
+        ref = ChunkRef()
+        if check(load().dabx_delivery_next(self._h, int(wait), C.byref(ref))) == 0:
+            return None
+        return Chunk(self, ref)
 
     def stats(self, stream):
         st = Stats()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DABX_ABI_VERSION 4
+#define DABX_ABI_VERSION 5
 
 typedef enum {
   DABX_OK = 0,
@@ -281,7 +281,11 @@ typedef struct {
   int64_t level_unanchored_events; /* ... after which it had to continue from the chunk-wise value (samples no longer in the ring) */
   int64_t level_healed_events;     /* ... after which the anchor was gone but two walks started 2^-9 either side of a frame boundary's
                                       chunk-wise value, four or more frames back in the ring, had merged into one float: exact all the same */
-  int64_t reserved[4];       /* zero; later fields go here without changing the record's size */
+  /* -- ABI 5 -- */
+  int64_t fic_ber_bits;      /* FicDecoder::mFicBits / mFicErrors (fic_decoder.h:74-75): transmitted FIC bits compared with the re-encoded */
+  int64_t fic_ber_errors;    /* decoder output and those that differed (ViterbiSpiral::calculate_BER, viterbi_spiral.cpp:128-164), both halved
+                                every 40 FIC blocks (fic_decoder.cpp:201-210); the channel BER the reference displays is errors / bits */
+  int64_t reserved[2];       /* zero; later fields go here without changing the record's size */
 } dabx_stats;
 
 void dabx_default_config(dabx_config *cfg);
@@ -388,6 +392,93 @@ typedef struct dabx_subch_stats_s {
 int  dabx_get_subch_stats(dabx_engine *e, int stream, int subch_idx, dabx_subch_stats *out);
 /* Sum of the counters over all streams of this engine (the values one RCCL all-reduce combines). */
 int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
+/* ------------------------------------------------------------------------------------------------------------
+ * Bulk delivery of the results to the host.  The reference hands every FIB to IFibDecoder::process_FIB
+ * (base/decoder/fib_decoder_if.h:81, called from fic_decoder.cpp:234-261) and every logical frame to
+ * FrameProcessor::add_to_frame (base/backend/frame_processor.h:43-46, called from backend.cpp:160) the moment it exists;
+ * Mp4Processor hands on the RS-corrected super frame (mp4processor.cpp:149-158).  For n_streams ensembles the engine does the
+ * same in bulk: with a delivery open, everything a CHUNK of frames produced -- a chunk is what one MSC batch decodes, at most
+ * DABX_CHUNK_FRAMES frames of every stream; a dabx_process call closes its last chunk -- is gathered on the device into ONE
+ * contiguous slab and copied with ONE asynchronous DMA (an SDMA engine) into a page-locked host slab, next to the decode of the following chunk.
+ * No call of the receiver waits for it, nothing is copied per stream or per CIF.  dabx_read_fibs / _msc / _superframes /
+ * _eti remain as the convenience form for single streams (they drain the engine and copy from the device rings).
+ *
+ * A slab starts with a dabx_chunk_header; all dabx_chunk_* offsets are bytes from the slab's first byte:
+ *   stream table  dabx_chunk_stream[n_streams]              which frames of the stream the chunk holds + the stream's scalars
+ *   slot table    dabx_chunk_subch[n_streams * max_subch]   which logical / super frames of the sub-channel + its counters
+ *   FIBs          [n_streams][max_frames][12][32] bytes, CRC flags [n_streams][max_frames][12], frame records
+ *                 dabx_chunk_frame[n_streams][max_frames]   (row f = frame first_frame + f of the stream, f < n_frames)
+ *   logical frames of slot (s, j): n_cifs x 3 * kbps bytes from msc_off -- the bytes dabx_read_msc returns, oldest first
+ *   super frames   of slot (s, j): n_sf rows of sf_pitch bytes (110 * kbps / 8 used) from sf_off -- dabx_read_superframes' bytes
+ * Chunks are numbered from 0 and delivered in order.  dabx_process fails with DABX_E_STATE, before it has started anything,
+ * when the call would close more chunks than there are free host slabs: a consumer that falls behind holds the receiver up,
+ * it never loses data silently.  What the device rings could not hold until the chunk was packed (a consumer of the FIB ring
+ * configured with out_frames < the frames of a chunk) is counted in frames_lost / cifs_lost / sf_lost, always 0 with out_frames
+ * >= DABX_CHUNK_FRAMES.
+ * Threads: dabx_delivery_next / dabx_delivery_release may be called from ONE consumer thread next to the thread that drives the
+ * engine (dabx_push_iq*, dabx_process, ...); everything else keeps the one-thread-per-handle rule. */
+#define DABX_CHUNK_FRAMES 7
+#define DABX_CHUNK_MAGIC 0x43584244u       /* "DBXC" */
+enum { DABX_DELIVER_FIB = 1, DABX_DELIVER_MSC = 2, DABX_DELIVER_SF = 4 };
+typedef struct {
+  int32_t host_slabs;       /* page-locked host slabs, >= 2 (0 = default 4) */
+  int32_t what;             /* DABX_DELIVER_* mask, 0 = everything */
+  int32_t copy_engine;      /* 0 (default): the slab goes to the host on an SDMA engine (HSA runtime, hsa_amd_memory_async_copy): no CU is
+                               involved, the receiver's kernels do not notice it.  1: hipMemcpyAsync -- on ROCm 7.2 a shader copy that holds up
+                               every kernel running next to it for its duration (kept for comparison: tools/copy_interference.hip) */
+  int32_t reserved[5];
+} dabx_delivery_config;
+typedef struct {
+  uint32_t magic, abi;      /* DABX_CHUNK_MAGIC, DABX_ABI_VERSION */
+  uint64_t seq;             /* chunk number */
+  int32_t  n_streams, max_subch, max_frames /* DABX_CHUNK_FRAMES */, what;
+  uint64_t bytes;           /* size of the slab as copied */
+  uint64_t off_stream, off_subch, off_fib, off_crc, off_frame, off_msc, off_sf;
+  uint64_t reserved[4];
+} dabx_chunk_header;        /* 128 bytes */
+typedef struct {
+  int64_t first_frame;      /* index, since the stream was opened, of the first frame in the chunk */
+  int32_t n_frames;         /* frames of this stream in the chunk, 0..max_frames (a stream out of lock delivers none) */
+  int32_t frames_lost;      /* frames decoded since the previous chunk that had left the FIB ring before this one was packed */
+  int32_t state, fic_ratio_percent, cif_count;      /* as in dabx_stats, after the chunk's last frame */
+  float   snr_db_est, freq_offs_bb_hz, clock_err_hz, signal_level;
+  int32_t fic_ber_bits, fic_ber_errors;             /* FicDecoder's channel-BER counters (dabx_stats) */
+  int32_t reserved;
+  int64_t fib_ok, fib_total;                        /* cumulative */
+} dabx_chunk_stream;        /* 72 bytes */
+typedef struct {
+  int64_t sym0_pos;         /* dabx_read_frame_info */
+  int32_t start_index, reserved;
+} dabx_chunk_frame;
+typedef struct {
+  int32_t active, subch_id, kbps, dab_plus;
+  int64_t start_cif;        /* dabx_subch_stats.start_cif: logical frame i of the slot belongs to CIF start_cif + 16 + i */
+  int64_t first_cif;        /* index of the chunk's first logical frame in the slot's sequence (0 = the slot's first) */
+  int32_t n_cifs;           /* logical frames in the chunk */
+  int32_t cifs_lost;
+  int64_t first_sf;         /* index of the chunk's first super frame in the slot's sequence */
+  int32_t n_sf, sf_lost;
+  uint64_t msc_off, sf_off;
+  int32_t sf_pitch, reserved;
+  int64_t sf_ok, sf_fail, rs_corrected, rs_failed, fc_corrected, au_ok, au_bad;      /* cumulative, as dabx_subch_stats */
+} dabx_chunk_subch;         /* 136 bytes */
+typedef struct {
+  uint64_t seq;
+  const void *data;         /* the host slab: valid until dabx_delivery_release(seq) */
+  uint64_t bytes;
+} dabx_chunk;
+int  dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg /* NULL = defaults */);
+int  dabx_delivery_close(dabx_engine *e);      /* drains the engine; chunks not yet fetched are dropped */
+/* The oldest chunk not yet handed out: returns 1 and fills *out when it is complete in host memory, 0 when no chunk is ready
+ * (wait == 0) or none is queued at all (wait != 0 waits for a queued one to land). */
+int  dabx_delivery_next(dabx_engine *e, int wait, dabx_chunk *out);
+int  dabx_delivery_release(dabx_engine *e, uint64_t seq);
+/* Back-pressure for the engine's thread: waits (at most timeout_ms, < 0 = for ever) until n host slabs are free and returns the
+ * number that are (>= n: a dabx_process call that closes n chunks will be accepted; < n: timed out). */
+int  dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms);
+/* Bytes one slab takes with the sub-channels configured now (what one chunk moves over the link). */
+long long dabx_delivery_slab_bytes(dabx_engine *e);
+
 /* Per-kernel timing with HIP events recorded on the engine's stream around every launch of a batch step
  * (bench.py's roofline leg).  dabx_get_profile drains the events recorded since the last call: for each of
  * the n kernels of a step it returns the accumulated milliseconds and the number of launches; names[i]

@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.dabx_abi_version() == 4
+    assert L.dabx_abi_version() == 5
 
 
 def test_fails_loudly_without_device():
@@ -63,10 +63,10 @@ def test_hipmodule_form_exports_the_same_abi_and_carries_no_device_code():
     L = C.CDLL(so)
     missing = [n for n in dx.declared_symbols() if not hasattr(L, n)]
     assert not missing, missing
-    assert L.dabx_abi_version() == 4 and L.dabx_internal_hipmodule() == 1 and dx.load().dabx_internal_hipmodule() == 0
+    assert L.dabx_abi_version() == 5 and L.dabx_internal_hipmodule() == 1 and dx.load().dabx_internal_hipmodule() == 0
     sections = subprocess.run(["readelf", "-S", "-W", so], capture_output=True, text=True, check=True).stdout
     assert ".hip_fatbin" not in sections
     assert ".hip_fatbin" in subprocess.run(["readelf", "-S", "-W", dx.lib_path()], capture_output=True, text=True, check=True).stdout
     exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout.split()
     assert not [n for n in exported if n.startswith(("hipLaunchKernel", "__hipRegister", "__hipPush", "__hipPop", "hipMemcpyToSymbol"))]
-    assert len([f for f in os.listdir(mod) if f.startswith("dabx_gfx950_") and f.endswith(".hsaco")]) == 6
+    assert len([f for f in os.listdir(mod) if f.startswith("dabx_gfx950_") and f.endswith(".hsaco")]) == 7

@@ -24,7 +24,7 @@ def test_bench_line_keeps_its_contract():
     assert j["data"] == "synthetic" and j["dtype"] == "f32+i32" and "workload" in j["config"] and "model" not in j["config"]
     assert j["value"] > 50000 and abs(j["value"] * j["ms_per_step"] * 1e-3 - 512) < 2            # frames per step = 512 streams
     # the timed work was really done: every stream in lock, every FIB good, 4 CIFs x 18 sub-channels x 192 bytes per frame
-    assert j["streams_locked"] == 512 and j["fib_crc_match_pct"] == 100.0 and j["superframes_failed"] == 0
+    assert j["streams_locked"] == 512 and j["fib_crc_pass_pct"] == 100.0 and j["superframes_failed"] == 0
     assert j["msc_bytes"] == 512 * 14 * 4 * 18 * 192 and j["superframes_ok"] > 0
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_msc_vitT"

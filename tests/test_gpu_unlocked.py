@@ -32,7 +32,7 @@ def test_eight_streams_in_a_drop_out_cost_the_other_504_less_than_ten_per_cent()
     for kind in ("silence", "floor"):
         r = _bench("--unlocked", "8", "--unlocked-kind", kind)
         assert r["streams_locked"] == 504 and r["unlocked_streams_per_gpu"] == 8, r["streams_locked"]
-        assert r["fib_crc_match_pct"] == 100.0 and r["superframes_failed"] == 0
+        assert r["fib_crc_pass_pct"] == 100.0 and r["superframes_failed"] == 0
         ratio = r["frames_per_s_per_locked_stream"] / per_stream
         print("unlocked 8 (%s): %.1f frames/s, %.3f of the all-locked rate per locked stream" % (kind, r["value"], ratio))
         assert ratio >= 0.90, (kind, r["value"], base["value"], ratio)

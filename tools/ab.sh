@@ -16,7 +16,7 @@ import json, sys
 try:
     j = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
     k = j["chain"].get("kernel_ms_per_step_standalone") or j["chain"].get("kernel_ms_per_step_warmup")
-    print("%-14s %9.0f frames/s  crc %.3f sf_fail %d  " % (sys.argv[2], j["value"], j["fib_crc_match_pct"], j["superframes_failed"]) +
+    print("%-14s %9.0f frames/s  crc %.3f sf_fail %d  " % (sys.argv[2], j["value"], j.get("fib_crc_pass_pct", j.get("fib_crc_match_pct")), j["superframes_failed"]) +
           " ".join("%s=%.3f" % (a.replace("k_", ""), b) for a, b in k.items() if b > 0.015))
 except Exception as ex:
     print(sys.argv[2], "FAILED", ex)

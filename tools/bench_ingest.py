@@ -81,7 +81,7 @@ def main():
             frames = c1["frames"] - c0["frames"]
             out["formats"][fmt + ":" + mode] = {"frames_per_s": round(frames / dt, 1), "host_GBps": round(frames * ds.TF * bytes_per_sample[fmt] / dt / 1e9, 2),
                                    "x_realtime": round(frames / dt / (2048000.0 / ds.TF), 1),
-                                   "fib_crc_match_pct": round(100.0 * (c1["fib_ok"] - c0["fib_ok"]) / max(1, c1["fib_total"] - c0["fib_total"]), 3),
+                                   "fib_crc_pass_pct": round(100.0 * (c1["fib_ok"] - c0["fib_ok"]) / max(1, c1["fib_total"] - c0["fib_total"]), 3),
                                    "superframes_failed": c1["sf_fail"] - c0["sf_fail"]}
             eng.close()
             if mode == "pinned":

@@ -7,5 +7,5 @@ for f in dabstar_amd/csrc/*.hip dabstar_amd/csrc/*.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -w "$@" -x hip -c $f -o /tmp/dabx_variant_$NAME/$(basename $f).o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/dabx_variant_$NAME/*.o -o dabstar_amd/_ab/libdabx_$NAME.so && echo built dabstar_amd/_ab/libdabx_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/dabx_variant_$NAME/*.o -lhsa-runtime64 -o dabstar_amd/_ab/libdabx_$NAME.so && echo built dabstar_amd/_ab/libdabx_$NAME.so
 rm -rf /tmp/dabx_variant_$NAME

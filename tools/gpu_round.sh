@@ -7,7 +7,7 @@ TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-line() { python3 -c "import json,sys; j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$1', j['value'], j['unit'], 'crc', j['fib_crc_match_pct'], 'sf_fail', j.get('superframes_failed'), 'locked', j.get('streams_locked'), 'host_us', j.get('host_us_per_step'))"; }
+line() { python3 -c "import json,sys; j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$1', j['value'], j['unit'], 'crc', j.get('fib_crc_pass_pct', j.get('fib_crc_match_pct')), 'sf_fail', j.get('superframes_failed'), 'locked', j.get('streams_locked'), 'host_us', j.get('host_us_per_step'))"; }
 for what in "$@"; do
   case $what in
     tests) timeout 2400 python3 -m pytest tests -m gpu -q --maxfail=10 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
