@@ -487,6 +487,8 @@ class DeliverySink:
                     if n and hasattr(ch, "fibs"):
                         self.fibs[s].append((int(st[s]["first_frame"]), ch.fibs[s, :n].copy(), ch.crc[s, :n].copy()))
                 ch.release()
+                if os.environ.get("DBG_TIMELINE"):
+                    sys.stderr.write("landed chunk %d at %.3f\n" % (self.chunks + 1, 1e3 * time.perf_counter()))
                 self.chunks += 1         # last: whoever sees the count sees the chunk's sums too
         except Exception as ex:          # reported by finish()
             self.error = ex
@@ -654,7 +656,7 @@ def main():
     subch = ds.default_subchannels(18, 64)
     dx = None
     if not dry and rank == 0 and n_joined == 1:
-        measure_valu_peak()                          # child process, done before this process creates its engine
+        if not os.environ.get('DBG_NOVALU'): measure_valu_peak()                          # child process, done before this process creates its engine
     if dry:
         eng = DryEngine(args.streams)
         ring_frames = 10
@@ -699,10 +701,19 @@ def main():
                     if sink.error is not None or not sink.th.is_alive():
                         raise SystemExit("bench.py: the delivery consumer died: %r" % (sink.error,))
                 closed[0] += (m + 6) // 7
+                if os.environ.get("DBG_TIMELINE"):
+                    sys.stderr.write("issue chunk %d at %.3f waited %.3f\n" % (closed[0], 1e3 * time.perf_counter(), 1e3 * (time.perf_counter() - h0)))
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=sync)
             host_time[0] += time.perf_counter() - h0      # host time inside the two calls (launches, event traffic): no device wait when sync=False
 
+    # No cyclic garbage collection from here to the end of the timed regions: a full collection of this process's objects (torch, numpy,
+    # the synthetic ensembles) holds the interpreter lock for 40-50 ms -- six steps' worth; seen as both python threads of --deliver
+    # standing still.  Collected once, here, before the priming steps (the GPU idles meanwhile and clocks down; the priming and warm-up
+    # steps bring it back up).
+    import gc
+    gc.collect()
+    gc.disable()
     # priming (untimed, not part of warmup): acquisition, CFO pull-in, 16-CIF de-interleaver fill, super-frame sync
     eng.commit(ring_frames * TF - TF)
     step(40)
@@ -734,11 +745,13 @@ def main():
     eng.synchronize()
     sink_catch_up()
     if not dry:
-        dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
+        dx.check(dx.load().dabx_set_profiling(eng._h, 0 if os.environ.get('DBG_NOPROF') else 2 + dom_idx))
     c1 = eng.counters()
     d1 = sink.totals() if sink else None
 
     barrier()
+    if os.environ.get("DBG_TIMELINE"):
+        sys.stderr.write("cpu.max %s | cpu.stat before: %s\n" % (open("/sys/fs/cgroup/cpu.max").read().strip(), open("/sys/fs/cgroup/cpu.stat").read().replace("\n", " ")))
     host_time[0] = 0.0
     t0 = time.perf_counter()
     step(args.steps)
@@ -747,6 +760,10 @@ def main():
     sink_catch_up()                      # ... and the consumer has taken (and given back) every one of them
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("DBG_TIMELINE"):
+        sys.stderr.write("cpu.stat after: %s\n" % open("/sys/fs/cgroup/cpu.stat").read().replace("\n", " "))
+        import threading
+        sys.stderr.write("python threads: %d; os threads: %d\n" % (threading.active_count(), len(os.listdir("/proc/self/task"))))
     c2 = eng.counters()
     d2 = sink.totals() if sink else None
     if not dry:
@@ -816,7 +833,7 @@ def main():
             lost = sink.totals()["lost"]
             if rank == 0 and args.layout == "uniform":
                 fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
-            slab_bytes = eng.delivery_slab_bytes()
+            slab_bytes, dinfo = eng.delivery_slab_bytes(), eng.delivery_info()
             eng.delivery_close()
             sink = None
             b1, b2, _, _, bdt = leg(n_steady)
@@ -827,7 +844,7 @@ def main():
             lost = sink.totals()["lost"]
             if rank == 0 and args.layout == "uniform":
                 fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
-            slab_bytes = eng.delivery_slab_bytes()
+            slab_bytes, dinfo = eng.delivery_slab_bytes(), eng.delivery_info()
             eng.delivery_close()
         steady["frames_per_s_without_delivery_same_steps"] = round(base_steady, 1)
         steady["frac_of_that"] = round(steady["frames_per_s"] / base_steady, 4)
@@ -836,8 +853,12 @@ def main():
                      what="every FIB + CRC flag + frame record, logical frame and RS-corrected super frame of every stream and sub-channel: one "
                           "slab and ONE SDMA transfer per 7-frame chunk into page-locked host slabs (dabx_delivery_*); consumer = a python "
                           "thread: dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release",
+                     copies={"count": dinfo["chunks_landed"], "link_GBps": round(dinfo["bytes_copied"] / max(1e-9, dinfo["copy_seconds"]) / 1e9, 2),
+                             "longest_ms": round(1e3 * dinfo["copy_seconds_max"], 3), "sdma_engine_mask": dinfo["sdma_engine_mask"],
+                             "note": "the library's own clock around every slab transfer (dabx_delivery_get_info)"},
                      scope="this rank's GPU")
 
+    gc.enable()
     if rank == 0:
         value = frames / dt
         roofline = None

@@ -38,7 +38,7 @@ int launch_i16_to_sym(const int16_t *soft, uint8_t *sym, size_t n, hipStream_t s
 using namespace dabx;
 
 // Bulk delivery (include/dabx.h): host slabs (page-locked) the chunks land in, device slabs they are packed into, and the copier --
-// a thread of the library that waits (blocked, not spinning) for a chunk's gather kernels and then moves the slab with ONE SDMA
+// a thread of the library that waits (polling every 50 us) for a chunk's gather kernels and then moves the slab with ONE SDMA
 // transfer (sdma.h: the HIP runtime's own device-to-host copy is a shader copy that stalls the receiver's kernels while it runs).
 struct Delivery {
   bool open = false;
@@ -62,7 +62,8 @@ struct Delivery {
   bool quit = false;
   int device = 0;
   std::string copier_error;
-  uint64_t next_seq = 0;
+  uint64_t next_seq = 0, landed = 0, bytes_copied = 0;
+  double copy_s = 0, copy_s_max = 0, gather_wait_s = 0;
   unsigned long long *layout_off = nullptr;      // device tables (DeliverDev)
   int32_t *subch_id = nullptr;
   long long *frames_done = nullptr, *cif_done = nullptr, *sf_done = nullptr;
@@ -351,7 +352,7 @@ int dabx_engine::delivery_finish(int slot, int devslab, hipStream_t tail)
   return 0;
 }
 
-// The copier: one chunk at a time, in order -- wait for the gather kernels (hipEventSynchronize on a blocking-sync event), ONE transfer of
+// The copier: one chunk at a time, in order -- wait for the gather kernels, ONE transfer of
 // the slab, wait for it, hand the slab to the consumer.
 static void delivery_copier(Delivery *Dp)
 {
@@ -367,12 +368,16 @@ static void delivery_copier(Delivery *Dp)
     }
     Delivery::Slot &sl = D.slots[(size_t)h];
     std::string err;
-    hipError_t he = hipEventSynchronize(D.packed[sl.devslab]);
-    if (he != hipSuccess) err = std::string("hipEventSynchronize: ") + hipGetErrorString(he);
+    const auto t_a = std::chrono::steady_clock::now();
+    // polled every 50 us, not hipEventSynchronize: see sdma_wait
+    hipError_t he;
+    while ((he = hipEventQuery(D.packed[sl.devslab])) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (he != hipSuccess) err = std::string("hipEventQuery: ") + hipGetErrorString(he);
+    const auto t_b = std::chrono::steady_clock::now();
 #ifndef DABX_DELIVER_NOCOPY            // experiment builds only (tools/build_variant.sh): what the gather kernels alone cost
     if (err.empty()) {
       if (D.copy_engine == 0) {
-        if (sdma_copy(D.sdma, sl.host, D.dev[sl.devslab], sl.bytes, true, sl.sig) || sdma_wait(sl.sig)) err = dabx::last_error();
+        if (sdma_copy(D.sdma, sl.host, D.dev[sl.devslab], sl.bytes, true, sl.sig) || sdma_wait(sl.sig, sl.bytes)) err = dabx::last_error();
       } else {
         he = hipMemcpyAsync(sl.host, D.dev[sl.devslab], sl.bytes, hipMemcpyDeviceToHost, D.cs);
         if (he == hipSuccess) he = hipStreamSynchronize(D.cs);
@@ -380,7 +385,14 @@ static void delivery_copier(Delivery *Dp)
       }
     }
 #endif
+    const auto t_c = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lk(D.mu);
+    {
+      const double cs_ = std::chrono::duration<double>(t_c - t_b).count();
+      D.gather_wait_s += std::chrono::duration<double>(t_b - t_a).count();
+      D.copy_s += cs_; D.copy_s_max = std::max(D.copy_s_max, cs_);
+      D.landed++; D.bytes_copied += sl.bytes;
+    }
     D.jobs.pop_front();
     D.dev_busy[sl.devslab] = false;
     sl.state = Delivery::LANDED;                 // (after an error too: nobody may wait for ever; the error is reported by the next call)
@@ -424,6 +436,7 @@ static void delivery_free(dabx_engine *e)
   D.cs = nullptr;
   D.copier_error.clear();
   D.open = false; D.capacity = D.bytes = 0; D.next_seq = 0;
+  D.landed = D.bytes_copied = 0; D.copy_s = D.copy_s_max = D.gather_wait_s = 0;
 }
 
 static int need_device_e()
@@ -1303,6 +1316,7 @@ static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out)
   out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;
   out->fib_ok = c.fib_ok; out->fib_total = c.fib_total;
   out->signal_level = c.s_level; out->peak_level = c.peak_level;
+  out->fic_ber_bits = c.fic_bits; out->fic_ber_errors = c.fic_errors;
   std::vector<SubchDev> sc(std::max(1, e->dev.max_subch));
   DABX_HIP(hipMemcpy(sc.data(), e->dev.subch + (size_t)stream * e->dev.max_subch, sizeof(SubchDev) * e->dev.max_subch, hipMemcpyDeviceToHost));
   for (int j = 0; j < e->dev.max_subch; j++) {
@@ -1373,8 +1387,8 @@ int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
   for (int k = 0; k < Delivery::NDEV; k++) {
     H(hipMalloc((void **)&D.dev[k], D.capacity));
     H(hipMemset(D.dev[k], 0, D.capacity));
-    // system scope (the SDMA engine and the host read what the gather kernels wrote) and blocking: the copier sleeps until it fires
-    H(hipEventCreateWithFlags(&D.packed[k], hipEventDisableTiming | hipEventBlockingSync));
+    // system scope: the SDMA engine and the host read what the gather kernels wrote
+    H(hipEventCreateWithFlags(&D.packed[k], hipEventDisableTiming));
   }
   D.slots.resize((size_t)n_slots);
   for (auto &sl : D.slots) {
@@ -1454,6 +1468,19 @@ int dabx_delivery_release(dabx_engine *e, uint64_t seq)
     if (sl.state == Delivery::HELD && sl.seq == seq) { sl.state = Delivery::FREE; D.cv.notify_all(); return 0; }
   set_error("dabx_delivery_release: chunk %llu is not held", (unsigned long long)seq);
   return DABX_E_ARG;
+}
+
+int dabx_delivery_get_info(dabx_engine *e, dabx_delivery_info *out)
+{
+  if (!e || !out) return DABX_E_ARG;
+  Delivery &D = e->dl;
+  if (!D.open) { set_error("dabx_delivery_get_info: no delivery open"); return DABX_E_STATE; }
+  std::lock_guard<std::mutex> lk(D.mu);
+  memset(out, 0, sizeof(*out));
+  out->chunks_closed = D.next_seq; out->chunks_landed = D.landed; out->bytes_copied = D.bytes_copied;
+  out->copy_seconds = D.copy_s; out->copy_seconds_max = D.copy_s_max; out->gather_wait_seconds = D.gather_wait_s;
+  out->copy_engine = D.copy_engine; out->sdma_engine_mask = D.copy_engine == 0 ? D.sdma.engine_to_host : 0;
+  return 0;
 }
 
 int dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms)
@@ -1659,6 +1686,16 @@ int dabx_fic_get_cif_count(dabx_fic *f)
   StreamCtl c;
   if (int rc = fic_ctl(f, &c)) return rc;
   return c.cif_count;
+}
+int dabx_fic_get_ber(dabx_fic *f, dabx_fic_ber *out)
+{
+  if (!f || !out) return DABX_E_ARG;
+  StreamCtl c;
+  if (int rc = fic_ctl(f, &c)) return rc;
+  memset(out, 0, sizeof(*out));
+  out->bits = c.fic_bits; out->errors = c.fic_errors; out->status_bits = c.fic_status_bits; out->status_errors = c.fic_status_errors;
+  out->blocks = c.fic_block;
+  return 0;
 }
 int dabx_fic_reset_decode_success_ratio(dabx_fic *f)
 {

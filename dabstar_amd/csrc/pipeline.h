@@ -38,7 +38,9 @@ struct StreamCtl {
   int32_t f_frame;                // round(f_bb) used for symbols 1..75
   int32_t fic_ratio;              // mFicDecodeSuccessRatio 0..10
   int32_t cif_count;              // FibDecoder::get_cif_count
-  int32_t fic_errors, fic_bits, fic_block;
+  int32_t fic_errors, fic_bits, fic_block;   // mFicErrors, mFicBits, mFicBlock (fic_decoder.h:73-75)
+  int32_t fic_status_errors, fic_status_bits;  // ... as they stood when the 40th block was reached: what signal_fic_status reports (fic_decoder.cpp:203-205)
+  int32_t pad4_;
   float snr_db;
   // counters (summed across streams / GPUs by dabx_get_counters)
   long long fib_ok, fib_total, sync_lost;

@@ -1170,6 +1170,8 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
   __shared__ uint32_t fibw[4][24];          // 4 x 768 decoded + de-dispersed bits, packed
   __shared__ uint32_t raw[4][32];           // chain-back output, 30 bits per word (26 words + padding)
   __shared__ uint8_t crc_ok[12];
+  __shared__ uint32_t encw[4][26];          // the decoded bits before de-dispersal (+ zero tail), for the BER re-encoder
+  __shared__ int ber_err[4];
   __shared__ uint16_t s_crc[256];           // CCITT table: the 30-step look-up chain of a FIB's CRC stays in LDS
   const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   StreamCtl &c = e.ctl[s];
@@ -1188,7 +1190,38 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     vit_traceback(dec, FIC_OUT, lane, raw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 24) fibw[fic][lane] = vit_output_word(raw[wave], lane) ^ t.prbs_words[lane];   // fic_decoder.cpp:219-222
+    uint32_t dw = 0;
+    if (lane < 24) { dw = vit_output_word(raw[wave], lane); fibw[fic][lane] = dw ^ t.prbs_words[lane]; }   // fic_decoder.cpp:219-222
+    // ViterbiSpiral::calculate_BER (viterbi_spiral.cpp:128-164, called fic_decoder.cpp:199 on the bits BEFORE the PRBS): the 768 + 6
+    // decoded bits re-encoded (polys 109, 79, 83, 109) and compared, at the 2304 transmitted positions, with the sign of the received
+    // soft bit.  Lane l re-encodes steps 13 l .. 13 l + 12; the hard decision is (Viterbi symbol > 127) == (soft > 0): exact for every
+    // int16 soft bit in the SIMD builds' conversion, and in the canonical one for all but soft >= 32641 (where the reference's own
+    // `soft + 127` wraps, viterbi_scalar.h:34-40).
+    if (lane < 24) encw[wave][lane] = dw;
+    if (lane >= 24 && lane < 26) encw[wave][lane] = 0;      // the six tail steps shift in zeros
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const uint8_t *eb = reinterpret_cast<const uint8_t *>(encw[wave]);
+      auto dbit = [&](int i) -> unsigned { return i < 0 ? 0u : (unsigned)((eb[i >> 3] >> (7 - (i & 7))) & 1); };
+      const int t0 = 13 * lane;
+      unsigned sr = 0;
+#pragma unroll
+      for (int q = 6; q >= 1; q--) sr = (sr << 1) | dbit(t0 - q);
+      int err = 0;
+      const uint8_t *sym = e.fic_sym + (size_t)s * 3 * K2 + fic * FIC_IN;
+      for (int i = t0; i < t0 + 13 && i < FIC_OUT + 6; i++) {
+        sr = ((sr << 1) | dbit(i)) & 0xFFu;
+        const ushort4 m = *reinterpret_cast<const ushort4 *>(t.fic_map + 4 * i);
+        const unsigned p0 = __builtin_popcount(sr & 109u) & 1u, p1 = __builtin_popcount(sr & 79u) & 1u, p2 = __builtin_popcount(sr & 83u) & 1u;
+        if (m.x != PUNCT) err += (unsigned)(sym[m.x] > 127) != p0;
+        if (m.y != PUNCT) err += (unsigned)(sym[m.y] > 127) != p1;
+        if (m.z != PUNCT) err += (unsigned)(sym[m.z] > 127) != p2;
+        if (m.w != PUNCT) err += (unsigned)(sym[m.w] > 127) != p0;
+      }
+      err = wave_sum_int(err);
+      if (lane == 0) ber_err[fic] = err;
+    }
   }
   __syncthreads();
   const int slot = (int)(c.frames % e.out_frames);
@@ -1229,6 +1262,13 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
     }
     c.fic_ratio = ratio; c.cif_count = cif_count;
     c.fib_ok += ok; c.fib_total += nfib;
+    // mFicBits / mFicErrors / mFicBlock, block by block (fic_decoder.cpp:199-210): every block adds its 2304 transmitted bits
+    int bits = c.fic_bits, errs = c.fic_errors, blk = c.fic_block;
+    for (int f = first; f < first + count; f++) {
+      bits += FIC_IN; errs += ber_err[f];
+      if (++blk == 40) { c.fic_status_errors = errs; c.fic_status_bits = bits; blk = 0; errs /= 2; bits /= 2; }
+    }
+    c.fic_bits = bits; c.fic_errors = errs; c.fic_block = blk;
   }
 }
 

@@ -5,7 +5,9 @@
 #include <hsa/hsa_ext_amd.h>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 namespace dabx {
 
@@ -46,6 +48,11 @@ int sdma_open(int hip_device, Sdma *out)
   }
   if (f.have_cpu) g_cpu = f.cpu;
   out->gpu_agent = f.gpu.handle;
+  // one engine per direction, from the runtime's preferred set for this pair of agents (lowest bit); 0 = leave it to the runtime
+  uint32_t pref = 0;
+  if (f.have_cpu && hsa_amd_memory_get_preferred_copy_engine(f.cpu, f.gpu, &pref) == HSA_STATUS_SUCCESS && pref) out->engine_to_host = pref & (~pref + 1u);
+  pref = 0;
+  if (f.have_cpu && hsa_amd_memory_get_preferred_copy_engine(f.gpu, f.cpu, &pref) == HSA_STATUS_SUCCESS && pref) out->engine_to_dev = pref & (~pref + 1u);
   out->ok = true;
   return 0;
 }
@@ -82,8 +89,14 @@ int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_h
   const hsa_agent_t gpu{s.gpu_agent};
   const hsa_signal_t done{sig};
   hsa_signal_store_relaxed(done, 1);
-  const hsa_status_t st = to_host ? hsa_amd_memory_async_copy(dst, host, src, gpu, bytes, 0, nullptr, done)
-                                  : hsa_amd_memory_async_copy(dst, gpu, src, host, bytes, 0, nullptr, done);
+  const uint32_t engine = to_host ? s.engine_to_host : s.engine_to_dev;
+  hsa_status_t st = HSA_STATUS_ERROR;
+  if (engine)
+    st = to_host ? hsa_amd_memory_async_copy_on_engine(dst, host, src, gpu, bytes, 0, nullptr, done, (hsa_amd_sdma_engine_id_t)engine, true)
+                 : hsa_amd_memory_async_copy_on_engine(dst, gpu, src, host, bytes, 0, nullptr, done, (hsa_amd_sdma_engine_id_t)engine, true);
+  if (st != HSA_STATUS_SUCCESS)              // no preferred engine known, or the runtime refuses it: its own choice
+    st = to_host ? hsa_amd_memory_async_copy(dst, host, src, gpu, bytes, 0, nullptr, done)
+                 : hsa_amd_memory_async_copy(dst, gpu, src, host, bytes, 0, nullptr, done);
   if (st != HSA_STATUS_SUCCESS) {
     const char *msg = nullptr;
     (void)hsa_status_string(st, &msg);
@@ -94,10 +107,13 @@ int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_h
   return 0;
 }
 
-int sdma_wait(uint64_t sig)
+int sdma_wait(uint64_t sig, size_t bytes_hint)
 {
+  // Polled, not blocked on the signal's interrupt: a missed wake-up cost a chunk 37 ms on this pool (a blocked
+  // hsa_signal_wait_scacquire / hipEventSynchronize after another GPU process had run next to this one); a poll every 20 us costs nothing.
   const hsa_signal_t s{sig};
-  while (hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+  if (bytes_hint) std::this_thread::sleep_for(std::chrono::nanoseconds((long long)(bytes_hint / 60.0)));       // no transfer beats 60 GB/s: sleep that long first
+  while (hsa_signal_load_scacquire(s) >= 1) std::this_thread::sleep_for(std::chrono::microseconds(20));
   return 0;
 }
 

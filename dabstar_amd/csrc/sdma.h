@@ -11,6 +11,11 @@ namespace dabx {
 
 struct Sdma {
   uint64_t gpu_agent = 0;       // hsa_agent_t::handle of the HIP device's agent
+  uint32_t engine_to_host = 0;  // hsa_amd_sdma_engine_id_t (one bit) the transfers of each direction are put on: the first of the engines the
+  uint32_t engine_to_dev = 0;   // runtime names as preferred for the GPU <-> CPU pair.  Not left to hsa_amd_memory_async_copy: of the MI355X's 16
+                                // engines only 0-3 reach the link's rate towards the host (56 GB/s; 4-7: 12.7, 8-15: 7-10 GB/s, tools/sdma_engines.hip),
+                                // and which one the runtime takes depends on what else has opened SDMA queues before (measured: a slab took
+                                // 10 ms instead of 1.8 ms after another GPU process had run, profiles/r05_sdma_engines.json)
   bool ok = false;
 };
 // Finds the HSA agent of HIP device `hip_device` (matched by PCI domain:bus:device.function).  0, or a dabx error with set_error().
@@ -20,7 +25,7 @@ void sdma_signal_destroy(uint64_t sig);
 // Submits dst <- src (one side device memory of the Sdma's GPU, the other page-locked host memory known to the runtime: hipHostMalloc,
 // hipHostRegister) and returns at once; `sig` is armed and completes when the bytes are in place.
 int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig);
-// Blocks (no spinning) until the copy armed on `sig` is complete.
-int sdma_wait(uint64_t sig);
+// Returns when the copy armed on `sig` is complete (sleeps bytes_hint / 60 GB/s, then polls the signal every 20 us: no spinning, no interrupt).
+int sdma_wait(uint64_t sig, size_t bytes_hint);
 
 }  // namespace dabx

@@ -336,6 +336,12 @@ class DeliveryConfig(C.Structure):
     _fields_ = [("host_slabs", C.c_int32), ("what", C.c_int32), ("copy_engine", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
+class DeliveryInfo(C.Structure):
+    _fields_ = [("chunks_closed", C.c_uint64), ("chunks_landed", C.c_uint64), ("bytes_copied", C.c_uint64), ("copy_seconds", C.c_double),
+                ("copy_seconds_max", C.c_double), ("gather_wait_seconds", C.c_double), ("copy_engine", C.c_int32),
+                ("sdma_engine_mask", C.c_uint32), ("reserved", C.c_uint64 * 4)]
+
+
 class ChunkRef(C.Structure):
     _fields_ = [("seq", C.c_uint64), ("data", C.c_void_p), ("bytes", C.c_uint64)]
 
@@ -550,6 +556,12 @@ class Engine:
     def delivery_slab_bytes(self):
         load().dabx_delivery_slab_bytes.restype = C.c_longlong
         return check(load().dabx_delivery_slab_bytes(self._h))
+
+    def delivery_info(self):
+        out = DeliveryInfo()
+        load().dabx_delivery_get_info.argtypes = [C.c_void_p, C.c_void_p]
+        check(load().dabx_delivery_get_info(self._h, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in DeliveryInfo._fields_ if k != "reserved"}
 
     def delivery_wait_free(self, n=1, timeout_ms=-1):
         return check(load().dabx_delivery_wait_free(self._h, int(n), int(timeout_ms)))

@@ -101,6 +101,12 @@ int  dabx_fic_stop(dabx_fic *f);                            /* stop(): process_b
 int  dabx_fic_restart(dabx_fic *f);                         /* restart(): ratio = 0, running, .cpp:270-275 */
 /* FibDecoder::get_cif_count as the FIG 0/0 walk of the decoded FIBs left it (fib_decoder_fig0.cpp:89-101): hi * 250 + lo */
 int  dabx_fic_get_cif_count(dabx_fic *f);
+/* The channel BER of the FIC (ViterbiSpiral::calculate_BER, viterbi_spiral.cpp:128-164, driven from fic_decoder.cpp:199-210): the decoded
+ * bits re-encoded and compared with the signs of the 2304 transmitted soft bits of every block; both counters are halved after every
+ * 40th block.  status_* = the pair as it stood at the newest 40th block BEFORE halving: errors / bits of it is the value the reference
+ * hands to signal_fic_status (fic_decoder.cpp:205); blocks = FIC blocks since the last such report (mFicBlock). */
+typedef struct { int32_t bits, errors, status_bits, status_errors, blocks, reserved[3]; } dabx_fic_ber;
+int  dabx_fic_get_ber(dabx_fic *f, dabx_fic_ber *out);
 
 /* ---- MscHandler, per OFDM symbol and stateful (base/backend/msc_handler.h:36-47, backend.cpp:60-161) --------------
  * The handle is the GPU-side MscHandler of ONE ensemble with up to max_services back ends: the CIF buffer, every back
@@ -476,6 +482,16 @@ int  dabx_delivery_release(dabx_engine *e, uint64_t seq);
 /* Back-pressure for the engine's thread: waits (at most timeout_ms, < 0 = for ever) until n host slabs are free and returns the
  * number that are (>= n: a dabx_process call that closes n chunks will be accepted; < n: timed out). */
 int  dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms);
+/* What the copies themselves took (the copier's own clock around each transfer): link rate = bytes_copied / copy_seconds. */
+typedef struct {
+  uint64_t chunks_closed, chunks_landed, bytes_copied;
+  double   copy_seconds, copy_seconds_max;     /* sum / longest single transfer */
+  double   gather_wait_seconds;                /* the copier's waits for the chunks' gather kernels (idle time, not a cost) */
+  int32_t  copy_engine;                        /* dabx_delivery_config.copy_engine */
+  uint32_t sdma_engine_mask;                   /* hsa_amd_sdma_engine_id_t the transfers are put on (0: the runtime's choice) */
+  uint64_t reserved[4];
+} dabx_delivery_info;
+int  dabx_delivery_get_info(dabx_engine *e, dabx_delivery_info *out);
 /* Bytes one slab takes with the sub-channels configured now (what one chunk moves over the link). */
 long long dabx_delivery_slab_bytes(dabx_engine *e);
 

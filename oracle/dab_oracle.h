@@ -241,6 +241,8 @@ typedef struct {
   int32_t *msc_overflow;  /* n_frames : the same for symbols 4..75 */
   float   *s_level;       /* n_frames : SampleReader::sLevel after the frame's last sample (sample_reader.cpp:245-248) */
   float   *peak_level;    /* n_frames : SampleReader::peakLevel likewise */
+  int32_t *fic_ber_bits;   /* n_frames : FicDecoder::mFicBits / mFicErrors after the frame's four FIC blocks (fic_decoder.cpp:199-210) */
+  int32_t *fic_ber_errors;
 } ora_rx_capture;
 void ora_rx_enable_soft_capture(ora_receiver *r, int on);
 const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);

@@ -188,7 +188,7 @@ void ora_rx_destroy(ora_receiver *r)
   free(r->back);
   free(r->cap.fibs); free(r->cap.fib_crc); free(r->cap.soft); free(r->cap.start_idx); free(r->cap.fbb); free(r->cap.sym0_pos);
   free(r->cap.fbb_end); free(r->cap.clock_err); free(r->cap.fic_ratio); free(r->cap.snr_db); free(r->cap.fic_overflow); free(r->cap.msc_overflow);
-  free(r->cap.s_level); free(r->cap.peak_level);
+  free(r->cap.s_level); free(r->cap.peak_level); free(r->cap.fic_ber_bits); free(r->cap.fic_ber_errors);
   free(r);
 }
 
@@ -215,6 +215,8 @@ static void cap_reserve(ora_receiver *r, int n)
   r->cap.msc_overflow = (int32_t *)realloc(r->cap.msc_overflow, sizeof(int32_t) * (size_t)na);
   r->cap.s_level = (float *)realloc(r->cap.s_level, sizeof(float) * (size_t)na);
   r->cap.peak_level = (float *)realloc(r->cap.peak_level, sizeof(float) * (size_t)na);
+  r->cap.fic_ber_bits = (int32_t *)realloc(r->cap.fic_ber_bits, sizeof(int32_t) * (size_t)na);
+  r->cap.fic_ber_errors = (int32_t *)realloc(r->cap.fic_ber_errors, sizeof(int32_t) * (size_t)na);
   if (r->want_soft) r->cap.soft = (int16_t *)realloc(r->cap.soft, sizeof(int16_t) * (size_t)na * 75 * ORA_2K);
   r->cap_alloc = na;
 }
@@ -314,6 +316,7 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
   r->cap.fbb_end[frame_no] = r->freq_offs_bb;
   r->cap.clock_err[frame_no] = r->clock_err;
   r->cap.fic_ratio[frame_no] = r->fic.success_ratio * 10;
+  r->cap.fic_ber_bits[frame_no] = r->fic.fic_bits; r->cap.fic_ber_errors[frame_no] = r->fic.fic_errors;
   r->cap.s_level[frame_no] = r->s_level; r->cap.peak_level[frame_no] = r->peak_level;
   return 1;
 }
@@ -408,6 +411,7 @@ int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 
     r->cap.start_idx[f] = 0; r->cap.fbb[f] = 0; r->cap.sym0_pos[f] = 0;
     r->cap.fbb_end[f] = 0; r->cap.clock_err[f] = clock_err[f]; r->cap.fic_ratio[f] = r->fic.success_ratio * 10;
     r->cap.s_level[f] = r->s_level; r->cap.peak_level[f] = r->peak_level;
+    r->cap.fic_ber_bits[f] = r->fic.fic_bits; r->cap.fic_ber_errors[f] = r->fic.fic_errors;
     r->cap.n_frames = f + 1;
   }
   return n_frames;

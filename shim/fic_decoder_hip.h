@@ -50,7 +50,16 @@ public:
         if (dump != nullptr) fwrite(&fibs[32 * k], 1, 32, dump);   // _dump_fib_to_file, :294-308
         mpFibDecoder->process_FIB(oneFib, (u16)fic);
       }
-      if (++mFicBlock == 40) mFicBlock = 0;                        // :201-210; the BER of signal_fic_status is a GUI statistic, not produced here
+      if (++mFicBlock == 40)                                       // :201-210
+      {
+        mFicBlock = 0;
+        dabx_fic_ber ber;
+        dabx_shim_check(dabx_fic_get_ber(mpFic, &ber), "dabx_fic_get_ber");
+        mLastBer = ber.status_bits > 0 ? (f32)ber.status_errors / (f32)ber.status_bits : 0.0f;
+#ifndef DABX_SHIM_STANDALONE
+        emit signal_fic_status(get_fic_decode_ratio_percent(), mLastBer);      // (mFicDecodeSuccessRatio * 10, mFicErrors / mFicBits), :205
+#endif
+      }
     }
   }
   void stop()                                                      // :264-268
@@ -80,11 +89,13 @@ public:
   void stop_fic_dump() { mpFicDump = nullptr; }
 
   IFibDecoder * get_fib_decoder() { return mpFibDecoder.get(); }
+  f32 dabx_last_fic_ber() const { return mLastBer; }               // (not a member of the reference's class: lets a test see the signal's value)
 
 private:
   std::unique_ptr<IFibDecoder> mpFibDecoder;
   dabx_fic * mpFic = nullptr;
   i32 mFicBlock = 0;
+  f32 mLastBer = 0.0f;                                             // what signal_fic_status last carried
   std::atomic<FILE *> mpFicDump{ nullptr };
 
   void dabx_shim_connect_gui(DabRadio *);

@@ -7,6 +7,7 @@
  */
 #pragma once
 #include "dabx_shim_env.h"
+#include <cmath>
 
 #ifdef DABX_SHIM_STANDALONE
 class OfdmDecoder
@@ -60,11 +61,33 @@ public:
   // :147-355.  iPhaseCorr only enters the LCD statistics (:296-300), never the soft bits.
   void decode_symbol(const TArrayTu & iV, const u16 iCurOfdmSymbIdx, const f32 iPhaseCorr, const f32 iClockErr, std::vector<i16> & oBits)
   {
-    (void)iCurOfdmSymbIdx; (void)iPhaseCorr;
     if (oBits.size() != (size_t)c2K) oBits.resize(c2K);
     const float ce = iClockErr;
+    ++mShowCntStatistics;                                          // :155-157: one statistics record about every 5 frames, on a rotating symbol
+    const bool showStatisticData = (mShowCntStatistics > 5 * 76 && iCurOfdmSymbIdx == mNextShownOfdmSymbIdx);
     dabx_shim_check(dabx_demap_decode_symbols(mpDemap, reinterpret_cast<const dabx_cf32 *>(iV.data()), 1, &ce, oBits.data()), "dabx_demap_decode_symbols");
+    const f32 freqCorr = iPhaseCorr / 6.28318530717958647692f * 1000.0f;      // iPhaseCorr / F_2_M_PI * cCarrDiff
+    if (iCurOfdmSymbIdx == 1) mMeanSigmaSqFreqCorr += 0.2f * (freqCorr * freqCorr - mMeanSigmaSqFreqCorr);   // :296-300 mean_filter(.., 0.2f)
+    if (showStatisticData)                                         // :326-352
+    {
+      float snr = 0.0f;
+      dabx_shim_check(dabx_demap_get_snr_db(mpDemap, &snr), "dabx_demap_get_snr_db");
+      mLcdData.CurOfdmSymbolNo = iCurOfdmSymbIdx + 1;
+      mLcdData.SNR = snr;                                          // 10 log10((mMeanPowerOvrAll - noise) / noise), computed on the device
+      mLcdData.MeanSigmaSqFreqCorr = std::sqrt(mMeanSigmaSqFreqCorr);
+      mLcdData.TestData2 = freqCorr;
+      mLcdData.MER = 0.0f;                                         // the phase-deviation IIR behind it (mStdDevSqPhaseVector) feeds no soft bit and is not kept on the device
+      mLcdData.TestData1 = 0.0f;
+#ifndef DABX_SHIM_STANDALONE
+      emit signal_show_lcd_data(mLcdData);
+#endif
+      mLcdEmitted++;
+      mShowCntStatistics = 0;
+      mNextShownOfdmSymbIdx = (mNextShownOfdmSymbIdx + 1) % 76;
+      if (mNextShownOfdmSymbIdx == 0) mNextShownOfdmSymbIdx = 1;
+    }
   }
+  const SLcdData & dabx_last_lcd_data(i32 * oCount = nullptr) const { if (oCount) *oCount = mLcdEmitted; return mLcdData; }   // (for tests: what the signal last carried)
 
   void set_select_carrier_plot_type(ECarrierPlotType iPlotType) { mCarrierPlotType = iPlotType; }   // scopes: not fed by this back end
   void set_select_iq_plot_type(EIqPlotType iPlotType) { mIqPlotType = iPlotType; }
@@ -84,6 +107,9 @@ private:
   std::atomic<EIqPlotType> mIqPlotType{ EIqPlotType::DEFAULT };
   std::atomic<ESoftBitType> mSoftBitType{ ESoftBitType::DEFAULT };
   cf32 mDcAdc{ 0.0f, 0.0f };
+  i32 mShowCntStatistics = 0, mNextShownOfdmSymbIdx = 1, mLcdEmitted = 0;      // ofdm_decoder.h:86-88
+  f32 mMeanSigmaSqFreqCorr = 0.0f;                                             // :103
+  SLcdData mLcdData{};
 
   void dabx_shim_connect_gui();
 

@@ -116,9 +116,12 @@ int main(int argc, char ** argv)
   fic.restart();
   const bool ratio_reset = fic.get_fic_decode_ratio_percent() == 0 && rec.connects == 2;
   msc.stop_all_services();
+  // the status signals of the replaced classes: signal_fic_status's BER (every 40th FIC block) and signal_show_lcd_data's record
+  i32 lcd_count = 0;
+  const OfdmDecoder::SLcdData & lcd = ofdm.dabx_last_lcd_data(&lcd_count);
   std::printf("{\"frames\": %d, \"fibs_delivered\": %zu, \"drivers\": %zu, \"logical_frames\": %zu, \"mean_fic_ratio\": %.1f, "
-              "\"stopped_ok\": %s, \"ratio_reset\": %s}\n",
+              "\"stopped_ok\": %s, \"ratio_reset\": %s, \"fic_status_ber\": %.9g, \"lcd_count\": %d, \"lcd_snr\": %.4f, \"lcd_symbol\": %d}\n",
               n_frames, rec.fibs.size(), rec.frames.size(), total_frames, (double)ratio_sum / n_frames, stopped_ok ? "true" : "false",
-              ratio_reset ? "true" : "false");
+              ratio_reset ? "true" : "false", (double)fic.dabx_last_fic_ber(), (int)lcd_count, (double)lcd.SNR, (int)lcd.CurOfdmSymbolNo);
   return 0;
 }

@@ -30,7 +30,8 @@ class RxCapture(C.Structure):
                 ("fbb", C.POINTER(C.c_float)), ("sym0_pos", C.POINTER(C.c_int32)),
                 ("fbb_end", C.POINTER(C.c_float)), ("clock_err", C.POINTER(C.c_float)), ("fic_ratio", C.POINTER(C.c_int32)),
                 ("snr_db", C.POINTER(C.c_float)), ("fic_overflow", C.POINTER(C.c_int32)), ("msc_overflow", C.POINTER(C.c_int32)),
-                ("s_level", C.POINTER(C.c_float)), ("peak_level", C.POINTER(C.c_float))]
+                ("s_level", C.POINTER(C.c_float)), ("peak_level", C.POINTER(C.c_float)),
+                ("fic_ber_bits", C.POINTER(C.c_int32)), ("fic_ber_errors", C.POINTER(C.c_int32))]
 
 
 def build_oracle():

@@ -34,6 +34,7 @@ def _oracle_run(x, subch, want_soft=False, config=None):
                fic_ratio=np.ctypeslib.as_array(cap.fic_ratio, (n,)).copy(), snr_db=np.ctypeslib.as_array(cap.snr_db, (n,)).copy(),
                s_level=np.ctypeslib.as_array(cap.s_level, (n,)).copy(), peak_level=np.ctypeslib.as_array(cap.peak_level, (n,)).copy(),
                sym0=np.ctypeslib.as_array(cap.sym0_pos, (n,)).copy(),
+               ber_bits=np.ctypeslib.as_array(cap.fic_ber_bits, (n,)).copy(), ber_errors=np.ctypeslib.as_array(cap.fic_ber_errors, (n,)).copy(),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
                sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
                stats=[ol.backend_stats(rx, i) for i in range(len(subch))])

@@ -28,7 +28,7 @@ def test_the_library_has_no_device_code_of_its_own():
     out = subprocess.run(["readelf", "-S", "-W", env["DABX_LIB"]], capture_output=True, text=True, check=True).stdout
     assert ".hip_fatbin" not in out                                    # the default build keeps its code objects there
     assert sorted(f for f in os.listdir(MOD_DIR) if f.endswith(".hsaco")) == [
-        "dabx_gfx950_%s.hsaco" % n for n in ("fec", "iqfile", "ofdm", "pipeline", "vit_t", "viterbi")]
+        "dabx_gfx950_%s.hsaco" % n for n in ("deliver", "fec", "iqfile", "ofdm", "pipeline", "vit_t", "viterbi")]
     syms = subprocess.run(["nm", "-D", "--defined-only", env["DABX_LIB"]], capture_output=True, text=True, check=True).stdout
     assert "hipLaunchKernel" not in syms and "__hipRegister" not in syms      # the runtime entry points it defines stay inside
 
