@@ -26,6 +26,7 @@ int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool as
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk, const DeliverDev *dv = nullptr,
                      hipStream_t *tail = nullptr);
 int launch_deliver_front(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
+void dabx_internal_fibdec_skip(dabx_fibdec *d, long long n_fibs);     // fib.cpp: FIBs the decoder never saw (they had left the ring)
 int launch_dciq(const EngineDev &e, int mode, hipStream_t st);
 int launch_level_exact(const EngineDev &e, hipStream_t st);
 int launch_stage_msc_block(const EngineDev &e, const int16_t *soft_dev, int blk, bool closes_cif, hipStream_t st);
@@ -1251,10 +1252,7 @@ int dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out)
   // FIB k of frame f is FIB 12 f + k of the stream: the decoder counts the FIBs of missed frames as skipped
   dabx_fibdec_info inf;
   dabx_fibdec_get_info(fd, &inf);
-  if (inf.fibs_processed < 12 * fed) {
-    std::vector<uint8_t> z((size_t)(12 * fed - inf.fibs_processed) * 32, 0), zc((size_t)(12 * fed - inf.fibs_processed), 0);
-    dabx_fibdec_process(fd, z.data(), zc.data(), (int)zc.size());
-  }
+  if (inf.fibs_processed < 12 * fed) dabx_internal_fibdec_skip(fd, 12 * fed - inf.fibs_processed);      // counted, not processed
   std::vector<uint8_t> fb(384), fc(12);
   for (; fed < c.frames; fed++) {
     const size_t slot = (size_t)stream * d.out_frames + (size_t)(fed % d.out_frames);
@@ -1270,8 +1268,11 @@ int dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out)
   if (inf.last_change_fib >= 0) out->last_change_cif = cif_of_fib(inf.last_change_fib);
   if (inf.change_flags != 0 && inf.fig00_fib >= 0) {
     out->pending = 1;
-    // the announcing FIG 0/0 carried the counter of ITS CIF: the change applies (occurrence - lo) mod 250 CIFs later
-    out->at_cif = cif_of_fib(inf.fig00_fib) + ((inf.occurrence_change - inf.cif_count_lo) % 250 + 250) % 250;
+    // the announcing FIG 0/0 carried the counter of ITS CIF: the change applies (occurrence - lo) mod 250 CIFs later.  While the flags
+    // are set the change has not happened yet: a distance of 0 is a full turn of the low counter (250 CIFs = the 6 s of lead)
+    int ahead = ((inf.occurrence_change - inf.cif_count_lo) % 250 + 250) % 250;
+    if (ahead == 0) ahead = 250;
+    out->at_cif = cif_of_fib(inf.fig00_fib) + ahead;
   }
   return 0;
 }

@@ -51,6 +51,7 @@ struct dabx_fibdec {
   long long fibs = 0, fig00_fib = -1, last_change_fib = -1;
   int n_changes = 0, n_restarts = 0;
   bool restart = false;                     // mRestartFibDecoding
+  bool strict = false;                      // dabx_fibdec_set_reference_quirks: swap only after change flags 3, like fib_decoder_fig0.cpp:103
   void reset_scalars() { cif_count = cif_hi = cif_lo = -1; change_flags = occurrence = prev_change_flag = 0; fig00_fib = -1; }   // FibDecoder::_reset
   void reset_all() { cfg[0].reset(); cfg[1].reset(); reset_scalars(); }
   void restart_decoding() { reset_all(); n_restarts++; restart = true; }            // _restart_fib_decoding, fib_decoder.cpp:131-141
@@ -78,7 +79,17 @@ static void walk_fib(const uint8_t *fib, dabx_fibdec &t)
         t.occurrence = len >= 6 ? (int)bits(d, 48, 8) : 0;             // OccurrenceChange: present while the change flags are set
         t.change_flags = flags;
         t.fig00_fib = t.fibs;
-        if (flags == 0 && t.prev_change_flag == 3) {                   // :103-110: the next configuration becomes the current one
+        // :103-110: the next configuration becomes the current one.  The reference swaps only after flags 3 (sub-channel AND service
+        // organisation): after an announcement with flags 1 or 2 (EN 300 401 6.4.1) its next table is never swapped or reset, and its
+        // stale entries ("first description wins") then shape the reconfiguration after that.  By default every announcement that ends
+        // (non-zero -> 0) switches; what the announcement did not cover -- a table the next configuration never received an entry for --
+        // is carried over from the current one.  dabx_fibdec_set_reference_quirks(1) restores the reference's rule.
+        if (flags == 0 && t.prev_change_flag != 0 && (t.prev_change_flag == 3 || !t.strict)) {
+          if (!t.strict) {
+            FibConfig &nx = t.cfg[t.cur ^ 1];
+            if (nx.subch.empty()) nx.subch = t.cfg[t.cur].subch;
+            if (nx.comps.empty()) nx.comps = t.cfg[t.cur].comps;
+          }
           t.cur ^= 1;
           t.cfg[t.cur ^ 1].reset();
           t.n_changes++;
@@ -180,6 +191,10 @@ bool fib_cif_count(const uint8_t *fib, int *hi, int *lo)
 
 using namespace dabx;
 
+namespace dabx {
+void dabx_internal_fibdec_skip(dabx_fibdec *d, long long n_fibs) { if (d && n_fibs > 0) d->fibs += n_fibs; }
+}
+
 extern "C" {
 
 int dabx_fibdec_create(dabx_fibdec **out)
@@ -192,7 +207,15 @@ void dabx_fibdec_destroy(dabx_fibdec *d) { delete d; }
 int dabx_fibdec_reset(dabx_fibdec *d)            // FibDecoder::connect_channel, fib_decoder.cpp:143-150
 {
   if (!d) return DABX_E_ARG;
+  const bool strict = d->strict;
   *d = dabx_fibdec();
+  d->strict = strict;
+  return 0;
+}
+int dabx_fibdec_set_reference_quirks(dabx_fibdec *d, int on)
+{
+  if (!d) return DABX_E_ARG;
+  d->strict = on != 0;
   return 0;
 }
 int dabx_fibdec_process(dabx_fibdec *d, const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs)

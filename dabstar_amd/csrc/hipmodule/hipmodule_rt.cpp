@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <dirent.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -28,9 +29,10 @@ namespace {
 struct Registry {
   std::mutex mu;
   std::unordered_map<const void *, std::string> kernels, vars;     // host handle -> device symbol
-  std::unordered_map<const void *, hipFunction_t> fn;              // resolved per handle (per device the modules are loaded once: one device per process)
+  std::unordered_map<const void *, hipFunction_t> fn;              // resolved per handle, all of them when the code objects are loaded (self_check)
   std::vector<hipModule_t> modules;
   bool loaded = false;
+  int device = -1;                                                 // the device the code objects were loaded for: ONE device per process in this form
   std::string error;
 };
 Registry &reg() { static Registry *r = new Registry(); return *r; }   // never destroyed: kernels are launched from static destructors' siblings
@@ -71,6 +73,30 @@ hipError_t load_modules(Registry &r)
     r.error = "no dabx_gfx950_*.hsaco next to the library in " + dir;
     std::fprintf(stderr, "libdabx (hipModule): %s\n", r.error.c_str());
     return hipErrorFileNotFound;
+  }
+  (void)hipGetDevice(&r.device);
+  // Self-check, once, at load: EVERY kernel the host stubs have registered (clang's module constructors ran before main) must be in one
+  // of the code objects.  This form leans on clang's private host-stub ABI (__hipRegisterFunction, __hipPushCallConfiguration, the
+  // stub's call of hipLaunchKernel): a toolchain that changes it -- stubs that register under other names, or not at all -- must stop the
+  // process here, with the versions, not surface later as one launch that fails.
+  std::string missing;
+  for (const auto &kv : r.kernels) {
+    hipFunction_t f = nullptr;
+    for (hipModule_t m : r.modules)
+      if (hipModuleGetFunction(&f, m, kv.second.c_str()) == hipSuccess && f) break;
+    if (f) r.fn[kv.first] = f;
+    else missing += (missing.empty() ? "" : ", ") + kv.second;
+  }
+  (void)hipGetLastError();                                 // the look-ups in the other code objects failed by design
+  if (r.kernels.empty() || !missing.empty()) {
+    int rt = 0, drv = 0;
+    (void)hipRuntimeGetVersion(&rt);
+    (void)hipDriverGetVersion(&drv);
+    std::fprintf(stderr, "libdabx (hipModule): FATAL: %s (HIP runtime %d, driver %d, built with clang %s; %zu kernels registered, %zu code objects in %s).\n"
+                         "The hipModule form depends on clang's host-stub ABI; use the default build (dabstar_amd/libdabx.so) with this toolchain.\n",
+                 r.kernels.empty() ? "the host stubs registered no kernel at all" : ("kernels registered by the host stubs are in none of the code objects: " + missing).c_str(),
+                 rt, drv, __clang_version__, r.kernels.size(), r.modules.size(), dir.c_str());
+    std::abort();
   }
   return hipSuccess;
 }
@@ -117,13 +143,17 @@ hipError_t hipLaunchKernel(const void *handle, dim3 grid, dim3 block, void **arg
     if (hit != r.fn.end()) f = hit->second;
     else {
       auto it = r.kernels.find(handle);
-      if (it == r.kernels.end()) return hipErrorInvalidDeviceFunction;
-      if (hipError_t err = load_modules(r)) return err;
-      for (hipModule_t m : r.modules)
-        if (hipModuleGetFunction(&f, m, it->second.c_str()) == hipSuccess && f) break;
-      if (!f) { std::fprintf(stderr, "libdabx (hipModule): kernel %s is in none of the code objects\n", it->second.c_str()); return hipErrorInvalidDeviceFunction; }
-      (void)hipGetLastError();                               // the look-ups in the other code objects failed by design
-      r.fn[handle] = f;
+      if (it == r.kernels.end()) { std::fprintf(stderr, "libdabx (hipModule): launch of a kernel no host stub has registered\n"); return hipErrorInvalidDeviceFunction; }
+      if (hipError_t err = load_modules(r)) return err;     // resolves every registered kernel (or aborts)
+      hit = r.fn.find(handle);
+      if (hit == r.fn.end()) return hipErrorInvalidDeviceFunction;
+      f = hit->second;
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != r.device) {
+      std::fprintf(stderr, "libdabx (hipModule): the code objects were loaded for device %d, this launch is for device %d: one device per process in this form "
+                           "(run one process per GPU, as bench.py does, or use the default build)\n", r.device, cur);
+      return hipErrorInvalidDevice;
     }
   }
   return hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)shmem, stream, args, nullptr);

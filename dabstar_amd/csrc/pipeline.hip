@@ -593,7 +593,10 @@ __device__ __forceinline__ void level_from_anchor(EngineDev &e, int s, int tid, 
       const unsigned long long hz = __hip_atomic_load(&e.wr_horizon[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
       int m = 0, pick = -1;
       if (attempt == 0) {
-        if (hz <= c.lvl_anchor_pos + len64) m = 1;
+        // (1 only over at most 20 frames: a producer that announced its ring once, a periodic test signal, passes the horizon check for ever,
+        //  and a stream that falls out of lock after a long time in it would walk every sample since the hand-over -- seconds of kernel time on
+        //  the step's critical path.  Beyond that the two-walk merge from the frame history gives the same float with a certificate.)
+        if (hz <= c.lvl_anchor_pos + len64 && p1 - c.lvl_anchor_pos <= 20ull * TF) m = 1;
         else {
           unsigned long long best = ~0ull;
           for (int h = 0; h < LVL_HIST; h++) {

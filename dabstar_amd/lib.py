@@ -691,9 +691,11 @@ class Reconf(C.Structure):
 class FibDecoder:
     """dabx_fibdec_*: FibDecoder's FIG 0/0-0/2 walk with a current and a next configuration (host only)."""
 
-    def __init__(self):
+    def __init__(self, reference_quirks=False):
         self._h = C.c_void_p()
         check(load().dabx_fibdec_create(C.byref(self._h)))
+        if reference_quirks:
+            check(load().dabx_fibdec_set_reference_quirks(self._h, 1))
 
     def process(self, fibs, crc_ok):
         fibs = np.ascontiguousarray(fibs, np.uint8).reshape(-1, 32)

@@ -180,8 +180,8 @@ int dabx_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs, stru
                     int32_t *cif_count);
 /* The same as a running decoder (FibDecoder::process_FIB, fib_decoder.cpp:59-106, fed FIB by FIB in transmission order): it keeps
  * the CURRENT and the NEXT multiplex configuration -- FIG 0/1 and 0/2 are filed under _get_config_ptr(C/N flag),
- * fib_decoder.h:97, fib_decoder_fig0.cpp:149, 240 -- and swaps them when the change flags of FIG 0/0 go from 3 back to 0
- * (fib_decoder_fig0.cpp:102-111: std::swap(curr, next); next->reset()).  A sub-channel that reaches beyond the CIF or overlaps a
+ * fib_decoder.h:97, fib_decoder_fig0.cpp:149, 240 -- and swaps them when the change flags of FIG 0/0 go back to 0
+ * (fib_decoder_fig0.cpp:102-111: std::swap(curr, next); next->reset(); see dabx_fibdec_set_reference_quirks for "from which value").  A sub-channel that reaches beyond the CIF or overlaps a
  * known one restarts the collection (fib_decoder.cpp:131-141), as in the reference. */
 typedef struct dabx_fibdec dabx_fibdec;
 typedef struct {
@@ -200,6 +200,12 @@ typedef struct {
 int  dabx_fibdec_create(dabx_fibdec **out);
 void dabx_fibdec_destroy(dabx_fibdec *d);
 int  dabx_fibdec_reset(dabx_fibdec *d);                              /* FibDecoder::connect_channel, fib_decoder.cpp:143-150 */
+/* When the two configurations are swapped.  0 (default): whenever an announcement ends -- the change flags of FIG 0/0 go from ANY non-zero
+ * value back to 0 (EN 300 401 6.4.1: 1 = sub-channel organisation, 2 = service organisation, 3 = both) -- and a table the announcement
+ * never filled (no FIG 0/1 resp. 0/2 with C/N = 1 seen) is carried over from the current configuration.  1: the reference's rule, bit for
+ * bit: only after flags 3 (fib_decoder_fig0.cpp:103); after flags 1 or 2 its next table is neither swapped nor reset, and the stale
+ * entries take part in the reconfiguration after that. */
+int  dabx_fibdec_set_reference_quirks(dabx_fibdec *d, int on);
 /* n_fibs x 32 bytes + CRC flags (what dabx_read_fibs / dabx_fic_decode deliver); returns the number of swaps made in this call */
 int  dabx_fibdec_process(dabx_fibdec *d, const uint8_t *fibs, const uint8_t *crc_ok, int n_fibs);
 int  dabx_fibdec_get_info(const dabx_fibdec *d, dabx_fibdec_info *out);
@@ -364,8 +370,9 @@ int  dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out,
  *                newest one, i.e. the first CIF of the new configuration as the reference sees it.
  * dabx_next_subchannels returns the announced (next) table.  To follow a reconfiguration: call dabx_process up to the frame that
  * holds at_cif (frames = at_cif / 4 - frames decoded), then dabx_set_subchannels_at(..., at_cif) with the table wanted from then
- * on, and go on -- slots whose description does not change keep running, slots that end deliver their logical frames up to
- * CIF at_cif - 1, new ones start their 16-CIF de-interleaver fill at at_cif (tests/test_gpu_reconfig.py). */
+ * on, and go on -- slots whose description does not change keep running, new ones start their 16-CIF de-interleaver fill at at_cif,
+ * slots that end stop with the call: their last logical frame is that of the last CIF of the frame decoded before it, also when
+ * at_cif lies inside the coming frame (tests/test_gpu_reconfig.py, cif_in_frame = 2). */
 typedef struct {
   int32_t pending, n_changes, frames_missed, reserved;
   int64_t at_cif, last_change_cif, frames_fed;

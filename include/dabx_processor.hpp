@@ -231,7 +231,15 @@ private:
       if (!slots_[j].kbps) continue;
       const dabx_subch_desc old = slots_[j];
       dabx_subch_desc now{};
-      for (int k = 0; k < n_next; k++) if (next[(size_t)k].subch_id == old.subch_id) now = next[(size_t)k];
+      bool listed = false, displaced = false;
+      for (int k = 0; k < n_next; k++) {
+        const dabx_subch_desc &q = next[(size_t)k];
+        if (q.subch_id == old.subch_id) { now = q; listed = true; }
+        else if (q.cu_start < old.cu_start + old.cu_size && old.cu_start < q.cu_start + q.cu_size) displaced = true;
+      }
+      // A running service stops only when the next table says so positively: its capacity units go to another sub-channel.  One that
+      // the table simply does not list (FIBs lost before the switch, or a multiplexer that announces only what changes) keeps running.
+      if (!listed && !displaced) now = old;
       if (now.kbps && now.dab_plus < 0) now.dab_plus = old.dab_plus;
       // (a sub-channel that only moves to other capacity units keeps running in the engine: same counters)
       const bool same = now.kbps == old.kbps && now.cu_size == old.cu_size &&

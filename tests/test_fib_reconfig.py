@@ -36,7 +36,7 @@ def _fib_stream(a, b, n_cif, switch, announce_from, cif_start=0):
 
 def _both(fibs, crc, step=3):
     """feeds both decoders `step` FIBs at a time; yields (index of the first FIB of the chunk, libdabx decoder, oracle decoder)"""
-    d, o = dx.FibDecoder(), ol.OraFibDecoder()
+    d, o = dx.FibDecoder(reference_quirks=True), ol.OraFibDecoder()        # the oracle restates the reference: its swap rule
     for i in range(0, len(fibs), step):
         nd, no = d.process(fibs[i:i + step], crc[i:i + step]), o.process(fibs[i:i + step], crc[i:i + step])
         assert nd == no
@@ -185,3 +185,59 @@ def test_random_fig_streams_with_both_configurations_follow_the_oracle():
         assert _tab(d.subchannels()) == o.subchannels() and _tab(d.subchannels(next=True)) == o.subchannels(next=True), i
         swaps, restarts = a["n_changes"], a["n_restarts"]
     assert swaps >= 5 and restarts >= 5                                   # the stream did exercise both mechanisms
+
+
+def _fib_stream_flags(cur, nxt, n_cif, switch, announce_from, flags, cif_start=0, only01=False):
+    """like _fib_stream with the announcement's change flags given; only01: the next configuration is announced with FIG 0/1 only
+    (flags 1 = sub-channel organisation: a multiplexer need not repeat the unchanged service organisation with C/N = 1)"""
+    out = []
+    for q in range(n_cif):
+        ann = announce_from <= q < switch
+        fb = ds.build_fibs_reconf(cur if q < switch else nxt, nxt if ann else None, cif_start + q, flags if ann else 0, (cif_start + switch) % 250)
+        if ann and only01 and (cif_start + q) % 4 == 3:        # the CIF that would carry the next FIG 0/2: the current one instead
+            fb = ds.build_fibs_reconf(cur, None, cif_start + q, flags, (cif_start + switch) % 250)
+        out.append(fb.reshape(3, 32))
+    return np.concatenate(out)
+
+
+def test_flags_1_reconfiguration_switches_too_and_the_one_after_it_starts_from_a_clean_next_table():
+    """the reference swaps only after change flags 3; after flags 1 (sub-channel organisation only) its next table is never
+    swapped or reset, so 'first description wins' keeps the stale entries for the reconfiguration after that.  libdabx's default:
+    every announcement that ends switches; a table the announcement never filled is carried over; the next table is clean afterwards."""
+    a, b = _layouts()
+    c = b[:4] + [ds.SubCh(4, 600, 72, 96, 2, 0), ds.SubCh(6, 192, 24, 32, 2, 0, dab_plus=0)]         # second change: sub-channel 4 moves again
+    s1 = _fib_stream_flags(a, b, 60, 40, 12, flags=1, only01=True)
+    s2 = _fib_stream_flags(b, c, 60, 40, 12, flags=3, cif_start=60)
+    fibs = np.concatenate([s1, s2]); crc = np.ones(len(fibs), np.uint8)
+    want = lambda L: sorted((g.subch_id, g.cu_start, g.cu_size, g.kbps, g.prot_level) for g in L)
+    got = lambda t: sorted(x[:5] for x in t)
+    d = dx.FibDecoder()
+    for q in range(120):
+        d.process(fibs[3 * q:3 * q + 3], crc[3 * q:3 * q + 3])
+        cur, nxt, inf = _tab(d.subchannels()), _tab(d.subchannels(next=True)), d.info()
+        if 2 <= q < 40:
+            assert got(cur) == want(a), q
+        if 40 <= q < 100:
+            assert got(cur) == want(b), q                      # switched after flags 1 ...
+            # ... and the service components (never re-announced with C/N = 1) were carried over; sub-channel 6 is new: its FIG 0/2
+            # comes with the current configuration's own FIGs a few CIFs later
+            assert all(x[6] in (0, 1) for x in cur if x[0] != 6), q
+            assert q < 44 or all(x[6] in (0, 1) for x in cur), q
+        if 40 <= q < 72:
+            assert nxt == [], q                                # next->reset()
+        if 76 <= q < 100:
+            assert got(nxt) == want(c), q                      # the second announcement fills a clean table: sub-channel 4 at its NEW address
+        if q >= 100:
+            assert got(cur) == want(c), q
+        assert inf["n_changes"] == (0 if q < 40 else 1 if q < 100 else 2) and inf["n_restarts"] == 0, q
+    d.close()
+    # the reference's rule on the same stream: no switch after flags 1 -- the new FIG 0/1 entries then collide with the remembered
+    # ones and the whole collection restarts (here that also wipes the stale next table; without a collision it would stay)
+    r, o = dx.FibDecoder(reference_quirks=True), ol.OraFibDecoder()
+    for q in range(120):
+        r.process(fibs[3 * q:3 * q + 3], crc[3 * q:3 * q + 3]); o.process(fibs[3 * q:3 * q + 3], crc[3 * q:3 * q + 3])
+        assert r.info() == o.info() and _tab(r.subchannels()) == o.subchannels() and _tab(r.subchannels(next=True)) == o.subchannels(next=True), q
+        if q == 39:
+            assert r.info()["n_changes"] == 0
+    assert r.info()["n_restarts"] >= 1
+    r.close(); o.close()
