@@ -76,6 +76,11 @@ def parse():
                          "stream lands in page-locked host memory (one DMA per 7-frame chunk) inside the timed region; without the flag "
                          "the same is measured in a second, equally long leg and reported as config.delivered_to_host")
     ap.add_argument("--no-deliver-leg", action="store_true", help="skip the delivered_to_host leg")
+    ap.add_argument("--sync-calls", action="store_true",
+                    help="not the headline: every dabx_process call of the timed region waits for its frames (sync = 1, a live receiver's form) -- "
+                         "with --unlocked: streams in a drop-out are searched next to the steps in this form too")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host leg (config.host_to_host)")
+    ap.add_argument("--no-single-legs", action="store_true", help="skip the single-ensemble legs (config.single_ensemble)")
     ap.add_argument("--deliver-copy-engine", type=int, default=0, choices=[0, 1], help="experiments: dabx_delivery_config.copy_engine (1 = hipMemcpyAsync)")
     ap.add_argument("--deliver-what", type=int, default=0, help="experiments: DABX_DELIVER_* mask (1 FIBs, 2 logical frames, 4 super frames; 0 = all)")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
@@ -113,6 +118,9 @@ def layout_of(args, subch, e):
     return mixed_multiplex() if getattr(args, "layout", "uniform") == "mixed" and e % 2 == 1 else subch
 
 
+_BASE_IQ = {}      # clean cyclic ensembles built so far (the single-ensemble legs reuse the first)
+
+
 def fill_rings(eng, torch, dev, args, rank, subch):
     """Synthetic IQ for every stream, generated on the GPU from a few clean cyclic ensembles (10 frames each)."""
     from tools import dab_synth as ds
@@ -120,8 +128,10 @@ def fill_rings(eng, torch, dev, args, rank, subch):
     n_frames = 10
     base = []
     for e in range(args.ensembles):
-        ens = ds.build_ensemble(n_frames, layout_of(args, subch, e), seed=1000 * rank + e, cyclic=True)
-        base.append(torch.from_numpy(ens.iq).to(dev))
+        key = (rank, e, getattr(args, "layout", "uniform"))
+        if key not in _BASE_IQ:
+            _BASE_IQ[key] = ds.build_ensemble(n_frames, layout_of(args, subch, e), seed=1000 * rank + e, cyclic=True).iq
+        base.append(torch.from_numpy(_BASE_IQ[key]).to(dev))
     n = n_frames * TF
     t = torch.arange(n, device=dev, dtype=torch.float64)
     H = hip()
@@ -150,19 +160,6 @@ def fill_rings(eng, torch, dev, args, rank, subch):
     # its lock still finds the samples it read in lock where the level tracker's anchor expects them (dabx_announce_write)
     eng.announce_write(n)
     return n_frames
-
-
-def load_pcie_inclusive():
-    """The PCIe-inclusive rate (every sample handed over as a host buffer) is measured by tools/bench_ingest.py, not in this
-    run -- value keeps the IQ resident in HBM -- and quoted from the kept profile so that it travels with the line."""
-    path = os.path.join(ROOT, "profiles", "r02_ingest_pcie.json")
-    try:
-        j = json.load(open(path))
-        best = max(j["formats"].items(), key=lambda kv: kv[1]["frames_per_s"])
-        return {"frames_per_s": best[1]["frames_per_s"], "host_GBps": best[1]["host_GBps"], "format_and_mode": best[0],
-                "streams": j["streams"], "measured_by": "tools/bench_ingest.py (separate run)", "source": "profiles/r02_ingest_pcie.json"}
-    except Exception:
-        return None
 
 
 def host_cpu():
@@ -449,6 +446,134 @@ class DryEngine:
         pass
 
 
+def single_ensemble_legs(torch, dev, args, rank, subch, dx):
+    """BASELINE configs[1] and [2] in the driver's own run: ONE ensemble on the GPU -- FIC only (76 FFTs, demapper, 4 FIC Viterbi blocks per
+    frame) and the full MSC (18 x 64 kbit/s EEP 3-A DAB+) -- 200 steps each after 20 of warm-up, issued like the headline (7 frames per
+    dabx_process call, no host wait inside).  One stream has no batch to hide latency in: the figure is the length of the frame's
+    dependent kernel chain (dab_processor.cpp:110-189 is what it serves), not a throughput claim."""
+    import types
+    out = {}
+    for name, fic_only in (("full", False), ("fic_only", True)):
+        a1 = types.SimpleNamespace(**dict(vars(args), streams=1, unlocked=0))
+        eng = dx.Engine(n_streams=1, ring_frames=10, max_subch=18, out_frames=8, fic_only=fic_only, viterbi_tie_mode=args.viterbi_tie_mode)
+        if not fic_only:
+            eng.set_subchannels(subch)
+        ring_frames = fill_rings(eng, torch, dev, a1, rank, subch)
+        eng.commit(ring_frames * TF - TF)
+
+        def run(n):
+            for m in step_chunks(n, 7):
+                eng.commit(m * TF)
+                eng.process(m, sync=False)
+        run(40)                                     # acquisition, CFO pull-in, de-interleaver fill, super-frame sync
+        eng.synchronize()
+        run(20)
+        eng.synchronize()
+        c1 = eng.counters()
+        t0 = time.perf_counter()
+        run(200)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        c2 = eng.counters()
+        fr = c2["frames"] - c1["frames"]
+        out[name] = {"frames_per_s": round(fr / dt, 1), "ms_per_frame": round(1e3 * dt / max(1, fr), 4), "steps": 200,
+                     "x_realtime": round(fr / dt / (2048000.0 / TF), 1),
+                     "fib_crc_pass_pct": round(100.0 * (c2["fib_ok"] - c1["fib_ok"]) / max(1, c2["fib_total"] - c1["fib_total"]), 3),
+                     "superframes_failed": c2["sf_fail"] - c1["sf_fail"]}
+        eng.close()
+    return out
+
+
+def measure_link_probe():
+    """tools/_build/sdma_engines (compiled by __graft_entry__.build()) as a child process before this process creates its engine: what a
+    bare 96-MiB SDMA transfer between page-locked host memory and the device gets on THIS box, each way (the engine the runtime picks)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "_build", "sdma_engines")
+    if not os.path.exists(exe) or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None
+    try:
+        j = json.loads(subprocess.run([exe, "96"], capture_output=True, text=True, timeout=120, check=True).stdout.strip().splitlines()[-1])
+        numa = "?"
+        try:
+            import glob
+            buf = C.create_string_buffer(64)
+            if hip().hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+                numa = open("/sys/bus/pci/devices/%s/numa_node" % buf.value.decode().lower()).read().strip()
+        except Exception:
+            pass
+        return {"h2d_GBps": j["h2d_GBps"]["runtime_choice"], "d2h_GBps": j["d2h_GBps"]["runtime_choice"], "MiB": j["MiB"], "gpu_numa_node": numa,
+                "tool": "tools/sdma_engines.hip (hsa_amd_memory_async_copy, page-locked host memory), run on this GPU in this bench invocation"}
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
+
+
+def host_to_host_leg(args, subch, dx, link):
+    """Host memory in, host memory out: uint8 IQ of every stream from page-locked host slabs (dabx_ingest_*: one slab
+    of 5 frames x all streams = 1 GB, one SDMA transfer, one conversion kernel), every FIB / logical frame / super frame back into
+    page-locked host slabs (dabx_delivery_*), 8 chunks timed after 8 of priming.  The link carries 393 216 B in and 14 208 B (+ super
+    frames) out per frame: the rate is the link's, not the decoder's."""
+    from tools import dab_synth as ds
+    CH, S = 5, args.streams
+    ens = ds.build_ensemble(10, subch, seed=3, cyclic=True)
+    x = (ds.channel(ens.iq, snr_db=args.snr, cfo_hz=300.0 / 0.96, timing_offset=4321, seed=3) * 1.0).astype(np.complex64)      # cyclic, 10 frames
+    u8 = np.clip(np.round(x.view(np.float32) * 128.0 + 127.38), 0, 255).astype(np.uint8)
+    eng = dx.Engine(n_streams=S, ring_frames=3 * CH, max_subch=18, out_frames=8, viterbi_tie_mode=args.viterbi_tie_mode)
+    eng.set_subchannels(subch)
+    slabs = eng.ingest_open(np.uint8, slabs=2, max_frames=CH)
+    per = CH * TF * 2
+    for k in range(2):                                   # the signal repeats after 10 frames: two slabs of 5, filled once
+        slabs[k].reshape(S, per)[:] = u8[k * per:(k + 1) * per]
+    n = CH * TF
+    state = {"k": 0}
+
+    def chunk(deliver):
+        k = state["k"]
+        eng.ingest_submit((k + 1) % 2, n)               # the next slab goes on the link ...
+        eng.ingest_commit(k % 2)                        # ... while this one is converted and decoded
+        if deliver:
+            eng.delivery_wait_free(1)
+        eng.process(CH, sync=False)
+        state["k"] = k + 1
+    eng.ingest_submit(0, n)
+    for _ in range(8):
+        chunk(False)
+    eng.synchronize()
+    eng.delivery_open(slots=4)
+    sink = DeliverySink(eng, [])
+    chunk(True)
+    eng.synchronize()
+    while sink.chunks < 1:
+        time.sleep(0.0002)
+    c1, q1 = eng.counters(), sink.totals()
+    N = 8
+    t0 = time.perf_counter()
+    for _ in range(N):
+        chunk(True)
+    eng.synchronize()
+    while sink.chunks < 1 + N and sink.error is None:
+        time.sleep(0.0001)
+    dt = time.perf_counter() - t0
+    c2, q2 = eng.counters(), sink.totals()
+    sink.finish()
+    info = eng.delivery_info()
+    eng.ingest_commit(state["k"] % 2)                   # the slab still on the link
+    eng.synchronize()
+    eng.delivery_close(); eng.ingest_close(); eng.close()
+    fr = c2["frames"] - c1["frames"]
+    in_gbps = fr * TF * 2 / dt / 1e9
+    out = {"frames_per_s": round(fr / dt, 1), "x_realtime": round(fr / dt / (2048000.0 / TF), 1), "in_GBps": round(in_gbps, 2),
+           "out_GBps": round((q2["slab_bytes"] - q1["slab_bytes"]) / dt / 1e9, 3), "chunks": N, "frames_per_chunk_and_stream": CH, "format": "uint8 IQ",
+           "frames_delivered": q2["frames"] - q1["frames"], "frames_decoded": fr, "lost": q2["lost"],
+           "fib_crc_pass_pct": round(100.0 * (c2["fib_ok"] - c1["fib_ok"]) / max(1, c2["fib_total"] - c1["fib_total"]), 3),
+           "superframes_failed": c2["sf_fail"] - c1["sf_fail"], "streams_locked": c2["streams_locked"],
+           "path": "dabx_ingest_submit / _commit (one SDMA transfer + one conversion kernel per 1-GB slab) -> dabx_process -> dabx_delivery_next / _release",
+           "delivery_link_GBps": round(info["bytes_copied"] / max(1e-9, info["copy_seconds"]) / 1e9, 2)}
+    if link and "h2d_GBps" in link:
+        out["link_probe"] = link
+        out["in_frac_of_link_probe"] = round(in_gbps / link["h2d_GBps"], 4)
+    return out
+
+
 class DeliverySink:
     """The host consumer of the bulk delivery (dabx_delivery_next / _release) on its own thread: takes every chunk as it lands,
     adds up what it carries from the slab's records and gives the slab back.  For `sample` streams it keeps the FIBs + CRC flags of
@@ -487,8 +612,6 @@ class DeliverySink:
                     if n and hasattr(ch, "fibs"):
                         self.fibs[s].append((int(st[s]["first_frame"]), ch.fibs[s, :n].copy(), ch.crc[s, :n].copy()))
                 ch.release()
-                if os.environ.get("DBG_TIMELINE"):
-                    sys.stderr.write("landed chunk %d at %.3f\n" % (self.chunks + 1, 1e3 * time.perf_counter()))
                 self.chunks += 1         # last: whoever sees the count sees the chunk's sums too
         except Exception as ex:          # reported by finish()
             self.error = ex
@@ -655,8 +778,10 @@ def main():
     from tools import dab_synth as ds
     subch = ds.default_subchannels(18, 64)
     dx = None
+    link_probe = [None]
     if not dry and rank == 0 and n_joined == 1:
-        if not os.environ.get('DBG_NOVALU'): measure_valu_peak()                          # child process, done before this process creates its engine
+        measure_valu_peak()                          # child processes, done before this process creates its engine
+        link_probe[0] = measure_link_probe()
     if dry:
         eng = DryEngine(args.streams)
         ring_frames = 10
@@ -701,8 +826,6 @@ def main():
                     if sink.error is not None or not sink.th.is_alive():
                         raise SystemExit("bench.py: the delivery consumer died: %r" % (sink.error,))
                 closed[0] += (m + 6) // 7
-                if os.environ.get("DBG_TIMELINE"):
-                    sys.stderr.write("issue chunk %d at %.3f waited %.3f\n" % (closed[0], 1e3 * time.perf_counter(), 1e3 * (time.perf_counter() - h0)))
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=sync)
             host_time[0] += time.perf_counter() - h0      # host time inside the two calls (launches, event traffic): no device wait when sync=False
@@ -745,25 +868,19 @@ def main():
     eng.synchronize()
     sink_catch_up()
     if not dry:
-        dx.check(dx.load().dabx_set_profiling(eng._h, 0 if os.environ.get('DBG_NOPROF') else 2 + dom_idx))
+        dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
     c1 = eng.counters()
     d1 = sink.totals() if sink else None
 
     barrier()
-    if os.environ.get("DBG_TIMELINE"):
-        sys.stderr.write("cpu.max %s | cpu.stat before: %s\n" % (open("/sys/fs/cgroup/cpu.max").read().strip(), open("/sys/fs/cgroup/cpu.stat").read().replace("\n", " ")))
     host_time[0] = 0.0
     t0 = time.perf_counter()
-    step(args.steps)
+    step(args.steps, sync=args.sync_calls)
     host_s = host_time[0]
     eng.synchronize()                    # with a delivery open: every chunk has landed in host memory
     sink_catch_up()                      # ... and the consumer has taken (and given back) every one of them
     barrier()
     dt = time.perf_counter() - t0
-    if os.environ.get("DBG_TIMELINE"):
-        sys.stderr.write("cpu.stat after: %s\n" % open("/sys/fs/cgroup/cpu.stat").read().replace("\n", " "))
-        import threading
-        sys.stderr.write("python threads: %d; os threads: %d\n" % (threading.active_count(), len(os.listdir("/proc/self/task"))))
     c2 = eng.counters()
     d2 = sink.totals() if sink else None
     if not dry:
@@ -858,6 +975,12 @@ def main():
                              "note": "the library's own clock around every slab transfer (dabx_delivery_get_info)"},
                      scope="this rank's GPU")
 
+    h2h = None
+    if not dry and rank == 0 and args.layout == "uniform" and not args.fic_only and not args.no_host_leg:
+        h2h = host_to_host_leg(args, subch, dx, link_probe[0])
+    single = None
+    if not dry and rank == 0 and args.layout == "uniform" and not args.no_single_legs:
+        single = single_ensemble_legs(torch, dev, args, rank, subch, dx)
     gc.enable()
     if rank == 0:
         value = frames / dt
@@ -936,11 +1059,13 @@ def main():
                       "frac_of_hbm_peak": round(value / n_joined * a_frame / HBM_PEAK, 6),
                       "kernel_ms_per_step_standalone": {k: round(v, 4) for k, v in share.items()}},
         }
+        if h2h is not None:
+            out["config"]["host_to_host"] = h2h
+        if single is not None:
+            out["config"]["single_ensemble"] = single
         if deliv is not None:
             deliv["at_timed_region_length"]["frac_of_value"] = round(deliv["at_timed_region_length"]["frames_per_s"] / (value / n_joined), 4)
             out["config"]["delivered_to_host"] = deliv
-        if not dry and not args.fic_only and args.layout == "uniform" and args.streams == 512:
-            out["config"]["pcie_inclusive"] = load_pcie_inclusive()
         if dry:
             out["dry"] = True
             out["data"] = "none (dry launch: control flow only)"
@@ -950,6 +1075,9 @@ def main():
                 args.unlocked, "silence" if args.unlocked_kind == "silence" else "the ensemble 60 dB down under its noise")
             out["unlocked_streams_per_gpu"] = args.unlocked
             out["frames_per_s_per_locked_stream"] = round(value / (n_joined * n_lock), 3)
+        if args.sync_calls:
+            out["config"]["workload"] += "; every dabx_process call synchronous (sync = 1)"
+            out["sync_calls"] = True
         if args.exact_level:
             out["config"]["workload"] += "; exact_level_tracker = 1"
             out["exact_level_tracker"] = 1

@@ -26,6 +26,7 @@ int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool as
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk, const DeliverDev *dv = nullptr,
                      hipStream_t *tail = nullptr);
 int launch_deliver_front(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
+int launch_ingest_convert(const EngineDev &e, const void *src, int fmt, size_t n, hipStream_t st);
 void dabx_internal_fibdec_skip(dabx_fibdec *d, long long n_fibs);     // fib.cpp: FIBs the decoder never saw (they had left the ring)
 int launch_dciq(const EngineDev &e, int mode, hipStream_t st);
 int launch_level_exact(const EngineDev &e, hipStream_t st);
@@ -69,6 +70,19 @@ struct Delivery {
   int32_t *subch_id = nullptr;
   long long *frames_done = nullptr, *cif_done = nullptr, *sf_done = nullptr;
   dabx_chunk_header hdr{};
+};
+
+// Bulk ingest (include/dabx.h "Bulk ingest"): page-locked input slabs, their device twins, one SDMA transfer per slab.
+struct Ingest {
+  bool open = false;
+  int fmt = 0, copy_engine = 0, max_frames = 0;
+  size_t capacity = 0;                           // bytes per slab
+  struct Slab { uint8_t *host = nullptr, *dev = nullptr; uint64_t sig = 0; size_t n = 0; bool in_flight = false; };
+  std::vector<Slab> slabs;
+  Sdma sdma;
+  hipStream_t cs = nullptr;                      // copy_engine 1 only
+  hipEvent_t committed = nullptr;                // the previous ingest commit has run on the front-end stream (the converter reads the committed indices)
+  bool committed_recorded = false;
 };
 
 struct dabx_engine {
@@ -118,6 +132,7 @@ struct dabx_engine {
   int32_t *locked_host = nullptr;              // hipHostMalloc'ed: number of streams in lock, kept by the device (EngineDev::locked_count)
   bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
   Delivery dl;
+  Ingest ing;
   int build_msc_classes();
   int delivery_layout();                       // offsets of every slot's bytes in a slab for the sub-channels configured now
   int delivery_begin(DeliverDev *dv, int *slot, int *devslab);     // a chunk closes: host + device slab, front gather on stream a
@@ -232,14 +247,17 @@ static int use_device(const dabx_engine *e)
 }
 
 static int delivery_drain(dabx_engine *e);
-static int sync_all(dabx_engine *e)
+// chain_only: what dabx_process(sync != 0) waits for -- the frame chain, the MSC batches and the delivery of the frames it issued -- but not
+// a search pass that runs next to them on stream q for streams out of lock (its results are picked up by the next step either way)
+static int sync_all(dabx_engine *e, bool chain_only = false)
 {
   if (int rc = use_device(e)) return rc;
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
   if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
-  if (e->ss.q) DABX_HIP(hipStreamSynchronize(e->ss.q));
   if (int rc = delivery_drain(e)) return rc;                       // every chunk closed so far has landed
+  if (chain_only && !e->dev.exact_level) return 0;
+  if (e->ss.q) DABX_HIP(hipStreamSynchronize(e->ss.q));
   e->ss.acq_in_flight = false;
   // cfg.exact_level_tracker: the level tracker follows the frame chain on its own; behind the last frame it is run once more, so
   // that what the host reads next (dabx_get_stats, the ring's read cursor) includes every sample the receiver has read
@@ -440,6 +458,21 @@ static void delivery_free(dabx_engine *e)
   D.landed = D.bytes_copied = 0; D.copy_s = D.copy_s_max = D.gather_wait_s = 0;
 }
 
+static void ingest_free(dabx_engine *e)
+{
+  Ingest &I = e->ing;
+  for (auto &sl : I.slabs) {
+    if (sl.in_flight && I.copy_engine == 0) (void)sdma_wait(sl.sig, 0);
+    if (sl.host) (void)hipHostFree(sl.host);
+    if (sl.dev) (void)hipFree(sl.dev);
+    sdma_signal_destroy(sl.sig);
+  }
+  I.slabs.clear();
+  if (I.cs) { (void)hipStreamSynchronize(I.cs); (void)hipStreamDestroy(I.cs); }
+  if (I.committed) (void)hipEventDestroy(I.committed);
+  I.cs = nullptr; I.committed = nullptr; I.committed_recorded = false; I.open = false; I.capacity = 0;
+}
+
 static int need_device_e()
 {
   int n = 0;
@@ -625,6 +658,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.prep_done) (void)hipEventDestroy(e->ss.prep_done);
   if (e->ss.msc_done) (void)hipEventDestroy(e->ss.msc_done);
   delivery_free(e);
+  ingest_free(e);
   for (dabx_tii *t : e->tii) dabx_tii_destroy(t);
   for (dabx_fibdec *f : e->fibdec) dabx_fibdec_destroy(f);
   if (e->ingest) { (void)hipStreamSynchronize(e->ingest); (void)hipStreamDestroy(e->ingest); }
@@ -988,8 +1022,9 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     if (int rc = e->build_msc_classes()) return rc;
     e->classes_dirty = false;
   }
-  // Streams out of lock: searched in step (every step waits for them) when the caller waits for the call's result anyway, next to
-  // the steps on their own HIP stream when it does not (pipelined use); cfg.acquire_mode 1 / 2 fixes either form.
+  // Streams out of lock are searched next to the steps, on their own HIP stream (k_acquire on q): a step of the streams in lock never waits
+  // for a stream in a drop-out -- with sync != 0 too: the call then waits for the frame chain it issued, not for the search pass beside it
+  // (a pass costs ~2 ms, two steps of 512 streams).  cfg.acquire_mode 1 / 2 fixes either form.
   // (With cfg.dc_iq_correction the committed samples are corrected in place on the front-end stream before anything reads them:
   // a search running next to that stream could read them uncorrected, so it stays in step.)
   // And while fewer than half of the streams are in lock (start-up of a whole engine; the device keeps the count in host memory, read
@@ -1010,7 +1045,7 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
     }
   }
   const bool some_locked = !e->locked_host || 2 * __atomic_load_n(e->locked_host, __ATOMIC_RELAXED) >= e->dev.n_streams;
-  const bool async_acquire = !e->cfg.dc_iq_correction && (e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && !sync && some_locked));
+  const bool async_acquire = !e->cfg.dc_iq_correction && (e->cfg.acquire_mode == 2 || (e->cfg.acquire_mode == 0 && some_locked));
   for (int i = 0; i < max_frames; i++) {
     // the 5th frame after a batch starts rewriting time-de-interleaver slots the previous batch's k_msc_prep (stream b) reads
     if (e->ss.prep_pending && e->pending_frames >= 4) {
@@ -1032,7 +1067,7 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
       e->pending_frames = 0;
     }
   }
-  if (sync && (max_frames = sync_all(e) ? -1 : max_frames) < 0) return DABX_E_HIP;
+  if (sync && (max_frames = sync_all(e, async_acquire) ? -1 : max_frames) < 0) return DABX_E_HIP;
   return max_frames;
 }
 
@@ -1285,6 +1320,14 @@ int dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int 
   return dabx_fibdec_subchannels(fd, 1, out, max_out);
 }
 
+int dabx_current_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || !out || max_out <= 0) return DABX_E_ARG;
+  dabx_fibdec *fd = e->fibdec[(size_t)stream];
+  if (!fd) { set_error("dabx_current_subchannels: call dabx_follow_fic first"); return DABX_E_STATE; }
+  return dabx_fibdec_subchannels(fd, 0, out, max_out);
+}
+
 #undef dabx_get_stats
 static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out);
 // The entry point binaries built against ABI 3 call: writes exactly the ABI-3 record (up to and including peak_level), so a
@@ -1358,6 +1401,100 @@ int dabx_get_counters(dabx_engine *e, int64_t out[16])
     out[14] += (int64_t)q.cif_out * 3 * q.kbps;                 // MSC bytes out
   }
   return 0;
+}
+
+int dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg)
+{
+  if (!e || (cfg && (cfg->host_slabs < 0 || cfg->host_slabs > 64 || cfg->fmt < 0 || cfg->fmt > 2 || cfg->max_frames < 0 || cfg->copy_engine < 0 || cfg->copy_engine > 1))) {
+    set_error("dabx_ingest_open: bad argument");
+    return DABX_E_ARG;
+  }
+  if (e->ing.open) { set_error("dabx_ingest_open: already open"); return DABX_E_STATE; }
+  if (int rc = use_device(e)) return rc;
+  Ingest &I = e->ing;
+  I.fmt = cfg ? cfg->fmt : 0;
+  I.copy_engine = cfg ? cfg->copy_engine : 0;
+  I.max_frames = cfg && cfg->max_frames ? cfg->max_frames : DL_FRAMES;
+  if ((long long)I.max_frames * TF > e->dev.ring_len) { set_error("dabx_ingest_open: a slab of %d frames does not fit the ring (%d frames)", I.max_frames, e->dev.ring_len / TF); return DABX_E_ARG; }
+  static const int bps[3] = {8, 4, 2};
+  I.capacity = (size_t)e->dev.n_streams * I.max_frames * TF * bps[I.fmt];
+  int rc;
+  if (I.copy_engine == 0 && (rc = sdma_open(e->device, &I.sdma))) return rc;
+#define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); ingest_free(e); return DABX_E_HIP; } } while (0)
+  if (I.copy_engine == 1) H(hipStreamCreateWithFlags(&I.cs, hipStreamNonBlocking));
+  H(hipEventCreateWithFlags(&I.committed, hipEventDisableTiming | hipEventReleaseToDevice));
+  I.slabs.resize((size_t)(cfg && cfg->host_slabs ? cfg->host_slabs : 2));
+  for (auto &sl : I.slabs) {
+    H(hipHostMalloc((void **)&sl.host, I.capacity, hipHostMallocDefault));
+    H(hipMalloc((void **)&sl.dev, I.capacity));
+    if (I.copy_engine == 0 && (rc = sdma_signal_create(&sl.sig))) { ingest_free(e); return rc; }
+  }
+#undef H
+  I.open = true;
+  return 0;
+}
+
+int dabx_ingest_close(dabx_engine *e)
+{
+  if (!e) return DABX_E_ARG;
+  if (!e->ing.open) return 0;
+  const int rc = sync_all(e);
+  ingest_free(e);
+  return rc;
+}
+
+int dabx_ingest_slab(dabx_engine *e, int k, void **host, size_t *capacity_bytes)
+{
+  if (!e || !host) return DABX_E_ARG;
+  if (!e->ing.open || k < 0 || k >= (int)e->ing.slabs.size()) { set_error("dabx_ingest_slab: no such slab"); return DABX_E_STATE; }
+  *host = e->ing.slabs[(size_t)k].host;
+  if (capacity_bytes) *capacity_bytes = e->ing.capacity;
+  return 0;
+}
+
+int dabx_ingest_submit(dabx_engine *e, int k, size_t n)
+{
+  if (!e) return DABX_E_ARG;
+  Ingest &I = e->ing;
+  if (!I.open || k < 0 || k >= (int)I.slabs.size()) { set_error("dabx_ingest_submit: no such slab"); return DABX_E_STATE; }
+  if (n == 0 || n > (size_t)I.max_frames * TF) { set_error("dabx_ingest_submit: %zu samples per stream, the slabs hold %d frames", n, I.max_frames); return DABX_E_ARG; }
+  if (int rc = use_device(e)) return rc;
+  Ingest::Slab &sl = I.slabs[(size_t)k];
+  if (sl.in_flight) { set_error("dabx_ingest_submit: slab %d has a transfer that was not committed", k); return DABX_E_STATE; }
+  static const int bps[3] = {8, 4, 2};
+  const size_t bytes = (size_t)e->dev.n_streams * n * bps[I.fmt];
+  // (the device twin is free: its converter ran on the ingest stream before the commit that cleared in_flight was queued, and a slab is
+  //  only reused after its commit -- by then, with two slabs, a whole chunk later)
+  DABX_HIP(hipStreamSynchronize(e->ingest));
+  if (I.copy_engine == 0) { if (int rc = sdma_copy(I.sdma, sl.dev, sl.host, bytes, false, sl.sig)) return rc; }
+  else DABX_HIP(hipMemcpyAsync(sl.dev, sl.host, bytes, hipMemcpyHostToDevice, I.cs));
+  sl.n = n; sl.in_flight = true;
+  return 0;
+}
+
+int dabx_ingest_commit(dabx_engine *e, int k)
+{
+  if (!e) return DABX_E_ARG;
+  Ingest &I = e->ing;
+  if (!I.open || k < 0 || k >= (int)I.slabs.size()) { set_error("dabx_ingest_commit: no such slab"); return DABX_E_STATE; }
+  if (int rc = use_device(e)) return rc;
+  Ingest::Slab &sl = I.slabs[(size_t)k];
+  if (!sl.in_flight) { set_error("dabx_ingest_commit: slab %d was not submitted", k); return DABX_E_STATE; }
+  for (int s = 0; s < e->dev.n_streams; s++)
+    if (int rc = push_room(e, s, sl.n, "dabx_ingest_commit")) return rc;          // (the transfer stays pending: process, then commit again)
+  if (I.copy_engine == 0) { if (int rc = sdma_wait(sl.sig, 0)) return rc; }
+  else DABX_HIP(hipStreamSynchronize(I.cs));
+  for (int s = 0; s < e->dev.n_streams; s++) announce_write(e, s, e->wr_host[s] + sl.n);
+  // the converter reads the committed indices on the device: behind the previous ingest commit (front-end stream), next to the decode
+  if (I.committed_recorded) DABX_HIP(hipStreamWaitEvent(e->ingest, I.committed, 0));
+  if (int rc = launch_ingest_convert(e->dev, sl.dev, I.fmt, sl.n, e->ingest)) return rc;
+  DABX_HIP(hipEventRecord(e->ingest_done, e->ingest));
+  DABX_HIP(hipStreamWaitEvent(e->stream, e->ingest_done, 0));
+  const int rc = commit_impl(e, -1, sl.n);
+  DABX_HIP(hipEventRecord(I.committed, e->stream));
+  I.committed_recorded = true;
+  sl.in_flight = false;
+  return rc;
 }
 
 int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)

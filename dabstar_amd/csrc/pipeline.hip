@@ -14,6 +14,7 @@
 //   k_dabplus      super-frame sync, RS(120,110), fire code, AU CRCs (mp4processor.cpp:96-333)
 #include <type_traits>
 #include "pipeline.h"
+#include <algorithm>
 #include "ofdm_core.h"
 #include "viterbi_core.h"
 #include "fec_core.h"
@@ -2004,6 +2005,29 @@ __global__ void k_convert_iq(const void *src, int fmt, float2 *ring, int ring_le
 int launch_convert_iq(const void *src, int fmt, float2 *ring, int ring_len, unsigned long long wr0, size_t n, hipStream_t st)
 {
   hipLaunchKernelGGL(k_convert_iq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, fmt, ring, ring_len, wr0, n);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+
+// bulk ingest (engine.cpp, dabx_ingest_commit): [S][n] samples of fmt in `src` -> every stream's ring behind its committed index
+__global__ __launch_bounds__(256) void k_ingest_convert(const void *src, int fmt, float2 *iq, int ring_len, const unsigned long long *wr, size_t n)
+{
+  const int s = blockIdx.y;
+  const unsigned long long wr0 = wr[s];
+  float2 *ring = iq + (size_t)s * ring_len;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = (size_t)s * n + i;
+    float2 v;
+    if (fmt == 0) v = reinterpret_cast<const float2 *>(src)[j];
+    else if (fmt == 1) { const short2 q = reinterpret_cast<const short2 *>(src)[j]; v = make_float2(q.x / 32768.0f, q.y / 32768.0f); }
+    else { const uchar2 q = reinterpret_cast<const uchar2 *>(src)[j]; v = make_float2((q.x - 127.38f) / 128.0f, (q.y - 127.38f) / 128.0f); }
+    ring[(size_t)((wr0 + i) % (unsigned long long)ring_len)] = v;
+  }
+}
+int launch_ingest_convert(const EngineDev &e, const void *src, int fmt, size_t n, hipStream_t st)
+{
+  const unsigned bx = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_ingest_convert, dim3(bx, e.n_streams), dim3(256), 0, st, src, fmt, e.iq, e.ring_len, e.wr, n);
   DABX_HIP(hipGetLastError());
   return 0;
 }

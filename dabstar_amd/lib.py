@@ -336,6 +336,10 @@ class DeliveryConfig(C.Structure):
     _fields_ = [("host_slabs", C.c_int32), ("what", C.c_int32), ("copy_engine", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
+class IngestConfig(C.Structure):
+    _fields_ = [("host_slabs", C.c_int32), ("fmt", C.c_int32), ("max_frames", C.c_int32), ("copy_engine", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 class DeliveryInfo(C.Structure):
     _fields_ = [("chunks_closed", C.c_uint64), ("chunks_landed", C.c_uint64), ("bytes_copied", C.c_uint64), ("copy_seconds", C.c_double),
                 ("copy_seconds_max", C.c_double), ("gather_wait_seconds", C.c_double), ("copy_engine", C.c_int32),
@@ -545,6 +549,30 @@ class Engine:
         out = np.zeros((75, 3072), np.int16)
         check(load().dabx_read_soft(self._h, stream, _p(out)))
         return out
+
+    def ingest_open(self, fmt, slabs=2, max_frames=0, copy_engine=0):
+        """fmt: numpy dtype (complex64 / int16 / uint8) or 0..2.  Returns the page-locked slabs as numpy arrays [n_streams * max_frames * TF (* 2)]."""
+        code = fmt if isinstance(fmt, int) else {np.dtype(np.complex64): 0, np.dtype(np.int16): 1, np.dtype(np.uint8): 2}[np.dtype(fmt)]
+        cfg = IngestConfig(host_slabs=slabs, fmt=code, max_frames=max_frames, copy_engine=copy_engine)
+        L = load()
+        L.dabx_ingest_submit.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        check(L.dabx_ingest_open(self._h, C.byref(cfg)))
+        out = []
+        for k in range(slabs):
+            p, cap = C.c_void_p(), C.c_size_t()
+            check(L.dabx_ingest_slab(self._h, k, C.byref(p), C.byref(cap)))
+            dt = (np.complex64, np.int16, np.uint8)[code]
+            out.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap.value,)).view(dt))
+        return out
+
+    def ingest_submit(self, k, n_samples):
+        check(load().dabx_ingest_submit(self._h, k, n_samples))
+
+    def ingest_commit(self, k):
+        check(load().dabx_ingest_commit(self._h, k))
+
+    def ingest_close(self):
+        check(load().dabx_ingest_close(self._h))
 
     def delivery_open(self, slots=4, what=0, copy_engine=0):
         cfg = DeliveryConfig(host_slabs=slots, what=what, copy_engine=copy_engine)

@@ -256,15 +256,14 @@ typedef struct {
                                  1: exact in lock too (a second pass over every sample on a HIP stream of its own: -27 % throughput
                                    at 512 streams);
                                  2: chunk-wise only, the search continues from that value (the behaviour before round 4). */
-  int32_t acquire_mode;       /* streams OUT of lock (null-symbol search + candidate correlations, k_acquire): 0 (default) -- by the
-                                 way dabx_process is called: sync != 0 searches in step (every step first gives every such stream a
-                                 frame's worth of search, exactly DabProcessor's order of events per stream), sync == 0 searches on
-                                 a HIP stream of its own next to the steps of the streams in lock, which never wait for it (a
-                                 stream joins the first step after its search has finished; while fewer than half of the streams are
-                                 in lock -- start-up -- the search runs in step even then); 1: always in step; 2: always
-                                 asynchronous.  Same samples, same decisions, same frames either way -- only WHEN differs.  (With
-                                 dc_iq_correction the search always runs in step: the correction of newly committed samples is ordered
-                                 on the front-end stream.) */
+  int32_t acquire_mode;       /* streams OUT of lock (null-symbol search + candidate correlations, k_acquire): 0 (default) -- searched on a HIP
+                                 stream of their own next to the steps of the streams in lock, which never wait for them (a stream joins the
+                                 first step after its search has finished); dabx_process(sync != 0) waits for the frames it issued, not for a
+                                 search pass beside them.  While fewer than half of the streams are in lock -- start-up, a lone stream that
+                                 lost its lock -- the search runs in step: every step first gives every such stream a frame's worth of
+                                 search, exactly DabProcessor's order of events per stream.  1: always in step; 2: always asynchronous.
+                                 Same samples, same decisions, same frames either way -- only WHEN differs.  (With dc_iq_correction the
+                                 search always runs in step: the correction of newly committed samples is ordered on the front-end stream.) */
 } dabx_config;
 
 /* SDescriptorType subset (common/dab_constants.h:119-135) */
@@ -379,6 +378,9 @@ typedef struct {
 } dabx_reconf;
 int  dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out);
 int  dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
+/* ... and the CURRENT table of the same decoder (after a swap: the former next table plus whatever the new configuration's own FIGs,
+ * C/N = 0, have added since -- first description wins). */
+int  dabx_current_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
 /* dabx_set_subchannels whose new and changed slots start at CIF at_cif instead of at the next CIF to be demodulated:
  * next CIF <= at_cif <= next CIF + 3 (a reconfiguration inside the coming frame).  stream >= 0. */
 int  dabx_set_subchannels_at(dabx_engine *e, int stream, const dabx_subch_desc *d, int n, int64_t at_cif);
@@ -501,6 +503,28 @@ typedef struct {
 int  dabx_delivery_get_info(dabx_engine *e, dabx_delivery_info *out);
 /* Bytes one slab takes with the sub-channels configured now (what one chunk moves over the link). */
 long long dabx_delivery_slab_bytes(dabx_engine *e);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Bulk ingest: the delivery's mirror image for the samples.  dabx_push_iq* hands over one stream's samples per call -- right for a
+ * device front end, 512 calls per chunk for a host that feeds 512 recordings.  With an ingest open the host fills ONE page-locked slab
+ * with the next n samples of EVERY stream ([n_streams][n] samples of fmt, stream after stream), ONE SDMA transfer moves it, one kernel
+ * converts it into all rings and one commit makes it readable:
+ *     fill slab k;  dabx_ingest_submit(e, k, n);            the transfer starts, the call returns
+ *     dabx_ingest_commit(e, k');                            waits for the transfer of slab k' (the previous one), converts, commits
+ *     dabx_process(e, frames, 0);                           decodes it while slab k is still on the link
+ * The raw_reader.cpp:66-70 / wav_reader.cpp:164 sample maps (fmt 2 / 1) run on the device: only 2 / 4 bytes per sample cross the link. */
+typedef struct {
+  int32_t host_slabs;       /* page-locked input slabs, >= 1 (0 = default 2) */
+  int32_t fmt;              /* 0 cf32, 1 int16 IQ, 2 uint8 IQ: as dabx_push_iq */
+  int32_t max_frames;       /* samples per stream a slab holds, in frames of T_F (0 = default DABX_CHUNK_FRAMES) */
+  int32_t copy_engine;      /* as dabx_delivery_config.copy_engine */
+  int32_t reserved[4];
+} dabx_ingest_config;
+int  dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg);
+int  dabx_ingest_close(dabx_engine *e);
+int  dabx_ingest_slab(dabx_engine *e, int k, void **host, size_t *capacity_bytes);
+int  dabx_ingest_submit(dabx_engine *e, int k, size_t n_samples);     /* DABX_E_STATE: the slab's previous transfer has not been committed */
+int  dabx_ingest_commit(dabx_engine *e, int k);                        /* DABX_E_STATE: a ring cannot take the samples (dabx_process first) */
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around every launch of a batch step
  * (bench.py's roofline leg).  dabx_get_profile drains the events recorded since the last call: for each of

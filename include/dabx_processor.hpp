@@ -109,6 +109,7 @@ public:
         else apply_next_configuration(before.frames == frame ? rc.at_cif : -1);     // (-1: the announcement was seen too late: switch now)
         if (before.frames >= frame) applied_cif_ = rc.at_cif;
       }
+      if (verify_frame_ >= 0 && before.frames >= verify_frame_) stop_services_that_ended();
     }
     check(dabx_process(eng_, max_frames, 1), "dabx_process");
     check(dabx_get_stats(eng_, 0, &after), "dabx_get_stats");
@@ -219,6 +220,7 @@ private:
   bool tii_on_ = false, tii_collisions_ = false;
   int tii_threshold_ = 6, tii_sub_id_ = 0;
   long long applied_cif_ = -1;                  // first CIF of the newest configuration that has been switched to
+  long long verify_frame_ = -1;                 // frame at which services kept through a switch without being listed are checked against the new table
 
   // carries the running services over to the NEXT configuration (FIG 0/1 and 0/2 with C/N = 1) from CIF at_cif on
   void apply_next_configuration(long long at_cif)
@@ -239,7 +241,7 @@ private:
       }
       // A running service stops only when the next table says so positively: its capacity units go to another sub-channel.  One that
       // the table simply does not list (FIBs lost before the switch, or a multiplexer that announces only what changes) keeps running.
-      if (!listed && !displaced) now = old;
+      if (!listed && !displaced) { now = old; verify_frame_ = std::max<long long>(0, at_cif) / 4 + 3; if (at_cif < 0) verify_frame_ = -2; }
       if (now.kbps && now.dab_plus < 0) now.dab_plus = old.dab_plus;
       // (a sub-channel that only moves to other capacity units keeps running in the engine: same counters)
       const bool same = now.kbps == old.kbps && now.cu_size == old.cu_size &&
@@ -252,6 +254,29 @@ private:
     if (at_cif >= 0) check(dabx_set_subchannels_at(eng_, 0, slots_.data(), n, at_cif), "dabx_set_subchannels_at");
     else check(dabx_set_subchannels(eng_, 0, slots_.data(), n), "dabx_set_subchannels");
     if (on_configuration_change) on_configuration_change(at_cif);
+    if (verify_frame_ == -2) {                   // (switched late, without a CIF to count from: three frames from now)
+      dabx_stats st;
+      check(dabx_get_stats(eng_, 0, &st), "dabx_get_stats");
+      verify_frame_ = st.frames + 3;
+    }
+  }
+  // Three frames into the new configuration its own FIGs (C/N = 0) have completed whatever the announcement left out of the table
+  // (first description wins): a service that was kept running only because the next table did not list it, and that the current
+  // table still does not list, has ended with the old configuration.
+  void stop_services_that_ended()
+  {
+    verify_frame_ = -1;
+    std::vector<dabx_subch_desc> cur(64);
+    const int n_cur = dabx_current_subchannels(eng_, 0, cur.data(), 64);
+    if (n_cur <= 0) return;
+    bool changed = false;
+    for (auto &sl : slots_) {
+      if (!sl.kbps) continue;
+      bool listed = false;
+      for (int k = 0; k < n_cur; k++) listed = listed || cur[(size_t)k].subch_id == sl.subch_id;
+      if (!listed) { sl = dabx_subch_desc{}; changed = true; }
+    }
+    if (changed) apply();
   }
 
   bool any_service() const

@@ -1057,6 +1057,16 @@ def test_streams_in_different_states_and_configurations_do_not_interact():
     for _ in range(30):
         eng.process(3)
     del late
+    # a stream that lost its lock is searched NEXT to the steps of the others (also with sync = 1, since round 5) and joins the first step
+    # after its search has finished: it needs a few more calls than a lone stream to get through the same samples
+    idle, last = 0, None
+    for _ in range(60):
+        eng.process(1)
+        now = [(eng.stats(s)["frames"], eng.stats(s)["samples_consumed"]) for s in range(4)]
+        idle = idle + 1 if now == last else 0
+        last = now
+        if idle >= 4:
+            break
     for s in range(3):
         ref = dx.Engine(n_streams=1, ring_frames=22, max_subch=18, out_frames=4)
         ref.set_subchannels(cfgs[s])

@@ -209,7 +209,7 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
                 pos, sti = eng.read_frame_info(s, new)
                 walk[s].extend(zip(pos.tolist(), sti.tolist()))
 
-    if fast.get("acquire_mode") == 2:
+    if fast.get("acquire_mode", 0) != 1:            # (0, the default, searches next to the steps too once half of the streams are in lock)
         # The search runs next to the steps and a pass is launched only when the previous one has finished: of a call that queues
         # several steps at once only the first starts one.  A stream that flaps on false peaks (lock, one junk frame, loss, search, ...)
         # therefore gets through one such cycle per CALL, not per step -- it holds nobody up, which is the point, but needs more calls

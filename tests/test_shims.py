@@ -89,9 +89,9 @@ def test_one_ensemble_symbol_by_symbol_through_the_three_shims(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["frames"] == n_frames and res["drivers"] == 4 and res["stopped_ok"] and res["ratio_reset"]
-    # the status signals: one signal_fic_status (48 FIC blocks: the 40th reports) with the channel BER of a clean 19-dB channel, two LCD
-    # records (one about every 5 frames, ofdm_decoder.cpp:155-157) whose SNR is the channel's
-    assert 0.0 <= res["fic_status_ber"] < 1e-3 and res["lcd_count"] == 2 and 15.0 < res["lcd_snr"] < 30.0 and 1 <= res["lcd_symbol"] <= 76
+    # the status signals: one signal_fic_status (48 FIC blocks: the 40th reports) with the channel BER of a 19-dB channel, one LCD record
+    # (after 5 frames of symbols, on symbol 1 of the frame that follows: ofdm_decoder.cpp:155-157; the next would fall into a 13th frame)
+    assert 0.0 <= res["fic_status_ber"] < 5e-3 and res["lcd_count"] == 1 and 15.0 < res["lcd_snr"] < 30.0 and res["lcd_symbol"] == 2
 
     # ---- oracle: the same per-symbol class calls on the same FFT outputs (all four services from frame 0)
     L = ol.oracle()
