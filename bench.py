@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--sync-calls", action="store_true",
                     help="not the headline: every dabx_process call of the timed region waits for its frames (sync = 1, a live receiver's form) -- "
                          "with --unlocked: streams in a drop-out are searched next to the steps in this form too")
+    ap.add_argument("--keep-gc", action="store_true", help="experiments: leave python's cyclic garbage collector on during the timed regions")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host leg (config.host_to_host)")
     ap.add_argument("--no-single-legs", action="store_true", help="skip the single-ensemble legs (config.single_ensemble)")
     ap.add_argument("--deliver-copy-engine", type=int, default=0, choices=[0, 1], help="experiments: dabx_delivery_config.copy_engine (1 = hipMemcpyAsync)")
@@ -676,7 +677,7 @@ def oracle_fib_check(eng, sink, subch, streams, ring_frames):
 
 def load_traffic(dom):
     """HBM bytes and VALU instructions per FRAME of kernel `dom` from the committed rocprofv3 --pmc passes (tools/prof_round.sh)."""
-    for name in ("r04_traffic.json", "r03_traffic_final.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic_final.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -836,7 +837,8 @@ def main():
     # steps bring it back up).
     import gc
     gc.collect()
-    gc.disable()
+    if not args.keep_gc:
+        gc.disable()
     # priming (untimed, not part of warmup): acquisition, CFO pull-in, 16-CIF de-interleaver fill, super-frame sync
     eng.commit(ring_frames * TF - TF)
     step(40)

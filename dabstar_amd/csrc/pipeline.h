@@ -4,10 +4,10 @@
 
 namespace dabx {
 
-constexpr int MSC_SLOTS = 32;     // ring of decoded logical frames per sub-channel (>= 16 new + 4 of the previous super frame)
 #ifndef DABX_MSC_BATCH               // experiment builds only (tools/build_variant.sh -DDABX_MSC_BATCH=n, bench.py --chunk n)
 #define DABX_MSC_BATCH 7
 #endif
+constexpr int MSC_SLOTS = DABX_MSC_BATCH > 7 ? 64 : 32;   // ring of decoded logical frames per sub-channel (>= 4 x batch new + 4 of the previous super frame)
 constexpr int MSC_BATCH_FRAMES = DABX_MSC_BATCH; // frames whose MSC CIFs are decoded together (the MSC has no feedback into the front end);
                                     // 7 x 4 CIFs x 18 sub-channels x 512 streams / 64 = 4032 waves = 3.94 per SIMD
 constexpr int SF_SLOTS = 16;      // ring of RS-corrected super frames per sub-channel: two chunks' worth (a 7-frame MSC batch completes up to 6)

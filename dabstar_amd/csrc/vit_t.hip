@@ -423,7 +423,12 @@ __device__ __forceinline__ void msc_vitT_body(const EngineDev &e, int cifs, cons
     }
   }
 }
-__global__ __launch_bounds__(64) void k_msc_vitT(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<0>(e, cifs, ML, prbs); }
+#ifdef DABX_VIT_WAVES                 // experiment builds only (tools/build_variant.sh -DDABX_VIT_WAVES=5 -DDABX_MSC_BATCH=9): ask for a fifth wave per SIMD
+#define DABX_VIT_OCC __attribute__((amdgpu_waves_per_eu(DABX_VIT_WAVES, DABX_VIT_WAVES)))
+#else
+#define DABX_VIT_OCC
+#endif
+__global__ __launch_bounds__(64) DABX_VIT_OCC void k_msc_vitT(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<0>(e, cifs, ML, prbs); }
 // the same trellises decoded with the arithmetic of the reference's VITERBI_AVX2 / VITERBI_SSE2 builds (cfg.viterbi_tie_mode)
 __global__ __launch_bounds__(64) void k_msc_vitT_avx2(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<1>(e, cifs, ML, prbs); }
 __global__ __launch_bounds__(64) void k_msc_vitT_sse2(EngineDev e, int cifs, MscLaunch ML, const uint32_t *prbs) { msc_vitT_body<2>(e, cifs, ML, prbs); }

@@ -6,15 +6,15 @@
 # 64-byte runs, one HBM line each (x1); WRITE_SIZE is exact for the coalesced patterns.
 # Usage: tools/prof_round.sh <tag> [commit]      -> gpurun_out/<tag>/...   (commit: `git rev-parse --short HEAD` of what is measured --
 #        .git does not travel to the GPU box; it is written into traffic.json and printed by bench.py as roofline.traffic_commit)
-TAG=${1:-r04}
+TAG=${1:-r05}
 export DABX_PROF_COMMIT=${2:-unknown}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-deliver-leg --no-host-leg --no-single-legs > $OUT/stats_bench.log 2>&1
 FILT="k_msc_vitT|k_msc_prep|k_demap_frame|k_demap_fic|k_symbols|k_dabplus|k_fic_frame|k_frame_head|k_frame_tail|k_acquire"
-ARGS="--steps 14 --warmup 7 --no-cpu-baseline"
+ARGS="--steps 14 --warmup 7 --no-cpu-baseline --no-deliver-leg --no-host-leg --no-single-legs"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY \
   --kernel-include-regex "$FILT" -d $OUT/p1 --output-format csv -- python3 bench.py $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
