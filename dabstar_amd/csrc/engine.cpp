@@ -22,7 +22,7 @@
 #include <vector>
 
 namespace dabx {
-int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool async_acquire);
+int launch_front_step(const EngineDev &e, EngineStreams &ss, Marker &mk, bool async_acquire, bool all_locked);
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk, const DeliverDev *dv = nullptr,
                      hipStream_t *tail = nullptr);
 int launch_deliver_front(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
@@ -1052,7 +1052,8 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
       DABX_HIP(hipStreamWaitEvent(e->stream, e->ss.prep_b_done, 0));
       e->ss.prep_pending = false;
     }
-    int rc = launch_front_step(e->dev, e->ss, e->mk, async_acquire);
+    const bool all_locked = e->locked_host && __atomic_load_n(e->locked_host, __ATOMIC_RELAXED) == e->dev.n_streams;
+    int rc = launch_front_step(e->dev, e->ss, e->mk, async_acquire, all_locked);
     if (rc) return rc;
     e->level_dirty = true;
     if (++e->pending_frames == MSC_BATCH_FRAMES || i == max_frames - 1) {

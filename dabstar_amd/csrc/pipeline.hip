@@ -1770,7 +1770,7 @@ const char *const kStepKernelNames[11] = {"k_acquire", "k_frame_head", "k_symbol
 // chain) and the frame tail follow on a, while the 72 MSC symbols are demapped on stream d: nothing on the chain of the NEXT
 // frame needs them, so a goes on to frame n + 1 while d is busy; the next frame's first demapper launch (and the MSC batch)
 // wait for d.  Serial schedule (cfg.schedule = 1, ss.d null): every kernel on a in program order.
-int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool async_acquire)
+int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool async_acquire, bool all_locked)
 {
   const DevTables *t;
   int rc = get_tables(&t);
@@ -1784,7 +1784,12 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   // cfg.exact_level_tracker: k_level_exact in front of every pass (same HIP stream).  The frame chain never waits for it: the level is
   // read nowhere in lock, the tracker walks whatever the receiver has read since its last pass ([level_pos, rd): 0.2 ms per frame
   // and stream since level_par.h, a fifth of a step), and the samples it still has to see stay in the ring (push_room, engine.cpp).
-  if (async_acquire && ss.q) {
+  // all_locked: the device's count of streams in lock (host memory, read by dabx_process without a wait) equals n_streams: nobody is
+  // searching, k_acquire would return from every block at once -- its launch, event record and query are left out (round 4 had put them on
+  // every step; the one-stream chain, 0.15 ms per frame, paid 8-11 % for them: profiles/r05_ab/ab3_single_ensemble_r3_r4_head.txt).  A
+  // stream that loses its lock decrements the count in k_frame_head: the first step issued after that launches the search again.
+  if (all_locked && !e.exact_level) {
+  } else if (async_acquire && ss.q) {
     // a search pass only when q has nothing left to do (a host that queues twenty steps in a millisecond starts one, not twenty: a pass can
     // take 2 ms); the level tracker with EVERY step -- it is short, and what it leaves undone the next one has to do
     const bool go = !ss.acq_in_flight || hipEventQuery(ss.acq_done) == hipSuccess;
