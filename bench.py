@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 TF = 196608
 A_FRAME = 2115456          # algorithmic HBM bytes per frame, SURVEY.md 8(d)
 A_FRAME_FIC = 1659264      # the same for config 2 (FIC only)
-# per-kernel share of those bytes (DESIGN.md "Kernels"): what each kernel must move at least
+# per-kernel share of those bytes: what each kernel must move at least
 A_KERNEL = {
     "k_msc_prep": 2 * 4 * 55296,                       # planar TDI read, transposed symbols written
     "k_msc_vitT": 4 * 55296 + 4 * 3456,                # transposed symbols read, packed logical frames out

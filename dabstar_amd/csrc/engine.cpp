@@ -513,7 +513,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // lo = least urgent (numerically greatest)
 #ifdef DABX_CU_SPLIT
-  // Experiment builds only (tools/build_variant.sh -DDABX_CU_SPLIT=n; DESIGN.md 6 "spatial partitioning"): the front-end stream gets
+  // Experiment builds only (tools/build_variant.sh -DDABX_CU_SPLIT=n; docs/history/r01-r04_design_notebook.md 6 "spatial partitioning"): the front-end stream gets
   // n of the 256 CUs, the decoder and the MSC symbols' demapper the other 256 - n.  The KFD deals the bits of a queue's CU mask
   // round-robin to the 8 XCDs, so the first n bits are n / 8 CUs on every XCD.
   uint32_t mask_front[8], mask_back[8];

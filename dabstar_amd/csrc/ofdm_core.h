@@ -278,7 +278,7 @@ __device__ __forceinline__ void cvt4_i16_x86(float a, float b, float c, float d,
 // -(pi/4 - r) or +(pi/4 - r): ONE magnitude and a sign = NOT[(|y| > |x|) xor (x < 0) xor (y < 0)], taken from the sign bits of
 // |y| - |x|, x and y.  On an axis (min = 0, incl. b = 0 with either sign of zero) the reference's fmod returns 0, i.e. -pi/4:
 // the sign is forced there.  No quadrant selects, no compares (the value only feeds the +-20 degree integrator with gain
-// 1e-3: far inside the soft-bit tolerance).
+// 1e-3: far inside the soft-bit tolerance, docs/history/r01-r04_design_notebook.md 4).
 __device__ __forceinline__ float atan_octant_poly(float t)
 {
   const float z = t * t;

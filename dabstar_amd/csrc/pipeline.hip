@@ -27,7 +27,7 @@ namespace dabx {
 // block per stream); the batched MSC decoder (k_msc_vitT, own HIP stream) keeps every SIMD's VALU busy with four waves of
 // independent work.  At equal priority the arbiter shares issue slots evenly and the front end -- the critical path of a
 // step -- runs at half speed whenever the decoder is resident.  s_setprio 3 lets front-end waves issue first; the decoder
-// fills the slots they leave (+2.5 % same-box).
+// fills the slots they leave (+2.5 % same-box, docs/history/r01-r04_design_notebook.md 6).
 __device__ __forceinline__ void front_prio() { __builtin_amdgcn_s_setprio(3); }
 
 // IQ ring addressing: one 64-bit modulo per thread and kernel (for the window base), then 32-bit

@@ -254,7 +254,7 @@ typedef struct {
                                    Failing that too, the level continues from the chunk-wise value: level_unanchored_events; the
                                    returns walked from the anchor itself are counted in level_rewalk_events;
                                  1: exact in lock too (a second pass over every sample on a HIP stream of its own: -27 % throughput
-                                   at 512 streams);
+                                   at 512 streams, docs/history/r01-r04_design_notebook.md 6);
                                  2: chunk-wise only, the search continues from that value (the behaviour before round 4). */
   int32_t acquire_mode;       /* streams OUT of lock (null-symbol search + candidate correlations, k_acquire): 0 (default) -- searched on a HIP
                                  stream of their own next to the steps of the streams in lock, which never wait for them (a stream joins the
@@ -552,7 +552,7 @@ int  dabx_get_profile(dabx_engine *e, double total_ms[DABX_MAX_KERNELS], int64_t
  * interpolated to 2048 output samples (wav_reader.cpp:67-82,190-206; xml_reader.cpp:76-81,226-248; the two readers
  * differ in their table arithmetic and in how the first block is primed, selected by `family`).
  * By default four defects of the reference's UFF reader are NOT reproduced (each evidently a typo, not a format rule;
- * DESIGN.md 9): QI/float32 is decoded as swapped IQ (the reference does not swap, xml_reader.cpp:530,540), int24/MSB takes
+ * docs/history/r01-r04_design_notebook.md 9): QI/float32 is decoded as swapped IQ (the reference does not swap, xml_reader.cpp:530,540), int24/MSB takes
  * the middle byte of Q from its own sample (the reference reads lbuf[4*i+4] of its 1-ms read block, :316 and :462),
  * QI/int24/MSB sign-extends with 0xFF000000 (the reference ORs 0x7F000000, :465,:469), QI/uint8 is decoded from the data
  * (the reference indexes its 256-entry table with the loop counter, :423).  With dabx_iq_format.reference_quirks = 1 the

@@ -8,7 +8,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
  * and only as the checker.  The product (dabstar_amd/, libdabx.so) never links it.
  *
- * Pinning status (see DESIGN.md "Oracle"):
+ * Pinning status:
  *   - integer stages (Viterbi, puncture tables, EEP/UEP depuncture, RS, Galois,
  *     fire code, CRC, frequency interleaver, PRS table) are PINNED: they are checked
  *     bit-for-bit against the reference's own object code built by oracle/ref/Makefile

@@ -258,12 +258,12 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
         # Frames in which soft values of the FIC symbols left the int16 range (the level returning after a drop-out before the
         # demapper's means have followed) are outside the comparison: the reference's `(i16)` cast is undefined behaviour
         # there, the x86 wrap-around both sides reproduce turns a last-ulp float difference into a full-scale one, and the
-        # decoder's answer to such symbols is arbitrary (fuzz seed 3003: one FIB of one frame).
+        # decoder's answer to such symbols is arbitrary (fuzz seed 3003: one FIB of one frame, docs/history/r01-r04_design_notebook.md 4).
         # the walk through the samples: every frame found at the same sample with the same start index, whatever the state
         # machine did in between (failed correlations, false dips, losses of lock) -- also for streams that never decode a FIB
         same_walk = [w[0] for w in walk[s][:n]] == ora["sym0"][:n].tolist() and [w[1] for w in walk[s][:n]] == ora["start"][:n].tolist()
         if not same_walk:
-            # The one deliberate approximation of the state machine: in lock the level tracker advances chunk by
+            # The one deliberate approximation of the state machine (docs/history/r01-r04_design_notebook.md 4): in lock the level tracker advances chunk by
             # chunk, not sample by sample, which moves s_level by ~1e-5 relative -- the size of the float noise of the
             # reference's own 196 608-step recurrence.  On a stream that only ever locks on false peaks the null-dip detector
             # of a later attempt can then fall on the other side of its threshold (hunt 5000-5047: seed 5030, stream 18 of
@@ -284,14 +284,14 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
         okm &= clean[:, None]
         assert np.array_equal(ef[okm], of[okm]), tag                  # every FIB that passes its CRC: identical bytes
         # FIBs that fail the CRC are the decoder's answer to noise; with the float demapper equal only within tolerance
-        #  a few of them may differ -- they must stay rare and confined to frames without a good FIB
+        # (docs/history/r01-r04_design_notebook.md 4) a few of them may differ -- they must stay rare and confined to frames without a good FIB
         bad_diff = (ef != of).any(axis=2) & ~okm & clean[:, None]
         n_bad_diff += int(bad_diff.sum()); n_bad += int((~okm & clean[:, None]).sum())
         if os.environ.get("DABX_FUZZ_VERBOSE") and bad_diff.any():
             print("garbage FIBs differ:", tag, "frames", np.nonzero(bad_diff.any(axis=1))[0].tolist(), "of", n, "crc ok per frame", okm.sum(axis=1).tolist())
         locked += int(ora["crc"][:n].sum() > 12 * n // 2)
         # MSC bytes are compared where the signal is decodable.  Below ~6 dB the EEP 3-A sub-channels decode with residual
-        # errors, and a soft bit that differs by one LSB (float demapper) can tip a survivor path: seen once in
+        # errors, and a soft bit that differs by one LSB (float demapper, docs/history/r01-r04_design_notebook.md 4) can tip a survivor path: seen once in
         # 2 600 streams, at 3.7 dB, identically on both MSC decoder kernels.  Above that the same happens inside the fades of
         # the mobile channels and under echoes (hunt 8000-8095: a stream at 8 dB in a fading channel, soft-bit generator 3, where
         # the oracle itself got 271 of its logical frames wrong and the engine's wrong frames differ from the oracle's wrong frames
@@ -367,7 +367,7 @@ def test_random_channels_and_layouts_follow_the_oracle(seed, cfg, fast, tie):
     assert msc_wrong_differ <= max(3, 0.25 * msc_oracle_wrong), (msc_wrong_differ, msc_oracle_wrong)
     assert eti_checked >= N_CASES // 4
     assert compared >= N_CASES // 3 and locked >= N_CASES // 2                                    # most of the draws do lock and decode
-    # FIBs that fail their CRC on both sides: a soft bit that differs by one LSB (2-4 in 10^5) anywhere in a FIC block
+    # FIBs that fail their CRC on both sides: a soft bit that differs by one LSB (2-4 in 10^5, docs/history/r01-r04_design_notebook.md 4) anywhere in a FIC block
     # that is noise anyway changes its junk.  A few per thousand failing FIBs (the fading streams produce hundreds of them);
     # generator 3 (no normalisation) is the touchiest
     assert n_bad_diff <= max(2 if soft_type != 3 else 6, 0.03 * n_bad), (n_bad_diff, n_bad)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of the spatial partitioning experiment: front-end HIP stream on n CUs, decoder (+ MSC demapper) on the
+# Same-box A/B of the spatial partitioning experiment (docs/history/r01-r04_design_notebook.md 6): front-end HIP stream on n CUs, decoder (+ MSC demapper) on the
 # other 256 - n (hipExtStreamCreateWithCUMask; variants built by tools/build_variant.sh cu<n> -DDABX_CU_SPLIT=<n>,
 # "df" = the MSC symbols' demapper on the front-end CUs).  Driver form of the bench, interleaved, three rounds.
 OUT=${1:-gpurun_out/ab26}

@@ -3,7 +3,7 @@
 on-device format conversion -> ring), 7 frames per stream and call, next to the decode of the previous chunk.  Two
 producers: `sync` = dabx_push_iq from pageable memory (returns when the caller's buffer is free: one host wait per push),
 `pinned` = dabx_push_iq_async from page-locked buffers (dabx_host_register), one dabx_push_wait per batch: the copies
-queue back to back as DMA.  Not the headline number (bench.py keeps the IQ resident in HBM); DESIGN.md section 6 quotes
+queue back to back as DMA.  Not the headline number (bench.py keeps the IQ resident in HBM); docs/history/r01-r04_design_notebook.md 6 quotes
 the rates printed here and bench.py reports the best as config.pcie_inclusive when profiles/r02_ingest_pcie.json exists.
 
     python tools/bench_ingest.py [--streams 512] [--batches 6] [--formats u8,i16,cf32] [--modes sync,pinned]

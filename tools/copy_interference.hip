@@ -1,5 +1,5 @@
 // copy_interference.hip -- what a 96-MiB device-to-host transfer costs the kernels that run next to it, by the means the delivery
-// could use (DESIGN.md "Delivery"): a victim kernel (an HBM-bound device-to-device stream, 64 MiB per launch, launched back to back
+// could use: a victim kernel (an HBM-bound device-to-device stream, 64 MiB per launch, launched back to back
 // on its own HIP stream) is timed alone and then while the transfer repeats next to it:
 //   hipMemcpyAsync      what the HIP runtime does for device -> page-locked host (on this image a shader copy, __amd_rocclr_copyBuffer)
 //   hsa_sdma            hsa_amd_memory_async_copy between the GPU agent and the CPU agent (an SDMA engine, no CU)

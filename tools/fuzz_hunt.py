@@ -45,7 +45,7 @@ def main():
         n_pass += ok; n_fail += (not ok)
         rec = {"seed": seed, "test": which, "cfg_threshold_strongest_softtype": cfg, "lane_per_trellis_classes": fast == 1 or fast is True, "acquire_mode": 2 if fast == 2 else 0, "viterbi_tie_mode": tie,
                "passed": ok, "seconds": round(time.time() - t0, 1), "exact_level_tracker": a.level_mode}
-        # streams whose walk needed the exact level tracker to follow the oracle (tests/test_gpu_fuzz.py)
+        # streams whose walk needed the exact level tracker to follow the oracle (tests/test_gpu_fuzz.py, docs/history/r01-r04_design_notebook.md 4)
         lv = [l for l in p.stdout.splitlines() if l.startswith("walk differs with the chunk-wise level tracker")]
         if lv:
             rec["level_tracker_streams"] = lv[0].split(":", 1)[1].strip()

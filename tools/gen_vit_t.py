@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generator for dabstar_amd/csrc/vit_t_gen.h: the lane-per-trellis K=7 r=1/4 Viterbi forward steps.
 
-Scheme (see DESIGN.md "Viterbi, lane = trellis"): one lane decodes one trellis; the 64 path metrics live in 32
+Scheme (see docs/history/r01-r04_design_notebook.md "Viterbi, lane = trellis"): one lane decodes one trellis; the 64 path metrics live in 32
 VGPRs as packed int16 pairs.  Label L (6 bits) = register index (bits 0..4) + half (bit 5); at step t of class
 c = t mod 6 label L holds state rotl6(L, c), so the butterfly partner is always L ^ (1 << p), p = (5 - c) mod 6:
 for c != 0 a different REGISTER (same half) -> pure packed add/sub/min on register pairs, nothing moves; for

@@ -1,4 +1,4 @@
-/* CPU model of the parallel form of SampleReader's level recurrence ("the level tracker in parallel"):
+/* CPU model of the parallel form of SampleReader's level recurrence (docs/history/r01-r04_design_notebook.md 3, "the level tracker in parallel"):
  *
  *     S <- S + 0.00001f * (a - S)              (three float operations per sample, sample_reader.cpp:245-248)
  *

@@ -1,6 +1,6 @@
 // overlap_probe.hip -- can a VALU-bound and an HBM-bound workload share the CUs of gfx950 when ONE kernel carries both block
 // types?  (As separate kernels on two HIP streams the decoder and the FFT kernel time-slice by register-file capacity:
-// DESIGN.md section 6.)  Block type A = "decoder": 4 waves of dependent-free packed-int16 / v_perm arithmetic in the mix of
+// docs/history/r01-r04_design_notebook.md 6.)  Block type A = "decoder": 4 waves of dependent-free packed-int16 / v_perm arithmetic in the mix of
 // k_msc_vitT, ~100 VGPRs by launch bound, no memory traffic.  Block type B = "transform": the persistent prefetching stub
 // of tools/sym_mem_bound.hip (a block walks 5 symbols of its stream, next symbol's loads in flight), 96 VGPRs max so that
 // both types can be resident on one SIMD.  Kernels: A alone, B alone, and the mixed grid (blockIdx -> type by a
