@@ -974,14 +974,16 @@ def main():
                           "thread: dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release",
                      copies={"count": dinfo["chunks_landed"], "link_GBps": round(dinfo["bytes_copied"] / max(1e-9, dinfo["copy_seconds"]) / 1e9, 2),
                              "longest_ms": round(1e3 * dinfo["copy_seconds_max"], 3), "sdma_engine_mask": dinfo["sdma_engine_mask"],
+                             "calibration_GBps": round(dinfo["calibration_GBps"], 2),
                              "note": "the library's own clock around every slab transfer (dabx_delivery_get_info)"},
                      scope="this rank's GPU")
 
     h2h = None
-    if not dry and rank == 0 and args.layout == "uniform" and not args.fic_only and not args.no_host_leg:
+    # (the one-GPU line carries the per-link and per-ensemble legs; an N-GPU run is the scaling measurement and stays lean)
+    if not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.fic_only and not args.no_host_leg:
         h2h = host_to_host_leg(args, subch, dx, link_probe[0])
     single = None
-    if not dry and rank == 0 and args.layout == "uniform" and not args.no_single_legs:
+    if not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.no_single_legs:
         single = single_ensemble_legs(torch, dev, args, rank, subch, dx)
     gc.enable()
     if rank == 0:

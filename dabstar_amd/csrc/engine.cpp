@@ -65,7 +65,7 @@ struct Delivery {
   int device = 0;
   std::string copier_error;
   uint64_t next_seq = 0, landed = 0, bytes_copied = 0;
-  double copy_s = 0, copy_s_max = 0, gather_wait_s = 0;
+  double copy_s = 0, copy_s_max = 0, gather_wait_s = 0, calib_gbps = 0;
   unsigned long long *layout_off = nullptr;      // device tables (DeliverDev)
   int32_t *subch_id = nullptr;
   long long *frames_done = nullptr, *cif_done = nullptr, *sf_done = nullptr;
@@ -793,7 +793,12 @@ static int set_subchannels_impl(dabx_engine *e, int stream, const dabx_subch_des
       DABX_HIP(hipMemcpy(e->dl.cif_done + sj, &zero, sizeof(zero), hipMemcpyHostToDevice));
       DABX_HIP(hipMemcpy(e->dl.sf_done + sj, &zero, sizeof(zero), hipMemcpyHostToDevice));
     }
-    if ((rc = e->delivery_layout())) return rc;
+    if ((rc = e->delivery_layout())) {             // the new sub-channels do not fit the slabs: no gather may run with a stale layout
+      const std::string why = dabx::last_error();
+      delivery_free(e);
+      set_error("%s -- the delivery has been closed", why.c_str());
+      return rc;
+    }
   }
   e->have_fast = false;
   e->classes_dirty = true;            // the decoder classes are rebuilt by the next dabx_process (one rebuild for a series of per-stream calls)
@@ -1431,6 +1436,10 @@ int dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg)
     if (I.copy_engine == 0 && (rc = sdma_signal_create(&sl.sig))) { ingest_free(e); return rc; }
   }
 #undef H
+  if (I.copy_engine == 0 && I.capacity >= ((size_t)16 << 20) && (rc = sdma_calibrate(I.sdma, I.slabs[0].host, I.slabs[0].dev, false, I.slabs[0].sig, nullptr))) {
+    ingest_free(e);
+    return rc;
+  }
   I.open = true;
   return 0;
 }
@@ -1555,6 +1564,11 @@ int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
   }
 #undef H
   if ((rc = e->delivery_layout())) { delivery_free(e); return rc; }
+  // the engine the slabs will travel on must be one of the fast ones (sdma.h): checked with a 16-MiB transfer, replaced if it is not
+  if (D.copy_engine == 0 && D.capacity >= ((size_t)16 << 20) && (rc = sdma_calibrate(D.sdma, D.slots[0].host, D.dev[0], true, D.slots[0].sig, &D.calib_gbps))) {
+    delivery_free(e);
+    return rc;
+  }
   D.quit = false;
   D.copier = std::thread(delivery_copier, &D);
   D.open = true;
@@ -1619,6 +1633,7 @@ int dabx_delivery_get_info(dabx_engine *e, dabx_delivery_info *out)
   out->chunks_closed = D.next_seq; out->chunks_landed = D.landed; out->bytes_copied = D.bytes_copied;
   out->copy_seconds = D.copy_s; out->copy_seconds_max = D.copy_s_max; out->gather_wait_seconds = D.gather_wait_s;
   out->copy_engine = D.copy_engine; out->sdma_engine_mask = D.copy_engine == 0 ? D.sdma.engine_to_host : 0;
+  out->calibration_GBps = D.calib_gbps;
   return 0;
 }
 

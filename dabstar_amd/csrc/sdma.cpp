@@ -5,6 +5,7 @@
 #include <hsa/hsa_ext_amd.h>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -104,6 +105,43 @@ int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_h
     hsa_signal_store_relaxed(done, 0);
     return DABX_E_HIP;
   }
+  return 0;
+}
+
+int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, double *gbps)
+{
+  constexpr size_t N = (size_t)16 << 20;
+  uint32_t &engine = to_host ? s.engine_to_host : s.engine_to_dev;
+  auto measure = [&](uint32_t eng, double *out) -> int {
+    const uint32_t keep = engine;
+    engine = eng;
+    double best = 0;
+    int rc = 0;
+    for (int r = 0; r < 2 && !rc; r++) {             // the first transfer of a queue includes its creation
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = sdma_copy(s, to_host ? host : dev, to_host ? dev : host, N, to_host, sig);
+      if (!rc) {
+        const hsa_signal_t sg{sig};
+        while (hsa_signal_load_scacquire(sg) >= 1) {}                                   // 0.3 ms: spinning is the measurement
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        best = std::max(best, (double)N / dt / 1e9);
+      }
+    }
+    engine = keep;
+    *out = best;
+    return rc;
+  };
+  double rate = 0;
+  if (int rc = measure(engine, &rate)) return rc;
+  if (rate < 35.0) {
+    uint32_t best_eng = engine;
+    for (int b = 0; b < 8; b++) {
+      double r = 0;
+      if (measure(1u << b, &r) == 0 && r > rate * 1.15) { rate = r; best_eng = 1u << b; }
+    }
+    engine = best_eng;
+  }
+  if (gbps) *gbps = rate;
   return 0;
 }
 

@@ -25,6 +25,10 @@ void sdma_signal_destroy(uint64_t sig);
 // Submits dst <- src (one side device memory of the Sdma's GPU, the other page-locked host memory known to the runtime: hipHostMalloc,
 // hipHostRegister) and returns at once; `sig` is armed and completes when the bytes are in place.
 int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig);
+// Makes sure the engine the transfers of one direction go to is a fast one: times a 16-MiB transfer between `host` and `dev` the way
+// sdma_copy would make it; below 35 GB/s (an engine that is not wired to the host link at full width: 7-13 GB/s on the MI355X) it tries
+// the engines 0..7 one by one and keeps the fastest.  *gbps (optional) = the rate of the engine kept.  Both buffers >= 16 MiB.
+int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, double *gbps);
 // Returns when the copy armed on `sig` is complete (sleeps bytes_hint / 60 GB/s, then polls the signal every 20 us: no spinning, no interrupt).
 int sdma_wait(uint64_t sig, size_t bytes_hint);
 

@@ -343,7 +343,7 @@ class IngestConfig(C.Structure):
 class DeliveryInfo(C.Structure):
     _fields_ = [("chunks_closed", C.c_uint64), ("chunks_landed", C.c_uint64), ("bytes_copied", C.c_uint64), ("copy_seconds", C.c_double),
                 ("copy_seconds_max", C.c_double), ("gather_wait_seconds", C.c_double), ("copy_engine", C.c_int32),
-                ("sdma_engine_mask", C.c_uint32), ("reserved", C.c_uint64 * 4)]
+                ("sdma_engine_mask", C.c_uint32), ("calibration_GBps", C.c_double), ("reserved", C.c_uint64 * 3)]
 
 
 class ChunkRef(C.Structure):

@@ -483,7 +483,8 @@ typedef struct {
   uint64_t bytes;
 } dabx_chunk;
 int  dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg /* NULL = defaults */);
-int  dabx_delivery_close(dabx_engine *e);      /* drains the engine; chunks not yet fetched are dropped */
+int  dabx_delivery_close(dabx_engine *e);      /* drains the engine; chunks not yet fetched are dropped.  The consumer thread must have
+                                                  left dabx_delivery_next before this (and before dabx_destroy) is called */
 /* The oldest chunk not yet handed out: returns 1 and fills *out when it is complete in host memory, 0 when no chunk is ready
  * (wait == 0) or none is queued at all (wait != 0 waits for a queued one to land). */
 int  dabx_delivery_next(dabx_engine *e, int wait, dabx_chunk *out);
@@ -498,7 +499,9 @@ typedef struct {
   double   gather_wait_seconds;                /* the copier's waits for the chunks' gather kernels (idle time, not a cost) */
   int32_t  copy_engine;                        /* dabx_delivery_config.copy_engine */
   uint32_t sdma_engine_mask;                   /* hsa_amd_sdma_engine_id_t the transfers are put on (0: the runtime's choice) */
-  uint64_t reserved[4];
+  double   calibration_GBps;                   /* rate of the 16-MiB probe transfer dabx_delivery_open made on that engine (an engine below
+                                                  35 GB/s is replaced by the fastest of engines 0..7) */
+  uint64_t reserved[3];
 } dabx_delivery_info;
 int  dabx_delivery_get_info(dabx_engine *e, dabx_delivery_info *out);
 /* Bytes one slab takes with the sub-channels configured now (what one chunk moves over the link). */

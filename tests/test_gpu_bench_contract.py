@@ -38,3 +38,18 @@ def test_bench_line_keeps_its_contract():
     c = j["chain"]
     assert c["algorithmic_bytes_per_frame"] == 2115456 and abs(c["frac_of_hbm_peak"] - j["value"] * 2115456 / 8e12) < 1e-4
     assert set(c["kernel_ms_per_step_standalone"]) >= {"k_symbols", "k_demap_frame", "k_fic_frame", "k_msc_prep", "k_msc_vitT", "k_dabplus"}
+    # round 5: the results really leave the device -- delivered_to_host (every FIB, logical frame and super frame of 512 x 18 in page-locked
+    # host memory, nothing lost), measured live; the FIBs that arrived equal the oracle's; host memory to host memory at the link's rate
+    d = j["config"]["delivered_to_host"]
+    assert d["lost"] == 0 and d["frames_delivered"] == d["frames_decoded"] == 512 * d["steps"] and d["steps"] >= 98
+    assert d["logical_frames_delivered"] == d["logical_frames_decoded"] == 512 * 18 * 4 * d["steps"]
+    assert d["superframes_delivered"] == d["superframes_decoded"] > 0 and d["frac_of_that"] > 0.85 and d["host_GBps"] > 8.0
+    s20 = d["at_timed_region_length"]
+    assert s20["steps"] == 14 and s20["frames_delivered"] == s20["frames_decoded"] == 512 * 14 and 0.6 < s20["frac_of_value"] <= 1.05
+    assert d["copies"]["link_GBps"] > 25.0 and d["copy_engine"].startswith("sdma")
+    assert j["fib_match_vs_oracle_pct"] == 100.0 and j["fib_match_vs_oracle"]["fibs_compared"] >= 8 * 12 * 100
+    h = j["config"]["host_to_host"]
+    assert h["lost"] == 0 and h["frames_delivered"] == h["frames_decoded"] == 512 * 5 * 8 and h["fib_crc_pass_pct"] == 100.0 and h["superframes_failed"] == 0
+    assert h["in_GBps"] > 30.0 and h["frames_per_s"] > 80000 and ("link_probe" not in h or h["in_frac_of_link_probe"] > 0.6)
+    one = j["config"]["single_ensemble"]
+    assert one["full"]["frames_per_s"] > 3000 and one["fic_only"]["frames_per_s"] > one["full"]["frames_per_s"] and one["full"]["superframes_failed"] == 0

@@ -40,7 +40,11 @@ for k, v in acc.items():
     res[k] = {"fetch_size_raw_bytes": f * 1024, "fetch_correction": fx, "fetch_bytes": fx * f * 1024, "write_bytes": w * 1024,
               "hbm_bytes_per_launch": fx * f * 1024 + w * 1024, "frames_per_launch": 512 * (7 if batched else 1),
               "valu_wave_insts_per_launch": va}
-tot = sum(v["hbm_bytes_per_launch"] / (7 if (k.startswith("k_msc") or k == "k_dabplus") else 1) for k, v in res.items())
+# k_acquire is not part of a step in lock any more (round 5: no search launch while every stream is in lock): its launches here are the
+# priming's, out of the steady-state sum
+tot = sum(v["hbm_bytes_per_launch"] / (7 if (k.startswith("k_msc") or k == "k_dabplus") else 1) for k, v in res.items() if k != "k_acquire")
+if "k_acquire" in res:
+    res["k_acquire"]["note"] = "acquisition during the priming steps only: not launched while every stream is in lock; excluded from chain_hbm_bytes_per_step"
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, mean over full-size launches; FETCH_SIZE x fetch_correction "
                    "(profiles/r02_fetch_calib.json: 0.5 counted for coalesced streams -> x2, exact for k_msc_prep's 64-B runs -> x1); SQ_INSTS_VALU = wave-level VALU instructions",
            "commit": os.environ.get("DABX_PROF_COMMIT", "unknown"),
