@@ -1927,6 +1927,10 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
     if (ss.b) {
       DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
       ss.msc_in_flight = true;
+#ifdef DABX_EXCLUSIVE_MSC            // experiment builds only: the next frames' front end waits for the batch (no overlap of the decoder with the frame chain)
+      DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0));
+      ss.msc_in_flight = false;
+#endif
     }
   } else {
     mk.begin(8, ss.a);
