@@ -36,19 +36,42 @@ def test_512_streams_round_trip_and_sampled_oracle_parity():
     base = [ds.build_ensemble(RING_FRAMES, subch, seed=e, cyclic=True) for e in range(args.ensembles)]   # fill_rings' seeds, rank 0
 
     eng.commit(RING_FRAMES * ds.TF - ds.TF)
+    # every result also leaves the device through the bulk delivery (one slab, one SDMA transfer per chunk); the last two slabs are kept
+    # (copies) and compared below with what dabx_read_* return for the sampled streams -- which are compared with the oracle
+    eng.delivery_open(slots=4)
+    kept, totals = [], dict(chunks=0, frames=0, cifs=0, sfs=0, lost=0)
+
+    def take(wait):
+        while True:
+            ch = eng.delivery_next(wait=wait)
+            if ch is None:
+                return
+            assert ch.seq == totals["chunks"] and ch.nbytes == eng.delivery_slab_bytes()
+            totals["chunks"] += 1
+            totals["frames"] += int(ch.streams["n_frames"].sum()); totals["cifs"] += int(ch.subch["n_cifs"].sum()); totals["sfs"] += int(ch.subch["n_sf"].sum())
+            totals["lost"] += int(ch.streams["frames_lost"].sum()) + int(ch.subch["cifs_lost"].sum()) + int(ch.subch["sf_lost"].sum())
+            kept.append(ch.raw.copy())
+            del kept[:-2]
+            ch.release()
     done, early = 0, None
     while done < N_STEPS:                          # as bench.py: 7 frames per MSC launch
         m = min(7, N_STEPS - done)
         eng.commit(m * ds.TF)
+        assert eng.delivery_wait_free(1, timeout_ms=20000) >= 1
         eng.process(m, sync=False)
+        take(wait=False)
         done += m
         if done == N_PRIME:                        # acquisition, CFO pull-in, de-interleaver fill and super-frame sync are over
             eng.synchronize()
             early = [eng.stats(s) for s in range(N_STREAMS)]
     eng.synchronize()
+    take(wait=False)
+    assert totals["chunks"] == 7 and totals["lost"] == 0
 
     # ---- totals
     c = eng.counters()
+    assert totals["frames"] == c["frames"] and totals["cifs"] == c["cifs_decoded"] and totals["sfs"] == c["sf_ok"]      # everything decoded was delivered
+    last2 = [dx.Chunk(None, dx.ChunkRef(seq=0, data=k.ctypes.data, bytes=k.nbytes)) for k in kept]                          # (views into the kept copies)
     assert c["streams_locked"] == N_STREAMS and c["sync_lost"] <= 4     # a first lock on a false PRS peak is dropped again;
     assert c["frames"] >= N_STREAMS * (N_STEPS - 2) - 8 * c["sync_lost"]  # those streams are checked against the oracle below
     assert c["fib_total"] == 12 * c["frames"]
@@ -109,12 +132,24 @@ def test_512_streams_round_trip_and_sampled_oracle_parity():
         assert n >= f
         fibs, crc = eng.read_fibs(s, 8)
         assert np.array_equal(fibs, o_fibs[f - 8:f]) and np.array_equal(crc, o_crc[f - 8:f]), s
+        # slab bytes == dabx_read_* bytes == oracle: the FIBs of the stream's newest 8 frames from the last two slabs ...
+        d_f = np.concatenate([q.fibs[s, :int(q.streams[s]["n_frames"])] for q in last2])
+        d_c = np.concatenate([q.crc[s, :int(q.streams[s]["n_frames"])] for q in last2])
+        assert len(d_f) >= 8 and np.array_equal(d_f[-8:], fibs) and np.array_equal(d_c[-8:], crc), s
+        assert int(last2[-1].streams[s]["first_frame"]) + int(last2[-1].streams[s]["n_frames"]) == f
         k = f * 4 - 16
         for j in range(N_SUB):
             o = ol.backend_bytes(rx, j, "msc").reshape(-1, 192)
-            assert np.array_equal(eng.read_msc(s, j, 16), o[k - 16:k]), (s, j)
+            got = eng.read_msc(s, j, 16)
+            assert np.array_equal(got, o[k - 16:k]), (s, j)
             sub = eng.subch_stats(s, j)
             o_sf = ol.backend_bytes(rx, j, "sf").reshape(-1, 880)
-            assert np.array_equal(eng.read_superframes(s, j, 4), o_sf[sub["sf_ok"] - 4:sub["sf_ok"]]), (s, j)
+            got_sf = eng.read_superframes(s, j, 4)
+            assert np.array_equal(got_sf, o_sf[sub["sf_ok"] - 4:sub["sf_ok"]]), (s, j)
+            # ... and every slot's newest 16 logical frames and 4 super frames
+            d_lf = np.concatenate([q.msc(s, j) for q in last2]); d_sf = np.concatenate([q.superframes(s, j) for q in last2])
+            assert len(d_lf) >= 16 and np.array_equal(d_lf[-16:], got) and len(d_sf) >= 4 and np.array_equal(d_sf[-4:], got_sf), (s, j)
+            r = last2[-1].subch[s, j]
+            assert int(r["first_cif"]) + int(r["n_cifs"]) == sub["cifs_decoded"] and int(r["first_sf"]) + int(r["n_sf"]) == sub["sf_count"], (s, j)
         L.ora_rx_destroy(rx)
     eng.close()
