@@ -355,7 +355,15 @@ int dabx_engine::delivery_begin(DeliverDev *dv, int *slot, int *devslab)
   dv->frames_done = D.frames_done; dv->cif_done = D.cif_done; dv->sf_done = D.sf_done;
   dv->hdr = D.hdr; dv->hdr.seq = seq;
   *slot = h;
-  return launch_deliver_front(dev, *dv, stream);
+  const int rc = launch_deliver_front(dev, *dv, stream);
+  if (rc) {                                                        // nothing was queued: give the slabs back
+    std::lock_guard<std::mutex> lk(D.mu);
+    D.dev_busy[*devslab] = false;
+    D.slots[(size_t)h].state = Delivery::FREE;
+    D.next_seq--;
+    D.cv.notify_all();
+  }
+  return rc;
 }
 
 // ... and once its slot gather is queued behind the DAB+ stage on `tail`: the copier takes over.

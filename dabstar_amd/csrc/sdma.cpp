@@ -122,7 +122,9 @@ int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, d
       rc = sdma_copy(s, to_host ? host : dev, to_host ? dev : host, N, to_host, sig);
       if (!rc) {
         const hsa_signal_t sg{sig};
-        while (hsa_signal_load_scacquire(sg) >= 1) {}                                   // 0.3 ms: spinning is the measurement
+        while (hsa_signal_load_scacquire(sg) >= 1) {                                    // 0.3 ms: spinning is the measurement
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { set_error("sdma: a 16-MiB probe transfer did not complete within 5 s"); return DABX_E_HIP; }
+        }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         best = std::max(best, (double)N / dt / 1e9);
       }
@@ -151,7 +153,12 @@ int sdma_wait(uint64_t sig, size_t bytes_hint)
   // hsa_signal_wait_scacquire / hipEventSynchronize after another GPU process had run next to this one); a poll every 20 us costs nothing.
   const hsa_signal_t s{sig};
   if (bytes_hint) std::this_thread::sleep_for(std::chrono::nanoseconds((long long)(bytes_hint / 60.0)));       // no transfer beats 60 GB/s: sleep that long first
-  while (hsa_signal_load_scacquire(s) >= 1) std::this_thread::sleep_for(std::chrono::microseconds(20));
+  const auto t0 = std::chrono::steady_clock::now();
+  while (hsa_signal_load_scacquire(s) >= 1) {
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+    // (a slab is at most a few GB: seconds even on the slowest engine; a transfer that never completes must not hang the caller silently)
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { set_error("sdma: transfer did not complete within 60 s"); return DABX_E_HIP; }
+  }
   return 0;
 }
 
