@@ -941,7 +941,7 @@ def main():
             eng.delivery_open(slots=4, what=args.deliver_what, copy_engine=args.deliver_copy_engine)
             sink = DeliverySink(eng, sample_streams)
             delivering[0] = True
-            step(7)                                    # first chunk: first touch of the slabs
+            step(21)                                   # three chunks: first touch of the slabs, and the clocks back up after the allocations' idle time
             steady = figures(*leg(n_steady), n_steady)
             short = figures(*leg(args.steps), args.steps)
         else:

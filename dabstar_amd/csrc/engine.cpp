@@ -271,6 +271,9 @@ static int sync_all(dabx_engine *e, bool chain_only = false)
 
 // ---- bulk delivery (include/dabx.h "Bulk delivery", deliver.hip) -------------------------------------------------------
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// the slab's records are ABI: hosts and the python binding (dabstar_amd/lib.py, CHUNK_*) parse them by these sizes
+static_assert(sizeof(dabx_chunk_header) == 128 && sizeof(dabx_chunk_stream) == 72 && sizeof(dabx_chunk_frame) == 16 && sizeof(dabx_chunk_subch) == 136,
+              "include/dabx.h: chunk record layout");
 static constexpr int DL_FRAMES = MSC_BATCH_FRAMES;                 // a chunk = what one MSC batch decodes
 static constexpr int DL_SF_CAP = (4 * DL_FRAMES + 4) / 5;          // super frames one chunk can complete (4 CIFs may be waiting from before)
 #if DABX_MSC_BATCH == 7

@@ -121,6 +121,7 @@ int  dabx_fic_get_ber(dabx_fic *f, dabx_fic_ber *out);
  * byte 0 first); returns the byte count, or 0 while the service's de-interleaver is still filling (first 16 CIFs).
  * dabx_msc_get_superframe: the RS-corrected DAB+ super frame completed by that CIF, if any (110 * kbps / 8 bytes, else 0). */
 typedef struct dabx_msc dabx_msc;
+struct dabx_subch_desc_s;
 int  dabx_msc_create(int max_services, dabx_msc **out);
 void dabx_msc_destroy(dabx_msc *m);
 int  dabx_msc_set_channel(dabx_msc *m, const struct dabx_subch_desc_s *d);

@@ -1,5 +1,6 @@
 """CPU-only: the C-ABI library loads and exports every symbol include/dabx.h declares."""
 import ctypes as C
+import os
 
 import pytest
 
@@ -70,3 +71,30 @@ def test_hipmodule_form_exports_the_same_abi_and_carries_no_device_code():
     exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout.split()
     assert not [n for n in exported if n.startswith(("hipLaunchKernel", "__hipRegister", "__hipPush", "__hipPop", "hipMemcpyToSymbol"))]
     assert len([f for f in os.listdir(mod) if f.startswith("dabx_gfx950_") and f.endswith(".hsaco")]) == 7
+
+
+def test_header_is_valid_c_and_the_chunk_records_have_the_sizes_the_binding_parses(tmp_path):
+    """include/dabx.h compiles as C99 without a warning, and the slab records of the bulk delivery (parsed by hosts and by
+    dabstar_amd/lib.py's numpy dtypes) have their documented sizes and field offsets."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text("""#include <stddef.h>
+#include <stdio.h>
+#include "dabx.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dabx_chunk_header), sizeof(dabx_chunk_stream), sizeof(dabx_chunk_frame), sizeof(dabx_chunk_subch),
+         offsetof(dabx_chunk_header, off_sf), offsetof(dabx_chunk_stream, fib_ok), offsetof(dabx_chunk_subch, msc_off), offsetof(dabx_chunk_subch, au_bad),
+         sizeof(dabx_delivery_info));
+  return 0;
+}
+""")
+    exe = tmp_path / "t"
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(os.path.dirname(__file__), "..", "include"),
+                        str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    d = dx
+    assert got[:4] == [d.CHUNK_HEADER.itemsize, d.CHUNK_STREAM.itemsize, d.CHUNK_FRAME.itemsize, d.CHUNK_SUBCH.itemsize] == [128, 72, 16, 136]
+    assert got[4] == d.CHUNK_HEADER.fields["off_sf"][1] and got[5] == d.CHUNK_STREAM.fields["fib_ok"][1]
+    assert got[6] == d.CHUNK_SUBCH.fields["msc_off"][1] and got[7] == d.CHUNK_SUBCH.fields["au_bad"][1]
+    assert got[8] == C.sizeof(d.DeliveryInfo)
