@@ -263,6 +263,9 @@ typedef struct {
                                  search pass beside them.  While fewer than half of the streams are in lock -- start-up, a lone stream that
                                  lost its lock -- the search runs in step: every step first gives every such stream a frame's worth of
                                  search, exactly DabProcessor's order of events per stream.  1: always in step; 2: always asynchronous.
+                                 While the device's count of streams in lock equals n_streams no search is launched at all (it would
+                                 return at once for every stream): a stream that then loses its lock is searched from the first step ISSUED
+                                 after the loss -- with sync = 0 the host may have queued steps ahead, which the stream sits out.
                                  Same samples, same decisions, same frames either way -- only WHEN differs.  (With dc_iq_correction the
                                  search always runs in step: the correction of newly committed samples is ordered on the front-end stream.) */
 } dabx_config;
