@@ -914,7 +914,7 @@ def main():
     # (like for like), and the timed region's own length (args.steps), where the last chunk's slab (100 MB for the measured
     # configuration = 1.8 ms of link time that nothing can hide) weighs as it does in any short run.  With --deliver the timed region
     # above WAS the second figure.
-    deliv = fibchk = None
+    deliv = fibchk = needs = None
     if not dry and not args.no_deliver_leg:
         def leg(n):
             eng.synchronize()
@@ -944,6 +944,29 @@ def main():
             step(21)                                   # three chunks: first touch of the slabs, and the clocks back up after the allocations' idle time
             steady = figures(*leg(n_steady), n_steady)
             short = figures(*leg(args.steps), args.steps)
+            # ... and what a receiver's host side needs (FIBs + super frames; logical frames only of services that are not DAB+ -- none in this
+            # multiplex): for DAB+ the logical frames' consumer runs on the device.  Half the bytes, half the un-overlappable last transfer.
+            if not args.deliver_what:
+                delivering[0] = False
+                sink.finish()
+                lost_all = sink.totals()["lost"]
+                if rank == 0 and args.layout == "uniform":
+                    fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
+                slab_bytes, dinfo = eng.delivery_slab_bytes(), eng.delivery_info()
+                eng.delivery_close()
+                eng.delivery_open(slots=4, what=dx.DELIVER_FIB | dx.DELIVER_SF | dx.DELIVER_MSC_NOT_DABPLUS, copy_engine=args.deliver_copy_engine)
+                sink = DeliverySink(eng, [])
+                closed[0] = 0
+                delivering[0] = True
+                step(21)
+                needs = figures(*leg(args.steps), args.steps)
+                needs["slab_bytes_per_chunk"] = eng.delivery_slab_bytes()
+                needs["what"] = "FIBs + CRC flags + frame records, super frames; logical frames only of services that are not DAB+ (DABX_DELIVER_MSC_NOT_DABPLUS)"
+                delivering[0] = False
+                sink.finish()
+                needs["lost"] = sink.totals()["lost"]
+                eng.delivery_close()
+                sink = None
         else:
             short = figures(c1, c2, d1, d2, dt, args.steps)
             steady = figures(*leg(n_steady), n_steady)
@@ -957,6 +980,8 @@ def main():
             sink = None
             b1, b2, _, _, bdt = leg(n_steady)
             base_steady = (b2["frames"] - b1["frames"]) / bdt
+        if sink is None and not args.deliver:
+            lost = lost_all
         if sink is not None:
             delivering[0] = False
             sink.finish()
@@ -967,7 +992,7 @@ def main():
             eng.delivery_close()
         steady["frames_per_s_without_delivery_same_steps"] = round(base_steady, 1)
         steady["frac_of_that"] = round(steady["frames_per_s"] / base_steady, 4)
-        deliv = dict(steady, at_timed_region_length=short, lost=lost, slab_bytes_per_chunk=slab_bytes, host_slabs=4,
+        deliv = dict(steady, at_timed_region_length=short, what_a_receiver_needs=needs, lost=lost, slab_bytes_per_chunk=slab_bytes, host_slabs=4,
                      in_timed_region=bool(args.deliver), copy_engine="sdma (hsa_amd_memory_async_copy)" if args.deliver_copy_engine == 0 else "hipMemcpyAsync",
                      what="every FIB + CRC flag + frame record, logical frame and RS-corrected super frame of every stream and sub-channel: one "
                           "slab and ONE SDMA transfer per 7-frame chunk into page-locked host slabs (dabx_delivery_*); consumer = a python "
@@ -1069,6 +1094,8 @@ def main():
             out["config"]["single_ensemble"] = single
         if deliv is not None:
             deliv["at_timed_region_length"]["frac_of_value"] = round(deliv["at_timed_region_length"]["frames_per_s"] / (value / n_joined), 4)
+            if deliv.get("what_a_receiver_needs"):
+                deliv["what_a_receiver_needs"]["frac_of_value"] = round(deliv["what_a_receiver_needs"]["frames_per_s"] / (value / n_joined), 4)
             out["config"]["delivered_to_host"] = deliv
         if dry:
             out["dry"] = True

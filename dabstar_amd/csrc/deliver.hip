@@ -81,7 +81,9 @@ __global__ __launch_bounds__(64) void k_deliver_msc(EngineDev e, DeliverDev dv)
     if (n_s < 0) n_s = 0;
     lost_s = (int)(have_s > n_s ? have_s - n_s : 0);
     first_s = sc.sf_count - n_s;
-    if (dv.hdr.what & DABX_DELIVER_MSC) {
+    const bool want_lf = (dv.hdr.what & DABX_DELIVER_MSC) || ((dv.hdr.what & DABX_DELIVER_MSC_NOT_DABPLUS) && !sc.dab_plus);
+    if (!want_lf) { lost_c = 0; first_c = sc.cif_out; n_c = 0; }      // not wanted: nothing is "lost"
+    if (want_lf) {
       const uint8_t *ring = e.msc_out + (size_t)sj * MSC_SLOTS * e.msc_stride;
       uint32_t *o = reinterpret_cast<uint32_t *>(slab + msc_off);
       const int wpf = nb / 4;

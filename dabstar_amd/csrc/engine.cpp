@@ -300,10 +300,10 @@ int dabx_engine::delivery_layout()
   h.off_frame = off; if (fib) off = align_up(off + S * F * sizeof(dabx_chunk_frame), 16);
   std::vector<unsigned long long> lo(2 * S * M + 2, 0);
   h.off_msc = off;
-  if ((D.what & DABX_DELIVER_MSC) && !d.fic_only)
+  if ((D.what & (DABX_DELIVER_MSC | DABX_DELIVER_MSC_NOT_DABPLUS)) && !d.fic_only)
     for (size_t sj = 0; sj < S * M; sj++) {
       const SubchDev &sc = subch_host[sj];
-      if (!sc.active) continue;
+      if (!sc.active || (!(D.what & DABX_DELIVER_MSC) && sc.dab_plus)) continue;
       lo[2 * sj] = off;
       off = align_up(off + (size_t)4 * F * 3 * sc.kbps, 16);
     }
@@ -1520,7 +1520,7 @@ int dabx_ingest_commit(dabx_engine *e, int k)
 
 int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
 {
-  if (!e || (cfg && (cfg->host_slabs < 0 || cfg->host_slabs == 1 || cfg->host_slabs > 64 || (cfg->what & ~7) || cfg->copy_engine < 0 || cfg->copy_engine > 1))) {
+  if (!e || (cfg && (cfg->host_slabs < 0 || cfg->host_slabs == 1 || cfg->host_slabs > 64 || (cfg->what & ~15) || cfg->copy_engine < 0 || cfg->copy_engine > 1))) {
     set_error("dabx_delivery_open: bad argument");
     return DABX_E_ARG;
   }

@@ -314,7 +314,7 @@ class Stats(C.Structure):
 # ---- bulk delivery (include/dabx.h "Bulk delivery"): the slab's records as numpy dtypes -----------------------------
 CHUNK_FRAMES = 7
 CHUNK_MAGIC = 0x43584244
-DELIVER_FIB, DELIVER_MSC, DELIVER_SF = 1, 2, 4
+DELIVER_FIB, DELIVER_MSC, DELIVER_SF, DELIVER_MSC_NOT_DABPLUS = 1, 2, 4, 8
 CHUNK_HEADER = np.dtype([("magic", "<u4"), ("abi", "<u4"), ("seq", "<u8"), ("n_streams", "<i4"), ("max_subch", "<i4"),
                          ("max_frames", "<i4"), ("what", "<i4"), ("bytes", "<u8"), ("off_stream", "<u8"), ("off_subch", "<u8"),
                          ("off_fib", "<u8"), ("off_crc", "<u8"), ("off_frame", "<u8"), ("off_msc", "<u8"), ("off_sf", "<u8"),

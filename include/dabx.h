@@ -438,7 +438,11 @@ int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
  * engine (dabx_push_iq*, dabx_process, ...); everything else keeps the one-thread-per-handle rule. */
 #define DABX_CHUNK_FRAMES 7
 #define DABX_CHUNK_MAGIC 0x43584244u       /* "DBXC" */
-enum { DABX_DELIVER_FIB = 1, DABX_DELIVER_MSC = 2, DABX_DELIVER_SF = 4 };
+enum { DABX_DELIVER_FIB = 1, DABX_DELIVER_MSC = 2, DABX_DELIVER_SF = 4,
+       /* logical frames only of the slots that are NOT DAB+ (instead of DABX_DELIVER_MSC): for a DAB+ service the logical frames' consumer,
+          Mp4Processor, runs on the device and the host's input is the super frame -- FIB | SF | this = what a receiver's host side needs,
+          half the bytes of "everything" for a DAB+ multiplex */
+       DABX_DELIVER_MSC_NOT_DABPLUS = 8 };
 typedef struct {
   int32_t host_slabs;       /* page-locked host slabs, >= 2 (0 = default 4) */
   int32_t what;             /* DABX_DELIVER_* mask, 0 = everything */

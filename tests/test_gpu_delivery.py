@@ -230,3 +230,31 @@ def test_delivery_follows_a_reconfiguration():
             assert len(got) == 4 * (f - f1) - 16 and np.array_equal(got, o[4 * f1:4 * f1 + len(got)]), j
             assert col.last[1][0, j]["start_cif"] == 4 * f1
     eng.close()                                        # closing the engine closes the delivery
+
+
+def test_what_a_receivers_host_side_needs():
+    """DABX_DELIVER_FIB | DABX_DELIVER_SF | DABX_DELIVER_MSC_NOT_DABPLUS: super frames for the DAB+ services (their logical frames are consumed by
+    the device-side Mp4Processor), logical frames for the others -- half the bytes of "everything"."""
+    subch = [ds.SubCh(1, 0, 48, 64, 2, 0), ds.SubCh(5, 60, 96, 128, 2, 0), ds.SubCh(9, 200, 84, 112, 2, 0), ds.SubCh(12, 400, 24, 32, 2, 0, dab_plus=0)]
+    ens = ds.build_ensemble(10, subch, seed=91)
+    x = ds.channel(ens.iq, snr_db=21.0, cfo_hz=77.0, timing_offset=2222, seed=91, n_out=30 * ds.TF)
+    ora = _oracle_run(x, subch)
+    eng = dx.Engine(n_streams=1, ring_frames=31, max_subch=4, out_frames=8)
+    eng.set_subchannels(subch)
+    eng.delivery_open(slots=2, what=dx.DELIVER_FIB | dx.DELIVER_SF | dx.DELIVER_MSC_NOT_DABPLUS)
+    everything = 128 + 72 + 4 * 136 + 7 * 412 + sum(28 * 3 * c.kbps + 6 * 110 * c.kbps // 8 for c in subch)
+    assert eng.delivery_slab_bytes() < 0.62 * everything
+    eng.push_iq(0, x)
+    col = Collector(1, 4)
+    for _ in range(4):
+        eng.process(7)
+        col.take(eng.delivery_next(wait=True))
+    f = eng.stats(0)["frames"]
+    for j, c in enumerate(subch):
+        lf, sf = col.cat(col.msc[0][j], 3 * c.kbps), col.cat(col.sf[0][j], 110 * c.kbps // 8)
+        if c.dab_plus:
+            assert len(lf) == 0 and len(sf) == eng.subch_stats(0, j)["sf_count"] >= 3
+            assert np.array_equal(sf, ora["sf"][j].reshape(-1, 110 * c.kbps // 8)[:len(sf)]), j
+        else:
+            assert len(sf) == 0 and len(lf) == 4 * f - 16 and np.array_equal(lf, ora["msc"][j].reshape(-1, 3 * c.kbps)[:len(lf)]), j
+    eng.close()
