@@ -1530,6 +1530,11 @@ int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
   Delivery &D = e->dl;
   const EngineDev &d = e->dev;
   D.what = cfg && cfg->what ? cfg->what : (DABX_DELIVER_FIB | DABX_DELIVER_MSC | DABX_DELIVER_SF);
+  if ((D.what & DABX_DELIVER_FIB) && d.out_frames < DL_FRAMES) {
+    set_error("dabx_delivery_open: the engine's FIB ring holds %d frames, a chunk up to %d: create it with dabx_config.out_frames >= %d "
+              "(the FIBs of a chunk's first frames would have left the ring before they are gathered)", d.out_frames, DL_FRAMES, DL_FRAMES);
+    return DABX_E_STATE;
+  }
   D.copy_engine = cfg ? cfg->copy_engine : 0;
   D.device = e->device;
   if (D.copy_engine == 0 && (rc = sdma_open(e->device, &D.sdma))) return rc;

@@ -431,9 +431,9 @@ int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
  *   super frames   of slot (s, j): n_sf rows of sf_pitch bytes (110 * kbps / 8 used) from sf_off -- dabx_read_superframes' bytes
  * Chunks are numbered from 0 and delivered in order.  dabx_process fails with DABX_E_STATE, before it has started anything,
  * when the call would close more chunks than there are free host slabs: a consumer that falls behind holds the receiver up,
- * it never loses data silently.  What the device rings could not hold until the chunk was packed (a consumer of the FIB ring
- * configured with out_frames < the frames of a chunk) is counted in frames_lost / cifs_lost / sf_lost, always 0 with out_frames
- * >= DABX_CHUNK_FRAMES.
+ * it never loses data silently.  dabx_delivery_open refuses an engine whose FIB ring is shorter than a chunk (dabx_config.out_frames
+ * < DABX_CHUNK_FRAMES) when FIBs are to be delivered; frames_lost / cifs_lost / sf_lost count what a device ring could not hold until
+ * the chunk was packed all the same (always 0 so far).
  * Threads: dabx_delivery_next / dabx_delivery_release may be called from ONE consumer thread next to the thread that drives the
  * engine (dabx_push_iq*, dabx_process, ...); everything else keeps the one-thread-per-handle rule. */
 #define DABX_CHUNK_FRAMES 7

@@ -156,6 +156,11 @@ def test_consumer_thread_and_partial_deliveries():
     ens = ds.build_ensemble(10, subch, seed=7)
     x = ds.channel(ens.iq, snr_db=18.0, cfo_hz=-420.0, timing_offset=99999, seed=7, n_out=40 * ds.TF)
     ora = _oracle_run(x, subch)
+    short = dx.Engine(n_streams=1, ring_frames=4, max_subch=1, out_frames=4, fic_only=True)      # a FIB ring shorter than a chunk is refused ...
+    with pytest.raises(dx.DabxError, match="out_frames >= 7"):
+        short.delivery_open(slots=2, what=dx.DELIVER_FIB)
+    short.delivery_open(slots=2, what=dx.DELIVER_SF)                                               # ... unless no FIBs are to be delivered
+    short.close()
     eng = dx.Engine(n_streams=1, ring_frames=41, max_subch=18, out_frames=8, fic_only=True)
     eng.push_iq(0, x)
     eng.process(6)                                     # nobody listens yet
