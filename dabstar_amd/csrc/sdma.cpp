@@ -29,7 +29,6 @@ hsa_status_t agent_cb(hsa_agent_t a, void *p)
 }
 std::once_flag g_hsa_once;
 bool g_hsa_ok = false;
-hsa_agent_t g_cpu{};
 }  // namespace
 
 int sdma_open(int hip_device, Sdma *out)
@@ -47,13 +46,14 @@ int sdma_open(int hip_device, Sdma *out)
     set_error("sdma: no HSA agent for HIP device %d (%s)", hip_device, bus);
     return DABX_E_HIP;
   }
-  if (f.have_cpu) g_cpu = f.cpu;
+  if (!f.have_cpu) { set_error("sdma: the HSA runtime lists no CPU agent"); return DABX_E_HIP; }
+  out->cpu_agent = f.cpu.handle;
   out->gpu_agent = f.gpu.handle;
   // one engine per direction, from the runtime's preferred set for this pair of agents (lowest bit); 0 = leave it to the runtime
   uint32_t pref = 0;
-  if (f.have_cpu && hsa_amd_memory_get_preferred_copy_engine(f.cpu, f.gpu, &pref) == HSA_STATUS_SUCCESS && pref) out->engine_to_host = pref & (~pref + 1u);
+  if (hsa_amd_memory_get_preferred_copy_engine(f.cpu, f.gpu, &pref) == HSA_STATUS_SUCCESS && pref) out->engine_to_host = pref & (~pref + 1u);
   pref = 0;
-  if (f.have_cpu && hsa_amd_memory_get_preferred_copy_engine(f.gpu, f.cpu, &pref) == HSA_STATUS_SUCCESS && pref) out->engine_to_dev = pref & (~pref + 1u);
+  if (hsa_amd_memory_get_preferred_copy_engine(f.gpu, f.cpu, &pref) == HSA_STATUS_SUCCESS && pref) out->engine_to_dev = pref & (~pref + 1u);
   out->ok = true;
   return 0;
 }
@@ -75,7 +75,7 @@ int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_h
 {
   if (!s.ok) { set_error("sdma: not open"); return DABX_E_STATE; }
   // the agent that owns the host allocation (the NUMA node hipHostMalloc took it from); any CPU agent would do for the engine choice
-  hsa_agent_t host = g_cpu;
+  hsa_agent_t host{s.cpu_agent};
   hsa_amd_pointer_info_t info;
   std::memset(&info, 0, sizeof(info));
   info.size = sizeof(info);
@@ -122,9 +122,11 @@ int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, d
       rc = sdma_copy(s, to_host ? host : dev, to_host ? dev : host, N, to_host, sig);
       if (!rc) {
         const hsa_signal_t sg{sig};
-        while (hsa_signal_load_scacquire(sg) >= 1) {                                    // 0.3 ms: spinning is the measurement
+        hsa_signal_value_t v;
+        while ((v = hsa_signal_load_scacquire(sg)) >= 1) {                              // 0.3 ms: spinning is the measurement
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { set_error("sdma: a 16-MiB probe transfer did not complete within 5 s"); return DABX_E_HIP; }
         }
+        if (v < 0) { set_error("sdma: a 16-MiB probe transfer failed (signal value %lld)", (long long)v); return DABX_E_HIP; }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         best = std::max(best, (double)N / dt / 1e9);
       }
@@ -149,16 +151,19 @@ int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, d
 
 int sdma_wait(uint64_t sig, size_t bytes_hint)
 {
-  // Polled, not blocked on the signal's interrupt: a missed wake-up cost a chunk 37 ms on this pool (a blocked
-  // hsa_signal_wait_scacquire / hipEventSynchronize after another GPU process had run next to this one); a poll every 20 us costs nothing.
+  // Polled, not blocked on the signal's interrupt: sleeping for the time the link needs at least and then looking every 20 us keeps no core
+  // busy, adds 10 us on average and does not depend on the interrupt path.  (The 37-ms stalls first blamed on missed interrupts were the
+  // Python consumer's garbage collector, docs/history/r05.md; the poll was kept because it costs nothing.)
   const hsa_signal_t s{sig};
   if (bytes_hint) std::this_thread::sleep_for(std::chrono::nanoseconds((long long)(bytes_hint / 60.0)));       // no transfer beats 60 GB/s: sleep that long first
   const auto t0 = std::chrono::steady_clock::now();
-  while (hsa_signal_load_scacquire(s) >= 1) {
+  hsa_signal_value_t v;
+  while ((v = hsa_signal_load_scacquire(s)) >= 1) {
     std::this_thread::sleep_for(std::chrono::microseconds(20));
     // (a slab is at most a few GB: seconds even on the slowest engine; a transfer that never completes must not hang the caller silently)
     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { set_error("sdma: transfer did not complete within 60 s"); return DABX_E_HIP; }
   }
+  if (v < 0) { set_error("sdma: the transfer failed (the runtime set its signal to %lld)", (long long)v); return DABX_E_HIP; }      // the runtime's way to report a fault
   return 0;
 }
 

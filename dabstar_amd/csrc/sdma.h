@@ -11,6 +11,7 @@ namespace dabx {
 
 struct Sdma {
   uint64_t gpu_agent = 0;       // hsa_agent_t::handle of the HIP device's agent
+  uint64_t cpu_agent = 0;       // ... of the first CPU agent (stands in for the owner of a host buffer the runtime cannot name)
   uint32_t engine_to_host = 0;  // hsa_amd_sdma_engine_id_t (one bit) the transfers of each direction are put on: the first of the engines the
   uint32_t engine_to_dev = 0;   // runtime names as preferred for the GPU <-> CPU pair.  Not left to hsa_amd_memory_async_copy: of the MI355X's 16
                                 // engines only 0-3 reach the link's rate towards the host (56 GB/s; 4-7: 12.7, 8-15: 7-10 GB/s, tools/sdma_engines.hip),
