@@ -81,6 +81,7 @@ def parse():
                          "with --unlocked: streams in a drop-out are searched next to the steps in this form too")
     ap.add_argument("--keep-gc", action="store_true", help="experiments: leave python's cyclic garbage collector on during the timed regions")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host leg (config.host_to_host)")
+    ap.add_argument("--host-leg-chunks", type=int, default=8, help="timed 5-frame chunks of the host-to-host leg (8; more = a soak of ingest + delivery)")
     ap.add_argument("--no-single-legs", action="store_true", help="skip the single-ensemble legs (config.single_ensemble)")
     ap.add_argument("--deliver-copy-engine", type=int, default=0, choices=[0, 1], help="experiments: dabx_delivery_config.copy_engine (1 = hipMemcpyAsync)")
     ap.add_argument("--deliver-what", type=int, default=0, help="experiments: DABX_DELIVER_* mask (1 FIBs, 2 logical frames, 4 super frames; 0 = all)")
@@ -511,7 +512,7 @@ def measure_link_probe():
 def host_to_host_leg(args, subch, dx, link):
     """Host memory in, host memory out: uint8 IQ of every stream from page-locked host slabs (dabx_ingest_*: one slab
     of 5 frames x all streams = 1 GB, one SDMA transfer, one conversion kernel), every FIB / logical frame / super frame back into
-    page-locked host slabs (dabx_delivery_*), 8 chunks timed after 8 of priming.  The link carries 393 216 B in and 14 208 B (+ super
+    page-locked host slabs (dabx_delivery_*), 8 chunks (--host-leg-chunks) timed after 8 of priming.  The link carries 393 216 B in and 14 208 B (+ super
     frames) out per frame: the rate is the link's, not the decoder's."""
     from tools import dab_synth as ds
     CH, S = 5, args.streams
@@ -546,7 +547,7 @@ def host_to_host_leg(args, subch, dx, link):
     while sink.chunks < 1:
         time.sleep(0.0002)
     c1, q1 = eng.counters(), sink.totals()
-    N = 8
+    N = max(1, args.host_leg_chunks)
     t0 = time.perf_counter()
     for _ in range(N):
         chunk(True)
