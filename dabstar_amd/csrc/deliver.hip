@@ -1,7 +1,7 @@
 // deliver.hip -- bulk delivery of a chunk's results (include/dabx.h, "Bulk delivery"): two gather kernels pack everything the
 // frames of one MSC batch produced -- FIBs + CRC flags + frame records (front-end stream), logical frames + super frames + the
 // slots' counters (behind the DAB+ stage, on the stream that ran it) -- into ONE device slab; engine.cpp then moves the slab to a
-// page-locked host slab with one hipMemcpyAsync on a copy stream.  The host side of what the reference does per item:
+// page-locked host slab with ONE transfer on an SDMA engine (sdma.h; the copier thread).  The host side of what the reference does per item:
 // IFibDecoder::process_FIB from fic_decoder.cpp:234-261, FrameProcessor::add_to_frame from backend.cpp:160, the super frame of
 // mp4processor.cpp:149-158.  Pure HBM copies: 14 208 B of results per frame + 13 % (super frames are the logical
 // frames' bytes again, RS-corrected) -- 0.7 % of the chain's algorithmic bytes.
