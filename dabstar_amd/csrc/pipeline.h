@@ -4,6 +4,21 @@
 
 namespace dabx {
 
+// Cache hints of the streaming accesses: a set bit makes the access __builtin_nontemporal_load / _store (the `nt` modifier: the line is not kept
+// in L2 beyond its use).  The defaults are the measured ones (same-box A/B over three sessions, profiles/r05_ab/ab10_nontemporal_hints.txt:
+// +1.9 % together); the other bits stay selectable for A/B builds (tools/build_variant.sh -DDABX_VIT_NT=0 ...).
+#ifndef DABX_VIT_NT
+#define DABX_VIT_NT 3      // k_msc_vitT: 1 = survivor-decision stores, 2 = their chain-back loads (3.6 + 3.2 GB per launch, each touched once: +1.1 %);
+#endif                     //             4 = the transposed input (slower: a dword row is read up to four times in a row)
+#ifndef DABX_SYM_NT
+#define DABX_SYM_NT 2      // k_symbols: 2 = spectra stores (read next by the demapper, 478 MB later); 1 = IQ loads (slower: the cyclic prefix is read twice)
+#endif
+#ifndef DABX_DEMAP_NT
+#define DABX_DEMAP_NT 1    // demapper: 1 = spectra loads; 2 = ring stores (no effect)
+#endif
+#ifndef DABX_PREP_NT
+#define DABX_PREP_NT 0     // k_msc_prep: 1 = ring reads (-2.4 %: 64-byte runs, the other half of the line follows), 2 = transposed stores (-0.8 %)
+#endif
 #ifndef DABX_MSC_BATCH               // experiment builds only (tools/build_variant.sh -DDABX_MSC_BATCH=n, bench.py --chunk n)
 #define DABX_MSC_BATCH 7
 #endif

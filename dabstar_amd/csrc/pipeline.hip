@@ -888,7 +888,12 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
   const bool two = tid + 256 < TG;
   float2 nx[12];
   auto request = [&](int o) {
+#if DABX_SYM_NT & 1          // (A/B builds: the samples past the caches, pipeline.h)
+    typedef float sym_f2 __attribute__((ext_vector_type(2)));
+    auto at = [&](unsigned i) { unsigned a = (unsigned)o + i; if (a >= len) a -= len; const sym_f2 q = __builtin_nontemporal_load(reinterpret_cast<const sym_f2 *>(ring + a)); return make_float2(q.x, q.y); };
+#else
     auto at = [&](unsigned i) { unsigned a = (unsigned)o + i; if (a >= len) a -= len; return ring[a]; };
+#endif
     nx[0] = at(tid); nx[1] = at(TU + tid);
     nx[2] = at(two ? tid + 256 : tid); nx[3] = at(two ? TU + tid + 256 : TU + tid);
 #pragma unroll
@@ -952,7 +957,16 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
     __syncthreads();
     float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
 #pragma unroll
+#if DABX_SYM_NT & 2          // the spectra, read next by the demapper after 478 MB more have been written: past the caches (pipeline.h)
+    for (int u = 0; u < K / 256; u++) {
+      typedef float sym_f2 __attribute__((ext_vector_type(2)));
+      const float2 q = lds[((tid + 256 * u) & ~15) | ((rd_lo >> (4 * u)) & 15u)];
+      sym_f2 qv; qv.x = q.x; qv.y = q.y;
+      __builtin_nontemporal_store(qv, reinterpret_cast<sym_f2 *>(dst + tid + 256 * u));
+    }
+#else
     for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[((tid + 256 * u) & ~15) | ((rd_lo >> (4 * u)) & 15u)];
+#endif
     if (l_next >= 75) break;
     l = l_next;
     __syncthreads();                                          // the exchange buffer and red3 are free again
@@ -967,6 +981,25 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
 constexpr int DEMAP_Q = DABX_DEMAP_Q, DEMAP_THREADS = K / DEMAP_Q, DEMAP_NP = DEMAP_Q / 2;   // carriers per thread (in pairs); 12 waves per stream
 constexpr int DEMAP_NOUT = (K2 / 4) / DEMAP_THREADS;              // output dwords per thread and symbol
 constexpr int TILE_PLANE = 196;                                   // LDS bytes per plane of the output tile (192 used)
+// cache hints of the demapper's streams (pipeline.h, DABX_DEMAP_NT): 1 = the spectra, read once, past the caches; 2 = the ring stores
+__device__ __forceinline__ float2 demap_ld_spec(const float2 *p)
+{
+#if DABX_DEMAP_NT & 1
+  typedef float dm_f2 __attribute__((ext_vector_type(2)));
+  const dm_f2 q = __builtin_nontemporal_load(reinterpret_cast<const dm_f2 *>(p));
+  return make_float2(q.x, q.y);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void demap_st_ring(uint32_t *p, uint32_t v)
+{
+#if DABX_DEMAP_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 // ESoftBitType 1..3 and the symbol conversion (SAT: the SIMD builds' saturating one, cfg.viterbi_tie_mode != 0) as compile-time
 // constants: no per-carrier branches on either
 template <int SOFT_TYPE, bool SAT>
@@ -1028,7 +1061,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   // immediate offsets of +- (DEMAP_Q / 2 - 1/2) * DEMAP_THREADS elements from it, no 64-bit address arithmetic in the loop
   const float2 *xp = spectra + ((size_t)s * 75 + l0) * K + tid + (DEMAP_Q / 2) * DEMAP_THREADS;
 #pragma unroll
-  for (int q = 0; q < DEMAP_Q; q++) xn[q] = xp[(q - DEMAP_Q / 2) * DEMAP_THREADS];
+  for (int q = 0; q < DEMAP_Q; q++) xn[q] = demap_ld_spec(xp + (q - DEMAP_Q / 2) * DEMAP_THREADS);
   // The 3072 Viterbi symbols of an OFDM symbol leave through LDS: every thread drops its bytes into a tile that is
   // already laid out like the planar ring (plane = i & 15, 192 positions per plane and symbol), and after the barrier of
   // the mean-value reduction the block stores aligned dwords -- one per thread with 768 threads, 48 consecutive dwords per
@@ -1053,7 +1086,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     uint8_t *tl = tile[PAR];
     float2 xc[DEMAP_Q];
 #pragma unroll
-    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = xp[(q - DEMAP_Q / 2) * DEMAP_THREADS]; }
+    for (int q = 0; q < DEMAP_Q; q++) { xc[q] = xn[q]; xn[q] = demap_ld_spec(xp + (q - DEMAP_Q / 2) * DEMAP_THREADS); }
     float part = 0.f;
 #pragma unroll
     for (int p = 0; p < DEMAP_NP; p++) {
@@ -1106,7 +1139,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
         static_assert(K2 % 16 == 0, "a symbol is a whole number of positions in every plane");
         uint8_t *const tdi_thr = tdi + (size_t)out_plane * (CIF_BITS / 16) + 4 * out_dw;
         const size_t uoff = (size_t)((cif0 + cif) & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)blk * (K2 / 16);
-        *reinterpret_cast<uint32_t *>(tdi_thr + uoff) = v;
+        demap_st_ring(reinterpret_cast<uint32_t *>(tdi_thr + uoff), v);
       }
     }
   };

@@ -37,6 +37,23 @@ __device__ __forceinline__ int msc_class_of_group(const MscLaunch &L, int g)
   return c;
 }
 
+// cache hints of k_msc_prep's streams (pipeline.h, DABX_PREP_NT; both off: measured slower)
+__device__ __forceinline__ uint32_t prep_ld(const uint32_t *p)
+{
+#if DABX_PREP_NT & 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void prep_st(uint32_t *p, uint32_t v)
+{
+#if DABX_PREP_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 constexpr int PREP_STG = PJB * 16 * (PCH / 4) / 256;             // (job, plane, dword) items per thread and chunk (32)
 __device__ __forceinline__ void prep_item(int it, int cw, bool full, int &d, int &pl, int &job)
 {
@@ -63,7 +80,7 @@ __device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int ti
       if (base) {
         const unsigned slot = (unsigned)(s_r[r] - 16 + brev) & (TDI_SLOTS - 1);      // out_r[idx] = in_{r-16+map[idx&15]}[idx], backend.cpp:129
         const int2 mv = s_mv[r];
-        v = *reinterpret_cast<const uint32_t *>(base + (brev < mv.x ? mv.y : 0) + (size_t)slot * CIF_BITS + in_plane);
+        v = prep_ld(reinterpret_cast<const uint32_t *>(base + (brev < mv.x ? mv.y : 0) + (size_t)slot * CIF_BITS + in_plane));
       }
       stage[r] = v;
     }
@@ -81,7 +98,7 @@ __device__ __forceinline__ void prep_request(uint32_t (&stage)[PREP_STG], int ti
         // out_r[idx] = in_{r-16+map[idx&15]}[idx], map = 4-bit reversal (backend.cpp:129); planar ring: plane = idx & 15
         const long long cif = s_r[job] - 16 + bitrev4(pl);
         const int2 mv = s_mv[job];
-        v = *reinterpret_cast<const uint32_t *>(base + (bitrev4(pl) < mv.x ? mv.y : 0) + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d);
+        v = prep_ld(reinterpret_cast<const uint32_t *>(base + (bitrev4(pl) < mv.x ? mv.y : 0) + (size_t)(cif & (TDI_SLOTS - 1)) * CIF_BITS + (size_t)pl * (CIF_BITS / 16) + p0 + 4 * d));
       }
     }
     stage[r] = v;
@@ -148,10 +165,10 @@ __global__ __launch_bounds__(256) void k_msc_prep(EngineDev e, int cifs, MscLaun
       const uint32_t a = __builtin_amdgcn_perm(m1, m0, 0x05010400u), b = __builtin_amdgcn_perm(m1, m0, 0x07030602u);
       const uint32_t c = __builtin_amdgcn_perm(m3, m2, 0x05010400u), f = __builtin_amdgcn_perm(m3, m2, 0x07030602u);
       const int P = p0 + 4 * d;                                    // position P + k holds idx = 16 (P + k) + plane: dword 4 (P + k) + pg
-      dst[(size_t)(4 * (P + 0) + pg) * 64] = __builtin_amdgcn_perm(c, a, 0x05040100u);
-      dst[(size_t)(4 * (P + 1) + pg) * 64] = __builtin_amdgcn_perm(c, a, 0x07060302u);
-      dst[(size_t)(4 * (P + 2) + pg) * 64] = __builtin_amdgcn_perm(f, b, 0x05040100u);
-      dst[(size_t)(4 * (P + 3) + pg) * 64] = __builtin_amdgcn_perm(f, b, 0x07060302u);
+      prep_st(&dst[(size_t)(4 * (P + 0) + pg) * 64], __builtin_amdgcn_perm(c, a, 0x05040100u));
+      prep_st(&dst[(size_t)(4 * (P + 1) + pg) * 64], __builtin_amdgcn_perm(c, a, 0x07060302u));
+      prep_st(&dst[(size_t)(4 * (P + 2) + pg) * 64], __builtin_amdgcn_perm(f, b, 0x05040100u));
+      prep_st(&dst[(size_t)(4 * (P + 3) + pg) * 64], __builtin_amdgcn_perm(f, b, 0x07060302u));
     }
     __syncthreads();
   }
@@ -176,6 +193,11 @@ __device__ __forceinline__ vt_rsrc vt_make_rsrc(const uint32_t *base, unsigned b
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword format (gfx9 / CDNA)
 }
+#if DABX_VIT_NT & 4          // (A/B builds: the transposed input past the caches; aux bit 1 = nt)
+constexpr int VT_IN_AUX = 2;
+#else
+constexpr int VT_IN_AUX = 0;
+#endif
 __device__ __forceinline__ void vt_fetch(VtCycle &c, vt_rsrc in_grp, int lane, vt_cmap map, int t0)
 {
   c.sh = 0;
@@ -185,7 +207,7 @@ __device__ __forceinline__ void vt_fetch(VtCycle &c, vt_rsrc in_grp, int lane, v
     const unsigned idx[4] = {m.x & 0xFFFFu, m.x >> 16, m.y & 0xFFFFu, m.y >> 16};
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      c.w[4 * s6 + p] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(in_grp, lane * 4, (int)((idx[p] >> 2) * 256u), 0);
+      c.w[4 * s6 + p] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(in_grp, lane * 4, (int)((idx[p] >> 2) * 256u), VT_IN_AUX);
       c.sh |= (unsigned long long)(idx[p] & 3) << (2 * (4 * s6 + p));
     }
   }
@@ -234,7 +256,11 @@ __device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t
   else if constexpr (C == 3) { vt::bm3(w, b, v2n, M); vt::step3<TIE, CLAMP>(R, M, acc0, acc1, lim); }
   else if constexpr (C == 4) { vt::bm4(w, b, v2n, M); vt::step4<TIE, CLAMP>(R, M, acc0, acc1, lim); }
   else { vt::bm5(w, b, v2n, M); vt::step5<TIE, CLAMP>(R, M, acc0, acc1, lim); }
+#if DABX_VIT_NT & 1          // decision words, written once and read once: past the caches (pipeline.h)
+  { typedef unsigned vt_u2 __attribute__((ext_vector_type(2))); vt_u2 dv_; dv_.x = acc0; dv_.y = acc1; __builtin_nontemporal_store(dv_, reinterpret_cast<vt_u2 *>(&dec_lane[(size_t)t * 64])); }
+#else
   dec_lane[(size_t)t * 64] = make_uint2(acc0, acc1);
+#endif
   if constexpr (TIE != 0 && (C & 1) != 0) {
     if (__builtin_amdgcn_ballot_w64(pre)) {              // some lane renormalises (wave-uniform branch; every ~100-200 steps per lane)
       const int mnv = vt::min64(R);
@@ -278,6 +304,12 @@ struct VtDec6 { uint2 w0, w1, w2, w3, w4, w5; };
 __device__ __forceinline__ VtDec6 vt_load_dec(const uint2 *dec_lane, int t0)
 {
   VtDec6 d;
+#if DABX_VIT_NT & 2
+  typedef unsigned vt_u2 __attribute__((ext_vector_type(2)));
+  auto ld = [&](int t) { const vt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const vt_u2 *>(&dec_lane[(size_t)t * 64])); return make_uint2(v.x, v.y); };
+  d.w0 = ld(t0); d.w1 = ld(t0 + 1); d.w2 = ld(t0 + 2); d.w3 = ld(t0 + 3); d.w4 = ld(t0 + 4); d.w5 = ld(t0 + 5);
+  return d;
+#endif
   d.w0 = dec_lane[(size_t)(t0 + 0) * 64]; d.w1 = dec_lane[(size_t)(t0 + 1) * 64]; d.w2 = dec_lane[(size_t)(t0 + 2) * 64];
   d.w3 = dec_lane[(size_t)(t0 + 3) * 64]; d.w4 = dec_lane[(size_t)(t0 + 4) * 64]; d.w5 = dec_lane[(size_t)(t0 + 5) * 64];
   return d;
