@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void k_deliver_msc(EngineDev e, DeliverDev dv)
   const int sj = blockIdx.x, lane = threadIdx.x;
   const SubchDev &sc = e.subch[sj];
   uint8_t *slab = dv.slab;
-  const unsigned long long msc_off = dv.layout_off[2 * (size_t)sj], sf_off = dv.layout_off[2 * (size_t)sj + 1];
+  const unsigned long long msc_off = dv.layout_off[3 * (size_t)sj], sf_off = dv.layout_off[3 * (size_t)sj + 1], sfi_off = dv.layout_off[3 * (size_t)sj + 2];
   const int R = sc.kbps / 8, nb = 3 * sc.kbps, sfb = 110 * R, pitch = (sfb + 3) & ~3;
   const int cap_cifs = 4 * dv.hdr.max_frames, cap_sf = (4 * dv.hdr.max_frames + 4) / 5;
   long long c_done = dv.cif_done[sj], s_done = dv.sf_done[sj];
@@ -100,6 +100,12 @@ __global__ __launch_bounds__(64) void k_deliver_msc(EngineDev e, DeliverDev dv)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + (size_t)((first_s + f) % SF_SLOTS) * e.sf_stride);
         for (int w = lane; w < wpf; w += 64) o[(size_t)f * wpf + w] = src[w];
       }
+      // ... and their records (32 bytes = 8 words each)
+      if (e.sf_info && lane < 8 * n_s) {
+        const uint32_t *inf = reinterpret_cast<const uint32_t *>(e.sf_info + (size_t)sj * SF_SLOTS);
+        uint32_t *oi = reinterpret_cast<uint32_t *>(slab + sfi_off);
+        for (int w = lane; w < 8 * n_s; w += 64) oi[w] = inf[(size_t)((first_s + (w >> 3)) % SF_SLOTS) * 8 + (w & 7)];
+      }
     }
   }
   if (lane == 0) {
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(64) void k_deliver_msc(EngineDev e, DeliverDev dv)
     r.start_cif = sc.start_cif; r.first_cif = first_c; r.n_cifs = n_c; r.cifs_lost = lost_c;
     r.first_sf = first_s; r.n_sf = n_s; r.sf_lost = lost_s; r.msc_off = msc_off; r.sf_off = sf_off; r.sf_pitch = pitch; r.reserved = 0;
     r.sf_ok = sc.sf_ok; r.sf_fail = sc.sf_fail; r.rs_corrected = sc.rs_corr; r.rs_failed = sc.rs_fail; r.fc_corrected = sc.fc_corr;
-    r.au_ok = sc.au_ok; r.au_bad = sc.au_bad;
+    r.au_ok = sc.au_ok; r.au_bad = sc.au_bad; r.sfi_off = sfi_off;
     reinterpret_cast<dabx_chunk_subch *>(slab + dv.hdr.off_subch)[sj] = r;
     if (live) { dv.cif_done[sj] = sc.cif_out; dv.sf_done[sj] = sc.sf_count; }
   }

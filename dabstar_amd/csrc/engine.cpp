@@ -48,7 +48,7 @@ struct Delivery {
   int copy_engine = 0;                           // dabx_delivery_config.copy_engine: 0 SDMA through the HSA runtime, 1 hipMemcpyAsync
   static constexpr int NDEV = 3;                 // device slabs: chunk n + 3 is packed into the slab of chunk n once its copy has left
   uint8_t *dev[NDEV] = {nullptr, nullptr, nullptr};
-  hipEvent_t packed[NDEV] = {nullptr, nullptr, nullptr};    // the chunk's gather kernels have finished (blocking-sync events)
+  hipEvent_t packed[NDEV] = {nullptr, nullptr, nullptr};    // the chunk's gather kernels have finished (system-scope release; the copier polls them)
   bool dev_busy[NDEV] = {false, false, false};   // packed into or being copied from (guarded by mu)
   hipStream_t cs = nullptr;                      // copy_engine 1 only
   Sdma sdma;
@@ -137,6 +137,7 @@ struct dabx_engine {
   int delivery_layout();                       // offsets of every slot's bytes in a slab for the sub-channels configured now
   int delivery_begin(DeliverDev *dv, int *slot, int *devslab);     // a chunk closes: host + device slab, front gather on stream a
   int delivery_finish(int slot, int devslab, hipStream_t tail);    // ... its slot gather is queued on `tail`: the one copy
+  void delivery_abort(int slot, int devslab);                      // ... or it cannot be: both slabs go back
 
   template <class T> int alloc(T **p, size_t count, bool zero = true)
   {
@@ -272,7 +273,8 @@ static int sync_all(dabx_engine *e, bool chain_only = false)
 // ---- bulk delivery (include/dabx.h "Bulk delivery", deliver.hip) -------------------------------------------------------
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the slab's records are ABI: hosts and the python binding (dabstar_amd/lib.py, CHUNK_*) parse them by these sizes
-static_assert(sizeof(dabx_chunk_header) == 128 && sizeof(dabx_chunk_stream) == 72 && sizeof(dabx_chunk_frame) == 16 && sizeof(dabx_chunk_subch) == 136,
+static_assert(sizeof(dabx_chunk_header) == 128 && sizeof(dabx_chunk_stream) == 72 && sizeof(dabx_chunk_frame) == 16 && sizeof(dabx_chunk_subch) == 144 &&
+              sizeof(dabx_superframe_info) == 32,
               "include/dabx.h: chunk record layout");
 static constexpr int DL_FRAMES = MSC_BATCH_FRAMES;                 // a chunk = what one MSC batch decodes
 static constexpr int DL_SF_CAP = (4 * DL_FRAMES + 4) / 5;          // super frames one chunk can complete (4 CIFs may be waiting from before)
@@ -298,13 +300,13 @@ int dabx_engine::delivery_layout()
   h.off_fib = off; if (fib) off = align_up(off + S * F * 384, 16);
   h.off_crc = off; if (fib) off = align_up(off + S * F * 12, 16);
   h.off_frame = off; if (fib) off = align_up(off + S * F * sizeof(dabx_chunk_frame), 16);
-  std::vector<unsigned long long> lo(2 * S * M + 2, 0);
+  std::vector<unsigned long long> lo(3 * S * M + 3, 0);
   h.off_msc = off;
   if ((D.what & (DABX_DELIVER_MSC | DABX_DELIVER_MSC_NOT_DABPLUS)) && !d.fic_only)
     for (size_t sj = 0; sj < S * M; sj++) {
       const SubchDev &sc = subch_host[sj];
       if (!sc.active || (!(D.what & DABX_DELIVER_MSC) && sc.dab_plus)) continue;
-      lo[2 * sj] = off;
+      lo[3 * sj] = off;
       off = align_up(off + (size_t)4 * F * 3 * sc.kbps, 16);
     }
   h.off_sf = off;
@@ -312,8 +314,10 @@ int dabx_engine::delivery_layout()
     for (size_t sj = 0; sj < S * M; sj++) {
       const SubchDev &sc = subch_host[sj];
       if (!sc.active || !sc.dab_plus) continue;
-      lo[2 * sj + 1] = off;
+      lo[3 * sj + 1] = off;
       off = align_up(off + (size_t)DL_SF_CAP * (size_t)((110 * (sc.kbps / 8) + 3) & ~3), 16);
+      lo[3 * sj + 2] = off;
+      off += (size_t)DL_SF_CAP * sizeof(dabx_superframe_info);
     }
   h.bytes = off;
   if (off > D.capacity) {
@@ -324,7 +328,7 @@ int dabx_engine::delivery_layout()
   D.hdr = h;
   D.bytes = off;
   if (S * M) {
-    DABX_HIP(hipMemcpy(D.layout_off, lo.data(), sizeof(unsigned long long) * 2 * S * M, hipMemcpyHostToDevice));
+    DABX_HIP(hipMemcpy(D.layout_off, lo.data(), sizeof(unsigned long long) * 3 * S * M, hipMemcpyHostToDevice));
     std::vector<int32_t> ids(subch_id_host.begin(), subch_id_host.begin() + S * M);
     DABX_HIP(hipMemcpy(D.subch_id, ids.data(), sizeof(int32_t) * S * M, hipMemcpyHostToDevice));
   }
@@ -346,8 +350,13 @@ int dabx_engine::delivery_begin(DeliverDev *dv, int *slot, int *devslab)
     seq = D.next_seq++;
     const int k = (int)(seq % Delivery::NDEV);
     // the copy of chunk seq - NDEV has left the device slab (long ago, unless the link is the bottleneck: then the receiver waits here)
-    D.cv.wait(lk, [&]() { return !D.dev_busy[k] || !D.copier_error.empty(); });
-    if (!D.copier_error.empty()) { set_error("delivery: %s", D.copier_error.c_str()); return DABX_E_HIP; }
+    // (bounded: a device slab that never comes back -- a copier that died -- must fail the call, not hang it)
+    if (!D.cv.wait_for(lk, std::chrono::seconds(30), [&]() { return !D.dev_busy[k] || !D.copier_error.empty(); })) {
+      D.next_seq--;
+      set_error("delivery: device slab %d still busy after 30 s (chunk %llu)", k, (unsigned long long)seq);
+      return DABX_E_STATE;
+    }
+    if (!D.copier_error.empty()) { D.next_seq--; set_error("delivery: %s", D.copier_error.c_str()); return DABX_E_HIP; }
     D.dev_busy[k] = true;
     D.slots[(size_t)h].state = Delivery::IN_FLIGHT;
     D.slots[(size_t)h].seq = seq;
@@ -369,11 +378,33 @@ int dabx_engine::delivery_begin(DeliverDev *dv, int *slot, int *devslab)
   return rc;
 }
 
+// A chunk that was begun cannot be finished (a launch of its MSC batch failed, or the event below): the host slab and the device slab go
+// back, so that neither is lost and no later chunk waits for a copy nobody will make.  The chunk number is given back too (nothing was queued
+// for the consumer); what the front gather already wrote into the device slab is overwritten by the next chunk that takes it.  The delivery
+// is marked failed: every later call reports why.
+void dabx_engine::delivery_abort(int slot, int devslab)
+{
+  Delivery &D = dl;
+  std::lock_guard<std::mutex> lk(D.mu);
+  D.slots[(size_t)slot].state = Delivery::FREE;
+  D.dev_busy[devslab] = false;
+  if (D.next_seq > 0) D.next_seq--;
+  if (D.copier_error.empty()) D.copier_error = "a chunk was abandoned after a failed launch: " + std::string(dabx::last_error());
+  D.cv.notify_all();
+}
+
 // ... and once its slot gather is queued behind the DAB+ stage on `tail`: the copier takes over.
 int dabx_engine::delivery_finish(int slot, int devslab, hipStream_t tail)
 {
   Delivery &D = dl;
-  DABX_HIP(hipEventRecord(D.packed[devslab], tail));
+  {
+    const hipError_t he = hipEventRecord(D.packed[devslab], tail);
+    if (he != hipSuccess) {
+      set_error("HIP error %d (%s) at %s:%d", (int)he, hipGetErrorString(he), __FILE__, __LINE__);
+      delivery_abort(slot, devslab);
+      return DABX_E_HIP;
+    }
+  }
   std::lock_guard<std::mutex> lk(D.mu);
   D.slots[(size_t)slot].bytes = D.bytes;
   D.queue.push_back(slot);
@@ -553,6 +584,12 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipEventCreateWithFlags(&e->ss.fic_go, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    H(hipEventCreateWithFlags(&e->ss.sym_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    // few streams: both demapper launches of a frame on stream d (pipeline.h, fic_on_d).  The threshold is k_symbols' own (sym_blocks_per_stream:
+    // below 48 streams a frame's symbols are spread over more blocks because latency, not throughput, is what is left); DABX_FIC_ON_D = 0 / 1
+    // overrides it for A/B runs
+    e->ss.fic_on_d = cfg->n_streams < 48;
+    if (const char *v = getenv("DABX_FIC_ON_D")) e->ss.fic_on_d = atoi(v) != 0;
     // the ingest stream BEFORE q: the runtime deals streams to its hardware queues in order of creation, and as the fifth stream the
     // ingest stream shared one (every synchronous push 20 us = 20 % dearer at 512 streams, tools/bench_ingest.py)
     H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
@@ -625,6 +662,7 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.frame_pos, (size_t)S * d.out_frames));
   A(e->alloc(&d.frame_start, (size_t)S * d.out_frames));
   if (d.capture_soft) A(e->alloc(&d.soft_cap, (size_t)S * 75 * K2));
+  A(e->alloc(&d.sf_info, (size_t)S * std::max(1, d.max_subch) * SF_SLOTS));
   // demapper state (constructor defaults: ofdm_decoder.h:101-104)
   A(demap_alloc(d.demap, S));
   d.demap.soft_type = cfg->soft_bit_type;
@@ -662,6 +700,7 @@ void dabx_destroy(dabx_engine *e)
   if (e->ss.prep_b_done) (void)hipEventDestroy(e->ss.prep_b_done);
   if (e->ss.d) { (void)hipStreamSynchronize(e->ss.d); (void)hipStreamDestroy(e->ss.d); }
   if (e->ss.demap_done) (void)hipEventDestroy(e->ss.demap_done);
+  if (e->ss.sym_done) (void)hipEventDestroy(e->ss.sym_done);
   if (e->ss.q) { (void)hipStreamSynchronize(e->ss.q); (void)hipStreamDestroy(e->ss.q); }
   if (e->ss.acq_done) (void)hipEventDestroy(e->ss.acq_done);
   if (e->ss.tail_done) (void)hipEventDestroy(e->ss.tail_done);
@@ -1079,7 +1118,11 @@ int dabx_process(dabx_engine *e, int max_frames, int sync)
       e->dev.snap = e->snap_buf[e->ss.batch_parity];
       hipStream_t tail = e->stream;
       rc = launch_msc_batch(e->dev, 4 * e->pending_frames, e->have_fast ? &e->fast : nullptr, e->ss, e->mk, e->dl.open ? &dv : nullptr, &tail);
-      if (rc) return rc;
+      if (rc) {
+        if (e->dl.open) e->delivery_abort(dl_slot, dl_dev);          // the slabs of the chunk that was begun: never left IN_FLIGHT without a copy job
+        e->pending_frames = 0;
+        return rc;
+      }
       if (e->dl.open && (rc = e->delivery_finish(dl_slot, dl_dev, tail))) return rc;
       e->pending_frames = 0;
     }
@@ -1173,6 +1216,21 @@ int dabx_read_superframes(dabx_engine *e, int stream, int j, int n, uint8_t *byt
                        e->dev.sf_out + (((size_t)stream * e->dev.max_subch + j) * SF_SLOTS + (size_t)(q % SF_SLOTS)) * e->dev.sf_stride,
                        nb, hipMemcpyDeviceToHost));
   }
+  return have;
+}
+
+int dabx_read_superframe_info(dabx_engine *e, int stream, int j, int n, dabx_superframe_info *out)
+{
+  if (!e || stream < 0 || stream >= e->dev.n_streams || j < 0 || j >= e->dev.max_subch || n <= 0 || n > SF_SLOTS || !out) return DABX_E_ARG;
+  SubchDev sc;
+  int rc = fetch_subch(e, stream, j, &sc);
+  if (rc) return rc;
+  if (!sc.active || !e->dev.sf_info) return 0;
+  const int have = (int)std::min<long long>(sc.sf_count, n);
+  std::vector<dabx_superframe_info> ring(SF_SLOTS);
+  DABX_HIP(hipMemcpy(ring.data(), e->dev.sf_info + ((size_t)stream * e->dev.max_subch + j) * SF_SLOTS, sizeof(dabx_superframe_info) * SF_SLOTS,
+                     hipMemcpyDeviceToHost));
+  for (int i = 0; i < have; i++) out[i] = ring[(size_t)((sc.sf_count - have + i) % SF_SLOTS)];
   return have;
 }
 
@@ -1544,22 +1602,22 @@ int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
   // of logical frames per CIF) for 4 F CIFs, and the same again for the super frames of up to DL_SF_CAP x 5 CIFs
   const size_t per_cif = 5632;
   size_t cap = sizeof(dabx_chunk_header) + S * sizeof(dabx_chunk_stream) + S * M * sizeof(dabx_chunk_subch) + S * F * (384 + 12 + sizeof(dabx_chunk_frame)) + 6 * 16;
-  if (M && !d.fic_only) cap += S * ((size_t)4 * F * per_cif + (size_t)DL_SF_CAP * 5 * per_cif + 2 * 16 * M);
+  if (M && !d.fic_only) cap += S * ((size_t)4 * F * per_cif + (size_t)DL_SF_CAP * 5 * per_cif + 2 * 16 * M + M * DL_SF_CAP * sizeof(dabx_superframe_info));
   D.capacity = align_up(cap, 4096);
 #define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); delivery_free(e); return DABX_E_HIP; } } while (0)
   if (D.copy_engine == 1) H(hipStreamCreateWithFlags(&D.cs, hipStreamNonBlocking));
   for (int k = 0; k < Delivery::NDEV; k++) {
     H(hipMalloc((void **)&D.dev[k], D.capacity));
     H(hipMemset(D.dev[k], 0, D.capacity));
-    // system scope: the SDMA engine and the host read what the gather kernels wrote
-    H(hipEventCreateWithFlags(&D.packed[k], hipEventDisableTiming));
+    // system-scope release, explicitly: the SDMA engine (raw HSA, outside HIP's own fences) and the host read what the gather kernels wrote
+    H(hipEventCreateWithFlags(&D.packed[k], hipEventDisableTiming | hipEventReleaseToSystem));
   }
   D.slots.resize((size_t)n_slots);
   for (auto &sl : D.slots) {
     H(hipHostMalloc((void **)&sl.host, D.capacity, hipHostMallocDefault));
     if (D.copy_engine == 0 && (rc = sdma_signal_create(&sl.sig))) { delivery_free(e); return rc; }
   }
-  H(hipMalloc((void **)&D.layout_off, sizeof(unsigned long long) * std::max<size_t>(2 * S * M, 2)));
+  H(hipMalloc((void **)&D.layout_off, sizeof(unsigned long long) * std::max<size_t>(3 * S * M, 3)));
   H(hipMalloc((void **)&D.subch_id, sizeof(int32_t) * std::max<size_t>(S * M, 1)));
   H(hipMalloc((void **)&D.frames_done, sizeof(long long) * S));
   H(hipMalloc((void **)&D.cif_done, sizeof(long long) * std::max<size_t>(S * M, 1)));
@@ -2009,6 +2067,15 @@ int dabx_msc_get_superframe(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes
   if (max_bytes < nb) { set_error("dabx_msc_get_superframe: %d bytes needed", nb); return DABX_E_ARG; }
   const int got = dabx_read_superframes(m->eng, 0, slot, 1, bytes);
   return got < 0 ? got : (got == 1 ? nb : 0);
+}
+
+int dabx_msc_get_superframe_info(dabx_msc *m, int slot, dabx_superframe_info *out)
+{
+  if (!m || slot < 0 || slot >= (int)m->slots.size() || !out) return DABX_E_ARG;
+  const size_t j = (size_t)slot;
+  if (!m->slots[j].kbps || m->sf_now[j] == m->sf_seen[j]) return 0;
+  const int got = dabx_read_superframe_info(m->eng, 0, slot, 1, out);
+  return got < 0 ? got : (got == 1 ? 1 : 0);
 }
 
 int dabx_msc_get_stats(dabx_msc *m, int slot, dabx_subch_stats *out)

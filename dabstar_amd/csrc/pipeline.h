@@ -154,6 +154,7 @@ struct EngineDev {
   int32_t *frame_start;           // [S][out_frames] its start index (PRS correlation peak, dab_processor.cpp:394)
   uint8_t *msc_out;               // [S][max_subch][MSC_SLOTS][msc_stride]
   uint8_t *sf_out;                // [S][max_subch][SF_SLOTS][sf_stride]
+  dabx_superframe_info *sf_info;  // [S][max_subch][SF_SLOTS] AU table, per-AU CRC verdicts, corrections of the super frame in that slot (k_dabplus)
   int16_t *soft_cap;              // [S][75][3072] or null
   BatchSnap *snap;                // [S] counters of the MSC batch being decoded
   float2 *tii_acc;                // [S][2048] sum of the FFTs of the TII null symbols (TiiDetector::mNullSymbolBufferVec)
@@ -163,7 +164,7 @@ struct EngineDev {
 // ---- bulk delivery (deliver.hip, include/dabx.h "Bulk delivery"): what the two gather kernels of a chunk are given, by value
 struct DeliverDev {
   uint8_t *slab;                          // device slab of this chunk
-  const unsigned long long *layout_off;   // [S * max_subch][2] offset of the slot's logical frames / super frames in a slab
+  const unsigned long long *layout_off;   // [S * max_subch][3] offset of the slot's logical frames / super frames / super-frame records in a slab
   const int32_t *subch_id;                // [S * max_subch] SubChId (host knowledge: the device never needs it otherwise)
   long long *frames_done;                 // [S] frames of the stream delivered so far
   long long *cif_done, *sf_done;          // [S * max_subch] logical / super frames of the slot delivered so far
@@ -203,6 +204,14 @@ struct EngineStreams {
   bool acq_a_pending = false;
   bool acq_in_flight = false;                          // a pass on q may still be running
   hipEvent_t prep_done = nullptr, msc_done = nullptr, fic_go = nullptr, prep_b_done = nullptr, demap_done = nullptr;
+  hipEvent_t sym_done = nullptr;
+  // Few streams (one ensemble: BASELINE configs[1] / [2]): the frame rate is the length of a dependency loop, not a throughput.  The loop that
+  // binds is the DEMAPPER's -- 75 symbols serial in one block per stream (per-carrier IIRs + the block-wide mean of every symbol), k_demap_fic (n + 1)
+  // behind k_demap_frame6 (n) -- and with the two launches on two HIP streams every frame paid two event hops of 17-19 us on it
+  // (profiles/r06_single_ensemble_timeline_before.txt: 7.5 + 19 + 88 + 17 = 132 us per frame).  fic_on_d puts both demapper launches on stream d,
+  // back to back; the frame chain on a (head -> symbols -> | FIC decoder -> tail) forks off behind k_demap_fic and joins in front of the next one:
+  // its 68 us + one hop run next to the 88 us of the MSC symbols.
+  bool fic_on_d = false;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
   unsigned step_count = 0;
   bool prep_pending = false;      // k_msc_prep of the previous batch may still be reading the TDI ring on stream b

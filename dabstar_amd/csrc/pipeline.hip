@@ -1743,9 +1743,10 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
       // (crc_xpow, in LDS) and XOR-ed together; the 0xFFFF start value rides on the first two bytes -- calc_crc (crc.cpp:75-86)
       // without a several-hundred-step look-up chain on one lane.
       int good = 0, bad = 0;
+      unsigned crc_mask = 0, len_mask = 0;     // per access unit: passed its CRC / failed the length check (dabx_superframe_info)
       for (int a = 0; a < n_au; a++) {
         const int st = s_au[a], len = s_au[a + 1] - st - 2;
-        if (len > 960 || len < 0 || st + len + 2 > 110 * R) { bad++; continue; }
+        if (len > 960 || len < 0 || st + len + 2 > 110 * R) { bad++; len_mask |= 1u << a; continue; }
         const int per = (len + 63) >> 6, from = lane * per, to = min(len, from + per);
         const unsigned xp_slice = s_xpow[from < to ? len - to : 0];
         // The 0xFFFF start value of a 16-bit CRC is the same as complementing the first two message bytes and starting from 0
@@ -1758,9 +1759,18 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
         if (len < 2 && lane == 0) acc ^= crc_mulmod(0xFFFFu, s_xpow[len]);      // a message shorter than the register: the start value's contribution as it was
         acc = wave_xor(acc);
         const unsigned want = ((unsigned)win[st + len] << 8) | win[st + len + 1];
-        if (((~acc) & 0xFFFFu) == want) good++; else bad++;
+        if (((~acc) & 0xFFFFu) == want) { good++; crc_mask |= 1u << a; } else bad++;
       }
       au_ok += good; au_bad += bad;
+      if (lane == 0 && e.sf_info) {            // what _process_super_frame knows when it hands the access units on (mp4processor.cpp:256-333)
+        dabx_superframe_info r;
+        r.num_aus = (uint8_t)n_au; r.au_crc_ok = (uint8_t)crc_mask; r.au_len_bad = (uint8_t)len_mask; r.stream_parms = (uint8_t)(win[2] & 0x7F);
+#pragma unroll
+        for (int a = 0; a < 7; a++) r.au_start[a] = a <= n_au ? (uint16_t)s_au[a] : (uint16_t)0;
+        r.rs_corrected = (uint16_t)corr; r.rs_failed = (uint8_t)fail; r.fc_corrected = (flag & 2) ? 1 : 0; r.reserved = 0;
+        r.first_frame = oldest;
+        e.sf_info[((size_t)s * e.max_subch + j) * SF_SLOTS + (size_t)(sf_count % SF_SLOTS)] = r;
+      }
       uint8_t *sfo = e.sf_out + (((size_t)s * e.max_subch + j) * SF_SLOTS + (size_t)(sf_count % SF_SLOTS)) * e.sf_stride;
       for (int i = lane; i < (110 * R + 3) / 4; i += 64)
         reinterpret_cast<uint32_t *>(sfo)[i] = reinterpret_cast<const uint32_t *>(win)[i];
@@ -1864,7 +1874,20 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   auto demap = [&](hipStream_t q, int l0, int l1) {
     DABX_DEMAP_DISPATCH(k_demap_frame6, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, q, e, *t, l0, l1);
   };
-  if (ss.d) {
+  if (ss.d && ss.fic_on_d) {
+    // few streams: both demapper launches on d (in order: no event between the per-carrier state's writer and its reader), the FIC decoder and the
+    // tail on a behind the FIC symbols (pipeline.h, EngineStreams::fic_on_d)
+    DABX_HIP(hipEventRecord(ss.sym_done, st));
+    DABX_HIP(hipStreamWaitEvent(ss.d, ss.sym_done, 0));
+    mk.begin(10, ss.d);
+    DABX_DEMAP_DISPATCH(k_demap_fic, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, ss.d, e, *t);
+    mk.end(10, ss.d);
+    DABX_HIP(hipEventRecord(ss.fic_go, ss.d));
+    mk.begin(3, ss.d); demap(ss.d, 3, 75); mk.end(3, ss.d);
+    DABX_HIP(hipEventRecord(ss.demap_done, ss.d));
+    ss.demap_in_flight = true;
+    DABX_HIP(hipStreamWaitEvent(st, ss.fic_go, 0));
+  } else if (ss.d) {
     if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
     mk.begin(10, st);
     DABX_DEMAP_DISPATCH(k_demap_fic, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, st, e, *t);
@@ -1966,14 +1989,31 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
 #endif
     }
   } else {
-    mk.begin(8, ss.a);
-    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, ss.a, e, *t, cifs, 0u);
-    mk.end(8, ss.a);
-    mk.begin(9, ss.a);
-    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, ss.a, e, *t);
-    hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e);
-    mk.end(9, ss.a);
-    if (dv && (rc = launch_deliver_msc(e, *dv, ss.a))) return rc;
+    // small batches (few streams / small profile classes only): the wave-per-trellis decoder.  With the overlapped schedule on stream b as
+    // well (round 6): for ONE ensemble its 0.1 ms + the DAB+ stage's 0.05 ms per 7-frame batch stood on the frame chain (23 us per frame of
+    // configs[2]'s 157).  It reads the time-de-interleaver ring in place: prep_b_done says when the front end may rewrite those slots.
+    hipStream_t sb = ss.b ? ss.b : ss.a;
+    if (ss.b) {
+      DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
+      DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
+    }
+    mk.begin(8, sb);
+    hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, sb, e, *t, cifs, 0u);
+    mk.end(8, sb);
+    if (ss.b) {
+      DABX_HIP(hipEventRecord(ss.prep_b_done, ss.b));
+      ss.prep_pending = true;
+    }
+    mk.begin(9, sb);
+    hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, sb, e, *t);
+    hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, sb, e);
+    mk.end(9, sb);
+    if (dv && (rc = launch_deliver_msc(e, *dv, sb))) return rc;
+    if (tail) *tail = sb;
+    if (ss.b) {
+      DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
+      ss.msc_in_flight = true;
+    }
   }
   ss.batch_parity ^= 1;
   DABX_HIP(hipGetLastError());

@@ -15,7 +15,7 @@ class DabxError(RuntimeError):
 
 def lib_path():
     """The product library.  DABX_LIB (read by this test/bench binding only -- the library itself reads no environment variable) names
-    an experiment build instead (tools/build_variant.sh -> dabstar_amd/_ab/*.so, same-box A/B runs of tools/ab.sh): nothing ever
+    an experiment build instead (tools/build_variant.sh -> tools/_build/ab/*.so, same-box A/B runs of tools/ab.sh): nothing ever
     overwrites libdabx.so."""
     return os.environ.get("DABX_LIB") or os.path.join(HERE, "libdabx.so")
 
@@ -328,8 +328,12 @@ CHUNK_SUBCH = np.dtype([("active", "<i4"), ("subch_id", "<i4"), ("kbps", "<i4"),
                         ("first_cif", "<i8"), ("n_cifs", "<i4"), ("cifs_lost", "<i4"), ("first_sf", "<i8"), ("n_sf", "<i4"),
                         ("sf_lost", "<i4"), ("msc_off", "<u8"), ("sf_off", "<u8"), ("sf_pitch", "<i4"), ("reserved", "<i4"),
                         ("sf_ok", "<i8"), ("sf_fail", "<i8"), ("rs_corrected", "<i8"), ("rs_failed", "<i8"),
-                        ("fc_corrected", "<i8"), ("au_ok", "<i8"), ("au_bad", "<i8")])
-assert CHUNK_HEADER.itemsize == 128 and CHUNK_STREAM.itemsize == 72 and CHUNK_FRAME.itemsize == 16 and CHUNK_SUBCH.itemsize == 136
+                        ("fc_corrected", "<i8"), ("au_ok", "<i8"), ("au_bad", "<i8"), ("sfi_off", "<u8")])
+# dabx_superframe_info: what Mp4Processor::_process_super_frame knows when it hands the access units on (mp4processor.cpp:249-333)
+SUPERFRAME_INFO = np.dtype([("num_aus", "u1"), ("au_crc_ok", "u1"), ("au_len_bad", "u1"), ("stream_parms", "u1"), ("au_start", "<u2", 7),
+                            ("rs_corrected", "<u2"), ("rs_failed", "u1"), ("fc_corrected", "u1"), ("reserved", "<u2"), ("first_frame", "<i8")])
+assert CHUNK_HEADER.itemsize == 128 and CHUNK_STREAM.itemsize == 72 and CHUNK_FRAME.itemsize == 16 and CHUNK_SUBCH.itemsize == 144
+assert SUPERFRAME_INFO.itemsize == 32
 
 
 class DeliveryConfig(C.Structure):
@@ -362,7 +366,7 @@ class Chunk:
         S, M, F = int(h["n_streams"]), int(h["max_subch"]), int(h["max_frames"])
         self.S, self.M, self.F = S, M, F
         self.streams = self.raw[int(h["off_stream"]):int(h["off_stream"]) + S * 72].view(CHUNK_STREAM)
-        self.subch = self.raw[int(h["off_subch"]):int(h["off_subch"]) + S * M * 136].view(CHUNK_SUBCH).reshape(S, M)
+        self.subch = self.raw[int(h["off_subch"]):int(h["off_subch"]) + S * M * 144].view(CHUNK_SUBCH).reshape(S, M)
         if h["what"] & DELIVER_FIB:
             self.fibs = self.raw[int(h["off_fib"]):int(h["off_fib"]) + S * F * 384].reshape(S, F, 12, 32)
             self.crc = self.raw[int(h["off_crc"]):int(h["off_crc"]) + S * F * 12].reshape(S, F, 12)
@@ -380,6 +384,12 @@ class Chunk:
         r = self.subch[s, j]
         nb, pitch, o = 110 * int(r["kbps"]) // 8, int(r["sf_pitch"]), int(r["sf_off"])
         return self.raw[o:o + int(r["n_sf"]) * pitch].reshape(int(r["n_sf"]), pitch)[:, :nb]
+
+    def superframe_info(self, s, j):
+        """Their records (AU table, per-AU CRC verdicts, corrections): [n_sf] SUPERFRAME_INFO (a view)."""
+        r = self.subch[s, j]
+        o = int(r["sfi_off"])
+        return self.raw[o:o + int(r["n_sf"]) * 32].view(SUPERFRAME_INFO)
 
     def release(self):
         if self._eng is not None:
@@ -543,6 +553,12 @@ class Engine:
         nb = 110 * self.subch[j].kbps // 8
         out = np.zeros((n, nb), np.uint8)
         k = check(load().dabx_read_superframes(self._h, stream, j, n, _p(out)))
+        return out[:k]
+
+    def read_superframe_info(self, stream, j, n=1):
+        """Records of the newest n super frames of slot j, oldest first (row i belongs to row i of read_superframes(stream, j, n))."""
+        out = np.zeros(n, SUPERFRAME_INFO)
+        k = check(load().dabx_read_superframe_info(self._h, stream, j, n, _p(out)))
         return out[:k]
 
     def read_soft(self, stream):

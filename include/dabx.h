@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DABX_ABI_VERSION 5
+#define DABX_ABI_VERSION 6
 
 typedef enum {
   DABX_OK = 0,
@@ -119,7 +119,8 @@ int  dabx_fic_get_ber(dabx_fic *f, dabx_fic_ber *out);
  * dabx_msc_get_frame: the logical frame Backend::_process_segment hands to BackendDriver::add_to_frame for that CIF
  * (backend.cpp:140-160) as 3 * kbps PACKED bytes (the reference's outV holds the same 24 * kbps bits one per byte, MSB of
  * byte 0 first); returns the byte count, or 0 while the service's de-interleaver is still filling (first 16 CIFs).
- * dabx_msc_get_superframe: the RS-corrected DAB+ super frame completed by that CIF, if any (110 * kbps / 8 bytes, else 0). */
+ * dabx_msc_get_superframe: the RS-corrected DAB+ super frame completed by that CIF, if any (110 * kbps / 8 bytes, else 0);
+ * dabx_msc_get_superframe_info: its dabx_superframe_info record (returns 1, else 0). */
 typedef struct dabx_msc dabx_msc;
 struct dabx_subch_desc_s;
 int  dabx_msc_create(int max_services, dabx_msc **out);
@@ -131,6 +132,8 @@ int  dabx_msc_is_service_running(dabx_msc *m, int slot);
 int  dabx_msc_process_block(dabx_msc *m, const int16_t *soft /* 3072 */, int blk_nr);
 int  dabx_msc_get_frame(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes);
 int  dabx_msc_get_superframe(dabx_msc *m, int slot, uint8_t *bytes, int max_bytes);
+struct dabx_superframe_info_s;
+int  dabx_msc_get_superframe_info(dabx_msc *m, int slot, struct dabx_superframe_info_s *out);
 struct dabx_subch_stats_s;
 int  dabx_msc_get_stats(dabx_msc *m, int slot, struct dabx_subch_stats_s *out);
 
@@ -392,6 +395,29 @@ int  dabx_set_subchannels_at(dabx_engine *e, int stream, const dabx_subch_desc *
 int  dabx_read_msc(dabx_engine *e, int stream, int subch_idx, int n_cifs, uint8_t *bytes);
 /* RS-corrected DAB+ super frames (110*kbps/8 bytes each), newest last; returns count copied. */
 int  dabx_read_superframes(dabx_engine *e, int stream, int subch_idx, int n, uint8_t *bytes);
+/* What Mp4Processor::_process_super_frame (base/backend/audio/mp4processor.cpp:249-333) knows about a super frame when it hands the
+ * access units to the AAC decoder: the stream parameters (:258-262), numAUs and mAuStartArr (:272-304), the verdict of the length check
+ * (:311) and of check_crc_bytes (:321) for every access unit, and what the RS decoder / the fire code corrected on the way
+ * (:184-241).  One record per super frame in the super-frame ring, written by the device stage that ran all of it (k_dabplus): a host
+ * that feeds an AAC decoder slices the super frame at au_start[] and looks at the masks -- it re-parses no header and re-runs no CRC:
+ *     for (a = 0; a < r.num_aus; a++)
+ *       if (r.au_crc_ok >> a & 1) decoder.decode(sf + r.au_start[a], r.au_start[a + 1] - r.au_start[a] - 2);   // the 2 CRC bytes excluded, :306
+ *       else                      decoder.conceal();                                                         // :316, :339
+ * 32 bytes, little-endian, no padding holes. */
+typedef struct dabx_superframe_info_s {
+  uint8_t  num_aus;        /* 2, 3, 4 or 6 */
+  uint8_t  au_crc_ok;      /* bit a: access unit a passed its CRC */
+  uint8_t  au_len_bad;     /* bit a: access unit a failed the length check (aacFrameLen > 960, < 0, or beyond the super frame); no CRC run */
+  uint8_t  stream_parms;   /* mOutVec[2] & 0x7F: dacRate 0x40, sbrFlag 0x20, aacChannelMode 0x10, psFlag 0x08, mpegSurround 0x07 */
+  uint16_t au_start[7];    /* mAuStartArr[0 .. num_aus]; au_start[num_aus] = 110 * kbps / 8 */
+  uint16_t rs_corrected;   /* byte corrections of the RS decoder in this super frame (sum of its returns >= 0) */
+  uint8_t  rs_failed;      /* code words the RS decoder gave up on (the fire code passed all the same) */
+  uint8_t  fc_corrected;   /* 1: check_and_correct_6bits changed the 11-byte header (mSumFcCorrections) */
+  uint16_t reserved;
+  int64_t  first_frame;    /* index, in the slot's sequence of logical frames, of the first of the super frame's five */
+} dabx_superframe_info;
+/* the records of the newest n super frames, oldest first: row i describes row i of dabx_read_superframes(..., n, ...) */
+int  dabx_read_superframe_info(dabx_engine *e, int stream, int subch_idx, int n, dabx_superframe_info *out);
 int  dabx_read_soft(dabx_engine *e, int stream, int16_t *soft /* 75*3072 */);
 /* dabx_get_stats_sized fills the first `size` bytes of a dabx_stats.  dabx_get_stats is that call with the caller's own
  * sizeof -- as a macro, so that a binary and the library never disagree about how much is written; the exported function of the
@@ -428,7 +454,8 @@ int  dabx_get_counters(dabx_engine *e, int64_t out[16]);
  *   FIBs          [n_streams][max_frames][12][32] bytes, CRC flags [n_streams][max_frames][12], frame records
  *                 dabx_chunk_frame[n_streams][max_frames]   (row f = frame first_frame + f of the stream, f < n_frames)
  *   logical frames of slot (s, j): n_cifs x 3 * kbps bytes from msc_off -- the bytes dabx_read_msc returns, oldest first
- *   super frames   of slot (s, j): n_sf rows of sf_pitch bytes (110 * kbps / 8 used) from sf_off -- dabx_read_superframes' bytes
+ *   super frames   of slot (s, j): n_sf rows of sf_pitch bytes (110 * kbps / 8 used) from sf_off -- dabx_read_superframes' bytes;
+ *                  their n_sf dabx_superframe_info records (AU table, per-AU CRC verdicts, corrections) from sfi_off
  * Chunks are numbered from 0 and delivered in order.  dabx_process fails with DABX_E_STATE, before it has started anything,
  * when the call would close more chunks than there are free host slabs: a consumer that falls behind holds the receiver up,
  * it never loses data silently.  dabx_delivery_open refuses an engine whose FIB ring is shorter than a chunk (dabx_config.out_frames
@@ -484,7 +511,8 @@ typedef struct {
   uint64_t msc_off, sf_off;
   int32_t sf_pitch, reserved;
   int64_t sf_ok, sf_fail, rs_corrected, rs_failed, fc_corrected, au_ok, au_bad;      /* cumulative, as dabx_subch_stats */
-} dabx_chunk_subch;         /* 136 bytes */
+  uint64_t sfi_off;         /* n_sf dabx_superframe_info records, row i for super-frame row i (ABI 6) */
+} dabx_chunk_subch;         /* 144 bytes */
 typedef struct {
   uint64_t seq;
   const void *data;         /* the host slab: valid until dabx_delivery_release(seq) */

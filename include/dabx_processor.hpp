@@ -37,6 +37,10 @@ public:
   std::function<void(const uint8_t *fib32, bool crc_ok, int fib_no)> on_fib;                      // IFibDecoder::process_FIB
   std::function<void(int subChId, const uint8_t *bytes, int n)> on_logical_frame;                 // FrameProcessor::add_to_frame
   std::function<void(int subChId, const uint8_t *bytes, int n)> on_super_frame;                   // Mp4Processor: RS-corrected super frame
+  // Mp4Processor::_process_super_frame's loop over the access units (mp4processor.cpp:306-345), with the verdicts the device stage already
+  // reached: au = the AAC frame WITHOUT its two CRC bytes (what _build_aac_stream is given, :324), crc_ok false = the frame the reference
+  // conceals (:316 length check, :339 CRC).  No header is parsed and no CRC is run on the host.
+  std::function<void(int subChId, const uint8_t *au, int len, bool crc_ok, int au_idx, const dabx_superframe_info &sf)> on_access_unit;
   std::function<void(int ficPercent, float freqOffsBbHz, float clockErrHz, float snrDb)> on_status;   // slot_show_fic_status, ..._freq_corr_bb_Hz, ..._clock_error
 
   std::function<void(const std::vector<dabx_tii_result> &)> on_tii;                                 // signal_show_tii
@@ -304,7 +308,7 @@ private:
   }
   void deliver_services()
   {
-    if (!on_logical_frame && !on_super_frame) return;
+    if (!on_logical_frame && !on_super_frame && !on_access_unit) return;
     std::vector<uint8_t> buf;
     for (size_t j = 0; j < slots_.size(); j++) {
       if (!slots_[j].kbps) continue;
@@ -319,13 +323,26 @@ private:
         for (int i = 0; i < got; i++) on_logical_frame(slots_[j].subch_id, buf.data() + (size_t)i * nb, nb);
         delivered_[j] = st.cifs_decoded;
       }
-      if (on_super_frame && st.sf_count > sf_delivered_[j]) {
+      if ((on_super_frame || on_access_unit) && st.sf_count > sf_delivered_[j]) {
         long long fresh = st.sf_count - sf_delivered_[j];
-        if (fresh > 4) fresh = 4;
+        if (fresh > 16) fresh = 16;                                   // ring depth
         const int nb = 110 * slots_[j].kbps / 8;
         buf.resize((size_t)fresh * nb);
         const int got = dabx_read_superframes(eng_, 0, (int)j, (int)fresh, buf.data());
-        for (int i = 0; i < got; i++) on_super_frame(slots_[j].subch_id, buf.data() + (size_t)i * nb, nb);
+        dabx_superframe_info info[16];
+        const int got_i = on_access_unit ? dabx_read_superframe_info(eng_, 0, (int)j, (int)fresh, info) : 0;
+        for (int i = 0; i < got; i++) {
+          const uint8_t *sf = buf.data() + (size_t)i * nb;
+          if (on_super_frame) on_super_frame(slots_[j].subch_id, sf, nb);
+          if (on_access_unit && i < got_i) {
+            const dabx_superframe_info &r = info[i];
+            for (int a = 0; a < r.num_aus; a++) {
+              const bool bad_len = (r.au_len_bad >> a) & 1;
+              on_access_unit(slots_[j].subch_id, bad_len ? nullptr : sf + r.au_start[a], bad_len ? 0 : r.au_start[a + 1] - r.au_start[a] - 2,
+                             ((r.au_crc_ok >> a) & 1) != 0, a, r);
+            }
+          }
+        }
         sf_delivered_[j] = st.sf_count;
       }
     }

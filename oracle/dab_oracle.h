@@ -145,6 +145,8 @@ typedef struct {
   /* sinks (optional, grown by the oracle) */
   uint8_t *msc_bytes; size_t msc_len, msc_cap;     /* 3*kbps bytes per CIF */
   uint8_t *sf_bytes;  size_t sf_len, sf_cap;       /* 110*kbps/8 bytes per good super frame */
+  uint8_t *sfi_bytes; size_t sfi_len, sfi_cap;     /* 32 bytes per good super frame: stream parameters, AU table, per-AU CRC verdicts,
+                                                      RS / fire-code corrections (mp4processor.cpp:249-333; layout = dabx_superframe_info) */
 } ora_backend;
 int  ora_backend_init(ora_backend *b, const ora_subch_desc *d);
 void ora_backend_free(ora_backend *b);
@@ -152,6 +154,7 @@ void ora_backend_free(ora_backend *b);
 void ora_backend_process(ora_backend *b, const int16_t *in);
 const uint8_t *ora_backend_msc_bytes(const ora_backend *b, size_t *len);
 const uint8_t *ora_backend_sf_bytes(const ora_backend *b, size_t *len);
+const uint8_t *ora_backend_sfi_bytes(const ora_backend *b, size_t *len);
 void ora_backend_stats(const ora_backend *b, long out[8]);
 
 /* FIB/FIG subset (fib.c): FIG 0/0, 0/1, 0/2 -- decoder/fib_decoder.cpp:59-110, fib_decoder_fig0.cpp */

@@ -42,7 +42,7 @@ int ora_backend_init(ora_backend *b, const ora_subch_desc *d)
 void ora_backend_free(ora_backend *b)
 {
   free(b->hist); free(b->tmp); free(b->map); free(b->prbs); free(b->outv);
-  free(b->frame_bytes); free(b->out_vec); free(b->msc_bytes); free(b->sf_bytes);
+  free(b->frame_bytes); free(b->out_vec); free(b->msc_bytes); free(b->sf_bytes); free(b->sfi_bytes);
   memset(b, 0, sizeof(*b));
 }
 
@@ -67,6 +67,7 @@ static int process_rs_frame(ora_backend *b, int base)
 /* mp4processor.cpp:249-333 : AU table + AU CRCs (the AAC decode after it is out of scope) */
 static int process_super_frame(ora_backend *b, int base)
 {
+  const long corr0 = b->n_rs_corr, fail0 = b->n_rs_fail, fc0 = b->n_fc_corr;
   if (!process_rs_frame(b, base)) return 0;
   const uint8_t *o = b->out_vec;
   const int dac = (o[2] >> 6) & 1, sbr = (o[2] >> 5) & 1;
@@ -82,11 +83,27 @@ static int process_super_frame(ora_backend *b, int base)
   default: n_au = 3; au[0] = 6; au[1] = o[3] * 16 + (o[4] >> 4); au[2] = (o[4] & 0xf) * 256 + o[5];
           au[3] = end; break;
   }
+  /* the super frame's record as include/dabx.h (dabx_superframe_info, 32 bytes little-endian) lays it out: what
+   * _process_super_frame knows about the super frame when it hands the access units on (:256-333) */
+  uint8_t rec[32];
+  memset(rec, 0, sizeof rec);
+  rec[0] = (uint8_t)n_au;
+  rec[3] = (uint8_t)(o[2] & 0x7F);                         /* dacRate, sbrFlag, aacChannelMode, psFlag, mpegSurround (:258-262) */
+  for (int i = 0; i <= n_au; i++) { rec[4 + 2 * i] = (uint8_t)(au[i] & 0xFF); rec[5 + 2 * i] = (uint8_t)(au[i] >> 8); }
   for (int i = 0; i < n_au; i++) {
     const int len = au[i + 1] - au[i] - 2;
-    if (len > 960 || len < 0 || au[i] + len + 2 > end) { b->n_au_bad++; continue; }
-    if (ora_check_crc_bytes(&o[au[i]], len)) b->n_au_ok++; else b->n_au_bad++;
+    if (len > 960 || len < 0 || au[i] + len + 2 > end) { b->n_au_bad++; rec[2] |= (uint8_t)(1u << i); continue; }
+    if (ora_check_crc_bytes(&o[au[i]], len)) { b->n_au_ok++; rec[1] |= (uint8_t)(1u << i); } else b->n_au_bad++;
   }
+  {
+    const long corr = b->n_rs_corr - corr0, fail = b->n_rs_fail - fail0;
+    const long long first = (long long)b->n_cif_out - 5;   /* the oldest of the five logical frames (0 = the slot's first) */
+    rec[18] = (uint8_t)(corr & 0xFF); rec[19] = (uint8_t)((corr >> 8) & 0xFF);
+    rec[20] = (uint8_t)fail;
+    rec[21] = (uint8_t)(b->n_fc_corr - fc0);
+    for (int i = 0; i < 8; i++) rec[24 + i] = (uint8_t)(((unsigned long long)first >> (8 * i)) & 0xFF);
+  }
+  sink_append(&b->sfi_bytes, &b->sfi_len, &b->sfi_cap, rec, sizeof rec);
   sink_append(&b->sf_bytes, &b->sf_len, &b->sf_cap, b->out_vec, (size_t)end);
   return 1;
 }
@@ -138,6 +155,7 @@ void ora_backend_process(ora_backend *b, const int16_t *in)
 /* accessors for ctypes-based tests */
 const uint8_t *ora_backend_msc_bytes(const ora_backend *b, size_t *len) { *len = b->msc_len; return b->msc_bytes; }
 const uint8_t *ora_backend_sf_bytes(const ora_backend *b, size_t *len) { *len = b->sf_len; return b->sf_bytes; }
+const uint8_t *ora_backend_sfi_bytes(const ora_backend *b, size_t *len) { *len = b->sfi_len; return b->sfi_bytes; }
 void ora_backend_stats(const ora_backend *b, long out[8])
 {
   out[0] = b->n_cif_out; out[1] = b->n_sf_ok; out[2] = b->n_sf_fail; out[3] = b->n_rs_corr;

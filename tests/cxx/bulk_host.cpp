@@ -57,14 +57,15 @@ int main(int argc, char **argv)
   // ---- the consumer thread
   const std::string prefix = argv[2];
   std::atomic<bool> producer_done{false};
-  long long n_chunks = 0, n_fibs = 0, n_fibs_ok = 0, n_lf = 0, n_sf = 0, n_lost = 0;
+  long long n_chunks = 0, n_fibs = 0, n_fibs_ok = 0, n_lf = 0, n_sf = 0, n_lost = 0, n_au = 0, n_au_ok = 0, n_au_bytes = 0;
   std::thread consumer([&] {
-    std::vector<std::FILE *> ffib((size_t)S), flf((size_t)S * M), fsf((size_t)S * M);
+    std::vector<std::FILE *> ffib((size_t)S), flf((size_t)S * M), fsf((size_t)S * M), fsfi((size_t)S * M);
     for (int s = 0; s < S; s++) {
       ffib[(size_t)s] = std::fopen((prefix + ".s" + std::to_string(s) + ".fibs").c_str(), "wb");
       for (int j = 0; j < M; j++) {
         flf[(size_t)s * M + j] = std::fopen((prefix + ".s" + std::to_string(s) + ".lf" + std::to_string(j)).c_str(), "wb");
         fsf[(size_t)s * M + j] = std::fopen((prefix + ".s" + std::to_string(s) + ".sf" + std::to_string(j)).c_str(), "wb");
+        fsfi[(size_t)s * M + j] = std::fopen((prefix + ".s" + std::to_string(s) + ".sfi" + std::to_string(j)).c_str(), "wb");
       }
     }
     for (;;) {
@@ -91,6 +92,14 @@ int main(int argc, char **argv)
           if (!r.active) continue;
           std::fwrite(b + r.msc_off, 1, (size_t)r.n_cifs * 3 * r.kbps, flf[(size_t)s * M + j]);
           for (int c = 0; c < r.n_sf; c++) std::fwrite(b + r.sf_off + (size_t)c * r.sf_pitch, 1, (size_t)(110 * r.kbps / 8), fsf[(size_t)s * M + j]);
+          // the access units as the AAC decoder's seat gets them (mp4processor.cpp:306-345): sliced by the record, judged by the record
+          const dabx_superframe_info *inf = (const dabx_superframe_info *)(b + r.sfi_off);
+          if (r.n_sf) std::fwrite(inf, sizeof(dabx_superframe_info), (size_t)r.n_sf, fsfi[(size_t)s * M + j]);
+          for (int c = 0; c < r.n_sf; c++)
+            for (int a = 0; a < inf[c].num_aus; a++) {
+              n_au++;
+              if (inf[c].au_crc_ok >> a & 1) { n_au_ok++; n_au_bytes += inf[c].au_start[a + 1] - inf[c].au_start[a] - 2; }
+            }
           n_lf += r.n_cifs; n_sf += r.n_sf;
         }
       }
@@ -100,6 +109,7 @@ int main(int argc, char **argv)
     for (auto f : ffib) std::fclose(f);
     for (auto f : flf) std::fclose(f);
     for (auto f : fsf) std::fclose(f);
+    for (auto f : fsfi) std::fclose(f);
   });
 
   // ---- the engine's thread: slab k + 1 goes on the link while slab k is converted and decoded
@@ -130,7 +140,8 @@ int main(int argc, char **argv)
   dabx_ingest_close(eng);
   dabx_destroy(eng);
   std::printf("{\"streams\": %d, \"chunks\": %lld, \"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"lost\": %lld, "
-              "\"copies\": %llu, \"link_GBps\": %.2f}\n", S, n_chunks, frames, n_fibs, n_fibs_ok, n_lf, n_sf, n_lost, (unsigned long long)info.chunks_landed,
+              "\"access_units\": %lld, \"access_units_ok\": %lld, \"au_bytes\": %lld, "
+              "\"copies\": %llu, \"link_GBps\": %.2f}\n", S, n_chunks, frames, n_fibs, n_fibs_ok, n_lf, n_sf, n_lost, n_au, n_au_ok, n_au_bytes, (unsigned long long)info.chunks_landed,
               info.copy_seconds > 0 ? (double)info.bytes_copied / info.copy_seconds / 1e9 : 0.0);
   return 0;
 }

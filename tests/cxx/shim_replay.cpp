@@ -24,6 +24,21 @@ int main(int argc, char **argv)
     rx.on_fib = [&](const uint8_t *, bool ok, int) { fibs++; fibs_ok += ok; };
     rx.on_logical_frame = [&](int id, const uint8_t *, int) { lf++; lf_per_service[id]++; lf_this_run[id]++; };
     rx.on_super_frame = [&](int, const uint8_t *, int) { sf++; };
+    // the AAC decoder's seat: access units arrive sliced and judged (dabx_superframe_info); this stub only counts -- and, being a TEST, checks
+    // the verdicts it was handed with a CRC of its own (crc.cpp:75-86: CCITT, start 0xFFFF, complemented, over the frame without its last two bytes)
+    long long aus = 0, aus_ok = 0, au_verdict_mismatch = 0, au_bytes = 0;
+    rx.on_access_unit = [&](int, const uint8_t *au, int len, bool crc_ok, int, const dabx_superframe_info &) {
+      aus++; aus_ok += crc_ok;
+      if (!au) { au_verdict_mismatch += crc_ok; return; }               // failed the length check: never "good"
+      au_bytes += len;
+      unsigned crc = 0xFFFF;
+      for (int i = 0; i < len; i++) {
+        crc ^= (unsigned)au[i] << 8;
+        for (int b = 0; b < 8; b++) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
+      }
+      const bool mine = ((~crc) & 0xFFFF) == (((unsigned)au[len] << 8) | au[len + 1]);
+      au_verdict_mismatch += mine != crc_ok;
+    };
     long long config_changes = 0, change_cif = -1;
     rx.on_configuration_change = [&](long long cif) { config_changes++; change_cif = cif; };
     const dabx_iq_format fmt = rx.open_recording(argv[1]);
@@ -65,8 +80,10 @@ int main(int argc, char **argv)
     for (const auto &kv : lf_per_service) per += (per.size() > 1 ? ", \"" : "\"") + std::to_string(kv.first) + "\": " + std::to_string(kv.second);
     per += "}";
     std::printf("{\"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"services\": %zu, "
-                "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"config_changes\": %lld, \"change_cif\": %lld, \"lf_per_service\": %s}\n",
-                frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, config_changes, change_cif, per.c_str());
+                "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"config_changes\": %lld, \"change_cif\": %lld, "
+                "\"access_units\": %lld, \"access_units_ok\": %lld, \"au_verdict_mismatch\": %lld, \"au_bytes\": %lld, \"lf_per_service\": %s}\n",
+                frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, config_changes, change_cif,
+                aus, aus_ok, au_verdict_mismatch, au_bytes, per.c_str());
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "shim_replay: %s\n", e.what());

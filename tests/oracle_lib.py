@@ -92,7 +92,7 @@ def oracle():
     L.ora_rx_get_capture.argtypes = [C.c_void_p]
     L.ora_rx_backend.restype = C.c_void_p
     L.ora_rx_backend.argtypes = [C.c_void_p, C.c_int]
-    for f in (L.ora_backend_msc_bytes, L.ora_backend_sf_bytes):
+    for f in (L.ora_backend_msc_bytes, L.ora_backend_sf_bytes, L.ora_backend_sfi_bytes):
         f.restype = C.POINTER(C.c_uint8)
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_backend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
@@ -255,7 +255,7 @@ def backend_bytes(rx, i, which="msc"):
     L = oracle()
     b = L.ora_rx_backend(rx, i)
     n = C.c_size_t(0)
-    p = (L.ora_backend_msc_bytes if which == "msc" else L.ora_backend_sf_bytes)(b, C.byref(n))
+    p = {"msc": L.ora_backend_msc_bytes, "sf": L.ora_backend_sf_bytes, "sfi": L.ora_backend_sfi_bytes}[which](b, C.byref(n))
     return np.ctypeslib.as_array(p, (n.value,)).copy() if n.value else np.zeros(0, np.uint8)
 
 

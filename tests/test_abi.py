@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.dabx_abi_version() == 5
+    assert L.dabx_abi_version() == 6
 
 
 def test_fails_loudly_without_device():
@@ -64,7 +64,7 @@ def test_hipmodule_form_exports_the_same_abi_and_carries_no_device_code():
     L = C.CDLL(so)
     missing = [n for n in dx.declared_symbols() if not hasattr(L, n)]
     assert not missing, missing
-    assert L.dabx_abi_version() == 5 and L.dabx_internal_hipmodule() == 1 and dx.load().dabx_internal_hipmodule() == 0
+    assert L.dabx_abi_version() == 6 and L.dabx_internal_hipmodule() == 1 and dx.load().dabx_internal_hipmodule() == 0
     sections = subprocess.run(["readelf", "-S", "-W", so], capture_output=True, text=True, check=True).stdout
     assert ".hip_fatbin" not in sections
     assert ".hip_fatbin" in subprocess.run(["readelf", "-S", "-W", dx.lib_path()], capture_output=True, text=True, check=True).stdout
@@ -82,9 +82,10 @@ def test_header_is_valid_c_and_the_chunk_records_have_the_sizes_the_binding_pars
 #include <stdio.h>
 #include "dabx.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dabx_chunk_header), sizeof(dabx_chunk_stream), sizeof(dabx_chunk_frame), sizeof(dabx_chunk_subch),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dabx_chunk_header), sizeof(dabx_chunk_stream), sizeof(dabx_chunk_frame), sizeof(dabx_chunk_subch),
          offsetof(dabx_chunk_header, off_sf), offsetof(dabx_chunk_stream, fib_ok), offsetof(dabx_chunk_subch, msc_off), offsetof(dabx_chunk_subch, au_bad),
-         sizeof(dabx_delivery_info));
+         sizeof(dabx_delivery_info), sizeof(dabx_superframe_info), offsetof(dabx_superframe_info, au_start), offsetof(dabx_superframe_info, rs_corrected),
+         offsetof(dabx_superframe_info, first_frame));
   return 0;
 }
 """)
@@ -94,7 +95,9 @@ int main(void) {
     assert p.returncode == 0, p.stderr
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     d = dx
-    assert got[:4] == [d.CHUNK_HEADER.itemsize, d.CHUNK_STREAM.itemsize, d.CHUNK_FRAME.itemsize, d.CHUNK_SUBCH.itemsize] == [128, 72, 16, 136]
+    assert got[:4] == [d.CHUNK_HEADER.itemsize, d.CHUNK_STREAM.itemsize, d.CHUNK_FRAME.itemsize, d.CHUNK_SUBCH.itemsize] == [128, 72, 16, 144]
     assert got[4] == d.CHUNK_HEADER.fields["off_sf"][1] and got[5] == d.CHUNK_STREAM.fields["fib_ok"][1]
     assert got[6] == d.CHUNK_SUBCH.fields["msc_off"][1] and got[7] == d.CHUNK_SUBCH.fields["au_bad"][1]
     assert got[8] == C.sizeof(d.DeliveryInfo)
+    f = d.SUPERFRAME_INFO.fields
+    assert got[9:] == [d.SUPERFRAME_INFO.itemsize, f["au_start"][1], f["rs_corrected"][1], f["first_frame"][1]] == [32, 4, 18, 24]

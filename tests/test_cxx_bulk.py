@@ -55,7 +55,7 @@ def test_cxx_host_loop_with_a_consumer_thread_delivers_the_oracles_output(tmp_pa
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["streams"] == S and res["lost"] == 0 and res["chunks"] == n_frames // 4 + 3 == res["copies"] and res["link_GBps"] > 0.0
-    total_frames = 0
+    total_frames = aus = 0
     for s in range(S):
         x = ((qs[s].astype(np.float32) - np.float32(127.38)) / np.float32(128.0)).view(np.complex64)
         ora = _oracle_run(np.ascontiguousarray(x), subch)
@@ -72,6 +72,11 @@ def test_cxx_host_loop_with_a_consumer_thread_delivers_the_oracles_output(tmp_pa
             if c.dab_plus:
                 o_sf = ora["sf"][j].reshape(-1, 110 * c.kbps // 8)
                 assert len(sf) >= (4 * f - 16) // 5 - 1 and np.array_equal(sf, o_sf[:len(sf)]), (s, j)
+                # ... and their records: AU table + per-AU CRC verdicts, as the oracle's _process_super_frame has them (mp4processor.cpp:249-333)
+                sfi = np.fromfile(out + ".s%d.sfi%d" % (s, j), np.uint8)
+                assert len(sfi) == 32 * len(sf) and np.array_equal(sfi, ora["sfi"][j][:len(sfi)]), (s, j)
+                aus += int(sfi.reshape(-1, 32)[:, 0].sum())
             else:
                 assert len(sf) == 0
+    assert res["access_units"] == aus == res["access_units_ok"] > 0 and res["au_bytes"] > 0       # 19-21 dB: every access unit good, none re-checked on the host
     assert res["frames"] == total_frames and res["fibs"] == 12 * total_frames and res["logical_frames"] == len(subch) * (4 * total_frames - 16 * S)

@@ -56,6 +56,9 @@ def test_adapter_replays_a_recording_to_eti(tmp_path, select):
     n_sel = len(select) if select else 18
     assert res["frames"] >= 22 and res["fibs_ok"] >= res["fibs"] - 36 and res["services"] == n_sel
     assert res["logical_frames"] >= n_sel * 40 and res["super_frames"] >= n_sel * 7
+    # the AAC decoder's seat (on_access_unit): three access units per super frame of this multiplex, sliced and judged on the device; the stub's own
+    # CRC (a test's check, not a host's duty) agrees with every verdict it was handed
+    assert res["access_units"] == 3 * res["super_frames"] == res["access_units_ok"] and res["au_verdict_mismatch"] == 0 and res["au_bytes"] > 0
     eti = np.fromfile(out, np.uint8).reshape(-1, 6144)
     assert len(eti) == res["eti_frames"] >= 40
     want_ids = select or list(range(18))

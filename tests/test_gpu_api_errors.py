@@ -51,4 +51,4 @@ def test_degenerate_and_illegal_calls_return_codes_and_change_nothing():
     st = dx.load().dabx_get_stats
     assert st(h, 9, None) == E_ARG
     eng.close()
-    assert L.dabx_abi_version() == 5
+    assert L.dabx_abi_version() == 6

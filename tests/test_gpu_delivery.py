@@ -88,8 +88,9 @@ def test_chunks_carry_the_complete_output_of_every_stream():
     eng.set_subchannels(subch)
     eng.delivery_open(slots=3)
     slab = eng.delivery_slab_bytes()
-    # tables + 3 streams x (28 logical frames x 192 B + 6 super frames x 880 B) x 18 slots, 16-byte aligned areas
-    assert 128 + S * 72 + S * 18 * 136 + S * 7 * (384 + 12 + 16) + S * 18 * (28 * 192 + 6 * 880) <= slab <= 128 + S * 72 + S * 18 * 136 + S * 7 * 412 + S * 18 * (28 * 192 + 6 * 880) + 6 * 16
+    # tables + 3 streams x (28 logical frames x 192 B + 6 super frames x 880 B + their 6 records x 32 B) x 18 slots, 16-byte aligned areas
+    body = S * 18 * (28 * 192 + 6 * 880 + 6 * 32)
+    assert 128 + S * 72 + S * 18 * 144 + S * 7 * (384 + 12 + 16) + body <= slab <= 128 + S * 72 + S * 18 * 144 + S * 7 * 412 + body + 6 * 16
     for s in range(S):
         eng.push_iq(s, xs[s])
     col = Collector(S, 18)
@@ -247,7 +248,7 @@ def test_what_a_receivers_host_side_needs():
     eng = dx.Engine(n_streams=1, ring_frames=31, max_subch=4, out_frames=8)
     eng.set_subchannels(subch)
     eng.delivery_open(slots=2, what=dx.DELIVER_FIB | dx.DELIVER_SF | dx.DELIVER_MSC_NOT_DABPLUS)
-    everything = 128 + 72 + 4 * 136 + 7 * 412 + sum(28 * 3 * c.kbps + 6 * 110 * c.kbps // 8 for c in subch)
+    everything = 128 + 72 + 4 * 144 + 7 * 412 + sum(28 * 3 * c.kbps + 6 * 110 * c.kbps // 8 for c in subch)
     assert eng.delivery_slab_bytes() < 0.62 * everything
     eng.push_iq(0, x)
     col = Collector(1, 4)

@@ -37,6 +37,7 @@ def _oracle_run(x, subch, want_soft=False, config=None):
                ber_bits=np.ctypeslib.as_array(cap.fic_ber_bits, (n,)).copy(), ber_errors=np.ctypeslib.as_array(cap.fic_ber_errors, (n,)).copy(),
                msc=[ol.backend_bytes(rx, i, "msc") for i in range(len(subch))],
                sf=[ol.backend_bytes(rx, i, "sf") for i in range(len(subch))],
+               sfi=[ol.backend_bytes(rx, i, "sfi") for i in range(len(subch))],
                stats=[ol.backend_stats(rx, i) for i in range(len(subch))])
     if want_soft:
         res["soft"] = np.ctypeslib.as_array(cap.soft, (n, 75, 3072)).copy()

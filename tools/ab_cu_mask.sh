@@ -6,6 +6,6 @@ OUT=${1:-gpurun_out/ab26}
 mkdir -p $OUT
 CFGS=("default|-|")
 for v in cu64 cu96 cu128 cu160 cu96df cu128df; do
-  [ -f dabstar_amd/_ab/libdabx_$v.so ] && CFGS+=("$v|dabstar_amd/_ab/libdabx_$v.so|")
+  [ -f tools/_build/ab/libdabx_$v.so ] && CFGS+=("$v|tools/_build/ab/libdabx_$v.so|")
 done
 BENCH_ARGS="--steps 20 --warmup 5" bash tools/ab.sh $OUT/runs ${AB_REPS:-3} "${CFGS[@]}"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session (through gpurun): GPU test suite, bench lines, same-box A/B of library builds, profiles.
 #   tools/gpu_round.sh <tag> [leg ...]            results under gpurun_out/<tag>/
-# Variant libraries (tools/build_variant.sh -> dabstar_amd/_ab/*.so) are selected with DABX_LIB, which the ctypes binding
+# Variant libraries (tools/build_variant.sh -> tools/_build/ab/*.so) are selected with DABX_LIB, which the ctypes binding
 # (dabstar_amd/lib.py) reads: no leg ever copies anything over the product dabstar_amd/libdabx.so.
 TAG=$1; shift
 OUT=gpurun_out/$TAG
@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 line() { python3 -c "import json,sys; j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$1', j['value'], j['unit'], 'crc', j.get('fib_crc_pass_pct', j.get('fib_crc_match_pct')), 'sf_fail', j.get('superframes_failed'), 'locked', j.get('streams_locked'), 'host_us', j.get('host_us_per_step'))"; }
 for what in "$@"; do
   case $what in
-    tests) timeout 2400 python3 -m pytest tests -m gpu -q --maxfail=10 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
+    tests) timeout 2400 python3 -m pytest tests -m "gpu or gpu_perf" -q --maxfail=10 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
     tq)    timeout 2400 python3 -m pytest ${PYTEST_ARGS:-tests/test_gpu_engine.py} -m gpu -q --maxfail=10 > $OUT/pytest_gpu_subset.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu_subset.log; tail -5 $OUT/pytest_gpu_subset.log ;;
     smoke) python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
     bench) python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
@@ -34,7 +34,7 @@ for what in "$@"; do
     profvariants) cd /tmp; IFS='|' read -ra PV <<< "${PROF_VARIANTS:---unlocked 8|--exact-level}"; for v in "${PV[@]}"; do tag=$(echo $v | tr -d ' -'); rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/stats_$tag --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline $v > $GRAFT_REPO_ROOT/$OUT/stats_$tag.log 2>&1; done; cd $GRAFT_REPO_ROOT;
            for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -14 $f | cut -c1-200; done > $OUT/profvariants.txt; cat $OUT/profvariants.txt ;;
     acqtime) python3 tools/acq_time.py 8 > $OUT/acq_time_8.jsonl 2>&1; python3 tools/acq_time.py 512 > $OUT/acq_time_512.jsonl 2>&1; cat $OUT/acq_time_8.jsonl $OUT/acq_time_512.jsonl ;;
-    acqphases) DABX_LIB=$(realpath dabstar_amd/_ab/libdabx_acqtime.so) python3 tools/acq_time.py 8 2>&1 | grep -E "^acq wave|case" | head -40 > $OUT/acq_phases.txt; cat $OUT/acq_phases.txt ;;
+    acqphases) DABX_LIB=$(realpath tools/_build/ab/libdabx_acqtime.so) python3 tools/acq_time.py 8 2>&1 | grep -E "^acq wave|case" | head -40 > $OUT/acq_phases.txt; cat $OUT/acq_phases.txt ;;
     levelpar) tools/_build/level_par_check ${LEVELPAR_N:-8000000} > $OUT/level_par_check.jsonl 2>&1; echo "rc=$?" >> $OUT/level_par_check.jsonl; cat $OUT/level_par_check.jsonl ;;
     walkbench) tools/_build/acq_walk_bench > $OUT/acq_walk_bench.jsonl 2>&1; cat $OUT/acq_walk_bench.jsonl ;;
   esac
