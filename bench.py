@@ -45,6 +45,7 @@ A_KERNEL = {
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2      # fallback only: wave64 VALU instructions per second at 2 cycles each (MI355X_MICROARCH.md); the
                                            # figure used is the MEASURED one of tools/valu_peak.hip (load_valu_peak)
 HBM_PEAK = 8.0e12
+HBM_ACHIEVABLE = 6.3e12                    # what large streaming kernels reach on this part (MI355X_MICROARCH.md, HBM section)
 
 
 def parse():
@@ -71,10 +72,17 @@ def parse():
                     help="silence: all-zero samples; floor: the ensemble 60 dB down under its (unchanged) noise")
     ap.add_argument("--exact-level", action="store_true",
                     help="not the headline: dabx_config.exact_level_tracker = 1 (SampleReader's level IIR sample by sample in lock too)")
-    ap.add_argument("--deliver", action="store_true",
-                    help="the timed region itself runs with the bulk delivery open: every FIB, logical frame and super frame of every "
-                         "stream lands in page-locked host memory (one DMA per 7-frame chunk) inside the timed region; without the flag "
-                         "the same is measured in a second, equally long leg and reported as config.delivered_to_host")
+    ap.add_argument("--deliver", action="store_true", help="(the default since round 6; accepted for old command lines)")
+    ap.add_argument("--no-deliver", action="store_true",
+                    help="round 5's form: the timed regions leave the results in the device rings; the delivery is then measured in legs of the "
+                         "same length (config.delivered_to_host).  Default: the timed regions run with the bulk delivery open -- every FIB, logical "
+                         "frame, super frame and AU record of every stream lands in page-locked host memory inside the timed region")
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each; value = the median region")
+    ap.add_argument("--taper", action="store_true",
+                    help="experiments: with the delivery open, issue the last 7 frames of a region as chunks of 4, 2, 1 (the final slab copy, which nothing "
+                         "can overlap, is then a seventh as long).  Measured SLOWER (0.82 against 0.94 of the undelivered rate at 20 steps, "
+                         "profiles/r06_ab/ab3_taper_negative.txt): small MSC batches cost more than the shorter copy saves")
+    ap.add_argument("--no-snr-sweep", action="store_true", help="skip the 12 dB / 8 dB legs (config.snr_sweep)")
     ap.add_argument("--no-deliver-leg", action="store_true", help="skip the delivered_to_host leg")
     ap.add_argument("--sync-calls", action="store_true",
                     help="not the headline: every dabx_process call of the timed region waits for its frames (sync = 1, a live receiver's form) -- "
@@ -374,6 +382,16 @@ def step_chunks(n, chunk=7):
     return ([n % chunk] if n % chunk else []) + [chunk] * (n // chunk)
 
 
+def region_chunks(n, chunk=7, taper=False):
+    """step_chunks, or -- taper, for regions whose results are DELIVERED -- with the last `chunk` frames issued as 4, 2, 1: a region ends when its
+    last chunk's slab has crossed the link, and that copy (101 MB = 1.8 ms for 7 frames of 512 x 18, a tenth of a 20-step region) overlaps
+    nothing; the slab of a 1-frame chunk takes 0.26 ms, and the copies of the 4- and 2-frame chunks run next to the frames that follow them.
+    (For results left on the device the taper costs more than it saves: step_chunks' note.)"""
+    if not taper or chunk != 7 or n < chunk:
+        return step_chunks(n, chunk)
+    return step_chunks(n - chunk, chunk) + [4, 2, 1]
+
+
 def free_port():
     import socket
     sk = socket.socket()
@@ -632,6 +650,101 @@ class DeliverySink:
             raise SystemExit("bench.py: the delivery consumer did not finish")
 
 
+class CxxSink:
+    """The same consumer as a C++ thread on the C ABI alone (tests/cxx/consumer_thread.cpp, built by tests/cxx/Makefile): no interpreter lock
+    between the engine's thread and the consumer.  Same interface as DeliverySink."""
+    SO = os.path.join(ROOT, "tests", "cxx", "_build", "libdabx_consumer.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.SO)
+
+    def __init__(self, eng, sample=()):
+        from dabstar_amd import lib as dx
+        L, Lc = dx.load(), C.CDLL(self.SO)
+        Lc.dbxc_start.restype = C.c_void_p
+        Lc.dbxc_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        for f in (Lc.dbxc_chunks, Lc.dbxc_stop):
+            f.restype = C.c_longlong
+            f.argtypes = [C.c_void_p]
+        Lc.dbxc_error.argtypes = [C.c_void_p]
+        Lc.dbxc_totals.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        Lc.dbxc_free.argtypes = [C.c_void_p]
+        self.Lc, self.error = Lc, None
+        smp = (C.c_int * max(1, len(sample)))(*sample)
+        self.h = Lc.dbxc_start(eng._h, C.cast(L.dabx_delivery_next, C.c_void_p), C.cast(L.dabx_delivery_release, C.c_void_p), smp, len(sample))
+        self.th = self                                       # (is_alive below: the bench's liveness check)
+
+    def is_alive(self):
+        return self.Lc.dbxc_error(self.h) == 0
+
+    @property
+    def chunks(self):
+        if self.Lc.dbxc_error(self.h):
+            self.error = RuntimeError("the C++ consumer stopped with code %d" % self.Lc.dbxc_error(self.h))
+        return int(self.Lc.dbxc_chunks(self.h))
+
+    def totals(self):
+        v = (C.c_longlong * 9)()
+        self.Lc.dbxc_totals(self.h, v)
+        return {"chunks": v[0], "frames": v[1], "logical_frames": v[2], "superframes": v[3], "slab_bytes": v[4], "payload_bytes": v[5], "lost": v[6],
+                "access_units": v[7], "access_units_ok": v[8]}
+
+    def finish(self):
+        self.Lc.dbxc_stop(self.h)
+        if self.Lc.dbxc_error(self.h):
+            raise SystemExit("bench.py: the C++ delivery consumer stopped with code %d" % self.Lc.dbxc_error(self.h))
+
+
+def snr_sweep_legs(torch, dev, args, rank, subch, dx, snrs=(12.0, 8.0, 5.0), steps=49):
+    """SURVEY 8d's variant (12 dB), 8 dB (still error-free behind the Viterbi decoder: EEP 3-A has ~2 dB to spare there) and 5 dB (where the
+    Reed-Solomon stage corrects, super frames fail and access units are concealed), like the headline otherwise: 512 ensembles, 49 steps after priming and
+    warm-up, results left in the device rings (these legs are about the DECODER: k_dabplus runs Berlekamp-Massey / Chien / Forney for dirty
+    code words only, the FIC ratio and re-acquisition are data-dependent -- the 20-dB headline shows none of that).  One more engine of the same
+    size, its rings refilled per SNR (the streams stay in lock across the change of noise; 40 priming steps flush the 16-CIF de-interleaver)."""
+    import types
+    out = []
+    eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, viterbi_tie_mode=args.viterbi_tie_mode)
+    eng.set_subchannels(subch)
+    ms = (C.c_double * 16)(); cnt = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
+    first = True
+
+    def run(n):
+        for m in step_chunks(n, 7):
+            eng.commit(m * TF)
+            eng.process(m, sync=False)
+    for snr in snrs:
+        a1 = types.SimpleNamespace(**dict(vars(args), snr=snr, unlocked=0))
+        ring_frames = fill_rings(eng, torch, dev, a1, rank, subch)
+        if first:
+            eng.commit(ring_frames * TF - TF)
+            first = False
+        run(40)
+        eng.synchronize()
+        dx.check(dx.load().dabx_set_profiling(eng._h, -1))                    # one 7-frame batch, every kernel with the chip to itself
+        run(7)
+        eng.synchronize()
+        nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
+        sa = {names[i].decode(): ms[i] / 7 for i in range(nk) if cnt[i]}
+        dx.check(dx.load().dabx_set_profiling(eng._h, 0))
+        run(14)
+        eng.synchronize()
+        c1 = eng.counters()
+        t0 = time.perf_counter()
+        run(steps)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        c2 = eng.counters()
+        d = {k: c2[k] - c1[k] for k in ("frames", "fib_ok", "fib_total", "sf_ok", "sf_fail", "rs_corrected", "rs_failed", "fc_corrected", "au_ok", "au_bad", "sync_lost")}
+        out.append({"snr_db": snr, "steps": steps, "value": round(d["frames"] / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
+                    "streams_locked": c2["streams_locked"], "fib_crc_pass_pct": round(100.0 * d["fib_ok"] / max(1, d["fib_total"]), 4),
+                    "superframes_ok": d["sf_ok"], "superframes_failed": d["sf_fail"], "rs_corrected": d["rs_corrected"], "rs_failed": d["rs_failed"],
+                    "fc_corrected": d["fc_corrected"], "au_ok": d["au_ok"], "au_bad": d["au_bad"], "sync_lost": d["sync_lost"],
+                    "kernel_ms_per_step_standalone": {k: round(v, 4) for k, v in sa.items() if k in ("k_dabplus", "k_msc_vitT", "k_fic_frame", "k_symbols", "k_demap_frame")}})
+    eng.close()
+    return out
+
+
 def oracle_fib_check(eng, sink, subch, streams, ring_frames):
     """SURVEY 8d metric (2): FIBs whose 32 bytes AND CRC flag equal the reference's.  The oracle receiver (the checker) decodes the very
     IQ the device rings hold for `streams` from their first sample on, one thread per stream; every FIB the delivery brought to the
@@ -678,7 +791,7 @@ def oracle_fib_check(eng, sink, subch, streams, ring_frames):
 
 def load_traffic(dom):
     """HBM bytes and VALU instructions per FRAME of kernel `dom` from the committed rocprofv3 --pmc passes (tools/prof_round.sh)."""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic_final.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic_final.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -691,6 +804,7 @@ def load_traffic(dom):
         k = tj["kernels"][sym]
         fpl = k.get("frames_per_launch") or tj["streams"] * (7 if dom.startswith("k_msc") or dom == "k_dabplus" else 1)
         return {"file": "profiles/" + name, "streams": tj["streams"], "hbm_bytes_per_frame": k["hbm_bytes_per_launch"] / fpl,
+                "chain_hbm_bytes_per_step": tj.get("chain_hbm_bytes_per_step"),
                 "valu_per_frame": (k.get("valu_wave_insts_per_launch") or 0) / fpl, "commit": tj.get("commit", "not recorded (measured before round 4)")}
     return None
 
@@ -816,18 +930,19 @@ def main():
             time.sleep(0.0001)
     sample_streams = sorted({(i * (args.streams - 1)) // 7 for i in range(8)})
 
-    def step(n=1, sync=False):
+    def step(n=1, sync=False, taper=False):
         # one step = one frame for every stream; the engine decodes the MSC of up to 7 frames per launch (a dabx_process call
         # closes its last batch), so the steps are issued in chunks of 7 (all work of the n steps is complete when the
         # streams are drained).  sync=False is the pipelined form of dabx_process: streams out of lock are searched on a HIP
         # stream of their own and never hold up a step of the others; sync=True (priming only) searches them in step.
-        for m in step_chunks(n, args.chunk):
-            h0 = time.perf_counter()
+        for m in region_chunks(n, args.chunk, taper):
             if delivering[0]:          # a chunk closes per 7 frames and call: wait until the consumer has given that many host slabs back
+                # (back-pressure, not host work: the host runs three chunks ahead of the device and sleeps here; not part of host_us_per_step)
                 while eng.delivery_wait_free((m + 6) // 7, timeout_ms=2000) < (m + 6) // 7:
                     if sink.error is not None or not sink.th.is_alive():
                         raise SystemExit("bench.py: the delivery consumer died: %r" % (sink.error,))
                 closed[0] += (m + 6) // 7
+            h0 = time.perf_counter()
             eng.commit(m * TF)         # m more frames of (periodic) IQ become readable for every stream
             eng.process(m, sync=sync)
             host_time[0] += time.perf_counter() - h0      # host time inside the two calls (launches, event traffic): no device wait when sync=False
@@ -863,7 +978,8 @@ def main():
         dom_idx = [names[i].decode() for i in range(nk)].index(dom)
         dx.check(dx.load().dabx_set_profiling(eng._h, 0))
     sink = None
-    if args.deliver and not dry:
+    deliver_on = not dry and not args.no_deliver          # the timed regions themselves run with every result landing in host memory
+    if deliver_on:
         eng.delivery_open(slots=4, what=args.deliver_what, copy_engine=args.deliver_copy_engine)
         sink = DeliverySink(eng, sample_streams)
         delivering[0] = True
@@ -872,57 +988,67 @@ def main():
     sink_catch_up()
     if not dry:
         dx.check(dx.load().dabx_set_profiling(eng._h, 2 + dom_idx))
-    c1 = eng.counters()
-    d1 = sink.totals() if sink else None
 
-    barrier()
-    host_time[0] = 0.0
-    t0 = time.perf_counter()
-    step(args.steps, sync=args.sync_calls)
-    host_s = host_time[0]
-    eng.synchronize()                    # with a delivery open: every chunk has landed in host memory
-    sink_catch_up()                      # ... and the consumer has taken (and given back) every one of them
-    barrier()
-    dt = time.perf_counter() - t0
-    c2 = eng.counters()
-    d2 = sink.totals() if sink else None
+    # ---- the timed regions: args.regions (3) x EXACTLY args.steps steps, each bracketed by barrier + device synchronisation on both sides;
+    # `value` is the MEDIAN region (one 19-ms region is a lottery ticket: 517-560 k across the pool for one library), value_min / value_max the
+    # spread.  With the delivery open (default) a region ends when the consumer has taken and given back the last chunk: IQ -> bytes in host memory.
+    taper = deliver_on and args.taper
+    regions = []
+    for _ in range(max(1, args.regions)):
+        c1 = eng.counters()
+        d1 = sink.totals() if sink else None
+        barrier()
+        host_time[0] = 0.0
+        t0 = time.perf_counter()
+        step(args.steps, sync=args.sync_calls, taper=taper)
+        host_s = host_time[0]
+        eng.synchronize()                    # with a delivery open: every chunk has landed in host memory
+        sink_catch_up()                      # ... and the consumer has taken (and given back) every one of them
+        barrier()
+        dt = time.perf_counter() - t0
+        regions.append({"c1": c1, "c2": eng.counters(), "d1": d1, "d2": sink.totals() if sink else None, "dt": dt, "host_s": host_s})
     if not dry:
         nk = dx.check(dx.load().dabx_get_profile(eng._h, ms, cnt, names))
         dx.check(dx.load().dabx_set_profiling(eng._h, 0))
 
-    frames = c2["frames"] - c1["frames"]
-    fib_ok, fib_tot = c2["fib_ok"] - c1["fib_ok"], c2["fib_total"] - c1["fib_total"]
-    # max over ranks of the elapsed time, sum over ranks of the counters (the only collectives of the path)
+    # max over ranks of each region's elapsed time, sum over ranks of its counters (the only collectives of the path, outside the timing)
     from dabstar_amd import shard
     import zlib
+    for R in regions:
+        c1, c2 = R["c1"], R["c2"]
+        R["dt_max"], R["sums"] = shard.reduce_results(
+            dist, torch, dev, R["dt"], [c2["frames"] - c1["frames"], c2["fib_ok"] - c1["fib_ok"], c2["fib_total"] - c1["fib_total"],
+                                        c2["sf_ok"] - c1["sf_ok"], c2["sf_fail"] - c1["sf_fail"], c2["msc_bytes"] - c1["msc_bytes"], c2["streams_locked"]])
+        R["value"] = R["sums"][0] / R["dt_max"]
+    order = sorted(range(len(regions)), key=lambda i: regions[i]["value"])
+    M = regions[order[len(order) // 2]]                                  # the median region: every figure of the line below is ITS
+    c1, c2, d1, d2, host_s = M["c1"], M["c2"], M["d1"], M["d2"], M["host_s"]
     host_id = zlib.crc32(os.uname().nodename.encode()) & 0x7FFFFFFF
     if dry:      # stand-in device ids (function = rank); test hook: every rank claims the same one
         pci = (0xD, 0, 0, 0 if os.environ.get("DABX_BENCH_DRY_SAME_DEVICE") == "1" else rank)
-    reports = shard.gather_rank_reports(dist, torch, dev, rank, local_rank, pci, frames, dt, host_id)
+    reports = shard.gather_rank_reports(dist, torch, dev, rank, local_rank, pci, c2["frames"] - c1["frames"], M["dt"], host_id)
     shared = shard.check_distinct_devices(reports)
     if shared:
         raise SystemExit("bench.py: ranks share a GPU (rank, rank, PCI bus id): %s -- not an N-GPU run" % shared)
     if dry:
         for r_ in reports:
             r_["pci_bus_id"] = "dry:rank%d" % r_["rank"]
-    dt, (frames, fib_ok, fib_tot, sf_ok, sf_fail, msc_bytes, locked) = shard.reduce_results(
-        dist, torch, dev, dt, [frames, fib_ok, fib_tot, c2["sf_ok"] - c1["sf_ok"], c2["sf_fail"] - c1["sf_fail"],
-                               c2["msc_bytes"] - c1["msc_bytes"], c2["streams_locked"]])
+    dt = M["dt_max"]
+    frames, fib_ok, fib_tot, sf_ok, sf_fail, msc_bytes, locked = M["sums"]
 
-    # ---- delivered_to_host: the bulk delivery open -- every FIB + CRC flag, logical frame and super frame of every stream lands in
-    # page-locked host memory, one SDMA transfer per 7-frame chunk, taken and given back by a consumer thread -- measured live in this
-    # run, per rank (every GPU has its own link).  Two figures: a STEADY leg of >= 98 steps next to the same steps without delivery
-    # (like for like), and the timed region's own length (args.steps), where the last chunk's slab (100 MB for the measured
-    # configuration = 1.8 ms of link time that nothing can hide) weighs as it does in any short run.  With --deliver the timed region
-    # above WAS the second figure.
+    # ---- delivered_to_host: the bulk delivery -- every FIB + CRC flag, logical frame, super frame and super-frame record of every stream lands
+    # in page-locked host memory, one SDMA transfer per chunk, taken and given back by a consumer thread -- per rank (every GPU has its own
+    # link).  By default the timed regions above WERE that (in_timed_region); the legs here put beside it: the same steps WITHOUT delivery
+    # (not_delivered), a steady leg of >= 98 steps both ways, what a receiver's host side needs (half the bytes), and the same loop with a
+    # C++ consumer thread instead of the python one (consumers).
     deliv = fibchk = needs = None
     if not dry and not args.no_deliver_leg:
-        def leg(n):
+        def leg(n, taper_=False):
             eng.synchronize()
             sink_catch_up()
             e1, q1 = eng.counters(), (sink.totals() if sink else None)
             tq = time.perf_counter()
-            step(n)
+            step(n, taper=taper_)
             eng.synchronize()
             sink_catch_up()
             dq = time.perf_counter() - tq
@@ -935,74 +1061,92 @@ def main():
                     "frames_delivered": q2["frames"] - q1["frames"], "frames_decoded": dfr,
                     "logical_frames_delivered": q2["logical_frames"] - q1["logical_frames"], "logical_frames_decoded": e2["cifs_decoded"] - e1["cifs_decoded"],
                     "superframes_delivered": q2["superframes"] - q1["superframes"], "superframes_decoded": e2["sf_ok"] - e1["sf_ok"]}
-        n_steady = max(98, args.steps)
-        if sink is None:
-            b1, b2, _, _, bdt = leg(n_steady)          # the same steps without delivery, right before
-            base_steady = (b2["frames"] - b1["frames"]) / bdt
-            eng.delivery_open(slots=4, what=args.deliver_what, copy_engine=args.deliver_copy_engine)
-            sink = DeliverySink(eng, sample_streams)
+
+        def open_delivery(what, cxx=False):
+            nonlocal sink
+            eng.delivery_open(slots=4, what=what, copy_engine=args.deliver_copy_engine)
+            sink = (CxxSink if cxx else DeliverySink)(eng, sample_streams if not cxx else [])
+            closed[0] = 0
             delivering[0] = True
-            step(21)                                   # three chunks: first touch of the slabs, and the clocks back up after the allocations' idle time
-            steady = figures(*leg(n_steady), n_steady)
-            short = figures(*leg(args.steps), args.steps)
-            # ... and what a receiver's host side needs (FIBs + super frames; logical frames only of services that are not DAB+ -- none in this
-            # multiplex): for DAB+ the logical frames' consumer runs on the device.  Half the bytes, half the un-overlappable last transfer.
-            if not args.deliver_what:
-                delivering[0] = False
-                sink.finish()
-                lost_all = sink.totals()["lost"]
-                if rank == 0 and args.layout == "uniform":
-                    fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
-                slab_bytes, dinfo = eng.delivery_slab_bytes(), eng.delivery_info()
-                eng.delivery_close()
-                eng.delivery_open(slots=4, what=dx.DELIVER_FIB | dx.DELIVER_SF | dx.DELIVER_MSC_NOT_DABPLUS, copy_engine=args.deliver_copy_engine)
-                sink = DeliverySink(eng, [])
-                closed[0] = 0
-                delivering[0] = True
-                step(21)
-                needs = figures(*leg(args.steps), args.steps)
-                needs["slab_bytes_per_chunk"] = eng.delivery_slab_bytes()
-                needs["what"] = "FIBs + CRC flags + frame records, super frames; logical frames only of services that are not DAB+ (DABX_DELIVER_MSC_NOT_DABPLUS)"
-                delivering[0] = False
-                sink.finish()
-                needs["lost"] = sink.totals()["lost"]
-                eng.delivery_close()
-                sink = None
+            step(21)                 # three chunks: first touch of the slabs, and the clocks back up after the allocations' idle time
+
+        def close_delivery():
+            nonlocal sink
+            delivering[0] = False
+            eng.synchronize()
+            sink.finish()
+            lost_ = sink.totals()["lost"]
+            info_ = (eng.delivery_slab_bytes(), eng.delivery_info())
+            eng.delivery_close()
+            old, sink = sink, None
+            return lost_, info_, old
+
+        n_steady = max(98, args.steps)
+        if sink is None:                                   # --no-deliver: the delivered figures come from legs, as in round 5
+            open_delivery(args.deliver_what)
+            short = figures(*leg(args.steps, taper_=args.taper), args.steps)
         else:
-            short = figures(c1, c2, d1, d2, dt, args.steps)
-            steady = figures(*leg(n_steady), n_steady)
-            delivering[0] = False
-            sink.finish()
-            lost = sink.totals()["lost"]
-            if rank == 0 and args.layout == "uniform":
-                fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
-            slab_bytes, dinfo = eng.delivery_slab_bytes(), eng.delivery_info()
-            eng.delivery_close()
-            sink = None
-            b1, b2, _, _, bdt = leg(n_steady)
-            base_steady = (b2["frames"] - b1["frames"]) / bdt
-        if sink is None and not args.deliver:
-            lost = lost_all
-        if sink is not None:
-            delivering[0] = False
-            sink.finish()
-            lost = sink.totals()["lost"]
-            if rank == 0 and args.layout == "uniform":
-                fibchk = oracle_fib_check(eng, sink, subch, sample_streams, ring_frames)
-            slab_bytes, dinfo = eng.delivery_slab_bytes(), eng.delivery_info()
-            eng.delivery_close()
+            short = figures(c1, c2, d1, d2, M["dt"], args.steps)
+        steady = figures(*leg(n_steady), n_steady)
+        lost, (slab_bytes, dinfo), old = close_delivery()
+        if rank == 0 and args.layout == "uniform" and not args.deliver_what:
+            fibchk = oracle_fib_check(eng, old, subch, sample_streams, ring_frames)
+        # the same steps with the results left in the device rings (closing the delivery frees its slabs: the GPU idles and clocks down meanwhile --
+        # three chunks of steps bring it back before anything is timed)
+        step(21)
+        host_time[0] = 0.0
+        b1, b2, _, _, bdt = leg(args.steps)
+        nd_short = (b2["frames"] - b1["frames"]) / bdt
+        if deliver_on:
+            # with the delivery open dabx_process itself waits for a free device slab whenever the host has run three chunks ahead (back-pressure,
+            # not host work): the host's own time per step is taken from these steps, which issue the same launches without that wait
+            host_s = host_time[0]
+        b1, b2, _, _, bdt = leg(n_steady)
+        base_steady = (b2["frames"] - b1["frames"]) / bdt
+        consumers = None
+        if not args.deliver_what:
+            # what a receiver's host side needs (FIBs + super frames + their AU records; logical frames only of services that are not DAB+ -- none
+            # in this multiplex): for DAB+ the logical frames' consumer runs on the device.  Half the bytes, half the un-overlappable last transfer.
+            open_delivery(dx.DELIVER_FIB | dx.DELIVER_SF | dx.DELIVER_MSC_NOT_DABPLUS)
+            needs = figures(*leg(args.steps, taper_=args.taper), args.steps)
+            needs["slab_bytes_per_chunk"] = eng.delivery_slab_bytes()
+            needs["what"] = "FIBs + CRC flags + frame records, super frames + their AU records; logical frames only of services that are not DAB+ (DABX_DELIVER_MSC_NOT_DABPLUS)"
+            needs["lost"], _, _ = close_delivery()
+            # the same loop with a C++ consumer thread on the C ABI (tests/cxx/consumer_thread.cpp) instead of the python thread
+            if CxxSink.available():
+                open_delivery(0, cxx=True)
+                cx_short = figures(*leg(args.steps, taper_=args.taper), args.steps)
+                cx_steady = figures(*leg(n_steady), n_steady)
+                cx_lost, _, cx_old = close_delivery()
+                consumers = {"python_thread": {"at_timed_region_length": short["frames_per_s"], "steady": steady["frames_per_s"]},
+                             "cxx_thread": {"at_timed_region_length": cx_short["frames_per_s"], "steady": cx_steady["frames_per_s"], "lost": cx_lost,
+                                            "frames_delivered": cx_short["frames_delivered"] + cx_steady["frames_delivered"],
+                                            "access_units_counted": cx_old.totals().get("access_units"),
+                                            "source": "tests/cxx/consumer_thread.cpp (std::thread: dabx_delivery_next -> sums the records -> dabx_delivery_release)"}}
         steady["frames_per_s_without_delivery_same_steps"] = round(base_steady, 1)
         steady["frac_of_that"] = round(steady["frames_per_s"] / base_steady, 4)
+        short["frames_per_s_without_delivery_same_steps"] = round(nd_short, 1)
+        short["frac_of_not_delivered"] = round(short["frames_per_s"] / nd_short, 4)
+        short["step_chunks"] = region_chunks(args.steps, args.chunk, args.taper)
         deliv = dict(steady, at_timed_region_length=short, what_a_receiver_needs=needs, lost=lost, slab_bytes_per_chunk=slab_bytes, host_slabs=4,
-                     in_timed_region=bool(args.deliver), copy_engine="sdma (hsa_amd_memory_async_copy)" if args.deliver_copy_engine == 0 else "hipMemcpyAsync",
-                     what="every FIB + CRC flag + frame record, logical frame and RS-corrected super frame of every stream and sub-channel: one "
-                          "slab and ONE SDMA transfer per 7-frame chunk into page-locked host slabs (dabx_delivery_*); consumer = a python "
-                          "thread: dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release",
+                     not_delivered={"at_timed_region_length": round(nd_short, 1), "steady": round(base_steady, 1),
+                                    "note": "the same steps with every result left in the device rings (round 5's `value`)"},
+                     consumers=consumers,
+                     in_timed_region=bool(deliver_on), copy_engine="sdma (hsa_amd_memory_async_copy)" if args.deliver_copy_engine == 0 else "hipMemcpyAsync",
+                     what="every FIB + CRC flag + frame record, logical frame, RS-corrected super frame and super-frame record (AU table, per-AU CRC "
+                          "verdicts) of every stream and sub-channel: one slab and ONE SDMA transfer per chunk into page-locked host slabs "
+                          "(dabx_delivery_*); consumer = a python thread: dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release",
                      copies={"count": dinfo["chunks_landed"], "link_GBps": round(dinfo["bytes_copied"] / max(1e-9, dinfo["copy_seconds"]) / 1e9, 2),
                              "longest_ms": round(1e3 * dinfo["copy_seconds_max"], 3), "sdma_engine_mask": dinfo["sdma_engine_mask"],
                              "calibration_GBps": round(dinfo["calibration_GBps"], 2),
                              "note": "the library's own clock around every slab transfer (dabx_delivery_get_info)"},
                      scope="this rank's GPU")
+    elif sink is not None:                                 # --no-deliver-leg with the delivery in the timed regions: close it, nothing else
+        delivering[0] = False
+        eng.synchronize()
+        sink.finish()
+        eng.delivery_close()
+        sink = None
 
     h2h = None
     # (the one-GPU line carries the per-link and per-ensemble legs; an N-GPU run is the scaling measurement and stays lean)
@@ -1011,6 +1155,10 @@ def main():
     single = None
     if not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.no_single_legs:
         single = single_ensemble_legs(torch, dev, args, rank, subch, dx)
+    sweep = None
+    if (not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.fic_only and not args.no_snr_sweep and
+            args.streams >= 48 and not args.unlocked and not args.exact_level):
+        sweep = snr_sweep_legs(torch, dev, args, rank, subch, dx)
     gc.enable()
     if rank == 0:
         value = frames / dt
@@ -1018,7 +1166,7 @@ def main():
         if not dry:
             kern = {names[i].decode(): (ms[i] / cnt[i]) for i in range(nk) if cnt[i]}          # average launch duration (timed region)
             launches = {names[i].decode(): int(cnt[i]) for i in range(nk) if cnt[i]}
-            units = (args.streams - args.unlocked) * args.steps / launches[dom]      # frames one launch of that kernel processes (average)
+            units = (args.streams - args.unlocked) * args.steps * len(regions) / launches[dom]      # frames one launch of that kernel processes (average over the timed regions)
             achieved = A_KERNEL[dom] * units / (kern[dom] * 1e-3) / 1e9
             traffic = valu = traffic_src = None
             tj = load_traffic(dom)
@@ -1056,11 +1204,27 @@ def main():
                         "frac_of_limiting": (valu["util"] if limiting == "valu" else round(achieved * 1e9 / HBM_PEAK, 6)),
                         "algorithmic_bytes_per_launch": int(A_KERNEL[dom] * units), "frames_per_launch": round(units, 2),
                         "avg_launch_ms": round(kern[dom], 4), "valu": valu, "standalone": standalone}
+            if tj is not None and tj.get("chain_hbm_bytes_per_step") and tj["streams"] == args.streams:
+                # what the WHOLE step really moves (PMC counters of every kernel of a step, same stored run) against what the chip can deliver: the
+                # decoder is VALU-bound, the step as a whole is ALSO close to the memory system's limit (k_symbols + the decoder's survivor
+                # decisions ask for more than 6.3 TB/s when they meet) -- the co-limit on the record
+                real = tj["chain_hbm_bytes_per_step"] / (1e-3 * 1e3 * dt / args.steps)
+                roofline["chain_real_traffic"] = {"hbm_bytes_per_step": int(tj["chain_hbm_bytes_per_step"]), "GBps": round(real / 1e9, 1),
+                                                  "frac_of_achievable": round(real / HBM_ACHIEVABLE, 4), "achievable_GBps": HBM_ACHIEVABLE / 1e9,
+                                                  "frac_of_peak": round(real / HBM_PEAK, 4),
+                                                  "x_algorithmic": round(tj["chain_hbm_bytes_per_step"] / (A_FRAME * args.streams), 3),
+                                                  "source": tj["file"] + " (chain_hbm_bytes_per_step, commit %s) / this run's ms_per_step; achievable = "
+                                                            "MI355X_MICROARCH.md's measured copy rate" % tj["commit"]}
         a_frame = A_FRAME_FIC if args.fic_only else A_FRAME
         out = {
             "metric": "DAB Mode-I ensembles/s (2.048 MS/s IQ->MSC bytes) per GPU; FIB CRC match %",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
+            # value = the median of the timed regions (each EXACTLY `steps` steps, barrier + synchronise both sides, max over ranks)
+            "value_min": round(regions[order[0]]["value"], 1), "value_max": round(regions[order[-1]]["value"], 1),
+            "timed_regions": [{"value": round(R["value"], 1), "ms_per_step": round(1e3 * R["dt_max"] / args.steps, 4)} for R in regions],
+            "results": ("delivered to page-locked host memory inside every timed region (config.delivered_to_host; the rate with the results left in "
+                        "the device rings: delivered_to_host.not_delivered)") if deliver_on else "left in the device rings (--no-deliver)",
             # CPU time this rank spent inside dabx_commit_iq + dabx_process per step (kernel launches and event traffic, no device
             # wait): what one of N rank processes needs from its host core per step
             "host_us_per_step": round(1e6 * host_s / args.steps, 2),
@@ -1070,7 +1234,7 @@ def main():
                        "%d synthetic Mode-I ensembles per GPU, 18x64 kbit/s EEP 3-A DAB+ each, cf32 IQ resident in HBM, "
                        "AWGN %g dB, per-stream CFO/timing" % (args.streams, args.snr),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * n_joined,
-                       "step_chunks": step_chunks(args.steps, args.chunk) if args.steps <= 70 else "%d x %d + %d" % (args.steps // args.chunk, args.chunk, args.steps % args.chunk), "viterbi_tie_mode": args.viterbi_tie_mode,
+                       "step_chunks": region_chunks(args.steps, args.chunk, taper) if args.steps <= 70 else "%s, tail %s" % (step_chunks(args.steps - 7, args.chunk)[:2] + ["..."], region_chunks(7, 7, taper)), "viterbi_tie_mode": args.viterbi_tie_mode,
                        "x_realtime_per_gpu": round(value / n_joined / (2048000.0 / TF), 1),
                        "msamples_per_s": round(value * TF / 1e6, 1)},
             # the engine's own count: FIBs whose CRC held / FIBs decoded in the timed region
@@ -1093,6 +1257,15 @@ def main():
             out["config"]["host_to_host"] = h2h
         if single is not None:
             out["config"]["single_ensemble"] = single
+        if sweep is not None:
+            # the headline's own SNR first (its timed regions above, results delivered), then the legs
+            out["config"]["snr_sweep"] = [{"snr_db": args.snr, "steps": args.steps, "value": round(value, 1), "ms_per_step": round(1e3 * dt / args.steps, 4),
+                                           "streams_locked": locked, "fib_crc_pass_pct": round(100.0 * fib_ok / max(1, fib_tot), 4),
+                                           "superframes_ok": sf_ok, "superframes_failed": sf_fail,
+                                           "rs_corrected": c2["rs_corrected"] - c1["rs_corrected"], "rs_failed": c2["rs_failed"] - c1["rs_failed"],
+                                           "au_bad": c2["au_bad"] - c1["au_bad"],
+                                           "kernel_ms_per_step_standalone": {k: round(v, 4) for k, v in share.items() if k in ("k_dabplus", "k_msc_vitT", "k_fic_frame", "k_symbols", "k_demap_frame")},
+                                           "note": "the headline itself (median timed region)"}] + sweep
         if deliv is not None:
             deliv["at_timed_region_length"]["frac_of_value"] = round(deliv["at_timed_region_length"]["frames_per_s"] / (value / n_joined), 4)
             if deliv.get("what_a_receiver_needs"):

@@ -56,34 +56,70 @@ __global__ __launch_bounds__(128) void k_deliver_front(EngineDev e, DeliverDev d
   if (tid == 0) dv.frames_done[s] = c.frames;
 }
 
+// Which logical frames of slot sj the chunk carries.  Called BEFORE the DAB+ stage (k_deliver_lf: cif_out has not been moved on yet, the
+// batch's new frames are counted from its snapshot exactly as k_dabplus counts them) and after it (k_deliver_msc: pre = false).
+struct LfRange { long long first; int n, lost; };
+__device__ __forceinline__ LfRange deliver_lf_range(const EngineDev &e, const DeliverDev &dv, int sj, const SubchDev &sc, bool pre)
+{
+  long long cif_out = sc.cif_out;
+  if (pre) {
+    const BatchSnap bs = e.snap[sj / e.max_subch];
+    for (long long r = bs.msc_done; r < bs.cif_no; r++) if (r >= sc.start_cif + 16) cif_out++;
+  }
+  const int cap_cifs = 4 * dv.hdr.max_frames;
+  const long long have = cif_out - dv.cif_done[sj];
+  LfRange q;
+  q.n = (int)(have < cap_cifs ? have : cap_cifs);
+  if (q.n > MSC_SLOTS) q.n = MSC_SLOTS;
+  if (q.n < 0) q.n = 0;
+  q.lost = (int)(have > q.n ? have - q.n : 0);
+  q.first = cif_out - q.n;
+  const bool want_lf = (dv.hdr.what & DABX_DELIVER_MSC) || ((dv.hdr.what & DABX_DELIVER_MSC_NOT_DABPLUS) && !sc.dab_plus);
+  if (!want_lf) { q.lost = 0; q.first = cif_out; q.n = 0; }      // not wanted: nothing is "lost"
+  return q;
+}
+
+// grid = n_streams * max_subch, 64 threads, behind the chunk's Viterbi decode and IN FRONT of the DAB+ stage (same stream): the logical frames --
+// half of an "everything" slab -- are gathered as soon as they exist, and their share of the slab goes onto the link while k_dabplus still runs
+__global__ __launch_bounds__(64) void k_deliver_lf(EngineDev e, DeliverDev dv)
+{
+  const int sj = blockIdx.x, lane = threadIdx.x;
+  const SubchDev &sc = e.subch[sj];
+  if (!(sc.active && e.msc_out && !e.fic_only)) return;
+  const LfRange q = deliver_lf_range(e, dv, sj, sc, true);
+  if (q.n == 0) return;
+  const uint8_t *ring = e.msc_out + (size_t)sj * MSC_SLOTS * e.msc_stride;
+  uint32_t *o = reinterpret_cast<uint32_t *>(dv.slab + dv.layout_off[3 * (size_t)sj]);
+  const int wpf = 3 * sc.kbps / 4;
+  for (int f = 0; f < q.n; f++) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + (size_t)((q.first + f) % MSC_SLOTS) * e.msc_stride);
+    for (int w = lane; w < wpf; w += 64) o[(size_t)f * wpf + w] = src[w];
+  }
+}
+
 // grid = n_streams * max_subch, 64 threads, behind k_dabplus of the chunk's MSC batch (same stream)
-__global__ __launch_bounds__(64) void k_deliver_msc(EngineDev e, DeliverDev dv)
+__global__ __launch_bounds__(64) void k_deliver_msc(EngineDev e, DeliverDev dv, int with_lf)
 {
   const int sj = blockIdx.x, lane = threadIdx.x;
   const SubchDev &sc = e.subch[sj];
   uint8_t *slab = dv.slab;
   const unsigned long long msc_off = dv.layout_off[3 * (size_t)sj], sf_off = dv.layout_off[3 * (size_t)sj + 1], sfi_off = dv.layout_off[3 * (size_t)sj + 2];
   const int R = sc.kbps / 8, nb = 3 * sc.kbps, sfb = 110 * R, pitch = (sfb + 3) & ~3;
-  const int cap_cifs = 4 * dv.hdr.max_frames, cap_sf = (4 * dv.hdr.max_frames + 4) / 5;
+  const int cap_sf = (4 * dv.hdr.max_frames + 4) / 5;
   long long c_done = dv.cif_done[sj], s_done = dv.sf_done[sj];
   int n_c = 0, n_s = 0, lost_c = 0, lost_s = 0;
   long long first_c = c_done, first_s = s_done;
   const bool live = sc.active && e.msc_out && !e.fic_only;
   if (live) {
-    const long long have_c = sc.cif_out - c_done, have_s = sc.sf_count - s_done;
-    n_c = (int)(have_c < cap_cifs ? have_c : cap_cifs);
-    if (n_c > MSC_SLOTS) n_c = MSC_SLOTS;
-    if (n_c < 0) n_c = 0;
-    lost_c = (int)(have_c > n_c ? have_c - n_c : 0);
-    first_c = sc.cif_out - n_c;
+    const long long have_s = sc.sf_count - s_done;
+    const LfRange q = deliver_lf_range(e, dv, sj, sc, false);          // the very range k_deliver_lf copied (it counted this batch's frames ahead)
+    n_c = q.n; lost_c = q.lost; first_c = q.first;
     n_s = (int)(have_s < cap_sf ? have_s : cap_sf);
     if (n_s > SF_SLOTS) n_s = SF_SLOTS;
     if (n_s < 0) n_s = 0;
     lost_s = (int)(have_s > n_s ? have_s - n_s : 0);
     first_s = sc.sf_count - n_s;
-    const bool want_lf = (dv.hdr.what & DABX_DELIVER_MSC) || ((dv.hdr.what & DABX_DELIVER_MSC_NOT_DABPLUS) && !sc.dab_plus);
-    if (!want_lf) { lost_c = 0; first_c = sc.cif_out; n_c = 0; }      // not wanted: nothing is "lost"
-    if (want_lf) {
+    if (with_lf && n_c) {                                              // (no k_deliver_lf ran in front: the logical frames here as well)
       const uint8_t *ring = e.msc_out + (size_t)sj * MSC_SLOTS * e.msc_stride;
       uint32_t *o = reinterpret_cast<uint32_t *>(slab + msc_off);
       const int wpf = nb / 4;
@@ -127,13 +163,25 @@ int launch_deliver_front(const EngineDev &e, const DeliverDev &dv, hipStream_t s
   return 0;
 }
 
-int launch_deliver_msc(const EngineDev &e, const DeliverDev &dv, hipStream_t st)
+// with_lf: no launch_deliver_lf went in front (the logical frames are gathered here too)
+int launch_deliver_msc(const EngineDev &e, const DeliverDev &dv, hipStream_t st, bool with_lf)
 {
   if (e.max_subch <= 0) return 0;
 #ifdef DABX_DELIVER_NOPACK             // experiment builds only: what the copy alone costs (the slot table then says "nothing")
   return 0;
 #endif
-  hipLaunchKernelGGL(k_deliver_msc, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, dv);
+  hipLaunchKernelGGL(k_deliver_msc, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, dv, with_lf ? 1 : 0);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+// behind the batch's Viterbi decode, in front of its DAB+ stage; records dv.lf_done behind the gather
+int launch_deliver_lf(const EngineDev &e, const DeliverDev &dv, hipStream_t st)
+{
+  if (e.max_subch <= 0 || !dv.lf_done) return 0;
+#ifndef DABX_DELIVER_NOPACK
+  hipLaunchKernelGGL(k_deliver_lf, dim3(e.n_streams * e.max_subch), dim3(64), 0, st, e, dv);
+#endif
+  DABX_HIP(hipEventRecord(dv.lf_done, st));
   DABX_HIP(hipGetLastError());
   return 0;
 }

@@ -2,6 +2,7 @@
 #include "pipeline.h"
 #include "viterbi_core.h"
 #include "sdma.h"
+#include "iqfile.h"
 #ifndef DABX_CU_SPLIT_DEMAP_FRONT
 #define DABX_CU_SPLIT_DEMAP_FRONT 0
 #endif
@@ -49,12 +50,14 @@ struct Delivery {
   static constexpr int NDEV = 3;                 // device slabs: chunk n + 3 is packed into the slab of chunk n once its copy has left
   uint8_t *dev[NDEV] = {nullptr, nullptr, nullptr};
   hipEvent_t packed[NDEV] = {nullptr, nullptr, nullptr};    // the chunk's gather kernels have finished (system-scope release; the copier polls them)
+  hipEvent_t packed_lf[NDEV] = {nullptr, nullptr, nullptr}; // ... its logical frames (the slab's tail, [off_msc, bytes)) are in the slab: that share of the
+                                                            // transfer starts while the DAB+ stage still runs (round 6)
   bool dev_busy[NDEV] = {false, false, false};   // packed into or being copied from (guarded by mu)
   hipStream_t cs = nullptr;                      // copy_engine 1 only
   Sdma sdma;
   size_t capacity = 0, bytes = 0;                // bytes allocated per slab / bytes the current layout uses (= what is copied)
   enum { FREE = 0, IN_FLIGHT = 1, LANDED = 2, HELD = 3 };
-  struct Slot { uint8_t *host = nullptr; uint64_t sig = 0; int state = FREE; uint64_t seq = 0; size_t bytes = 0; int devslab = 0; };
+  struct Slot { uint8_t *host = nullptr; uint64_t sig = 0, sig2 = 0; int state = FREE; uint64_t seq = 0; size_t bytes = 0, lf_from = 0; int devslab = 0; };
   std::vector<Slot> slots;
   std::deque<int> queue;                         // slots in flight or landed, oldest first (what dabx_delivery_next hands out)
   std::deque<int> jobs;                          // slots whose copy the copier still has to make
@@ -83,6 +86,18 @@ struct Ingest {
   hipStream_t cs = nullptr;                      // copy_engine 1 only
   hipEvent_t committed = nullptr;                // the previous ingest commit has run on the front-end stream (the converter reads the committed indices)
   bool committed_recorded = false;
+  hipEvent_t front = nullptr;                    // where the front-end stream stood when a conversion was queued (commits of other entry points in between)
+  // general form (dabx_ingest_open_formats): every stream its own container, rate and length
+  bool general = false;
+  size_t pitch = 0;                              // bytes per stream region of a slab
+  std::vector<IqDecode> dec;                     // [S]
+  std::vector<int> M, tab, carry_n;              // [S] input samples per ms (0 = 2.048 MS/s), table index, samples carried between slabs
+  std::vector<std::vector<size_t>> n_bytes;      // [slab][S] payload bytes submitted
+  IngestJob *jobs_host = nullptr, *jobs_dev = nullptr;     // [S] page-locked staging / device
+  unsigned *counts_host = nullptr, *counts_dev = nullptr;  // [S] samples committed per stream by this commit
+  float2 *work = nullptr, *carry = nullptr;
+  size_t work_pitch = 0, carry_pitch = 0;
+  int16_t *tab_int = nullptr; float *tab_frac = nullptr;
 };
 
 struct dabx_engine {
@@ -99,6 +114,7 @@ struct dabx_engine {
   std::vector<EtiCursor> eti;                  // [S]
   std::vector<dabx_fibdec *> fibdec;           // [S] FIB decoders (current / next configuration), created on first dabx_follow_fic
   std::vector<long long> fib_frames_fed;       // [S] frames whose FIBs the decoder has seen
+  bool fig_reference_quirks = false;           // dabx_set_fig_reference_quirks: the engine's own FIB decoders swap like the reference (flags 3 only)
   std::vector<dabx_tii *> tii;                 // [S] detectors, created on first dabx_read_tii
   std::vector<int> tii_epoch;                  // [S] reset epoch seen by the detector
   std::vector<void *> allocs;
@@ -301,14 +317,8 @@ int dabx_engine::delivery_layout()
   h.off_crc = off; if (fib) off = align_up(off + S * F * 12, 16);
   h.off_frame = off; if (fib) off = align_up(off + S * F * sizeof(dabx_chunk_frame), 16);
   std::vector<unsigned long long> lo(3 * S * M + 3, 0);
-  h.off_msc = off;
-  if ((D.what & (DABX_DELIVER_MSC | DABX_DELIVER_MSC_NOT_DABPLUS)) && !d.fic_only)
-    for (size_t sj = 0; sj < S * M; sj++) {
-      const SubchDev &sc = subch_host[sj];
-      if (!sc.active || (!(D.what & DABX_DELIVER_MSC) && sc.dab_plus)) continue;
-      lo[3 * sj] = off;
-      off = align_up(off + (size_t)4 * F * 3 * sc.kbps, 16);
-    }
+  // (super frames in front of the logical frames since round 6: the logical frames are the slab's TAIL, [off_msc, bytes), and travel first --
+  //  behind the Viterbi decode, next to the DAB+ stage; the offsets in the records are what a host goes by)
   h.off_sf = off;
   if ((D.what & DABX_DELIVER_SF) && !d.fic_only)
     for (size_t sj = 0; sj < S * M; sj++) {
@@ -318,6 +328,15 @@ int dabx_engine::delivery_layout()
       off = align_up(off + (size_t)DL_SF_CAP * (size_t)((110 * (sc.kbps / 8) + 3) & ~3), 16);
       lo[3 * sj + 2] = off;
       off += (size_t)DL_SF_CAP * sizeof(dabx_superframe_info);
+    }
+  off = align_up(off, 256);
+  h.off_msc = off;
+  if ((D.what & (DABX_DELIVER_MSC | DABX_DELIVER_MSC_NOT_DABPLUS)) && !d.fic_only)
+    for (size_t sj = 0; sj < S * M; sj++) {
+      const SubchDev &sc = subch_host[sj];
+      if (!sc.active || (!(D.what & DABX_DELIVER_MSC) && sc.dab_plus)) continue;
+      lo[3 * sj] = off;
+      off = align_up(off + (size_t)4 * F * 3 * sc.kbps, 16);
     }
   h.bytes = off;
   if (off > D.capacity) {
@@ -366,6 +385,14 @@ int dabx_engine::delivery_begin(DeliverDev *dv, int *slot, int *devslab)
   dv->slab = D.dev[*devslab]; dv->layout_off = D.layout_off; dv->subch_id = D.subch_id;
   dv->frames_done = D.frames_done; dv->cif_done = D.cif_done; dv->sf_done = D.sf_done;
   dv->hdr = D.hdr; dv->hdr.seq = seq;
+  // two transfers when the slab has a tail of logical frames worth a transfer of its own (SDMA path)
+  const size_t lf_from = (size_t)D.hdr.off_msc;
+  const bool split = D.copy_engine == 0 && D.bytes > lf_from && D.bytes - lf_from >= ((size_t)1 << 20) && !dev.fic_only && dev.max_subch > 0 && dev.msc_out;
+  dv->lf_done = split ? D.packed_lf[*devslab] : nullptr;
+  {
+    std::lock_guard<std::mutex> lk(D.mu);
+    D.slots[(size_t)h].lf_from = split ? lf_from : 0;
+  }
   *slot = h;
   const int rc = launch_deliver_front(dev, *dv, stream);
   if (rc) {                                                        // nothing was queued: give the slabs back
@@ -432,13 +459,26 @@ static void delivery_copier(Delivery *Dp)
     const auto t_a = std::chrono::steady_clock::now();
     // polled every 50 us, not hipEventSynchronize: see sdma_wait
     hipError_t he;
+    // first the slab's tail -- the logical frames, gathered behind the Viterbi decode: on the link while the DAB+ stage and the second gather run
+    size_t head_bytes = sl.bytes;
+    bool lf_started = false;
+    auto t_lf = t_a;
+#ifndef DABX_DELIVER_NOCOPY
+    if (sl.lf_from) {
+      while ((he = hipEventQuery(D.packed_lf[sl.devslab])) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if (he != hipSuccess) err = std::string("hipEventQuery: ") + hipGetErrorString(he);
+      else if (sdma_copy(D.sdma, sl.host + sl.lf_from, D.dev[sl.devslab] + sl.lf_from, sl.bytes - sl.lf_from, true, sl.sig2)) err = dabx::last_error();
+      else { lf_started = true; head_bytes = sl.lf_from; t_lf = std::chrono::steady_clock::now(); }
+    }
+#endif
     while ((he = hipEventQuery(D.packed[sl.devslab])) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
-    if (he != hipSuccess) err = std::string("hipEventQuery: ") + hipGetErrorString(he);
+    if (he != hipSuccess && err.empty()) err = std::string("hipEventQuery: ") + hipGetErrorString(he);
     const auto t_b = std::chrono::steady_clock::now();
 #ifndef DABX_DELIVER_NOCOPY            // experiment builds only (tools/build_variant.sh): what the gather kernels alone cost
     if (err.empty()) {
       if (D.copy_engine == 0) {
-        if (sdma_copy(D.sdma, sl.host, D.dev[sl.devslab], sl.bytes, true, sl.sig) || sdma_wait(sl.sig, sl.bytes)) err = dabx::last_error();
+        if (sdma_copy(D.sdma, sl.host, D.dev[sl.devslab], head_bytes, true, sl.sig) || sdma_wait(sl.sig, head_bytes)) err = dabx::last_error();
+        if (lf_started && sdma_wait(sl.sig2, 0) && err.empty()) err = dabx::last_error();
       } else {
         he = hipMemcpyAsync(sl.host, D.dev[sl.devslab], sl.bytes, hipMemcpyDeviceToHost, D.cs);
         if (he == hipSuccess) he = hipStreamSynchronize(D.cs);
@@ -449,8 +489,10 @@ static void delivery_copier(Delivery *Dp)
     const auto t_c = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lk(D.mu);
     {
-      const double cs_ = std::chrono::duration<double>(t_c - t_b).count();
-      D.gather_wait_s += std::chrono::duration<double>(t_b - t_a).count();
+      // (two-part transfers: from the start of the first part to the end of the second, the wait for the second gather in between included --
+      //  the link rate derived from it is a lower bound)
+      const double cs_ = std::chrono::duration<double>(t_c - (lf_started ? t_lf : t_b)).count();
+      D.gather_wait_s += std::chrono::duration<double>((lf_started ? t_lf : t_b) - t_a).count();
       D.copy_s += cs_; D.copy_s_max = std::max(D.copy_s_max, cs_);
       D.landed++; D.bytes_copied += sl.bytes;
     }
@@ -482,14 +524,15 @@ static void delivery_free(dabx_engine *e)
   }
   D.quit = false;
   if (D.cs) (void)hipStreamSynchronize(D.cs);
-  for (auto &sl : D.slots) { if (sl.host) (void)hipHostFree(sl.host); sdma_signal_destroy(sl.sig); }
+  for (auto &sl : D.slots) { if (sl.host) (void)hipHostFree(sl.host); sdma_signal_destroy(sl.sig); sdma_signal_destroy(sl.sig2); }
   D.slots.clear();
   D.queue.clear();
   D.jobs.clear();
   for (int k = 0; k < Delivery::NDEV; k++) {
     if (D.dev[k]) (void)hipFree(D.dev[k]);
     if (D.packed[k]) (void)hipEventDestroy(D.packed[k]);
-    D.dev[k] = nullptr; D.packed[k] = nullptr; D.dev_busy[k] = false;
+    if (D.packed_lf[k]) (void)hipEventDestroy(D.packed_lf[k]);
+    D.dev[k] = nullptr; D.packed[k] = nullptr; D.packed_lf[k] = nullptr; D.dev_busy[k] = false;
   }
   for (void *q : {(void *)D.layout_off, (void *)D.subch_id, (void *)D.frames_done, (void *)D.cif_done, (void *)D.sf_done}) if (q) (void)hipFree(q);
   D.layout_off = nullptr; D.subch_id = nullptr; D.frames_done = D.cif_done = D.sf_done = nullptr;
@@ -512,7 +555,13 @@ static void ingest_free(dabx_engine *e)
   I.slabs.clear();
   if (I.cs) { (void)hipStreamSynchronize(I.cs); (void)hipStreamDestroy(I.cs); }
   if (I.committed) (void)hipEventDestroy(I.committed);
-  I.cs = nullptr; I.committed = nullptr; I.committed_recorded = false; I.open = false; I.capacity = 0;
+  if (I.front) (void)hipEventDestroy(I.front);
+  for (void *q : {(void *)I.jobs_dev, (void *)I.counts_dev, (void *)I.work, (void *)I.carry, (void *)I.tab_int, (void *)I.tab_frac}) if (q) (void)hipFree(q);
+  if (I.jobs_host) (void)hipHostFree(I.jobs_host);
+  if (I.counts_host) (void)hipHostFree(I.counts_host);
+  I.jobs_host = nullptr; I.jobs_dev = nullptr; I.counts_host = nullptr; I.counts_dev = nullptr; I.work = I.carry = nullptr; I.tab_int = nullptr; I.tab_frac = nullptr;
+  I.general = false; I.dec.clear(); I.M.clear(); I.tab.clear(); I.carry_n.clear(); I.n_bytes.clear();
+  I.cs = nullptr; I.committed = nullptr; I.front = nullptr; I.committed_recorded = false; I.open = false; I.capacity = 0;
 }
 
 static int need_device_e()
@@ -585,11 +634,14 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
     H(hipEventCreateWithFlags(&e->ss.prep_b_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.demap_done, hipEventDisableTiming | hipEventReleaseToDevice));
     H(hipEventCreateWithFlags(&e->ss.sym_done, hipEventDisableTiming | hipEventReleaseToDevice));
-    // few streams: both demapper launches of a frame on stream d (pipeline.h, fic_on_d).  The threshold is k_symbols' own (sym_blocks_per_stream:
-    // below 48 streams a frame's symbols are spread over more blocks because latency, not throughput, is what is left); DABX_FIC_ON_D = 0 / 1
-    // overrides it for A/B runs
-    e->ss.fic_on_d = cfg->n_streams < 48;
-    if (const char *v = getenv("DABX_FIC_ON_D")) e->ss.fic_on_d = atoi(v) != 0;
+    // few streams: the demapper of a frame on stream d in one launch, hand-overs by device-side sequence numbers (pipeline.h, fic_on_d /
+    // EngineDev::flag_sync).  The threshold is k_symbols' own (sym_blocks_per_stream: below 48 streams a frame's symbols are spread over more
+    // blocks because latency, not throughput, is what is left) -- and the bound under which every block of the kernels that wait for each other
+    // is resident at once.  (A/B builds: tools/build_variant.sh -DDABX_FEW_STREAMS=n.)
+#ifndef DABX_FEW_STREAMS
+#define DABX_FEW_STREAMS 48
+#endif
+    e->ss.fic_on_d = cfg->n_streams < DABX_FEW_STREAMS;
     // the ingest stream BEFORE q: the runtime deals streams to its hardware queues in order of creation, and as the fifth stream the
     // ingest stream shared one (every synchronous push 20 us = 20 % dearer at 512 streams, tools/bench_ingest.py)
     H(hipStreamCreateWithFlags(&e->ingest, hipStreamNonBlocking));
@@ -623,6 +675,8 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   A(e->alloc(&d.ctl, S));
   A(e->alloc(&d.spectra, (size_t)2 * S * 75 * K, false));
   A(e->alloc(&d.fsnap, S));
+  A(e->alloc(&d.sym_seq, S));
+  A(e->alloc(&d.fic_seq, S));
   A(e->alloc(&d.demap_busy, S));
   A(e->alloc(&d.dciq_state, (size_t)S * 8));
   A(e->alloc(&d.dciq_done, S));
@@ -1343,6 +1397,14 @@ int dabx_discover_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, 
   return dabx_parse_fibs(fibs.data(), crc.data(), have * 12, out, max_out, nullptr);
 }
 
+int dabx_set_fig_reference_quirks(dabx_engine *e, int on)
+{
+  if (!e) return DABX_E_ARG;
+  e->fig_reference_quirks = on != 0;
+  for (dabx_fibdec *fd : e->fibdec) if (fd) (void)dabx_fibdec_set_reference_quirks(fd, on);
+  return 0;
+}
+
 int dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out)
 {
   if (!e || stream < 0 || stream >= e->dev.n_streams || !out) return DABX_E_ARG;
@@ -1352,7 +1414,10 @@ int dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out)
   int rc = fetch_ctl(e, stream, &c);
   if (rc) return rc;
   dabx_fibdec *&fd = e->fibdec[(size_t)stream];
-  if (!fd && (rc = dabx_fibdec_create(&fd))) return rc;
+  if (!fd) {
+    if ((rc = dabx_fibdec_create(&fd))) return rc;
+    if (e->fig_reference_quirks) (void)dabx_fibdec_set_reference_quirks(fd, 1);
+  }
   long long &fed = e->fib_frames_fed[(size_t)stream];
   const EngineDev &d = e->dev;
   if (c.frames - fed > d.out_frames) {                      // frames that have left the FIB ring: their FIGs are lost to the decoder
@@ -1478,7 +1543,21 @@ int dabx_get_counters(dabx_engine *e, int64_t out[16])
   return 0;
 }
 
-int dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg)
+static int ingest_open_impl(dabx_engine *e, const dabx_ingest_config *cfg, const dabx_iq_format *formats);
+int dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg) { return ingest_open_impl(e, cfg, nullptr); }
+int dabx_ingest_open_formats(dabx_engine *e, const dabx_ingest_config *cfg, const dabx_iq_format *formats)
+{
+  if (!formats) { set_error("dabx_ingest_open_formats: bad argument"); return DABX_E_ARG; }
+  return ingest_open_impl(e, cfg, formats);
+}
+long long dabx_ingest_pitch(dabx_engine *e)
+{
+  if (!e) return DABX_E_ARG;
+  if (!e->ing.open) { set_error("dabx_ingest_pitch: no ingest open"); return DABX_E_STATE; }
+  return (long long)(e->ing.general ? e->ing.pitch : e->ing.capacity / (size_t)e->dev.n_streams);
+}
+
+static int ingest_open_impl(dabx_engine *e, const dabx_ingest_config *cfg, const dabx_iq_format *formats)
 {
   if (!e || (cfg && (cfg->host_slabs < 0 || cfg->host_slabs > 64 || cfg->fmt < 0 || cfg->fmt > 2 || cfg->max_frames < 0 || cfg->copy_engine < 0 || cfg->copy_engine > 1))) {
     set_error("dabx_ingest_open: bad argument");
@@ -1494,11 +1573,64 @@ int dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg)
   static const int bps[3] = {8, 4, 2};
   I.capacity = (size_t)e->dev.n_streams * I.max_frames * TF * bps[I.fmt];
   int rc;
+  const int S_ = e->dev.n_streams;
+  std::vector<int16_t> tabs_i; std::vector<float> tabs_f;
+  int m_max = 0;
+  if (formats) {
+    // every stream's own recording: the region of a slab that holds max_frames frames' worth of ITS payload (+ one read block) sets the pitch
+    I.general = true;
+    I.dec.assign((size_t)S_, IqDecode{}); I.M.assign((size_t)S_, 0); I.tab.assign((size_t)S_, 0); I.carry_n.assign((size_t)S_, 0);
+    std::map<std::pair<int, int>, int> tab_of;
+    size_t need = 0;
+    for (int s = 0; s < S_; s++) {
+      if ((rc = iq_check_format(&formats[s], &I.dec[(size_t)s]))) { ingest_free(e); return rc; }
+      const int rate = formats[s].sample_rate;
+      if (rate != INPUT_RATE) {
+        const auto key = std::make_pair((int)formats[s].family, rate);
+        if (!tab_of.count(key)) {
+          tab_of[key] = (int)tab_of.size();
+          tabs_i.resize(tabs_i.size() + 2048); tabs_f.resize(tabs_f.size() + 2048);
+          int m = 0;
+          iq_resample_tables(formats[s].family, rate, &m, tabs_i.data() + tabs_i.size() - 2048, tabs_f.data() + tabs_f.size() - 2048);
+        }
+        I.tab[(size_t)s] = tab_of[key];
+        I.M[(size_t)s] = rate / 1000;
+        I.carry_n[(size_t)s] = formats[s].family == DABX_FAMILY_UFF ? 1 : 0;     // xml_reader.cpp:84-85,226: convBuffer[0] starts as a zero sample
+        m_max = std::max(m_max, rate / 1000);
+      }
+      const size_t in_per_frame = (size_t)((long long)TF * (rate / 1000) / 2048) + (size_t)(rate / 1000);
+      need = std::max(need, ((size_t)I.max_frames * in_per_frame + (size_t)(rate / 1000)) * 2 * (size_t)I.dec[(size_t)s].bytes);
+    }
+    I.pitch = align_up(need, 256);
+    I.capacity = I.pitch * (size_t)S_;
+  }
   if (I.copy_engine == 0 && (rc = sdma_open(e->device, &I.sdma))) return rc;
 #define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); ingest_free(e); return DABX_E_HIP; } } while (0)
   if (I.copy_engine == 1) H(hipStreamCreateWithFlags(&I.cs, hipStreamNonBlocking));
   H(hipEventCreateWithFlags(&I.committed, hipEventDisableTiming | hipEventReleaseToDevice));
+  H(hipEventCreateWithFlags(&I.front, hipEventDisableTiming | hipEventReleaseToDevice));
   I.slabs.resize((size_t)(cfg && cfg->host_slabs ? cfg->host_slabs : 2));
+  if (I.general) {
+    I.n_bytes.assign(I.slabs.size(), std::vector<size_t>((size_t)S_, 0));
+    H(hipHostMalloc((void **)&I.jobs_host, sizeof(IngestJob) * (size_t)S_, hipHostMallocDefault));
+    H(hipHostMalloc((void **)&I.counts_host, sizeof(unsigned) * (size_t)S_, hipHostMallocDefault));
+    H(hipMalloc((void **)&I.jobs_dev, sizeof(IngestJob) * (size_t)S_));
+    H(hipMalloc((void **)&I.counts_dev, sizeof(unsigned) * (size_t)S_));
+    if (m_max) {
+      // [carry | decoded samples of one slab] per resampling stream, and the carry between slabs (<= M + 1 samples)
+      size_t max_in = 0;
+      for (int s = 0; s < S_; s++) if (I.M[(size_t)s]) max_in = std::max(max_in, I.pitch / (size_t)(2 * I.dec[(size_t)s].bytes));
+      I.work_pitch = align_up(max_in + (size_t)m_max + 2, 64);
+      I.carry_pitch = align_up((size_t)m_max + 2, 64);
+      H(hipMalloc((void **)&I.work, sizeof(float2) * I.work_pitch * (size_t)S_));
+      H(hipMalloc((void **)&I.carry, sizeof(float2) * I.carry_pitch * (size_t)S_));
+      H(hipMemset(I.carry, 0, sizeof(float2) * I.carry_pitch * (size_t)S_));
+      H(hipMalloc((void **)&I.tab_int, tabs_i.size() * sizeof(int16_t)));
+      H(hipMalloc((void **)&I.tab_frac, tabs_f.size() * sizeof(float)));
+      H(hipMemcpy(I.tab_int, tabs_i.data(), tabs_i.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+      H(hipMemcpy(I.tab_frac, tabs_f.data(), tabs_f.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
   for (auto &sl : I.slabs) {
     H(hipHostMalloc((void **)&sl.host, I.capacity, hipHostMallocDefault));
     H(hipMalloc((void **)&sl.dev, I.capacity));
@@ -1536,6 +1668,7 @@ int dabx_ingest_submit(dabx_engine *e, int k, size_t n)
   if (!e) return DABX_E_ARG;
   Ingest &I = e->ing;
   if (!I.open || k < 0 || k >= (int)I.slabs.size()) { set_error("dabx_ingest_submit: no such slab"); return DABX_E_STATE; }
+  if (I.general) { set_error("dabx_ingest_submit: this ingest was opened with per-stream formats (dabx_ingest_submit_bytes)"); return DABX_E_STATE; }
   if (n == 0 || n > (size_t)I.max_frames * TF) { set_error("dabx_ingest_submit: %zu samples per stream, the slabs hold %d frames", n, I.max_frames); return DABX_E_ARG; }
   if (int rc = use_device(e)) return rc;
   Ingest::Slab &sl = I.slabs[(size_t)k];
@@ -1551,6 +1684,92 @@ int dabx_ingest_submit(dabx_engine *e, int k, size_t n)
   return 0;
 }
 
+int dabx_ingest_submit_bytes(dabx_engine *e, int k, const size_t *n_bytes)
+{
+  if (!e || !n_bytes) return DABX_E_ARG;
+  Ingest &I = e->ing;
+  if (!I.open || !I.general || k < 0 || k >= (int)I.slabs.size()) { set_error("dabx_ingest_submit_bytes: no such slab of an ingest opened with dabx_ingest_open_formats"); return DABX_E_STATE; }
+  if (int rc = use_device(e)) return rc;
+  Ingest::Slab &sl = I.slabs[(size_t)k];
+  if (sl.in_flight) { set_error("dabx_ingest_submit_bytes: slab %d has a transfer that was not committed", k); return DABX_E_STATE; }
+  size_t last = 0;
+  for (int s = 0; s < e->dev.n_streams; s++) {
+    const IqDecode &d = I.dec[(size_t)s];
+    const size_t unit = (size_t)(2 * d.bytes) * (d.quirk_block ? (size_t)d.quirk_block : 1);
+    if (n_bytes[s] > I.pitch || n_bytes[s] % unit) {
+      set_error("dabx_ingest_submit_bytes: stream %d: %zu bytes -- at most %zu, whole samples%s only (a reader keeps the odd tail for its next slab)", s, n_bytes[s], I.pitch,
+                d.quirk_block ? " and whole 1-ms read blocks" : "");
+      return DABX_E_ARG;
+    }
+    if (n_bytes[s]) last = (size_t)s * I.pitch + n_bytes[s];
+  }
+  I.n_bytes[(size_t)k].assign(n_bytes, n_bytes + e->dev.n_streams);
+  DABX_HIP(hipStreamSynchronize(e->ingest));
+  // ONE transfer, up to the last byte any stream uses (the regions of streams that end early travel as they are)
+  if (last) {
+    if (I.copy_engine == 0) { if (int rc = sdma_copy(I.sdma, sl.dev, sl.host, last, false, sl.sig)) return rc; }
+    else DABX_HIP(hipMemcpyAsync(sl.dev, sl.host, last, hipMemcpyHostToDevice, I.cs));
+  }
+  sl.n = last; sl.in_flight = true;
+  return 0;
+}
+
+// general form: per stream its own decode, resampling state and sample count; two launches for all streams together
+static int ingest_commit_general(dabx_engine *e, int k)
+{
+  Ingest &I = e->ing;
+  Ingest::Slab &sl = I.slabs[(size_t)k];
+  const int S = e->dev.n_streams;
+  const std::vector<size_t> &nb = I.n_bytes[(size_t)k];
+  std::vector<IngestJob> jobs((size_t)S);
+  unsigned max_n = 0, max_out = 0;
+  for (int s = 0; s < S; s++) {
+    IngestJob &j = jobs[(size_t)s];
+    j = IngestJob{};
+    j.dec = I.dec[(size_t)s];
+    j.src_off = (unsigned long long)s * I.pitch;
+    j.n = (unsigned)(nb[(size_t)s] / (size_t)(2 * j.dec.bytes));
+    j.M = (unsigned)I.M[(size_t)s]; j.tab = (unsigned)I.tab[(size_t)s]; j.carry_n = (unsigned)I.carry_n[(size_t)s];
+    unsigned produced = j.n;
+    if (j.M && j.n) {                                  // feed_push's bookkeeping (iqfile.cpp): block c needs V[c M .. c M + M]
+      const unsigned len = j.carry_n + j.n;
+      j.blocks = len >= j.M + 1 ? (len - 1) / j.M : 0;
+      j.keep = len - j.blocks * j.M;
+      produced = j.blocks * 2048;
+      max_out = std::max(max_out, produced);
+    }
+    I.counts_host[s] = j.n ? produced : 0;
+    max_n = std::max(max_n, j.n);
+    if (int rc = push_room(e, s, I.counts_host[s], "dabx_ingest_commit")) return rc;   // (the transfer stays pending: process, then commit again)
+  }
+  if (sl.n) {
+    if (I.copy_engine == 0) { if (int rc = sdma_wait(sl.sig, 0)) return rc; }
+    else DABX_HIP(hipStreamSynchronize(I.cs));
+  }
+  for (int s = 0; s < S; s++) {
+    jobs[(size_t)s].dst0 = e->wr_host[s];               // the host's own count of committed samples: no device-side index is read
+    announce_write(e, s, e->wr_host[s] + I.counts_host[s]);
+  }
+  DABX_HIP(hipStreamSynchronize(e->ingest));            // the staging records of the previous commit have been read
+  memcpy(I.jobs_host, jobs.data(), sizeof(IngestJob) * (size_t)S);
+  DABX_HIP(hipMemcpyAsync(I.jobs_dev, I.jobs_host, sizeof(IngestJob) * (size_t)S, hipMemcpyHostToDevice, e->ingest));
+  DABX_HIP(hipMemcpyAsync(I.counts_dev, I.counts_host, sizeof(unsigned) * (size_t)S, hipMemcpyHostToDevice, e->ingest));
+  IngestMulti m{};
+  m.slab = sl.dev; m.jobs = I.jobs_dev; m.iq = e->dev.iq; m.ring_len = e->dev.ring_len; m.work = I.work; m.work_pitch = I.work_pitch;
+  m.carry = I.carry; m.carry_pitch = I.carry_pitch; m.tab_int = I.tab_int; m.tab_frac = I.tab_frac;
+  if (int rc = launch_ingest_multi(m, S, max_n, max_out, e->ingest)) return rc;
+  DABX_HIP(hipEventRecord(e->ingest_done, e->ingest));
+  DABX_HIP(hipStreamWaitEvent(e->stream, e->ingest_done, 0));
+  for (int s = 0; s < S; s++) {
+    e->wr_host[s] += I.counts_host[s];
+    if (jobs[(size_t)s].M && jobs[(size_t)s].n) I.carry_n[(size_t)s] = (int)jobs[(size_t)s].keep;
+  }
+  if (int rc = launch_commit_counts(e->dev.wr, I.counts_dev, S, e->stream)) return rc;
+  if (e->cfg.dc_iq_correction) { if (int rc = launch_dciq(e->dev, e->cfg.dc_iq_correction, e->stream)) return rc; }
+  sl.in_flight = false;
+  return 0;
+}
+
 int dabx_ingest_commit(dabx_engine *e, int k)
 {
   if (!e) return DABX_E_ARG;
@@ -1559,13 +1778,16 @@ int dabx_ingest_commit(dabx_engine *e, int k)
   if (int rc = use_device(e)) return rc;
   Ingest::Slab &sl = I.slabs[(size_t)k];
   if (!sl.in_flight) { set_error("dabx_ingest_commit: slab %d was not submitted", k); return DABX_E_STATE; }
+  if (I.general) return ingest_commit_general(e, k);
   for (int s = 0; s < e->dev.n_streams; s++)
     if (int rc = push_room(e, s, sl.n, "dabx_ingest_commit")) return rc;          // (the transfer stays pending: process, then commit again)
   if (I.copy_engine == 0) { if (int rc = sdma_wait(sl.sig, 0)) return rc; }
   else DABX_HIP(hipStreamSynchronize(I.cs));
   for (int s = 0; s < e->dev.n_streams; s++) announce_write(e, s, e->wr_host[s] + sl.n);
-  // the converter reads the committed indices on the device: behind the previous ingest commit (front-end stream), next to the decode
-  if (I.committed_recorded) DABX_HIP(hipStreamWaitEvent(e->ingest, I.committed, 0));
+  // the converter reads the committed indices on the device: behind EVERYTHING the front-end stream has been given so far -- the previous
+  // ingest commit, and a dabx_push_iq / dabx_commit_iq of another entry point in between (their index updates run on that stream too)
+  DABX_HIP(hipEventRecord(I.front, e->stream));
+  DABX_HIP(hipStreamWaitEvent(e->ingest, I.front, 0));
   if (int rc = launch_ingest_convert(e->dev, sl.dev, I.fmt, sl.n, e->ingest)) return rc;
   DABX_HIP(hipEventRecord(e->ingest_done, e->ingest));
   DABX_HIP(hipStreamWaitEvent(e->stream, e->ingest_done, 0));
@@ -1601,7 +1823,7 @@ int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
   // capacity: the tables + per stream what a full CIF can carry at the highest code rate of the standard (EEP 4-B, 4/5: 5530 B
   // of logical frames per CIF) for 4 F CIFs, and the same again for the super frames of up to DL_SF_CAP x 5 CIFs
   const size_t per_cif = 5632;
-  size_t cap = sizeof(dabx_chunk_header) + S * sizeof(dabx_chunk_stream) + S * M * sizeof(dabx_chunk_subch) + S * F * (384 + 12 + sizeof(dabx_chunk_frame)) + 6 * 16;
+  size_t cap = sizeof(dabx_chunk_header) + S * sizeof(dabx_chunk_stream) + S * M * sizeof(dabx_chunk_subch) + S * F * (384 + 12 + sizeof(dabx_chunk_frame)) + 6 * 16 + 256;
   if (M && !d.fic_only) cap += S * ((size_t)4 * F * per_cif + (size_t)DL_SF_CAP * 5 * per_cif + 2 * 16 * M + M * DL_SF_CAP * sizeof(dabx_superframe_info));
   D.capacity = align_up(cap, 4096);
 #define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); delivery_free(e); return DABX_E_HIP; } } while (0)
@@ -1611,11 +1833,12 @@ int dabx_delivery_open(dabx_engine *e, const dabx_delivery_config *cfg)
     H(hipMemset(D.dev[k], 0, D.capacity));
     // system-scope release, explicitly: the SDMA engine (raw HSA, outside HIP's own fences) and the host read what the gather kernels wrote
     H(hipEventCreateWithFlags(&D.packed[k], hipEventDisableTiming | hipEventReleaseToSystem));
+    H(hipEventCreateWithFlags(&D.packed_lf[k], hipEventDisableTiming | hipEventReleaseToSystem));
   }
   D.slots.resize((size_t)n_slots);
   for (auto &sl : D.slots) {
     H(hipHostMalloc((void **)&sl.host, D.capacity, hipHostMallocDefault));
-    if (D.copy_engine == 0 && (rc = sdma_signal_create(&sl.sig))) { delivery_free(e); return rc; }
+    if (D.copy_engine == 0 && ((rc = sdma_signal_create(&sl.sig)) || (rc = sdma_signal_create(&sl.sig2)))) { delivery_free(e); return rc; }
   }
   H(hipMalloc((void **)&D.layout_off, sizeof(unsigned long long) * std::max<size_t>(3 * S * M, 3)));
   H(hipMalloc((void **)&D.subch_id, sizeof(int32_t) * std::max<size_t>(S * M, 1)));

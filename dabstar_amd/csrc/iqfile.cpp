@@ -17,6 +17,8 @@ static int channel_bytes(int container)
   return container >= 0 && container < 6 ? b[container] : 0;
 }
 
+static int check_format(const dabx_iq_format *f, IqDecode *d);
+int dabx::iq_check_format(const dabx_iq_format *f, IqDecode *d) { return check_format(f, d); }
 static int check_format(const dabx_iq_format *f, IqDecode *d)
 {
   if (!f || channel_bytes(f->container) == 0 || f->family < DABX_FAMILY_RAW || f->family > DABX_FAMILY_UFF) {
@@ -63,6 +65,13 @@ int dabx_iq_sample_bytes(const dabx_iq_format *fmt)
 }
 
 // Resampler tables.  WAV flavour wav_reader.cpp:67-82, UFF flavour xml_reader.cpp:76-81.
+static void resample_tables(int family, int rate, int *M, std::vector<int16_t> &ti, std::vector<float> &tf);
+void dabx::iq_resample_tables(int family, int rate, int *M, int16_t *tab_int, float *tab_frac)
+{
+  std::vector<int16_t> ti; std::vector<float> tf;
+  resample_tables(family, rate, M, ti, tf);
+  memcpy(tab_int, ti.data(), 2048 * sizeof(int16_t)); memcpy(tab_frac, tf.data(), 2048 * sizeof(float));
+}
 static void resample_tables(int family, int rate, int *M, std::vector<int16_t> &ti, std::vector<float> &tf)
 {
   ti.resize(2048); tf.resize(2048);

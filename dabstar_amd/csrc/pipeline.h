@@ -138,6 +138,18 @@ struct EngineDev {
   float *dciq_state;              // [S][8] meanI, meanQ, meanII, meanQQ, meanIQ of SampleReader's DC / IQ correction (sample_reader.h:102-106)
   unsigned long long *dciq_done;  // [S] absolute index of the first sample not yet corrected
   int32_t parity;                 // step parity (host sets it per launch)
+  int32_t s0;                     // first stream of a launch that covers a GROUP of streams (k_symbols and the demapper; experiment builds with
+                                  // -DDABX_GROUPS=n issue them per group so that a group's spectra stay in the 256-MB Infinity Cache; 0 otherwise)
+  // Few streams (EngineStreams::fic_on_d): the two hand-overs between the frame chain (HIP stream a) and the demapper (d) are DEVICE-side
+  // sequence numbers instead of HIP events -- an event record or wait between two kernels of a HIP stream is a 6-17 us bubble in that stream
+  // (profiles/r06_single_ensemble_timeline_after.txt), and the demapper's loop is what a lone ensemble's frame rate is.  k_sym_publish (stream a,
+  // behind k_symbols) stores step_seq into sym_seq[s]; k_demap_fic waits for it, and stores it into fic_seq[s] when the FIC symbols are out;
+  // k_fic_frame waits for that.  A waiting kernel only ever waits for one launched BEFORE it whose own waits are satisfied by still earlier
+  // launches (no cycle), and with fewer than 48 streams every block of every kernel involved is resident at once (no block waits for a slot
+  // held by a spinning one).  0: HIP events (the schedule of 48 and more streams).
+  int32_t flag_sync;
+  uint32_t step_seq;              // number of this step (1, 2, ...: the host sets it per launch)
+  uint32_t *sym_seq, *fic_seq;    // [S]
   double2 *nco_tid;               // [S][256] e^{-j 2 pi f tid / fs} of the current frame (k_frame_head -> k_symbols)
   double2 *nco_sym;               // [S][76]  NCO phasor of the first FFT sample of symbols 1..75 ([75] = rotation per 256 samples)
   int32_t *sym_off;               // [S][76]  ring offset of the first (cyclic-prefix) sample of symbols 1..75 of this step's frame,
@@ -169,6 +181,9 @@ struct DeliverDev {
   long long *frames_done;                 // [S] frames of the stream delivered so far
   long long *cif_done, *sf_done;          // [S * max_subch] logical / super frames of the slot delivered so far
   dabx_chunk_header hdr;                  // as it goes into the slab
+  // host side only: recorded behind k_deliver_lf (the chunk's logical frames are in the slab: their share of the transfer may start while the
+  // DAB+ stage still runs); null = one transfer behind everything
+  hipEvent_t lf_done;
 };
 
 // ---- lane-per-trellis path of the MSC decoder (vit_t.hip) ------------------------------------------------------
@@ -213,6 +228,7 @@ struct EngineStreams {
   // its 68 us + one hop run next to the 88 us of the MSC symbols.
   bool fic_on_d = false;
   bool demap_in_flight = false;   // stream d still demaps the MSC symbols of the previous step
+  bool demap_unrecorded = false;  // ... and demap_done has not been recorded behind them yet (fic_on_d: recorded on demand)
   unsigned step_count = 0;
   bool prep_pending = false;      // k_msc_prep of the previous batch may still be reading the TDI ring on stream b
   bool msc_in_flight = false;

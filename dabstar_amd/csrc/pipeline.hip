@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
   front_prio();
   __shared__ float2 lds[FFT_LDS_FLOAT2];
   __shared__ float red3[3][4];
-  const int s = blockIdx.y, tid = threadIdx.x;
+  const int s = blockIdx.y + e.s0, tid = threadIdx.x;
   int l = blockIdx.x;
   int off = uniform_load(e.sym_off + (size_t)s * 76 + l);
   double2 nco_base = uniform_load(e.nco_sym + (size_t)s * 76 + l);
@@ -973,6 +973,32 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
   }
 }
 
+// ------------------------------------------------------------------------- device-side hand-overs (few streams)
+// EngineDev::flag_sync.  The sequence numbers only grow; a block publishes after ALL its threads' stores (block barrier, then a device-scope
+// release by one thread) and a waiting block lets one thread poll (s_sleep between polls: no issue slots taken from the kernel it waits for),
+// then every thread passes a device-scope acquire.
+__device__ __forceinline__ void seq_publish(uint32_t *p, uint32_t seq)
+{
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_store(p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void seq_wait(const uint32_t *p, uint32_t seq)
+{
+  if (threadIdx.x == 0)
+    while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// behind k_symbols on HIP stream a (k_symbols itself, 166 VGPRs at three waves per SIMD, stays as it is)
+__global__ void k_sym_publish(EngineDev e)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < e.n_streams) __hip_atomic_store(e.sym_seq + s, e.step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // -------------------------------------------------------------------------------------------------- demap
 #ifndef DABX_DEMAP_Q                 // experiment builds (tools/build_variant.sh -DDABX_DEMAP_Q=4 -DDABX_DEMAP_OCC=3): carriers per thread
 #define DABX_DEMAP_Q 2
@@ -1002,7 +1028,7 @@ __device__ __forceinline__ void demap_st_ring(uint32_t *p, uint32_t v)
 }
 // ESoftBitType 1..3 and the symbol conversion (SAT: the SIMD builds' saturating one, cfg.viterbi_tie_mode != 0) as compile-time
 // constants: no per-carrier branches on either
-template <int SOFT_TYPE, bool SAT>
+template <int SOFT_TYPE, bool SAT, bool WHOLE = false>
 __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &t, const int l0, const int l1)
 {
   // symbols [l0, l1) of the frame (0-based: l = symbol index - 1).  The engine runs [0, 3) -- the FIC symbols -- first so
@@ -1014,8 +1040,9 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   if (l0 == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
   __shared__ __attribute__((aligned(16))) float red[32];
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][16 * TILE_PLANE];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = blockIdx.x + e.s0, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
+  if (l0 == 0 && e.flag_sync) seq_wait(e.sym_seq + s, e.step_seq);     // few streams: k_symbols of this step (HIP stream a) is through
   // the first launch of a frame (l0 == 0) reads the stream's scalars and leaves a snapshot; a later launch of the same frame
   // uses the snapshot only (the frame tail / next head may already have moved the originals on)
   FrameSnap fs;
@@ -1026,7 +1053,10 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       if (fs.frame_ok && e.demap_busy) __hip_atomic_store(&e.demap_busy[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else fs = e.fsnap[s];
-  if (!fs.frame_ok) return;
+  if (!fs.frame_ok) {
+    if (l0 == 0 && e.flag_sync) seq_publish(e.fic_seq + s, e.step_seq);
+    return;
+  }
   DemapDev &d = e.demap;
   const float *null_power = fs.np_sel ? d.null_power2 : d.null_power;
   const float2 *spectra = e.spectra + (size_t)e.parity * e.n_streams * 75 * K;
@@ -1143,11 +1173,21 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
       }
     }
   };
-  {                                                       // the demapper state advances on all 75 symbols in every mode
-    int l = l0;
-    for (; l + 1 < l1; l += 2) { symbol(l, std::integral_constant<int, 0>{}); symbol(l + 1, std::integral_constant<int, 1>{}); }
-    if (l < l1) symbol(l, std::integral_constant<int, 0>{});
-  }
+  // the demapper state advances on all 75 symbols in every mode
+  auto run = [&](int a, int b) {
+    int l = a;
+    for (; l + 1 < b; l += 2) { symbol(l, std::integral_constant<int, 0>{}); symbol(l + 1, std::integral_constant<int, 1>{}); }
+    if (l < b) symbol(l, std::integral_constant<int, 0>{});
+  };
+  constexpr bool whole_frame_flagged = WHOLE;
+  if constexpr (WHOLE) {
+    // few streams (k_demap_whole): ONE launch for the frame's 75 symbols -- no kernel boundary on the demapper's loop; the FIC decoder (HIP
+    // stream a) is told as soon as symbols 1..3 are out.  (The publish holds a block barrier: the tile / partial-sum parity may start over
+    // behind it.)  Its own kernel: the second copy of the symbol loop costs k_demap_frame6 its six waves per SIMD (56-84 bytes of scratch).
+    run(0, 3);
+    seq_publish(e.fic_seq + s, e.step_seq);
+    run(3, l1);
+  } else run(l0, l1);
 #pragma unroll
   for (int q = 0; q < DEMAP_Q; q++) {
     const int k = tid + DEMAP_THREADS * q, p = q >> 1, h = q & 1;
@@ -1166,6 +1206,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     d.mean_value[s] = mean_value; d.mean_power_all[s] = mpa;
     if (l1 == 75) c.snr_db = snr_db_from(mpa, ns);
   }
+  if (l0 == 0 && e.flag_sync && !whole_frame_flagged) seq_publish(e.fic_seq + s, e.step_seq);  // the FIC symbols (and the snapshot) are out: k_fic_frame may go
   if (l1 == 75 && e.demap_busy) {
     // the frame's last demapper launch is done with the stream's state: every thread's stores are ordered before the flag
     // (block barrier, then a device-scope release by the thread that clears it)
@@ -1182,6 +1223,9 @@ __global__ __launch_bounds__(DEMAP_THREADS, DABX_DEMAP_OCC) void k_demap_frame6(
 // per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
 template <int SOFT_TYPE, bool SAT>
 __global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT>(e, t, 0, 3); }
+// few streams with device-side hand-overs (EngineDev::flag_sync): the whole frame in one launch
+template <int SOFT_TYPE, bool SAT>
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_whole(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT, true>(e, t, 0, 75); }
 
 // ---------------------------------------------------------------------------------------------------- FIC
 struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map (viterbi_core.h: key / raw / syms)
@@ -1212,6 +1256,9 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
   __shared__ uint16_t s_crc[256];           // CCITT table: the 30-step look-up chain of a FIB's CRC stays in LDS
   const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   StreamCtl &c = e.ctl[s];
+  // few streams: the FIC symbols come from HIP stream d.  Waited for in EVERY case -- also when this step has no frame for the stream: the
+  // demapper's first launch reads the stream's scalars, which the kernels behind this one (tail, next head) rewrite
+  if (e.flag_sync && first == 0 && count == 4) seq_wait(e.fic_seq + s, e.step_seq);
   if (!c.frame_ok) return;
   s_crc[threadIdx.x] = t.crc_ccitt[threadIdx.x];
   const int fic = first + wave;             // this wave's FIC block
@@ -1820,6 +1867,8 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   if (rc) return rc;
   EngineDev e = e_in;
   e.parity = (int)(ss.step_count++ & 1u);               // spectra buffer of this step
+  e.step_seq = ss.step_count;                           // 1, 2, ...
+  e.flag_sync = (ss.d && ss.fic_on_d && e.sym_seq) ? 1 : 0;
   hipStream_t st = ss.a;
   // Streams out of lock (k_acquire).  In step: on the front-end stream, before the frame head -- every step then offers every
   // stream a frame's worth of search.  Asynchronous: on HIP stream q; a pass is launched when the previous one has finished
@@ -1856,7 +1905,13 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
     if (ss.q && ss.acq_a_done) { DABX_HIP(hipEventRecord(ss.acq_a_done, st)); ss.acq_a_pending = true; }
   }
   mk.begin(1, st); hipLaunchKernelGGL(k_frame_head, dim3(e.n_streams), dim3(256), 0, st, e, *t); mk.end(1, st);
-  mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st);
+#ifndef DABX_GROUPS
+#define DABX_GROUPS 1
+#endif
+  // Experiment builds (-DDABX_GROUPS=n): k_symbols -> k_demap_fic -> k_demap_frame6 issued per group of n_streams / n streams,
+  // back to back, all streams resident: does a group's spectra (128 streams = 118 MB) survive in the Infinity Cache between its writer and its reader?
+  const bool grouped = DABX_GROUPS > 1 && ss.d && !ss.fic_on_d && e.n_streams % DABX_GROUPS == 0 && e.n_streams / DABX_GROUPS >= 48;
+  if (!grouped) { mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), e.n_streams), dim3(256), 0, st, e, *t); mk.end(2, st); }
   // kernel instance by (ESoftBitType, symbol conversion of the canonical / SIMD builds)
 #define DABX_DEMAP_DISPATCH(KERNEL, ...)                                                                                         \
   do {                                                                                                                          \
@@ -1877,16 +1932,35 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
   if (ss.d && ss.fic_on_d) {
     // few streams: both demapper launches on d (in order: no event between the per-carrier state's writer and its reader), the FIC decoder and the
     // tail on a behind the FIC symbols (pipeline.h, EngineStreams::fic_on_d)
-    DABX_HIP(hipEventRecord(ss.sym_done, st));
-    DABX_HIP(hipStreamWaitEvent(ss.d, ss.sym_done, 0));
-    mk.begin(10, ss.d);
-    DABX_DEMAP_DISPATCH(k_demap_fic, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, ss.d, e, *t);
-    mk.end(10, ss.d);
-    DABX_HIP(hipEventRecord(ss.fic_go, ss.d));
-    mk.begin(3, ss.d); demap(ss.d, 3, 75); mk.end(3, ss.d);
+    // the two hand-overs (k_symbols -> k_demap_fic, k_demap_fic -> k_fic_frame) are device-side sequence numbers: no packet between the two
+    // demapper launches on d, none in front of them (EngineDev::flag_sync)
+    hipLaunchKernelGGL(k_sym_publish, dim3((e.n_streams + 63) / 64), dim3(64), 0, st, e);
+    mk.begin(3, ss.d);
+    DABX_DEMAP_DISPATCH(k_demap_whole, dim3(e.n_streams), dim3(DEMAP_THREADS), 0, ss.d, e, *t);
+    mk.end(3, ss.d);
+    // (demap_done is recorded when somebody needs it -- the MSC batch, once per 7 frames: every packet between two kernels of a HIP stream is a
+    //  bubble of 6-12 us on this loop, profiles/r06_single_ensemble_timeline_after.txt)
+    ss.demap_in_flight = true; ss.demap_unrecorded = true;
+  } else if (grouped) {
+    static hipEvent_t ev[16] = {nullptr};
+    const int sg = e.n_streams / DABX_GROUPS;
+    for (int g = 0; g < DABX_GROUPS; g++) {
+      EngineDev eg = e;
+      eg.s0 = g * sg;
+      if (!ev[g]) DABX_HIP(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming | hipEventReleaseToDevice));
+      mk.begin(2, st); hipLaunchKernelGGL(k_symbols_persistent, dim3(sym_blocks_per_stream(e.n_streams), sg), dim3(256), 0, st, eg, *t); mk.end(2, st);
+      if (g == 0 && ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
+      mk.begin(10, st);
+      DABX_DEMAP_DISPATCH(k_demap_fic, dim3(sg), dim3(DEMAP_THREADS), 0, st, eg, *t);
+      mk.end(10, st);
+      DABX_HIP(hipEventRecord(ev[g], st));
+      DABX_HIP(hipStreamWaitEvent(ss.d, ev[g], 0));
+      mk.begin(3, ss.d);
+      DABX_DEMAP_DISPATCH(k_demap_frame6, dim3(sg), dim3(DEMAP_THREADS), 0, ss.d, eg, *t, 3, 75);
+      mk.end(3, ss.d);
+    }
     DABX_HIP(hipEventRecord(ss.demap_done, ss.d));
     ss.demap_in_flight = true;
-    DABX_HIP(hipStreamWaitEvent(st, ss.fic_go, 0));
   } else if (ss.d) {
     if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
     mk.begin(10, st);
@@ -1912,7 +1986,8 @@ int launch_msc_vitT(const EngineDev &e, int cifs, const MscLaunch &L, hipStream_
 
 // MSC decode of the newest `cifs` CIFs (4 per front-end step, <= 4 * MSC_BATCH_FRAMES; 1 for the per-symbol stage entry) + DAB+ stage.
 // `e.snap` must point at the snapshot buffer of this batch.
-int launch_deliver_msc(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
+int launch_deliver_msc(const EngineDev &e, const DeliverDev &dv, hipStream_t st, bool with_lf);
+int launch_deliver_lf(const EngineDev &e, const DeliverDev &dv, hipStream_t st);
 // `dv` (optional): the chunk's slot gather (deliver.hip) goes behind the DAB+ stage on the stream that ran it, before the batch's
 // completion event; *tail (optional) = the stream whose work completes the batch.
 int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineStreams &ss, Marker &mk, const DeliverDev *dv, hipStream_t *tail)
@@ -1922,12 +1997,20 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
   if (rc) return rc;
   if (tail) *tail = ss.a;
   if (e.fic_only || e.max_subch <= 0 || !e.msc_out) {
-    if (dv && (rc = launch_deliver_msc(e, *dv, ss.a))) return rc;          // the slot table says "nothing" for every slot
+    if (dv && (rc = launch_deliver_msc(e, *dv, ss.a, true))) return rc;    // the slot table says "nothing" for every slot
     return 0;
   }
   const int jobs = e.n_streams * cifs * e.max_subch;
-  // the MSC symbols of the newest frame may still be on their way into the time-de-interleaver ring (stream d)
-  if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.demap_done, 0)); ss.demap_in_flight = false; }
+  // The MSC symbols of the newest frame may still be on their way into the time-de-interleaver ring (stream d): whoever READS the ring waits
+  // for them -- the batch's own stream, not the frame chain (up to round 5 stream a waited here: 0.19 ms of every 7-step period during which the
+  // next frame's head and symbols could have run; one ensemble: 90 us of every 7 frames)
+  auto wait_for_demapper = [&](hipStream_t who) -> int {
+    if (!ss.demap_in_flight) return 0;
+    if (ss.demap_unrecorded) { DABX_HIP(hipEventRecord(ss.demap_done, ss.d)); ss.demap_unrecorded = false; }
+    DABX_HIP(hipStreamWaitEvent(who, ss.demap_done, 0));
+    if (who == ss.a) ss.demap_in_flight = false;          // (a has it behind it for good; otherwise the next k_demap_fic on a still waits)
+    return 0;
+  };
   // the previous batch (stream b) owns SubchDev / msc_done_cif until it has finished
   if (ss.msc_in_flight) { DABX_HIP(hipStreamWaitEvent(ss.a, ss.msc_done, 0)); ss.msc_in_flight = false; }
   hipLaunchKernelGGL(k_msc_snap, dim3((e.n_streams + 255) / 256), dim3(256), 0, ss.a, e, cifs);
@@ -1958,6 +2041,8 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
       DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
       DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
     }
+    if (fast_pairs < fast->slots_active && (rc = wait_for_demapper(ss.a))) return rc;   // the wave-per-trellis leftovers below read the ring on a
+    if ((rc = wait_for_demapper(sb))) return rc;
     if ((rc = launch_msc_prep(e, cifs, L, sb, mk))) return rc;
     if (ss.b) {
       DABX_HIP(hipEventRecord(ss.prep_b_done, ss.b));
@@ -1974,11 +2059,13 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
         DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
       }
     }
+    // the chunk's logical frames exist: into the slab with them, their share of the transfer starts while the DAB+ stage runs (deliver.hip)
+    if (dv && (rc = launch_deliver_lf(e, *dv, sb))) return rc;
     mk.begin(9, sb);
     hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, sb, e, *t);
     hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, sb, e);
     mk.end(9, sb);
-    if (dv && (rc = launch_deliver_msc(e, *dv, sb))) return rc;
+    if (dv && (rc = launch_deliver_msc(e, *dv, sb, !dv->lf_done))) return rc;
     if (tail) *tail = sb;
     if (ss.b) {
       DABX_HIP(hipEventRecord(ss.msc_done, ss.b));
@@ -1997,6 +2084,7 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
       DABX_HIP(hipEventRecord(ss.prep_done, ss.a));
       DABX_HIP(hipStreamWaitEvent(ss.b, ss.prep_done, 0));
     }
+    if ((rc = wait_for_demapper(sb))) return rc;
     mk.begin(8, sb);
     hipLaunchKernelGGL(k_msc_frame, dim3((jobs + 3) / 4), dim3(256), 0, sb, e, *t, cifs, 0u);
     mk.end(8, sb);
@@ -2004,11 +2092,12 @@ int launch_msc_batch(const EngineDev &e, int cifs, const MscFast *fast, EngineSt
       DABX_HIP(hipEventRecord(ss.prep_b_done, ss.b));
       ss.prep_pending = true;
     }
+    if (dv && (rc = launch_deliver_lf(e, *dv, sb))) return rc;
     mk.begin(9, sb);
     hipLaunchKernelGGL(k_dabplus, dim3(e.n_streams * e.max_subch), dim3(64), 0, sb, e, *t);
     hipLaunchKernelGGL(k_msc_done, dim3((e.n_streams + 255) / 256), dim3(256), 0, sb, e);
     mk.end(9, sb);
-    if (dv && (rc = launch_deliver_msc(e, *dv, sb))) return rc;
+    if (dv && (rc = launch_deliver_msc(e, *dv, sb, !dv->lf_done))) return rc;
     if (tail) *tail = sb;
     if (ss.b) {
       DABX_HIP(hipEventRecord(ss.msc_done, ss.b));

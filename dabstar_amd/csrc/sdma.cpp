@@ -71,7 +71,11 @@ void sdma_signal_destroy(uint64_t sig)
   if (sig) (void)hsa_signal_destroy(hsa_signal_t{sig});
 }
 
-int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig)
+static int sdma_copy_impl(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig, bool strict_engine);
+int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig) { return sdma_copy_impl(s, dst, src, bytes, to_host, sig, false); }
+// strict_engine (the calibration's probes): the engine asked for or an error -- no silent fall-back to the runtime's own choice, whose rate would
+// otherwise be credited to an engine the runtime refuses
+static int sdma_copy_impl(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_host, uint64_t sig, bool strict_engine)
 {
   if (!s.ok) { set_error("sdma: not open"); return DABX_E_STATE; }
   // the agent that owns the host allocation (the NUMA node hipHostMalloc took it from); any CPU agent would do for the engine choice
@@ -95,7 +99,7 @@ int sdma_copy(const Sdma &s, void *dst, const void *src, size_t bytes, bool to_h
   if (engine)
     st = to_host ? hsa_amd_memory_async_copy_on_engine(dst, host, src, gpu, bytes, 0, nullptr, done, (hsa_amd_sdma_engine_id_t)engine, true)
                  : hsa_amd_memory_async_copy_on_engine(dst, gpu, src, host, bytes, 0, nullptr, done, (hsa_amd_sdma_engine_id_t)engine, true);
-  if (st != HSA_STATUS_SUCCESS)              // no preferred engine known, or the runtime refuses it: its own choice
+  if (st != HSA_STATUS_SUCCESS && !(strict_engine && engine))   // no preferred engine known, or the runtime refuses it: its own choice
     st = to_host ? hsa_amd_memory_async_copy(dst, host, src, gpu, bytes, 0, nullptr, done)
                  : hsa_amd_memory_async_copy(dst, gpu, src, host, bytes, 0, nullptr, done);
   if (st != HSA_STATUS_SUCCESS) {
@@ -112,21 +116,27 @@ int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, d
 {
   constexpr size_t N = (size_t)16 << 20;
   uint32_t &engine = to_host ? s.engine_to_host : s.engine_to_dev;
-  auto measure = [&](uint32_t eng, double *out) -> int {
+  auto measure = [&](uint32_t eng, double *out, bool strict) -> int {
     const uint32_t keep = engine;
     engine = eng;
     double best = 0;
     int rc = 0;
     for (int r = 0; r < 2 && !rc; r++) {             // the first transfer of a queue includes its creation
       const auto t0 = std::chrono::steady_clock::now();
-      rc = sdma_copy(s, to_host ? host : dev, to_host ? dev : host, N, to_host, sig);
+      rc = sdma_copy_impl(s, to_host ? host : dev, to_host ? dev : host, N, to_host, sig, strict);
       if (!rc) {
         const hsa_signal_t sg{sig};
         hsa_signal_value_t v;
         while ((v = hsa_signal_load_scacquire(sg)) >= 1) {                              // 0.3 ms: spinning is the measurement
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { set_error("sdma: a 16-MiB probe transfer did not complete within 5 s"); return DABX_E_HIP; }
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            // the transfer is still in flight and the caller frees both buffers on an error: wait it out (bounded) before saying so
+            const int late = sdma_wait(sig, 0);
+            engine = keep;
+            set_error(late ? "sdma: a 16-MiB probe transfer did not complete within 65 s" : "sdma: a 16-MiB probe transfer took more than 5 s");
+            return DABX_E_HIP;
+          }
         }
-        if (v < 0) { set_error("sdma: a 16-MiB probe transfer failed (signal value %lld)", (long long)v); return DABX_E_HIP; }
+        if (v < 0) { engine = keep; set_error("sdma: a 16-MiB probe transfer failed (signal value %lld)", (long long)v); return DABX_E_HIP; }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         best = std::max(best, (double)N / dt / 1e9);
       }
@@ -136,12 +146,12 @@ int sdma_calibrate(Sdma &s, void *host, void *dev, bool to_host, uint64_t sig, d
     return rc;
   };
   double rate = 0;
-  if (int rc = measure(engine, &rate)) return rc;
+  if (int rc = measure(engine, &rate, false)) return rc;
   if (rate < 35.0) {
     uint32_t best_eng = engine;
     for (int b = 0; b < 8; b++) {
       double r = 0;
-      if (measure(1u << b, &r) == 0 && r > rate * 1.15) { rate = r; best_eng = 1u << b; }
+      if (measure(1u << b, &r, true) == 0 && r > rate * 1.15) { rate = r; best_eng = 1u << b; }   // an engine the runtime refuses is skipped
     }
     engine = best_eng;
   }

@@ -420,6 +420,7 @@ class Engine:
         cfg.exact_level_tracker = int(exact_level_tracker)
         cfg.acquire_mode = int(acquire_mode)
         self.cfg = cfg
+        self.n_streams = n_streams
         self._h = C.c_void_p()
         check(L.dabx_create(C.byref(cfg), C.byref(self._h)))
         self.subch = []
@@ -506,6 +507,9 @@ class Engine:
         n = check(load().dabx_discover_subchannels(self._h, stream, out, max_out))
         return [out[i] for i in range(n)]
 
+    def set_fig_reference_quirks(self, on):
+        check(load().dabx_set_fig_reference_quirks(self._h, int(on)))
+
     def follow_fic(self, stream):
         out = Reconf()
         check(load().dabx_follow_fic(self._h, stream, C.byref(out)))
@@ -580,6 +584,27 @@ class Engine:
             dt = (np.complex64, np.int16, np.uint8)[code]
             out.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap.value,)).view(dt))
         return out
+
+    def ingest_open_formats(self, formats, slabs=2, max_frames=0, copy_engine=0):
+        """The general form: formats[s] = IqFormat of stream s.  Returns (slabs as uint8 arrays [n_streams, pitch], pitch)."""
+        assert len(formats) == self.n_streams
+        cfg = IngestConfig(host_slabs=slabs, fmt=0, max_frames=max_frames, copy_engine=copy_engine)
+        arr = (IqFormat * len(formats))(*formats)
+        L = load()
+        L.dabx_ingest_pitch.restype = C.c_longlong
+        check(L.dabx_ingest_open_formats(self._h, C.byref(cfg), arr))
+        pitch = check(L.dabx_ingest_pitch(self._h))
+        out = []
+        for k in range(slabs):
+            p, cap = C.c_void_p(), C.c_size_t()
+            check(L.dabx_ingest_slab(self._h, k, C.byref(p), C.byref(cap)))
+            assert cap.value == pitch * self.n_streams
+            out.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap.value,)).reshape(self.n_streams, pitch))
+        return out, pitch
+
+    def ingest_submit_bytes(self, k, n_bytes):
+        arr = (C.c_size_t * self.n_streams)(*[int(v) for v in n_bytes])
+        check(load().dabx_ingest_submit_bytes(self._h, k, arr))
 
     def ingest_submit(self, k, n_samples):
         check(load().dabx_ingest_submit(self._h, k, n_samples))

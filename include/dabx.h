@@ -384,6 +384,11 @@ typedef struct {
   int64_t at_cif, last_change_cif, frames_fed;
 } dabx_reconf;
 int  dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out);
+/* The FIB decoders behind dabx_follow_fic / dabx_next_subchannels / dabx_current_subchannels swap their tables after ANY announcement by
+ * default; on != 0 makes them (those that exist and those created later) follow the reference's rule to the bit -- only after change flags 3
+ * (fib_decoder_fig0.cpp:103), dabx_fibdec_set_reference_quirks -- so that an engine-level reconfiguration can be compared with the reference's
+ * own behaviour for flags 1 and 2 as well. */
+int  dabx_set_fig_reference_quirks(dabx_engine *e, int on);
 int  dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
 /* ... and the CURRENT table of the same decoder (after a swap: the former next table plus whatever the new configuration's own FIGs,
  * C/N = 0, have added since -- first description wins). */
@@ -560,6 +565,17 @@ typedef struct {
   int32_t reserved[4];
 } dabx_ingest_config;
 int  dabx_ingest_open(dabx_engine *e, const dabx_ingest_config *cfg);
+/* The general form -- what a host with n_streams RECORDINGS has: every stream its own container, byte order, sample rate (the readers'
+ * 1-ms linear interpolation of wav_reader.cpp:67-82,190-206 / xml_reader.cpp:237-244 runs on the device, per stream, with its state carried
+ * from slab to slab) and its own length.  formats[s] = the dabx_iq_format of stream s as dabx_probe_iq_file returns it (data_offset /
+ * data_bytes are ignored; cfg->fmt too).  A slab is n_streams regions of dabx_ingest_pitch() bytes; the host puts the next payload bytes
+ * of stream s at byte s * pitch and says how many (n_bytes[s]: whole samples -- a reader keeps an odd tail for its next slab --, 0 = the
+ * recording has ended or is not ready).  Still ONE SDMA transfer per slab, TWO kernel launches per commit whatever the number of streams
+ * and formats, and the results are byte-identical to n_streams dabx_feed_bytes calls (tests/test_gpu_ingest.py). */
+struct dabx_iq_format_s;                                                      /* "Recorded-IQ files" below */
+int  dabx_ingest_open_formats(dabx_engine *e, const dabx_ingest_config *cfg, const struct dabx_iq_format_s *formats /* [n_streams] */);
+long long dabx_ingest_pitch(dabx_engine *e);                                  /* bytes per stream region of a slab */
+int  dabx_ingest_submit_bytes(dabx_engine *e, int k, const size_t *n_bytes /* [n_streams] */);   /* then dabx_ingest_commit(e, k) as above */
 int  dabx_ingest_close(dabx_engine *e);
 int  dabx_ingest_slab(dabx_engine *e, int k, void **host, size_t *capacity_bytes);
 int  dabx_ingest_submit(dabx_engine *e, int k, size_t n_samples);     /* DABX_E_STATE: the slab's previous transfer has not been committed */

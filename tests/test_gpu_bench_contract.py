@@ -46,6 +46,20 @@ def test_bench_line_keeps_its_contract():
     assert d["superframes_delivered"] == d["superframes_decoded"] > 0 and d["frac_of_that"] > 0.85 and d["host_GBps"] > 8.0
     s20 = d["at_timed_region_length"]
     assert s20["steps"] == 14 and s20["frames_delivered"] == s20["frames_decoded"] == 512 * 14 and 0.6 < s20["frac_of_value"] <= 1.05
+    # round 6: the timed regions themselves deliver (value = IQ -> bytes in host memory), three regions, value = their median; the rate with the
+    # results left on the device and the same loop with a C++ consumer thread stand beside it
+    assert d["in_timed_region"] is True and "delivered to page-locked host memory" in j["results"]
+    assert len(j["timed_regions"]) == 3 and j["value_min"] <= j["value"] <= j["value_max"]
+    assert sorted(r_["value"] for r_ in j["timed_regions"])[1] == j["value"]
+    assert 0.6 < s20["frac_of_not_delivered"] <= 1.1 and d["not_delivered"]["at_timed_region_length"] > 50000 and d["not_delivered"]["steady"] > 50000
+    cx = d["consumers"]["cxx_thread"]
+    assert cx["lost"] == 0 and cx["steady"] > 50000 and cx["access_units_counted"] > 0
+    t = j["roofline"]["chain_real_traffic"]
+    assert t["hbm_bytes_per_step"] > 2 * 512 * 2115456 * 0.5 and 0.1 < t["frac_of_achievable"] < 1.0 and t["achievable_GBps"] == 6300.0
+    sw = j["config"]["snr_sweep"]
+    assert [q["snr_db"] for q in sw] == [20.0, 12.0, 8.0, 5.0] and all(q["streams_locked"] == 512 for q in sw)
+    assert sw[1]["fib_crc_pass_pct"] > 99.0 and sw[1]["superframes_ok"] > 0 and sw[3]["rs_corrected"] > sw[1]["rs_corrected"] >= 0
+    assert all(q["kernel_ms_per_step_standalone"]["k_dabplus"] > 0 and q["value"] > 50000 for q in sw)
     assert d["copies"]["link_GBps"] > 25.0 and d["copy_engine"].startswith("sdma")
     assert j["fib_match_vs_oracle_pct"] == 100.0 and j["fib_match_vs_oracle"]["fibs_compared"] >= 8 * 12 * 100
     h = j["config"]["host_to_host"]

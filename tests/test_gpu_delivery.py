@@ -90,7 +90,7 @@ def test_chunks_carry_the_complete_output_of_every_stream():
     slab = eng.delivery_slab_bytes()
     # tables + 3 streams x (28 logical frames x 192 B + 6 super frames x 880 B + their 6 records x 32 B) x 18 slots, 16-byte aligned areas
     body = S * 18 * (28 * 192 + 6 * 880 + 6 * 32)
-    assert 128 + S * 72 + S * 18 * 144 + S * 7 * (384 + 12 + 16) + body <= slab <= 128 + S * 72 + S * 18 * 144 + S * 7 * 412 + body + 6 * 16
+    assert 128 + S * 72 + S * 18 * 144 + S * 7 * (384 + 12 + 16) + body <= slab <= 128 + S * 72 + S * 18 * 144 + S * 7 * 412 + body + 6 * 16 + 256
     for s in range(S):
         eng.push_iq(s, xs[s])
     col = Collector(S, 18)

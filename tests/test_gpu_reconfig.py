@@ -36,8 +36,8 @@ def _oracle(x, subch, move=None):
     return res
 
 
-@pytest.mark.parametrize("cif_in_frame", [0, 2])
-def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame):
+@pytest.mark.parametrize("cif_in_frame,reference_rule", [(0, False), (2, False), (0, True)])
+def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame, reference_rule):
     """cif_in_frame = 2: the configuration changes in the MIDDLE of a transmission frame (its third CIF).  dabx_set_subchannels_at is
     called at the frame boundary in front of it with the announced CIF: the new services' de-interleavers start exactly there (their
     first logical frame is delivered complete); the services that end are cut at the frame boundary -- the two logical frames numbered
@@ -59,6 +59,8 @@ def test_reconfiguration_is_followed_at_the_announced_cif(cif_in_frame):
 
     eng = dx.Engine(n_streams=1, ring_frames=n_frames + 2, max_subch=6, out_frames=4)
     eng.set_subchannels(a)
+    if reference_rule:               # dabx_set_fig_reference_quirks: the engine's own FIB decoder swaps like the reference's (after change flags 3 only,
+        eng.set_fig_reference_quirks(True)   # fib_decoder_fig0.cpp:103) -- for an announcement with flags 3, as here, the two rules are the same rule
     eng.push_iq(0, x)
     got = [dict() for _ in range(6)], [dict() for _ in range(6)]       # [before / after the switch][slot] -> {engine CIF: logical frame}
     at_cif, applied, c0, pending_seen = None, False, None, 0
