@@ -77,6 +77,10 @@ def parse():
                     help="round 5's form: the timed regions leave the results in the device rings; the delivery is then measured in legs of the "
                          "same length (config.delivered_to_host).  Default: the timed regions run with the bulk delivery open -- every FIB, logical "
                          "frame, super frame and AU record of every stream lands in page-locked host memory inside the timed region")
+    ap.add_argument("--cxx-consumer", action="store_true",
+                    help="the timed regions' delivery consumer as the C++ thread of tests/cxx/consumer_thread.cpp instead of a python thread; the other one is "
+                         "measured in a leg either way (delivered_to_host.consumers).  Same-box pairs at 20 steps: python 463 k, C++ 440 k in the timed regions "
+                         "(profiles/r06_ab/ab10_consumers.txt; as a leg both reach 455-468 k): the python thread stays the default")
     ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--taper", action="store_true",
                     help="experiments: with the delivery open, issue the last 7 frames of a region as chunks of 4, 2, 1 (the final slab copy, which nothing "
@@ -670,7 +674,9 @@ class CxxSink:
         Lc.dbxc_error.argtypes = [C.c_void_p]
         Lc.dbxc_totals.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         Lc.dbxc_free.argtypes = [C.c_void_p]
-        self.Lc, self.error = Lc, None
+        Lc.dbxc_fib_log.argtypes = [C.c_void_p, C.c_void_p]
+        self.Lc, self.error, self.sample = Lc, None, list(sample)
+        self.fibs = {s: [] for s in self.sample}
         smp = (C.c_int * max(1, len(sample)))(*sample)
         self.h = Lc.dbxc_start(eng._h, C.cast(L.dabx_delivery_next, C.c_void_p), C.cast(L.dabx_delivery_release, C.c_void_p), smp, len(sample))
         self.th = self                                       # (is_alive below: the bench's liveness check)
@@ -691,9 +697,19 @@ class CxxSink:
                 "access_units": v[7], "access_units_ok": v[8]}
 
     def finish(self):
-        self.Lc.dbxc_stop(self.h)
+        n = int(self.Lc.dbxc_stop(self.h))
         if self.Lc.dbxc_error(self.h):
             raise SystemExit("bench.py: the C++ delivery consumer stopped with code %d" % self.Lc.dbxc_error(self.h))
+        if n:                        # the sampled streams' FIBs + CRC flags, chunk by chunk (consumer_thread.cpp: stream, n, first frame, n x 396 bytes)
+            buf = np.zeros(n, np.uint8)
+            self.Lc.dbxc_fib_log(self.h, buf.ctypes.data_as(C.c_void_p))
+            at = 0
+            while at < n:
+                s, k = (int(v) for v in buf[at:at + 8].view(np.int32))
+                first = int(buf[at + 8:at + 16].view(np.int64)[0])
+                rows = buf[at + 16:at + 16 + k * 396].reshape(k, 396)
+                self.fibs[s].append((first, rows[:, :384].reshape(k, 12, 32).copy(), rows[:, 384:].copy()))
+                at += 16 + k * 396
 
 
 def snr_sweep_legs(torch, dev, args, rank, subch, dx, snrs=(12.0, 8.0, 5.0), steps=49):
@@ -927,7 +943,7 @@ def main():
     def sink_catch_up():
         """After eng.synchronize() every chunk has landed; this waits until the consumer thread has taken and released them all."""
         while sink is not None and sink.chunks < closed[0] and sink.error is None:
-            time.sleep(0.0001)
+            time.sleep(0.00002)
     sample_streams = sorted({(i * (args.streams - 1)) // 7 for i in range(8)})
 
     def step(n=1, sync=False, taper=False):
@@ -979,9 +995,10 @@ def main():
         dx.check(dx.load().dabx_set_profiling(eng._h, 0))
     sink = None
     deliver_on = not dry and not args.no_deliver          # the timed regions themselves run with every result landing in host memory
+    cxx_main = not dry and CxxSink.available() and args.cxx_consumer               # which consumer serves the timed regions
     if deliver_on:
         eng.delivery_open(slots=4, what=args.deliver_what, copy_engine=args.deliver_copy_engine)
-        sink = DeliverySink(eng, sample_streams)
+        sink = (CxxSink if cxx_main else DeliverySink)(eng, sample_streams)
         delivering[0] = True
     step(args.warmup)
     eng.synchronize()
@@ -1065,7 +1082,7 @@ def main():
         def open_delivery(what, cxx=False):
             nonlocal sink
             eng.delivery_open(slots=4, what=what, copy_engine=args.deliver_copy_engine)
-            sink = (CxxSink if cxx else DeliverySink)(eng, sample_streams if not cxx else [])
+            sink = (CxxSink if cxx else DeliverySink)(eng, sample_streams)
             closed[0] = 0
             delivering[0] = True
             step(21)                 # three chunks: first touch of the slabs, and the clocks back up after the allocations' idle time
@@ -1083,7 +1100,7 @@ def main():
 
         n_steady = max(98, args.steps)
         if sink is None:                                   # --no-deliver: the delivered figures come from legs, as in round 5
-            open_delivery(args.deliver_what)
+            open_delivery(args.deliver_what, cxx=cxx_main)
             short = figures(*leg(args.steps, taper_=args.taper), args.steps)
         else:
             short = figures(c1, c2, d1, d2, M["dt"], args.steps)
@@ -1112,17 +1129,19 @@ def main():
             needs["slab_bytes_per_chunk"] = eng.delivery_slab_bytes()
             needs["what"] = "FIBs + CRC flags + frame records, super frames + their AU records; logical frames only of services that are not DAB+ (DABX_DELIVER_MSC_NOT_DABPLUS)"
             needs["lost"], _, _ = close_delivery()
-            # the same loop with a C++ consumer thread on the C ABI (tests/cxx/consumer_thread.cpp) instead of the python thread
+            # the same loop with the OTHER consumer: a python thread where the timed regions had the C++ thread of tests/cxx/consumer_thread.cpp
+            # (std::thread on the C ABI: dabx_delivery_next -> sums the records -> dabx_delivery_release), and the other way round
             if CxxSink.available():
-                open_delivery(0, cxx=True)
-                cx_short = figures(*leg(args.steps, taper_=args.taper), args.steps)
-                cx_steady = figures(*leg(n_steady), n_steady)
-                cx_lost, _, cx_old = close_delivery()
-                consumers = {"python_thread": {"at_timed_region_length": short["frames_per_s"], "steady": steady["frames_per_s"]},
-                             "cxx_thread": {"at_timed_region_length": cx_short["frames_per_s"], "steady": cx_steady["frames_per_s"], "lost": cx_lost,
-                                            "frames_delivered": cx_short["frames_delivered"] + cx_steady["frames_delivered"],
-                                            "access_units_counted": cx_old.totals().get("access_units"),
-                                            "source": "tests/cxx/consumer_thread.cpp (std::thread: dabx_delivery_next -> sums the records -> dabx_delivery_release)"}}
+                open_delivery(0, cxx=not cxx_main)
+                o_short = figures(*leg(args.steps, taper_=args.taper), args.steps)
+                o_steady = figures(*leg(n_steady), n_steady)
+                o_lost, _, o_old = close_delivery()
+                mine = {"at_timed_region_length": short["frames_per_s"], "steady": steady["frames_per_s"], "lost": lost, "serves": "the timed regions"}
+                other = {"at_timed_region_length": o_short["frames_per_s"], "steady": o_steady["frames_per_s"], "lost": o_lost, "serves": "this leg",
+                         "frames_delivered": o_short["frames_delivered"] + o_steady["frames_delivered"]}
+                au = (old if cxx_main else o_old).totals().get("access_units")
+                consumers = {"cxx_thread": dict(mine if cxx_main else other, access_units_counted=au, source="tests/cxx/consumer_thread.cpp"),
+                             "python_thread": other if cxx_main else mine}
         steady["frames_per_s_without_delivery_same_steps"] = round(base_steady, 1)
         steady["frac_of_that"] = round(steady["frames_per_s"] / base_steady, 4)
         short["frames_per_s_without_delivery_same_steps"] = round(nd_short, 1)
@@ -1135,7 +1154,8 @@ def main():
                      in_timed_region=bool(deliver_on), copy_engine="sdma (hsa_amd_memory_async_copy)" if args.deliver_copy_engine == 0 else "hipMemcpyAsync",
                      what="every FIB + CRC flag + frame record, logical frame, RS-corrected super frame and super-frame record (AU table, per-AU CRC "
                           "verdicts) of every stream and sub-channel: one slab and ONE SDMA transfer per chunk into page-locked host slabs "
-                          "(dabx_delivery_*); consumer = a python thread: dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release",
+                          "(dabx_delivery_*); consumer = " + ("a C++ thread on the C ABI (tests/cxx/consumer_thread.cpp)" if cxx_main else "a python thread") +
+                          ": dabx_delivery_next(wait) -> sums the slab's records -> dabx_delivery_release (the other consumer: `consumers`)",
                      copies={"count": dinfo["chunks_landed"], "link_GBps": round(dinfo["bytes_copied"] / max(1e-9, dinfo["copy_seconds"]) / 1e9, 2),
                              "longest_ms": round(1e3 * dinfo["copy_seconds_max"], 3), "sdma_engine_mask": dinfo["sdma_engine_mask"],
                              "calibration_GBps": round(dinfo["calibration_GBps"], 2),

@@ -146,6 +146,7 @@ struct dabx_engine {
   std::vector<char> announcing;                // per stream: the zero-copy producer uses dabx_announce_write
   unsigned long long *horizon_host = nullptr;  // hipHostMalloc'ed, EngineDev::wr_horizon: what pushes may have overwritten (written BEFORE a copy is issued)
   int32_t *locked_host = nullptr;              // hipHostMalloc'ed: number of streams in lock, kept by the device (EngineDev::locked_count)
+  int32_t *seq_timeouts_host = nullptr;        // hipHostMalloc'ed: device-side waits that gave up (EngineDev::seq_timeouts)
   bool level_dirty = false;                    // exact_level_tracker: steps have been issued since k_level_exact last ran behind them
   Delivery dl;
   Ingest ing;
@@ -272,6 +273,11 @@ static int sync_all(dabx_engine *e, bool chain_only = false)
   DABX_HIP(hipStreamSynchronize(e->stream));
   if (e->ss.b) DABX_HIP(hipStreamSynchronize(e->ss.b));
   if (e->ss.d) DABX_HIP(hipStreamSynchronize(e->ss.d));
+  if (e->seq_timeouts_host && __atomic_load_n(e->seq_timeouts_host, __ATOMIC_RELAXED) != 0) {
+    set_error("%d device-side hand-overs of the few-stream schedule timed out (a kernel launch in front of them failed): the results since are undefined",
+              (int)__atomic_load_n(e->seq_timeouts_host, __ATOMIC_RELAXED));
+    return DABX_E_HIP;
+  }
   if (int rc = delivery_drain(e)) return rc;                       // every chunk closed so far has landed
   if (chain_only && !e->dev.exact_level) return 0;
   if (e->ss.q) DABX_HIP(hipStreamSynchronize(e->ss.q));
@@ -688,6 +694,9 @@ int dabx_create(const dabx_config *cfg, dabx_engine **out)
   e->announcing.assign(S, 0);
   H(hipHostGetDevicePointer((void **)&d.wr_horizon, e->horizon_host, 0));
   H(hipHostGetDevicePointer((void **)&d.locked_count, e->locked_host, 0));
+  H(hipHostMalloc((void **)&e->seq_timeouts_host, sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+  *e->seq_timeouts_host = 0;
+  H(hipHostGetDevicePointer((void **)&d.seq_timeouts, e->seq_timeouts_host, 0));
   {
     std::vector<float> st8((size_t)S * 8, 0.0f);                  // sample_reader.h:102-106: meanII = meanQQ = 1
     for (int s_ = 0; s_ < S; s_++) { st8[(size_t)s_ * 8 + 2] = 1.0f; st8[(size_t)s_ * 8 + 3] = 1.0f; }
@@ -775,6 +784,7 @@ void dabx_destroy(dabx_engine *e)
   }
   for (void *p : e->allocs) (void)hipFree(p);
   if (e->locked_host) (void)hipHostFree(e->locked_host);
+  if (e->seq_timeouts_host) (void)hipHostFree(e->seq_timeouts_host);
   if (e->horizon_host) (void)hipHostFree(e->horizon_host);
   for (auto &ev : e->mk.pool) (void)hipEventDestroy(ev);
   demap_free(e->dev.demap);

@@ -150,6 +150,8 @@ struct EngineDev {
   int32_t flag_sync;
   uint32_t step_seq;              // number of this step (1, 2, ...: the host sets it per launch)
   uint32_t *sym_seq, *fic_seq;    // [S]
+  int32_t *seq_timeouts;          // host memory: waits that gave up after ~2 s (a launch in front of them must have failed): the next dabx_synchronize /
+                                  // dabx_process(sync) reports it instead of the GPU hanging
   double2 *nco_tid;               // [S][256] e^{-j 2 pi f tid / fs} of the current frame (k_frame_head -> k_symbols)
   double2 *nco_sym;               // [S][76]  NCO phasor of the first FFT sample of symbols 1..75 ([75] = rotation per 256 samples)
   int32_t *sym_off;               // [S][76]  ring offset of the first (cyclic-prefix) sample of symbols 1..75 of this step's frame,

@@ -956,6 +956,18 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
     }
     __syncthreads();
     float2 *dst = e.spectra + (((size_t)e.parity * e.n_streams + s) * 75 + l) * K;
+#ifdef DABX_SYM_ST_AUX       // experiment builds: the spectra through raw-buffer stores with the cache-policy bits of choice (16 = sc1: write-through)
+    {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, K * 8, 0x00020000);
+      typedef float sym_f2b __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int u = 0; u < K / 256; u++) {
+        const float2 q = lds[((tid + 256 * u) & ~15) | ((rd_lo >> (4 * u)) & 15u)];
+        sym_f2b qv; qv.x = q.x; qv.y = q.y;
+        __builtin_amdgcn_raw_buffer_store_b64(qv, rs, (tid + 256 * u) * 8, 0, DABX_SYM_ST_AUX);
+      }
+    }
+#else
 #pragma unroll
 #if DABX_SYM_NT & 2          // the spectra, read next by the demapper after 478 MB more have been written: past the caches (pipeline.h)
     for (int u = 0; u < K / 256; u++) {
@@ -966,6 +978,7 @@ __global__ __launch_bounds__(256, 3) void k_symbols_persistent(EngineDev e, DevT
     }
 #else
     for (int u = 0; u < K / 256; u++) dst[tid + 256 * u] = lds[((tid + 256 * u) & ~15) | ((rd_lo >> (4 * u)) & 15u)];
+#endif
 #endif
     if (l_next >= 75) break;
     l = l_next;
@@ -985,10 +998,20 @@ __device__ __forceinline__ void seq_publish(uint32_t *p, uint32_t seq)
     __hip_atomic_store(p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ __forceinline__ void seq_wait(const uint32_t *p, uint32_t seq)
+__device__ __forceinline__ void seq_wait(const uint32_t *p, uint32_t seq, int32_t *timeouts)
 {
-  if (threadIdx.x == 0)
-    while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    // bounded: what is waited for was launched BEFORE this kernel; if it never arrives a launch failed on the host, and a kernel that spins for
+    // ever would take the GPU with it -- after ~2 s (8 M polls of ~0.25 us) the wait gives up, counts itself (host memory) and lets the block go on
+    int spins = 0;
+    while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (8 << 20)) {
+        if (timeouts) __hip_atomic_fetch_add(timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
@@ -1042,7 +1065,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][16 * TILE_PLANE];
   const int s = blockIdx.x + e.s0, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
-  if (l0 == 0 && e.flag_sync) seq_wait(e.sym_seq + s, e.step_seq);     // few streams: k_symbols of this step (HIP stream a) is through
+  if (l0 == 0 && e.flag_sync) seq_wait(e.sym_seq + s, e.step_seq, e.seq_timeouts);     // few streams: k_symbols of this step (HIP stream a) is through
   // the first launch of a frame (l0 == 0) reads the stream's scalars and leaves a snapshot; a later launch of the same frame
   // uses the snapshot only (the frame tail / next head may already have moved the originals on)
   FrameSnap fs;
@@ -1258,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_fic_frame(EngineDev e, DevTables t, int
   StreamCtl &c = e.ctl[s];
   // few streams: the FIC symbols come from HIP stream d.  Waited for in EVERY case -- also when this step has no frame for the stream: the
   // demapper's first launch reads the stream's scalars, which the kernels behind this one (tail, next head) rewrite
-  if (e.flag_sync && first == 0 && count == 4) seq_wait(e.fic_seq + s, e.step_seq);
+  if (e.flag_sync && first == 0 && count == 4) seq_wait(e.fic_seq + s, e.step_seq, e.seq_timeouts);
   if (!c.frame_ok) return;
   s_crc[threadIdx.x] = t.crc_ccitt[threadIdx.x];
   const int fic = first + wave;             // this wave's FIC block

@@ -193,6 +193,57 @@ __device__ __forceinline__ vt_rsrc vt_make_rsrc(const uint32_t *base, unsigned b
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword format (gfx9 / CDNA)
 }
+// The lane's column of the group's decision words.  Default: a per-lane pointer, `nt` stores and loads (pipeline.h, DABX_VIT_NT).  Experiment builds
+// (-DDABX_VIT_BUF=1 -DDABX_VIT_ST_AUX=a -DDABX_VIT_LD_AUX=b): raw-buffer accesses over the group's words -- the step's row is a
+// scalar offset -- with the cache-policy bits free to choose: aux 0 plain, 1 sc0, 2 nt, 16 sc1 (write-through / L2 bypass), 17 sc0 sc1.
+struct VtDec {
+  uint2 *p;
+#if DABX_VIT_BUF
+  vt_rsrc rs;
+  int voff;
+#endif
+};
+__device__ __forceinline__ VtDec vt_make_dec(uint2 *group_base, int nsteps, int lane)
+{
+  VtDec d;
+  d.p = group_base + lane;
+#if DABX_VIT_BUF
+  d.rs = vt_make_rsrc(reinterpret_cast<const uint32_t *>(group_base), (unsigned)nsteps * 512u);
+  d.voff = lane * 8;
+#else
+  (void)nsteps;
+#endif
+  return d;
+}
+#ifndef DABX_VIT_ST_AUX
+#define DABX_VIT_ST_AUX 2
+#define DABX_VIT_LD_AUX 2
+#endif
+typedef unsigned vt_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void vt_dec_store(const VtDec &d, int t, unsigned acc0, unsigned acc1)
+{
+#if DABX_VIT_BUF
+  vt_u2v v; v.x = acc0; v.y = acc1;
+  __builtin_amdgcn_raw_buffer_store_b64(v, d.rs, d.voff, t * 512, DABX_VIT_ST_AUX);
+#elif DABX_VIT_NT & 1        // decision words, written once and read once: past the caches (pipeline.h)
+  vt_u2v v; v.x = acc0; v.y = acc1;
+  __builtin_nontemporal_store(v, reinterpret_cast<vt_u2v *>(&d.p[(size_t)t * 64]));
+#else
+  d.p[(size_t)t * 64] = make_uint2(acc0, acc1);
+#endif
+}
+__device__ __forceinline__ uint2 vt_dec_load(const VtDec &d, int t)
+{
+#if DABX_VIT_BUF
+  const vt_u2v v = __builtin_amdgcn_raw_buffer_load_b64(d.rs, d.voff, t * 512, DABX_VIT_LD_AUX);
+  return make_uint2(v.x, v.y);
+#elif DABX_VIT_NT & 2
+  const vt_u2v v = __builtin_nontemporal_load(reinterpret_cast<const vt_u2v *>(&d.p[(size_t)t * 64]));
+  return make_uint2(v.x, v.y);
+#else
+  return d.p[(size_t)t * 64];
+#endif
+}
 #if DABX_VIT_NT & 4          // (A/B builds: the transposed input past the caches; aux bit 1 = nt)
 constexpr int VT_IN_AUX = 2;
 #else
@@ -228,7 +279,7 @@ template <> struct VtTie<1> { static constexpr int LIMTOP = 2 * 65535, REN2 = 2 
 template <> struct VtTie<2> { static constexpr int LIMTOP = 2 * 32767, REN2 = 2 * 30000; };
 
 template <int C, int TIE = 0, bool CLAMP = false>
-__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, uint2 *dec_lane, vt::s2 v2n, int &Coff)
+__device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t, const VtDec &dec_lane, vt::s2 v2n, int &Coff)
 {
   // the step's four symbols: dword + byte lane each (the lanes are wave-uniform and end up in SGPR selectors); the packed
   // branch metrics come straight from those (vit_t_gen.h, bm<C>): no scalar extraction, no 32-bit sums
@@ -256,11 +307,7 @@ __device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t
   else if constexpr (C == 3) { vt::bm3(w, b, v2n, M); vt::step3<TIE, CLAMP>(R, M, acc0, acc1, lim); }
   else if constexpr (C == 4) { vt::bm4(w, b, v2n, M); vt::step4<TIE, CLAMP>(R, M, acc0, acc1, lim); }
   else { vt::bm5(w, b, v2n, M); vt::step5<TIE, CLAMP>(R, M, acc0, acc1, lim); }
-#if DABX_VIT_NT & 1          // decision words, written once and read once: past the caches (pipeline.h)
-  { typedef unsigned vt_u2 __attribute__((ext_vector_type(2))); vt_u2 dv_; dv_.x = acc0; dv_.y = acc1; __builtin_nontemporal_store(dv_, reinterpret_cast<vt_u2 *>(&dec_lane[(size_t)t * 64])); }
-#else
-  dec_lane[(size_t)t * 64] = make_uint2(acc0, acc1);
-#endif
+  vt_dec_store(dec_lane, t, acc0, acc1);
   if constexpr (TIE != 0 && (C & 1) != 0) {
     if (__builtin_amdgcn_ballot_w64(pre)) {              // some lane renormalises (wave-uniform branch; every ~100-200 steps per lane)
       const int mnv = vt::min64(R);
@@ -270,7 +317,7 @@ __device__ __forceinline__ void vt_one(vt::s2 (&R)[32], const VtCycle &cy, int t
 }
 
 template <int TIE, bool CLAMP>
-__device__ __forceinline__ void vt_cycle6(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane, vt::s2 v2n, int &Coff)
+__device__ __forceinline__ void vt_cycle6(vt::s2 (&R)[32], const VtCycle &cy, int t0, const VtDec &dec_lane, vt::s2 v2n, int &Coff)
 {
   vt_one<0, TIE, CLAMP>(R, cy, t0 + 0, dec_lane, v2n, Coff);
   vt_one<1, TIE, CLAMP>(R, cy, t0 + 1, dec_lane, v2n, Coff);
@@ -280,7 +327,7 @@ __device__ __forceinline__ void vt_cycle6(vt::s2 (&R)[32], const VtCycle &cy, in
   vt_one<5, TIE, CLAMP>(R, cy, t0 + 5, dec_lane, v2n, Coff);
 }
 template <int TIE, bool ALWAYS_CLAMP>
-__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, uint2 *dec_lane, vt::s2 v2n, int &Coff)
+__device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int t0, const VtDec &dec_lane, vt::s2 v2n, int &Coff)
 {
   if constexpr (TIE == 0) vt_cycle6<0, false>(R, cy, t0, dec_lane, v2n, Coff);
   else {
@@ -301,17 +348,11 @@ __device__ __forceinline__ void vt_cycle(vt::s2 (&R)[32], const VtCycle &cy, int
 
 // ---- chain-back helpers: one 6-step cycle of decision words in named registers
 struct VtDec6 { uint2 w0, w1, w2, w3, w4, w5; };
-__device__ __forceinline__ VtDec6 vt_load_dec(const uint2 *dec_lane, int t0)
+__device__ __forceinline__ VtDec6 vt_load_dec(const VtDec &dec_lane, int t0)
 {
   VtDec6 d;
-#if DABX_VIT_NT & 2
-  typedef unsigned vt_u2 __attribute__((ext_vector_type(2)));
-  auto ld = [&](int t) { const vt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const vt_u2 *>(&dec_lane[(size_t)t * 64])); return make_uint2(v.x, v.y); };
-  d.w0 = ld(t0); d.w1 = ld(t0 + 1); d.w2 = ld(t0 + 2); d.w3 = ld(t0 + 3); d.w4 = ld(t0 + 4); d.w5 = ld(t0 + 5);
-  return d;
-#endif
-  d.w0 = dec_lane[(size_t)(t0 + 0) * 64]; d.w1 = dec_lane[(size_t)(t0 + 1) * 64]; d.w2 = dec_lane[(size_t)(t0 + 2) * 64];
-  d.w3 = dec_lane[(size_t)(t0 + 3) * 64]; d.w4 = dec_lane[(size_t)(t0 + 4) * 64]; d.w5 = dec_lane[(size_t)(t0 + 5) * 64];
+  d.w0 = vt_dec_load(dec_lane, t0); d.w1 = vt_dec_load(dec_lane, t0 + 1); d.w2 = vt_dec_load(dec_lane, t0 + 2);
+  d.w3 = vt_dec_load(dec_lane, t0 + 3); d.w4 = vt_dec_load(dec_lane, t0 + 4); d.w5 = vt_dec_load(dec_lane, t0 + 5);
   return d;
 }
 // step t of class C (viterbi_spiral.cpp:114-125 in label space): the decision of label L is bit pos_c[L] of the word; it
@@ -347,7 +388,7 @@ __device__ unsigned g_vt_timeline_n = 0;
 // with PUNCT remapped to the 0x7F row; dec_lane: this lane's column of the group's decision words; out: where the lane's
 // packed, de-dispersed bytes go (nullptr: nothing is stored).
 template <int TIE, bool ALWAYS_CLAMP>
-__device__ __forceinline__ void vt_decode(vt_rsrc in_grp, vt_cmap cmap, int nsteps, uint2 *dec_lane, uint32_t *out, const uint32_t *prbs,
+__device__ __forceinline__ void vt_decode(vt_rsrc in_grp, vt_cmap cmap, int nsteps, const VtDec &dec_lane, uint32_t *out, const uint32_t *prbs,
                                           const unsigned char (*pos_tab)[64], int lane, unsigned long long &t_forward_end, bool want_time)
 {
   vt::s2 R[32];
@@ -434,7 +475,7 @@ __device__ __forceinline__ void msc_vitT_body(const EngineDev &e, int cifs, cons
   const MscJob q = msc_class_job(e, cl, g * 64 + lane, cifs);
   const int nsteps = cl.nbits + 6, rows = cl.n_in / 4 + 1;
   const vt_rsrc in_grp = vt_make_rsrc(cl.inT + (size_t)g * rows * 64, (unsigned)rows * 256u);
-  uint2 *dec_lane = cl.decT + (size_t)g * nsteps * 64 + lane;
+  const VtDec dec_lane = vt_make_dec(cl.decT + (size_t)g * nsteps * 64, nsteps, lane);
   const vt_cmap cmap = (vt_cmap)(const void *)cl.map2;
   uint32_t *out = nullptr;
   if (q.valid)
@@ -477,7 +518,7 @@ __global__ __launch_bounds__(64) void k_vitT_stage(const uint32_t *symT, const u
   const int nsteps = nbits + 6, rows = nsteps + 1;
   const vt_rsrc in_grp = vt_make_rsrc(symT + (size_t)g * rows * 64, (unsigned)rows * 256u);
   unsigned long long unused = 0;
-  vt_decode<TIE, ALWAYS_CLAMP>(in_grp, (vt_cmap)(const void *)map, nsteps, decT + (size_t)g * nsteps * 64 + lane,
+  vt_decode<TIE, ALWAYS_CLAMP>(in_grp, (vt_cmap)(const void *)map, nsteps, vt_make_dec(decT + (size_t)g * nsteps * 64, nsteps, lane),
                                outw + ((size_t)g * 64 + lane) * (nbits / 32), zeros, pos_tab, lane, unused, false);
 }
 

@@ -52,8 +52,9 @@ def test_bench_line_keeps_its_contract():
     assert len(j["timed_regions"]) == 3 and j["value_min"] <= j["value"] <= j["value_max"]
     assert sorted(r_["value"] for r_ in j["timed_regions"])[1] == j["value"]
     assert 0.6 < s20["frac_of_not_delivered"] <= 1.1 and d["not_delivered"]["at_timed_region_length"] > 50000 and d["not_delivered"]["steady"] > 50000
-    cx = d["consumers"]["cxx_thread"]
-    assert cx["lost"] == 0 and cx["steady"] > 50000 and cx["access_units_counted"] > 0
+    cx, py = d["consumers"]["cxx_thread"], d["consumers"]["python_thread"]
+    assert cx["lost"] == 0 and cx["steady"] > 50000 and cx["access_units_counted"] > 0 and cx["serves"] == "this leg"
+    assert py["lost"] == 0 and py["steady"] > 50000 and py["at_timed_region_length"] > 50000 and py["serves"] == "the timed regions"
     t = j["roofline"]["chain_real_traffic"]
     assert t["hbm_bytes_per_step"] > 2 * 512 * 2115456 * 0.5 and 0.1 < t["frac_of_achievable"] < 1.0 and t["achievable_GBps"] == 6300.0
     sw = j["config"]["snr_sweep"]
