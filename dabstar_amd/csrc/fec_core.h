@@ -83,24 +83,18 @@ struct CwStrided {    // code word j of an RS-interleaved super frame: bytes j +
 // ReedSolomon::dec(in, out, 135) with (8, 0435, 0, 1, 10): base/backend/reed_solomon.cpp:140-439.
 // cw: 120 received bytes (data 110 + parity 10), corrected in place exactly where the reference
 // corrects (including the partial corrections of its failure paths).  Returns #corrected / 0 / -1.
-template <class CW>   // CW: byte accessor with uint8_t get(int k) / void xor_at(int k, uint8_t v), k < 120
-__device__ inline int rs_decode_120(CW cw, const Gf &gf)
+// The decoder in its three parts (reed_solomon.cpp:296-439), so that k_dabplus can run the middle one -- the Chien search over all 255 positions, the
+// longest -- with the whole wave on one code word instead of one lane on each.
+constexpr int RS_NR = 10, RS_NN = 255, RS_PAD = 135;
+// :296-361 Berlekamp-Massey: syndromes -> the locator in index form (255 = zero coefficient) and its degree
+__device__ inline void rs_berlekamp_massey(const uint8_t syn[RS_NR], const Gf &gf, uint8_t lambda[RS_NR + 1], int &deg_lambda)
 {
-  constexpr int NR = 10, NN = 255, PAD = 135;
-  uint8_t syn[NR];
-  int syn_err = 0;
-  for (int r = 0; r < NR; r++) {             // :254-290 Horner; the 135 leading zeros contribute nothing
-    int s = 0;
-    for (int j = 0; j < 120; j++) { const int b = cw.get(j); s = (s == 0) ? b : (b ^ gf.ex[gf.lg[s] + r]); }
-    syn[r] = (uint8_t)s;
-    syn_err |= s;
-  }
-  if (!syn_err) return 0;
-
-  uint8_t lambda[NR + 1], corr[NR], oldl[NR];   // :296-361 Berlekamp-Massey
+  constexpr int NR = RS_NR;
+  uint8_t corr[NR], oldl[NR];
   for (int i = 0; i < NR; i++) { lambda[i] = 0; corr[i] = 0; }
   lambda[NR] = 0;
-  int Kk = 1, Ll = 0, deg_lambda = 0, error = syn[0];
+  int Kk = 1, Ll = 0, error = syn[0];
+  deg_lambda = 0;
   lambda[0] = 1; corr[1] = 1;
   while (Kk < NR) {
     for (int i = 0; i < NR; i++) oldl[i] = lambda[i];
@@ -120,8 +114,12 @@ __device__ inline int rs_decode_120(CW cw, const Gf &gf)
     if (lambda[i] != 0) deg_lambda = i;
     lambda[i] = gf.lg[lambda[i]];            // to index form; 255 = zero
   }
-
-  uint8_t work[NR], root_tab[NR], loc_tab[NR];   // :367-402 Chien search over all 255 positions
+}
+// :367-402 Chien search over all 255 positions, one lane: the first NR roots (and their locations) in the order found, and how many there are
+__device__ inline int rs_chien(const uint8_t lambda[RS_NR + 1], int deg_lambda, const Gf &gf, uint8_t root_tab[RS_NR], uint8_t loc_tab[RS_NR])
+{
+  constexpr int NR = RS_NR, NN = RS_NN;
+  uint8_t work[NR];
   for (int i = 0; i < NR; i++) work[i] = lambda[i];
   int root_count = 0;
   for (int i = 1; i <= NN; i++) {
@@ -132,9 +130,24 @@ __device__ inline int rs_decode_120(CW cw, const Gf &gf)
     if (root_count < NR) { root_tab[root_count] = (uint8_t)i; loc_tab[root_count] = (uint8_t)(i - 1); }
     root_count++;
   }
-  if (root_count != deg_lambda) return -1;
-
-  uint8_t omega[NR + 1];                     // :411-439
+  return root_count;
+}
+// ... the same value for ONE position (what a lane of the wave-wide search evaluates): position i is a root when this is 0.  (The serial loop's
+// running work[j] is (lambda[j] + i j) mod 255 at position i.)
+__device__ __forceinline__ int rs_chien_at(const uint8_t *lambda, int deg_lambda, const uint8_t *ex, int i)
+{
+  int result = 1;
+  for (int j = deg_lambda; j > 0; j--)
+    if (lambda[j] != RS_NN) result ^= ex[(lambda[j] + i * j) % RS_NN];
+  return result;
+}
+// :411-439 omega, :189-251 Forney: the corrections, in place exactly where the reference corrects (root_count == deg_lambda has been checked)
+template <class CW>
+__device__ inline int rs_forney(CW cw, const Gf &gf, const uint8_t syn[RS_NR], const uint8_t lambda[RS_NR + 1], int deg_lambda,
+                                const uint8_t *root_tab, int root_count)
+{
+  constexpr int NR = RS_NR, NN = RS_NN, PAD = RS_PAD;
+  uint8_t omega[NR + 1];
   int deg_omega = 0;
   for (int i = 0; i < NR; i++) {
     int tmp = 0;
@@ -144,9 +157,8 @@ __device__ inline int rs_decode_120(CW cw, const Gf &gf)
     omega[i] = gf.lg[tmp];
   }
   omega[NR] = NN;
-
-  for (int j = root_count - 1; j >= 0; j--) {   // :189-251 Forney
-    const int root = root_tab[j];
+  for (int j = root_count - 1; j >= 0; j--) {
+    const int root = root_tab[j], loc = root - 1;
     int num1 = 0;
     for (int i = deg_omega; i >= 0; i--)
       if (omega[i] != NN) num1 ^= gf.ex[modnn(omega[i] + (i * root) % NN)];
@@ -157,16 +169,43 @@ __device__ inline int rs_decode_120(CW cw, const Gf &gf)
       if (lambda[i + 1] != NN) den ^= gf.ex[modnn(lambda[i + 1] + (i * root) % NN)];
     if (den == 0) return -1;
     if (num1 != 0) {
-      if (loc_tab[j] >= NN - NR) root_count--;
+      if (loc >= NN - NR) root_count--;
       else {
         int t2 = modnn(gf.lg[num1] + gf.lg[num2]);
         t2 = modnn(t2 + NN - gf.lg[den]);
-        const int k = (int)loc_tab[j] - PAD;
+        const int k = loc - PAD;
         if (k >= 0) cw.xor_at(k, gf.ex[t2]);   // positions < 135 lie in the virtual zero padding (discarded)
       }
     }
   }
   return root_count;
+}
+
+// syn_in (optional): the ten syndromes S_r = XOR_k c_k alpha^(r (119 - k)) when the caller has them already (k_dabplus evaluates them lane-parallel for
+// all code words of a super frame: the Horner recursion below is the same sum, 1200 dependent table look-ups on one lane)
+template <class CW>   // CW: byte accessor with uint8_t get(int k) / void xor_at(int k, uint8_t v), k < 120
+__device__ inline int rs_decode_120(CW cw, const Gf &gf, const uint8_t *syn_in = nullptr)
+{
+  constexpr int NR = RS_NR;
+  uint8_t syn[NR];
+  int syn_err = 0;
+  if (syn_in) {
+    for (int r = 0; r < NR; r++) { syn[r] = syn_in[r]; syn_err |= syn[r]; }
+  } else {
+    for (int r = 0; r < NR; r++) {           // :254-290 Horner; the 135 leading zeros contribute nothing
+      int s = 0;
+      for (int j = 0; j < 120; j++) { const int b = cw.get(j); s = (s == 0) ? b : (b ^ gf.ex[gf.lg[s] + r]); }
+      syn[r] = (uint8_t)s;
+      syn_err |= s;
+    }
+  }
+  if (!syn_err) return 0;
+  uint8_t lambda[NR + 1], root_tab[NR], loc_tab[NR];
+  int deg_lambda;
+  rs_berlekamp_massey(syn, gf, lambda, deg_lambda);
+  const int root_count = rs_chien(lambda, deg_lambda, gf, root_tab, loc_tab);
+  if (root_count != deg_lambda) return -1;
+  return rs_forney(cw, gf, syn, lambda, deg_lambda, root_tab, root_count);
 }
 
 }  // namespace dabx

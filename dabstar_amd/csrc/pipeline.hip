@@ -1678,6 +1678,9 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
   __shared__ uint16_t s_crc[256], s_fc[256];                // CCITT and fire-code CRC tables (serial look-up chains: keep them in LDS)
   __shared__ __attribute__((aligned(16))) uint16_t s_xpow[1024];   // x^(8 m) mod P, m <= 960: two look-ups per access unit sat behind an L2 round trip each
   __shared__ unsigned syn_or[48];                           // != 0: some syndrome of the code word is non-zero
+  __shared__ __attribute__((aligned(4))) unsigned syn_w[48][3];   // the code word's ten syndromes (bytes 0..9 of the three words): the full decoder starts from them
+  __shared__ uint8_t s_lam[48][12], s_deg[48], s_root[48][RS_NR];  // per dirty code word: locator (index form) + degree -> roots found by the wave-wide Chien search
+  __shared__ int s_rootn[48];
   __shared__ uint8_t hdr0[12];
   __shared__ int s_flag;
   __shared__ int s_au[8];
@@ -1756,20 +1759,57 @@ __global__ __launch_bounds__(64, 4) void k_dabplus(EngineDev e, DevTables t)   /
       syn_partial(cw, a0, a1, a2);
       syn_partial(cw + 1, b0, b1, b2);
       a0 = wave_xor(a0); b0 = wave_xor(b0); a1 = wave_xor(a1); b1 = wave_xor(b1); a2 = wave_xor(a2); b2 = wave_xor(b2);
-      if (lane == 0) { syn_or[cw] = a0 | a1 | a2; syn_or[cw + 1] = b0 | b1 | b2; }
+      if (lane == 0) {
+        syn_or[cw] = a0 | a1 | a2; syn_or[cw + 1] = b0 | b1 | b2;
+        syn_w[cw][0] = a0; syn_w[cw][1] = a1; syn_w[cw][2] = a2; syn_w[cw + 1][0] = b0; syn_w[cw + 1][1] = b1; syn_w[cw + 1][2] = b2;
+      }
     }
     if (cw < R) {
       unsigned a0, a1, a2;
       syn_partial(cw, a0, a1, a2);
       a0 = wave_xor(a0); a1 = wave_xor(a1); a2 = wave_xor(a2);
-      if (lane == 0) syn_or[cw] = a0 | a1 | a2;
+      if (lane == 0) { syn_or[cw] = a0 | a1 | a2; syn_w[cw][0] = a0; syn_w[cw][1] = a1; syn_w[cw][2] = a2; }
     }
     __syncthreads();
-    // ---- full decoder only where needed (one lane per dirty code word)
+    // ---- full decoder only where needed.  Berlekamp-Massey and Forney: one lane per dirty code word, from the syndromes summed above (byte r of
+    //      syn_w[code word]: no second, 1200-step pass over the 120 bytes on one lane).  The Chien search over all 255 positions, the longest part
+    //      (255 x deg dependent table look-ups per lane), is made by the WHOLE wave for one dirty code word after the other: 4 positions per lane, the
+    //      roots collected in the order the serial loop finds them (ballot + prefix count).  At 5 dB, where most super frames have dirty code words,
+    //      the kernel went 0.178 -> 0.117 (syndromes) -> see docs/history/r06.md ms per step; at 8 dB and above nothing of this runs.
     int my_ret = 0;
-    if (lane < R && syn_or[lane]) {
-      const Gf gf{gexp, glog};
-      my_ret = rs_decode_120(CwStrided{win + lane, R}, gf);   // corrects in place
+    const bool dirty = lane < R && syn_or[lane];
+    const Gf gf{gexp, glog};
+    uint8_t lam[RS_NR + 1];
+    int deg_lambda = 0;
+    if (__builtin_amdgcn_ballot_w64(dirty)) {                  // wave-uniform: clean super frames skip all of it
+      if (dirty) {
+        rs_berlekamp_massey(reinterpret_cast<const uint8_t *>(syn_w[lane]), gf, lam, deg_lambda);
+#pragma unroll
+        for (int i = 0; i <= RS_NR; i++) s_lam[lane][i] = lam[i];
+        s_deg[lane] = (uint8_t)deg_lambda;
+      }
+      __syncthreads();
+      unsigned long long dm = __builtin_amdgcn_ballot_w64(dirty);
+      while (dm) {
+        const int c = __builtin_ctzll(dm);
+        dm &= dm - 1;
+        const int dg = s_deg[c];
+        int count = 0;
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+          const int i = 64 * pass + lane + 1;
+          const bool root = i <= RS_NN && rs_chien_at(s_lam[c], dg, gexp, i) == 0;
+          const unsigned long long b = __builtin_amdgcn_ballot_w64(root);
+          const int idx = count + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+          if (root && idx < RS_NR) s_root[c][idx] = (uint8_t)i;
+          count += __builtin_popcountll(b);
+        }
+        if (lane == 0) s_rootn[c] = count;
+      }
+      __syncthreads();
+      if (dirty)
+        my_ret = s_rootn[lane] != deg_lambda ? -1
+                                             : rs_forney(CwStrided{win + lane, R}, gf, reinterpret_cast<const uint8_t *>(syn_w[lane]), lam, deg_lambda, s_root[lane], s_rootn[lane]);
     }
     int corr = my_ret > 0 ? my_ret : 0, fail = my_ret < 0 ? 1 : 0;
     corr = wave_sum_int(corr); fail = wave_sum_int(fail);
@@ -1964,8 +2004,9 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
     // (demap_done is recorded when somebody needs it -- the MSC batch, once per 7 frames: every packet between two kernels of a HIP stream is a
     //  bubble of 6-12 us on this loop, profiles/r06_single_ensemble_timeline_after.txt)
     ss.demap_in_flight = true; ss.demap_unrecorded = true;
+#if DABX_GROUPS > 1          // experiment builds only (profiles/r06_ab/ab7_grouped_issue_negative.txt)
   } else if (grouped) {
-    static hipEvent_t ev[16] = {nullptr};
+    static hipEvent_t ev[16] = {nullptr};      // (one engine per process in the A/B runs)
     const int sg = e.n_streams / DABX_GROUPS;
     for (int g = 0; g < DABX_GROUPS; g++) {
       EngineDev eg = e;
@@ -1984,6 +2025,7 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
     }
     DABX_HIP(hipEventRecord(ss.demap_done, ss.d));
     ss.demap_in_flight = true;
+#endif
   } else if (ss.d) {
     if (ss.demap_in_flight) { DABX_HIP(hipStreamWaitEvent(st, ss.demap_done, 0)); ss.demap_in_flight = false; }
     mk.begin(10, st);
