@@ -712,9 +712,9 @@ class CxxSink:
                 at += 16 + k * 396
 
 
-def snr_sweep_legs(torch, dev, args, rank, subch, dx, snrs=(12.0, 8.0, 5.0), steps=49):
+def snr_sweep_legs(torch, dev, args, rank, subch, dx, snrs=(12.0, 8.0, 5.0, 4.0), steps=49):
     """SURVEY 8d's variant (12 dB), 8 dB (still error-free behind the Viterbi decoder: EEP 3-A has ~2 dB to spare there) and 5 dB (where the
-    Reed-Solomon stage corrects, super frames fail and access units are concealed), like the headline otherwise: 512 ensembles, 49 steps after priming and
+    Reed-Solomon stage corrects) and 4 dB (where code words and super frames fail and access units must be concealed), like the headline otherwise: 512 ensembles, 49 steps after priming and
     warm-up, results left in the device rings (these legs are about the DECODER: k_dabplus runs Berlekamp-Massey / Chien / Forney for dirty
     code words only, the FIC ratio and re-acquisition are data-dependent -- the 20-dB headline shows none of that).  One more engine of the same
     size, its rings refilled per SNR (the streams stay in lock across the change of noise; 40 priming steps flush the 16-CIF de-interleaver)."""

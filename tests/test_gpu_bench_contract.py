@@ -58,7 +58,8 @@ def test_bench_line_keeps_its_contract():
     t = j["roofline"]["chain_real_traffic"]
     assert t["hbm_bytes_per_step"] > 2 * 512 * 2115456 * 0.5 and 0.1 < t["frac_of_achievable"] < 1.0 and t["achievable_GBps"] == 6300.0
     sw = j["config"]["snr_sweep"]
-    assert [q["snr_db"] for q in sw] == [20.0, 12.0, 8.0, 5.0] and all(q["streams_locked"] == 512 for q in sw)
+    assert [q["snr_db"] for q in sw] == [20.0, 12.0, 8.0, 5.0, 4.0] and all(q["streams_locked"] == 512 for q in sw[:4])
+    assert sw[4]["rs_failed"] + sw[4]["au_bad"] > 0                                             # at 4 dB the failure paths run
     assert sw[1]["fib_crc_pass_pct"] > 99.0 and sw[1]["superframes_ok"] > 0 and sw[3]["rs_corrected"] > sw[1]["rs_corrected"] >= 0
     assert all(q["kernel_ms_per_step_standalone"]["k_dabplus"] > 0 and q["value"] > 50000 for q in sw)
     assert d["copies"]["link_GBps"] > 25.0 and d["copy_engine"].startswith("sdma")
