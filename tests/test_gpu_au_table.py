@@ -145,3 +145,63 @@ def test_records_where_access_units_fail(snr):
     if snr < 4.5:
         assert seen_bad > 0                                                      # access units a decoder must conceal were present
     eng.close()
+
+
+def test_per_symbol_msc_handle_returns_the_super_frame_and_its_record():
+    """The per-symbol stage handle (dabx_msc_*: the GPU side of one MscHandler object, msc_handler.cpp:140-168) with a DAB+ service: fed the soft
+    bits of OFDM symbols 4..75 frame by frame, dabx_msc_get_superframe hands out each RS-corrected super frame when the CIF that completes it
+    closes and dabx_msc_get_superframe_info its 32-byte record -- the same bytes the frame-batched engine produces from the same soft bits."""
+    import ctypes as C
+    subch = [ds.SubCh(1, 0, 48, 64, 2, 0), ds.SubCh(5, 60, 96, 128, 2, 0)]
+    ens = ds.build_ensemble(10, subch, seed=77)
+    n_frames = 14
+    x = ds.channel(ens.iq, snr_db=6.0, cfo_hz=250.0, timing_offset=4321, seed=77, n_out=(n_frames + 2) * ds.TF)
+    eng = dx.Engine(n_streams=1, ring_frames=n_frames + 3, max_subch=2, out_frames=8, capture_soft=True)
+    eng.set_subchannels(subch)
+    eng.push_iq(0, x)
+    L = dx.load()
+    h = C.c_void_p()
+    dx.check(L.dabx_msc_create(4, C.byref(h)))
+    slots = []
+    for c in subch:
+        d = dx.SubchDesc(c.subch_id, c.cu_start, c.cu_size, c.kbps, c.prot_level, c.short_form, 1, 0)
+        slots.append(dx.check(L.dabx_msc_set_channel(h, C.byref(d))))
+    got_sf = [[] for _ in subch]
+    got_info = [[] for _ in subch]
+    frames = 0
+    while frames < n_frames:
+        eng.process(1)
+        if eng.stats(0)["frames"] == frames:
+            break
+        frames += 1
+        soft = eng.read_soft(0)                                  # [75, 3072] int16: OFDM symbols 1..75 of the newest frame (row l = symbol l + 1; 0 is the PRS)
+        for blk in range(4, 76):                                 # MscHandler::process_block's block numbers = the MSC symbols' indices 4..75
+            row = np.ascontiguousarray(soft[blk - 1])
+            closed = dx.check(L.dabx_msc_process_block(h, row.ctypes.data_as(C.c_void_p), blk))
+            if not closed:
+                continue
+            for j, c in enumerate(subch):
+                buf = np.zeros(110 * c.kbps // 8, np.uint8)
+                nb = dx.check(L.dabx_msc_get_superframe(h, slots[j], buf.ctypes.data_as(C.c_void_p), buf.size))
+                rec = np.zeros(1, dx.SUPERFRAME_INFO)
+                k = dx.check(L.dabx_msc_get_superframe_info(h, slots[j], rec.ctypes.data_as(C.c_void_p)))
+                assert (nb > 0) == (k == 1)
+                if nb:
+                    assert nb == buf.size
+                    got_sf[j].append(buf.copy()); got_info[j].append(rec[0].copy())
+    assert frames >= 12
+    corrected = 0
+    for j, c in enumerate(subch):
+        st = eng.subch_stats(0, j)
+        n = st["sf_count"]
+        assert len(got_sf[j]) == n >= 6, (j, len(got_sf[j]), n)
+        k = min(n, 16)
+        e_sf, e_info = eng.read_superframes(0, j, k), eng.read_superframe_info(0, j, k)
+        assert np.array_equal(np.stack(got_sf[j][n - k:]), e_sf), j
+        assert np.stack(got_info[j][n - k:]).tobytes() == e_info.tobytes(), j
+        for i in range(k):
+            _check_record_against_its_super_frame(e_info[i], e_sf[i], c.kbps)
+        corrected += int(e_info["rs_corrected"].astype(np.int64).sum())
+    assert corrected > 0                                         # 6 dB: the RS decoder had work, the records say how much
+    L.dabx_msc_destroy(h)
+    eng.close()
