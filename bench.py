@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host leg (config.host_to_host)")
     ap.add_argument("--host-leg-chunks", type=int, default=8, help="timed 5-frame chunks of the host-to-host leg (8; more = a soak of ingest + delivery)")
     ap.add_argument("--no-single-legs", action="store_true", help="skip the single-ensemble legs (config.single_ensemble)")
+    ap.add_argument("--single-legs-only", action="store_true", help=argparse.SUPPRESS)      # the child process of single_legs_in_child
     ap.add_argument("--deliver-copy-engine", type=int, default=0, choices=[0, 1], help="experiments: dabx_delivery_config.copy_engine (1 = hipMemcpyAsync)")
     ap.add_argument("--deliver-what", type=int, default=0, help="experiments: DABX_DELIVER_* mask (1 FIBs, 2 logical frames, 4 super frames; 0 = all)")
     ap.add_argument("--layout", choices=["uniform", "mixed"], default="uniform",
@@ -508,6 +509,24 @@ def single_ensemble_legs(torch, dev, args, rank, subch, dx):
     return out
 
 
+def single_legs_in_child(args):
+    """single_ensemble_legs in a fresh python process (see the call site); None under rocprofv3 (the child would be profiled into the same output)."""
+    import subprocess
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-legs-only", "--viterbi-tie-mode", str(args.viterbi_tie_mode),
+                            "--snr", str(args.snr), "--ensembles", str(args.ensembles)], capture_output=True, text=True, timeout=600)
+        rec = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or len(rec) != 1:
+            return {"error": "the child process failed (rc %d): %s" % (p.returncode, p.stderr[-300:])}
+        out = json.loads(rec[0])
+        out["measured_in"] = "a child process of its own, before the main engine exists (one receiver per process: the first two engines of a process)"
+        return out
+    except Exception as ex:
+        return {"error": str(ex)[:300]}
+
+
 def measure_link_probe():
     """tools/_build/sdma_engines (compiled by __graft_entry__.build()) as a child process before this process creates its engine: what a
     bare 96-MiB SDMA transfer between page-locked host memory and the device gets on THIS box, each way (the engine the runtime picks)."""
@@ -863,6 +882,16 @@ def load_valu_peak():
 
 def main():
     args = parse()
+    if args.single_legs_only:
+        import torch
+        from tools import dab_synth as ds
+        from dabstar_amd import lib as dx
+        torch.cuda.set_device(0)
+        dx.check(dx.load().dabx_set_device(0))
+        import gc
+        gc.collect(); gc.disable()
+        print(json.dumps(single_ensemble_legs(torch, torch.device("cuda", 0), args, 0, ds.default_subchannels(18, 64), dx)), flush=True)
+        return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -914,12 +943,20 @@ def main():
     if not dry and rank == 0 and n_joined == 1:
         measure_valu_peak()                          # child processes, done before this process creates its engine
         link_probe[0] = measure_link_probe()
+    single = None
     if dry:
         eng = DryEngine(args.streams)
         ring_frames = 10
     else:
         from dabstar_amd import lib as dx
         dx.check(dx.load().dabx_set_device(local_rank))
+        # BASELINE configs[1] / [2] in a CHILD process of their own, before this process creates its engine: the state a receiver for one ensemble
+        # runs in.  HIP deals a process's streams to four hardware queues per priority; from the third engine created in a process on (closed ones
+        # count) an engine's streams share queues with other engines' -- a one-stream engine with the MSC on, whose frame rate is a dependency loop
+        # across its streams, then runs 22 % slower (10 750 -> 8 300 frames/s), and the 512-stream engine 1.7 % (both measured:
+        # profiles/r06_ab/ab12_engines_per_process.txt): neither measurement may be the other's third engine.
+        if rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.no_single_legs:
+            single = single_legs_in_child(args)
         eng = dx.Engine(n_streams=args.streams, ring_frames=10, max_subch=18, out_frames=8, fic_only=args.fic_only,
                         viterbi_tie_mode=args.viterbi_tie_mode, exact_level_tracker=args.exact_level)
         if not args.fic_only:
@@ -1168,13 +1205,13 @@ def main():
         eng.delivery_close()
         sink = None
 
+    # the main engine has done its part: closed before the legs below create theirs
+    eng.close()
+    eng = None
     h2h = None
     # (the one-GPU line carries the per-link and per-ensemble legs; an N-GPU run is the scaling measurement and stays lean)
     if not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.fic_only and not args.no_host_leg:
         h2h = host_to_host_leg(args, subch, dx, link_probe[0])
-    single = None
-    if not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.no_single_legs:
-        single = single_ensemble_legs(torch, dev, args, rank, subch, dx)
     sweep = None
     if (not dry and rank == 0 and n_joined == 1 and args.layout == "uniform" and not args.fic_only and not args.no_snr_sweep and
             args.streams >= 48 and not args.unlocked and not args.exact_level):
@@ -1314,7 +1351,6 @@ def main():
         line = json.dumps(out)
     else:
         line = None
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()          # RCCL prints its version banner to stdout here: the JSON line goes out after it, last
     if line is not None:

@@ -68,4 +68,7 @@ def test_bench_line_keeps_its_contract():
     assert h["lost"] == 0 and h["frames_delivered"] == h["frames_decoded"] == 512 * 5 * 8 and h["fib_crc_pass_pct"] == 100.0 and h["superframes_failed"] == 0
     assert h["in_GBps"] > 30.0 and h["frames_per_s"] > 80000 and ("link_probe" not in h or h["in_frac_of_link_probe"] > 0.6)
     one = j["config"]["single_ensemble"]
-    assert one["full"]["frames_per_s"] > 3000 and one["fic_only"]["frames_per_s"] > one["full"]["frames_per_s"] and one["full"]["superframes_failed"] == 0
+    # (round 6: measured in a child process of its own -- one receiver per process -- and bound by the demapper's loop in both forms: FIC only is
+    #  no longer far ahead of the full receiver)
+    assert one["full"]["frames_per_s"] > 5000 and one["fic_only"]["frames_per_s"] > 0.95 * one["full"]["frames_per_s"] and one["full"]["superframes_failed"] == 0
+    assert "child process" in one["measured_in"]

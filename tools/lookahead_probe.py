@@ -3,7 +3,7 @@
 enqueue time into nothing, and into a barrier packet otherwise -- and round 6's timelines show every such packet as a bubble in its stream.  A host that
 issues its 20 steps in 0.6 ms makes every cross-stream wait of the engine a real packet; a host held back to k chunks ahead resolves some at enqueue.
 (Seen first as: the bulk delivery's python consumer, which holds the host back, beats the C++ consumer, which does not.)
-    tools/lookahead_probe.py [steps] [chunks_ahead ...]      0 = unthrottled"""
+    tools/lookahead_probe.py [steps] [chunks_ahead ...]      0 = unthrottled;  DABX_PROBE_STREAMS=n (default 512) for few-stream engines"""
 import ctypes as C
 import os
 import sys
@@ -23,8 +23,11 @@ dev = torch.device("cuda", 0)
 dx.check(dx.load().dabx_set_device(0))
 subch = ds.default_subchannels(18, 64)
 TF = ds.TF
-args = types.SimpleNamespace(ensembles=4, snr=20.0, streams=512, unlocked=0, unlocked_kind="silence", layout="uniform")
-e = dx.Engine(n_streams=512, ring_frames=10, max_subch=18, out_frames=8)
+S = int(os.environ.get("DABX_PROBE_STREAMS", "512"))
+# DABX_PROBE_OTHER_ENGINES=n: n idle engines created FIRST (their HIP streams take hardware queues: does the measured engine then share one between its own streams?)
+others = [dx.Engine(n_streams=8, ring_frames=4, max_subch=18, out_frames=8) for _ in range(int(os.environ.get("DABX_PROBE_OTHER_ENGINES", "0")))]
+args = types.SimpleNamespace(ensembles=min(4, S), snr=20.0, streams=S, unlocked=0, unlocked_kind="silence", layout="uniform")
+e = dx.Engine(n_streams=S, ring_frames=10, max_subch=18, out_frames=8)
 e.set_subchannels(subch)
 bench.fill_rings(e, torch, dev, args, 0, subch)
 e.commit(9 * TF)
@@ -64,5 +67,5 @@ for rep in range(3):
         run(steps, ahead)
         e.synchronize()
         dt = time.perf_counter() - t0
-        print("host at most %d chunk(s) ahead (0 = unthrottled), %d steps: %.0f frames/s" % (ahead, steps, (e.counters()["frames"] - c1) / dt), flush=True)
+        print("%d stream(s), host at most %d chunk(s) ahead (0 = unthrottled), %d steps: %.0f frames/s" % (S, ahead, steps, (e.counters()["frames"] - c1) / dt), flush=True)
 e.close()
