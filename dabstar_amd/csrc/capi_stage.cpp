@@ -231,6 +231,24 @@ int dabx_demap_get_snr_db(dabx_demap *d, float *snr_db)
   DABX_HIP(hipStreamSynchronize(0));
   return dout.to_host(snr_db, (size_t)d->d.batch * 4);
 }
+int dabx_demap_get_lcd_data(dabx_demap *d, float *snr_db, float *mer_db, float *mean_value)
+{
+  if (!d) return DABX_E_ARG;
+  const int B = d->d.batch;
+  DevBuf dout;
+  int rc;
+  if ((rc = dout.alloc((size_t)B * 12))) return rc;
+  if ((rc = launch_demap_lcd(d->d, dout.as<float>(), 0))) return rc;
+  DABX_HIP(hipStreamSynchronize(0));
+  std::vector<float> h((size_t)B * 3);
+  if ((rc = dout.to_host(h.data(), (size_t)B * 12))) return rc;
+  for (int s = 0; s < B; s++) {
+    if (snr_db) snr_db[s] = h[3 * (size_t)s];
+    if (mer_db) mer_db[s] = h[3 * (size_t)s + 1];
+    if (mean_value) mean_value[s] = h[3 * (size_t)s + 2];
+  }
+  return 0;
+}
 int dabx_demap_decode_symbols(dabx_demap *d, const dabx_cf32 *fft, int n_sym, const float *clock_err, int16_t *soft)
 {
   if (!d || !fft || !clock_err || !soft || n_sym <= 0) return DABX_E_ARG;

@@ -63,8 +63,10 @@ struct DemapDev {
   float *null_power2;   // [B][2048] second buffer: the engine's frame tail writes the one the demapper of the frame in flight does not read
   float *mean_value;    // [B]       mMeanValue
   float *mean_power_all;// [B]       mMeanPowerOvrAll (display / SNR only, ofdm_decoder.cpp:214)
+  float *std_dev;       // [B][1536] mStdDevSqPhaseVector (ofdm_decoder.cpp:204-208): feeds the LCD record's MER (:331-340) and no soft bit
   int batch;
   int soft_type;        // 1..3
+  int track_mer;        // the phase-deviation IIR is advanced (per-symbol handles: always; the engine: dabx_set_lcd_statistics)
 };
 int demap_alloc(DemapDev &d, int batch);
 void demap_free(DemapDev &d);
@@ -89,5 +91,6 @@ int launch_demap_store_ref(DemapDev &d, const float2 *fft, hipStream_t st);
 int launch_demap_store_null(DemapDev &d, const float2 *fft, hipStream_t st);
 int launch_demap_symbols(DemapDev &d, const float2 *fft, int n_sym, const float *clock_err, int16_t *soft, hipStream_t st);
 int launch_demap_snr(DemapDev &d, float *snr_db_dev, hipStream_t st);
+int launch_demap_lcd(DemapDev &d, float *out3_dev /* [B][3]: SNR dB, MER dB, mMeanValue */, hipStream_t st);
 
 }  // namespace dabx

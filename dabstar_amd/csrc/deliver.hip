@@ -28,7 +28,7 @@ __global__ __launch_bounds__(128) void k_deliver_front(EngineDev e, DeliverDev d
     r.state = c.state == ST_EVAL_SYNC ? 2 : (c.state == ST_WAIT_SYNC ? 1 : 0);
     r.fic_ratio_percent = c.fic_ratio * 10; r.cif_count = c.cif_count;
     r.snr_db_est = c.snr_db; r.freq_offs_bb_hz = c.f_bb; r.clock_err_hz = c.clock_err; r.signal_level = c.s_level;
-    r.fic_ber_bits = c.fic_bits; r.fic_ber_errors = c.fic_errors; r.reserved = 0;
+    r.fic_ber_bits = c.fic_bits; r.fic_ber_errors = c.fic_errors; r.mer_db_est = c.mer_db;
     r.fib_ok = c.fib_ok; r.fib_total = c.fib_total;
     reinterpret_cast<dabx_chunk_stream *>(slab + dv.hdr.off_stream)[s] = r;
   }

@@ -1507,7 +1507,7 @@ static int get_stats_full(dabx_engine *e, int stream, dabx_stats *out)
   out->level_rewalk_events = c.lvl_rewalks; out->level_unanchored_events = c.lvl_unanchored; out->level_healed_events = c.lvl_healed;
   out->frames = c.frames; out->samples_consumed = (int64_t)c.rd; out->state = c.state;
   out->fic_ratio_percent = c.fic_ratio * 10; out->freq_offs_bb_hz = c.f_bb; out->clock_err_hz = c.clock_err;
-  out->snr_db_est = c.snr_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;
+  out->snr_db_est = c.snr_db; out->mer_db_est = c.mer_db; out->last_start_index = c.start_index; out->cif_count = c.cif_count;
   out->fib_ok = c.fib_ok; out->fib_total = c.fib_total;
   out->signal_level = c.s_level; out->peak_level = c.peak_level;
   out->fic_ber_bits = c.fic_bits; out->fic_ber_errors = c.fic_errors;
@@ -1954,6 +1954,14 @@ int dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms)
   if (timeout_ms < 0) D.cv.wait(lk, [&]() { return free_now() >= n; });
   else D.cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&]() { return free_now() >= n; });
   return free_now();
+}
+
+int dabx_set_lcd_statistics(dabx_engine *e, int on)
+{
+  if (!e) return DABX_E_ARG;
+  if (int rc = sync_all(e)) return rc;          // no frame may see the switch between its two demapper launches
+  e->dev.demap.track_mer = on != 0;
+  return 0;
 }
 
 int dabx_set_profiling(dabx_engine *e, int on)

@@ -51,6 +51,8 @@ int demap_alloc(DemapDev &d, int batch)
 {
   d.batch = batch;
   d.soft_type = 1;
+  d.track_mer = 0;
+  DABX_HIP(hipMalloc((void **)&d.std_dev, sizeof(float) * K * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.phase_ref, sizeof(float2) * TU * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.integ, sizeof(float) * K * (size_t)batch));
   DABX_HIP(hipMalloc((void **)&d.mean_power, sizeof(float) * K * (size_t)batch));
@@ -66,6 +68,7 @@ void demap_free(DemapDev &d)
 {
   (void)hipFree(d.phase_ref); (void)hipFree(d.integ); (void)hipFree(d.mean_power);
   (void)hipFree(d.mean_sigma); (void)hipFree(d.null_power); (void)hipFree(d.null_power2); (void)hipFree(d.mean_value); (void)hipFree(d.mean_power_all);
+  (void)hipFree(d.std_dev);
   d = DemapDev{};
 }
 
@@ -75,6 +78,7 @@ __global__ void k_demap_reset(DemapDev d, int first)
   const int s = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < K; i += blockDim.x) {
     d.integ[(size_t)s * K + i] = 0.f; d.mean_power[(size_t)s * K + i] = 0.f; d.mean_sigma[(size_t)s * K + i] = 0.f;
+    d.std_dev[(size_t)s * K + i] = 0.f;                       // :92
   }
   for (int i = tid; i < TU; i += blockDim.x) { d.null_power[(size_t)s * TU + i] = 0.f; d.null_power2[(size_t)s * TU + i] = 0.f; }
   if (first && tid == 0) d.mean_value[s] = 1.0f;
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(512) void k_demap_symbols(DemapDev d, const float2 
     c[q].mean_power = d.mean_power[(size_t)s * K + k];
     c[q].mean_sigma_sq = d.mean_sigma[(size_t)s * K + k];
     c[q].null_power = d.null_power[(size_t)s * TU + bin[q]];
+    c[q].std_dev_sq = d.std_dev[(size_t)s * K + k];
   }
   float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
   const float ce = clock_err[s];
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(512) void k_demap_symbols(DemapDev d, const float2 
     d.integ[(size_t)s * K + k] = c[q].integ;
     d.mean_power[(size_t)s * K + k] = c[q].mean_power;
     d.mean_sigma[(size_t)s * K + k] = c[q].mean_sigma_sq;
+    d.std_dev[(size_t)s * K + k] = c[q].std_dev_sq;
   }
   // :354 mPhaseReference <- last symbol (all 2048 bins)
   if (n_sym > 0) {
@@ -177,6 +183,21 @@ __global__ __launch_bounds__(256) void k_demap_snr(DemapDev d, float *snr_db)
   }
   ns = block_sum(ns, red, tid);
   if (tid == 0) snr_db[s] = snr_db_from(d.mean_power_all[s], ns);
+}
+
+// The LCD record's device-side numbers (ofdm_decoder.cpp:326-345) from the state as it stands: SNR, MER, mMeanValue (TestData1)
+__global__ __launch_bounds__(256) void k_demap_lcd(DemapDev d, float *out3)
+{
+  __shared__ float red[32];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  float ns = 0.f, sd = 0.f;
+  for (int i = tid; i < K; i += 256) {
+    const int idx = i - K / 2;
+    ns += d.null_power[(size_t)s * TU + (idx < 0 ? idx + TU : idx + 1)];
+    sd += d.std_dev[(size_t)s * K + i];
+  }
+  block_sum2w(ns, sd, red, tid);
+  if (tid == 0) { out3[3 * s] = snr_db_from(d.mean_power_all[s], ns); out3[3 * s + 1] = mer_db_from(sd); out3[3 * s + 2] = d.mean_value[s]; }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------
@@ -212,6 +233,12 @@ int launch_demap_reset(DemapDev &d, hipStream_t st)
 int launch_demap_init(DemapDev &d, hipStream_t st)
 {
   hipLaunchKernelGGL(k_demap_reset, dim3(d.batch), dim3(256), 0, st, d, 1);
+  DABX_HIP(hipGetLastError());
+  return 0;
+}
+int launch_demap_lcd(DemapDev &d, float *out3_dev, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_demap_lcd, dim3(d.batch), dim3(256), 0, st, d, out3_dev);
   DABX_HIP(hipGetLastError());
   return 0;
 }

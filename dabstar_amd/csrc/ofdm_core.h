@@ -236,6 +236,7 @@ __device__ inline int coarse_cfo_block(const float2 X[8], const DevTables &t, fl
 struct DemapCarrier {        // per-carrier state kept in registers across the 75 symbols of a frame
   float2 prev;               // mPhaseReference[bin]
   float integ, mean_power, mean_sigma_sq, null_power;
+  float std_dev_sq;          // mStdDevSqPhaseVector[k]: the LCD record's MER only (ofdm_decoder.cpp:204-208, 331-340)
 };
 
 __device__ __forceinline__ int16_t cvt_i16_x86(float x)
@@ -349,6 +350,7 @@ __device__ __forceinline__ float demap_one(DemapCarrier &c, float2 x, int rel, f
   const float off = phase_offset_from_diagonal(b.y, b.x);      // :197-201: fmod(arg(b) in [0, pi], pi/2) - pi/4
   const float lim = F_RAD_PER_DEG * 20.0f;
   c.integ = __builtin_amdgcn_fmed3f(c.integ + 0.2f * ALPHA * off, -lim, lim);   // :201-202 (limit())
+  c.std_dev_sq += ALPHA * (off * off - c.std_dev_sq);           // :205-208
   const float power = b.x * b.x + b.y * b.y;                    // :211-213
   power_out = power;
   c.mean_power += ALPHA * (power - c.mean_power);
@@ -413,7 +415,7 @@ __device__ __forceinline__ v2f phase_offset_from_diagonal2(v2f y, v2f x, v2f ay,
 
 template <int SOFT_TYPE>
 __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f rel_f, float clock_err, float w2,
-                                          int16_t (&soft_re)[2], int16_t (&soft_im)[2], v2f &power_out)
+                                          int16_t (&soft_re)[2], int16_t (&soft_im)[2], v2f &power_out, v2f *std_dev_sq = nullptr)
 {
   constexpr float ALPHA = 0.005f;
   const float F_PI = 3.14159265358979323846f;
@@ -435,6 +437,9 @@ __device__ __forceinline__ v2f demap_pair(DemapPair &c, v2f x_re, v2f x_im, v2f 
   const v2f integ = c.integ + 0.2f * ALPHA * off;                 // :201-202
   const float lim = F_RAD_PER_DEG * 20.0f;
   c.integ = (v2f){__builtin_amdgcn_fmed3f(integ.x, -lim, lim), __builtin_amdgcn_fmed3f(integ.y, -lim, lim)};
+  // :205-208 mStdDevSqPhaseVector -- the LCD record's MER, no soft bit: block-uniformly on or off, its state parked in LDS (the engine's
+  // demapper has no two registers to spare at six waves per SIMD)
+  if (std_dev_sq) { v2f sd = *std_dev_sq; sd += ALPHA * (off * off - sd); *std_dev_sq = sd; }
   const v2f power = b_re * b_re + b_im * b_im;                    // :211-213
   power_out = power;
   c.mean_power += ALPHA * (power - c.mean_power);
@@ -483,6 +488,13 @@ __device__ __forceinline__ float snr_db_from(float mean_power_all, float null_su
   float snr = (mean_power_all - noise) / noise;
   if (snr <= 0.0f) snr = 0.1f;
   return 10.0f * log10f(snr);
+}
+
+// MER of the LCD record (ofdm_decoder.cpp:331-340): 10 log10((pi/4)^2 / mean_k mStdDevSqPhaseVector[k])
+__device__ __forceinline__ float mer_db_from(float std_dev_sq_sum)
+{
+  const float F_PI_4 = 0.78539816339744830962f;
+  return 10.0f * log10f(F_PI_4 * F_PI_4 / (std_dev_sq_sum / (float)K));
 }
 
 __device__ __forceinline__ uint8_t soft_to_sym(int16_t s)       // viterbi_scalar.h:34-40

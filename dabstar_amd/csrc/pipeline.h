@@ -55,7 +55,7 @@ struct StreamCtl {
   int32_t cif_count;              // FibDecoder::get_cif_count
   int32_t fic_errors, fic_bits, fic_block;   // mFicErrors, mFicBits, mFicBlock (fic_decoder.h:73-75)
   int32_t fic_status_errors, fic_status_bits;  // ... as they stood when the 40th block was reached: what signal_fic_status reports (fic_decoder.cpp:203-205)
-  int32_t pad4_;
+  float mer_db;                   // MER of the LCD record after the frame's last symbol (0 unless dabx_set_lcd_statistics)
   float snr_db;
   // counters (summed across streams / GPUs by dabx_get_counters)
   long long fib_ok, fib_total, sync_lost;

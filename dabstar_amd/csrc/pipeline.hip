@@ -254,6 +254,7 @@ __device__ __forceinline__ int acquire_stream(EngineDev &e, int s, int tid, int 
   // WAIT_FOR_TIME_SYNC_MARKER entry (dab_processor.cpp:146-153): decoder reset
   for (int i = tid; i < K; i += T) {
     e.demap.integ[(size_t)s * K + i] = 0.f; e.demap.mean_power[(size_t)s * K + i] = 0.f; e.demap.mean_sigma[(size_t)s * K + i] = 0.f;
+    e.demap.std_dev[(size_t)s * K + i] = 0.f;
   }
   for (int i = tid; i < TU; i += T) { e.demap.null_power[(size_t)s * TU + i] = 0.f; e.demap.null_power2[(size_t)s * TU + i] = 0.f; }
   if (tid == 0) e.demap.mean_power_all[s] = 1.0f;
@@ -1051,7 +1052,9 @@ __device__ __forceinline__ void demap_st_ring(uint32_t *p, uint32_t v)
 }
 // ESoftBitType 1..3 and the symbol conversion (SAT: the SIMD builds' saturating one, cfg.viterbi_tie_mode != 0) as compile-time
 // constants: no per-carrier branches on either
-template <int SOFT_TYPE, bool SAT, bool WHOLE = false>
+// MER: the LCD record's phase-deviation IIR is advanced too (dabx_set_lcd_statistics) -- its own instances: even as a block-uniform branch it
+// cost k_demap_frame6 48 bytes of scratch at six waves per SIMD
+template <int SOFT_TYPE, bool SAT, bool WHOLE = false, bool MER = false>
 __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &t, const int l0, const int l1)
 {
   // symbols [l0, l1) of the frame (0-based: l = symbol index - 1).  The engine runs [0, 3) -- the FIC symbols -- first so
@@ -1063,6 +1066,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
   if (l0 == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
   __shared__ __attribute__((aligned(16))) float red[32];
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][16 * TILE_PLANE];
+  __shared__ v2f sd_lds[MER ? DEMAP_NP * DEMAP_THREADS : 1];        // mStdDevSqPhaseVector of the thread's carriers (LCD statistics on: ofdm_core.h, demap_pair)
   const int s = blockIdx.x + e.s0, tid = threadIdx.x;
   StreamCtl &c = e.ctl[s];
   if (l0 == 0 && e.flag_sync) seq_wait(e.sym_seq + s, e.step_seq, e.seq_timeouts);     // few streams: k_symbols of this step (HIP stream a) is through
@@ -1099,6 +1103,7 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     cr[p].null_power[h] = null_power[(size_t)s * TU + bin];
     wk[p][h] = mpa_weight(k);
     pacc[p][h] = 0.0f;
+    if constexpr (MER) sd_lds[p * DEMAP_THREADS + tid][h] = d.std_dev[(size_t)s * K + k];
   }
   float mean_value = d.mean_value[s], mpa = d.mean_power_all[s];
   const float ce = fs.clock_err;                          // mClockErrHz of the previous frame, dab_processor.cpp:342
@@ -1145,7 +1150,8 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     for (int p = 0; p < DEMAP_NP; p++) {
       int16_t sr[2], si[2];
       v2f pw;
-      const v2f mag = demap_pair<SOFT_TYPE>(cr[p], (v2f){xc[2 * p].x, xc[2 * p + 1].x}, (v2f){xc[2 * p].y, xc[2 * p + 1].y}, rel_f[p], ce, w2, sr, si, pw);
+      const v2f mag = demap_pair<SOFT_TYPE>(cr[p], (v2f){xc[2 * p].x, xc[2 * p + 1].x}, (v2f){xc[2 * p].y, xc[2 * p + 1].y}, rel_f[p], ce, w2, sr, si, pw,
+                                            MER ? &sd_lds[p * DEMAP_THREADS + tid] : nullptr);
       part = p == 0 ? mag.x + mag.y : part + (mag.x + mag.y);
       pacc[p] = pacc[p] * mpa_decay() + pw;                 // per carrier: sum_l d^(74-l) p_l, reduced once per frame below
 #pragma unroll
@@ -1218,6 +1224,20 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
     d.mean_power[(size_t)s * K + k] = cr[p].mean_power[h];
     d.mean_sigma[(size_t)s * K + k] = cr[p].mean_sigma_sq[h];
   }
+  if constexpr (MER) {
+    float sd = 0.f;
+#pragma unroll
+    for (int q = 0; q < DEMAP_Q; q++) {
+      const float v = sd_lds[(q >> 1) * DEMAP_THREADS + tid][q & 1];
+      d.std_dev[(size_t)s * K + tid + DEMAP_THREADS * q] = v;
+      sd += v;
+    }
+    if (l1 == 75) {                                          // :331-340 after the frame's last symbol, like the SNR below
+      sd = block_sum(sd, red, tid);
+      if (tid == 0) c.mer_db = mer_db_from(sd);
+      __syncthreads();                                       // red is used again below
+    }
+  }
   // SNR estimate as the LCD statistics compute it (ofdm_decoder.cpp:326-343) after the last symbol of the frame
   // mMeanPowerOvrAll (ofdm_decoder.cpp:214) over the 75 symbols in closed form: x d^75 + sum_k w_k sum_l d^(74-l) p_(k,l)
   float ns = cr[0].null_power.x + cr[0].null_power.y, wsum = wk[0].x * pacc[0].x + wk[0].y * pacc[0].y;
@@ -1240,15 +1260,15 @@ __device__ __forceinline__ void demap_frame_body(EngineDev &e, const DevTables &
 
 // Built for six waves per SIMD (<= 80 VGPRs, 7 values spilled outside the loop): two 12-wave blocks share a CU instead of
 // taking turns (at 94 VGPRs only one fitted: 0.32 -> 0.24 ms per step).
-template <int SOFT_TYPE, bool SAT>
-__global__ __launch_bounds__(DEMAP_THREADS, DABX_DEMAP_OCC) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE, SAT>(e, t, l0, l1); }
+template <int SOFT_TYPE, bool SAT, bool MER>
+__global__ __launch_bounds__(DEMAP_THREADS, DABX_DEMAP_OCC) void k_demap_frame6(EngineDev e, DevTables t, int l0, int l1) { demap_frame_body<SOFT_TYPE, SAT, false, MER>(e, t, l0, l1); }
 // the FIC symbols alone (first launch of a frame in the overlapped schedule): its own kernel symbol so that rocprofv3's
 // per-kernel statistics keep the 3-symbol and the 72-symbol launches apart, as bench.py's event pairs do
-template <int SOFT_TYPE, bool SAT>
-__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT>(e, t, 0, 3); }
+template <int SOFT_TYPE, bool SAT, bool MER>
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_fic(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT, false, MER>(e, t, 0, 3); }
 // few streams with device-side hand-overs (EngineDev::flag_sync): the whole frame in one launch
-template <int SOFT_TYPE, bool SAT>
-__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_whole(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT, true>(e, t, 0, 75); }
+template <int SOFT_TYPE, bool SAT, bool MER>
+__global__ __launch_bounds__(DEMAP_THREADS) void k_demap_whole(EngineDev e, DevTables t) { demap_frame_body<SOFT_TYPE, SAT, true, MER>(e, t, 0, 75); }
 
 // ---------------------------------------------------------------------------------------------------- FIC
 struct SrcFic {                       // 2304 Viterbi symbols of one FIC + depuncture map (viterbi_core.h: key / raw / syms)
@@ -1979,14 +1999,24 @@ int launch_front_step(const EngineDev &e_in, EngineStreams &ss, Marker &mk, bool
 #define DABX_DEMAP_DISPATCH(KERNEL, ...)                                                                                         \
   do {                                                                                                                          \
     const int st_ = e.demap.soft_type == 3 ? 3 : e.demap.soft_type == 2 ? 2 : 1;                                                \
-    if (e.tie_mode) {                                                                                                           \
-      if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, true>), __VA_ARGS__);                                                         \
-      else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__);                                                    \
-      else hipLaunchKernelGGL((KERNEL<1, true>), __VA_ARGS__);                                                                  \
+    if (e.demap.track_mer) {                                   /* LCD statistics on: the instances that advance the MER's IIR too */ \
+      if (e.tie_mode) {                                                                                                         \
+        if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, true, true>), __VA_ARGS__);                                                 \
+        else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, true, true>), __VA_ARGS__);                                            \
+        else hipLaunchKernelGGL((KERNEL<1, true, true>), __VA_ARGS__);                                                          \
+      } else {                                                                                                                  \
+        if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, false, true>), __VA_ARGS__);                                                \
+        else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, false, true>), __VA_ARGS__);                                           \
+        else hipLaunchKernelGGL((KERNEL<1, false, true>), __VA_ARGS__);                                                         \
+      }                                                                                                                         \
+    } else if (e.tie_mode) {                                                                                                    \
+      if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, true, false>), __VA_ARGS__);                                                  \
+      else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, true, false>), __VA_ARGS__);                                             \
+      else hipLaunchKernelGGL((KERNEL<1, true, false>), __VA_ARGS__);                                                           \
     } else {                                                                                                                    \
-      if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, false>), __VA_ARGS__);                                                        \
-      else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, false>), __VA_ARGS__);                                                   \
-      else hipLaunchKernelGGL((KERNEL<1, false>), __VA_ARGS__);                                                                 \
+      if (st_ == 3) hipLaunchKernelGGL((KERNEL<3, false, false>), __VA_ARGS__);                                                 \
+      else if (st_ == 2) hipLaunchKernelGGL((KERNEL<2, false, false>), __VA_ARGS__);                                            \
+      else hipLaunchKernelGGL((KERNEL<1, false, false>), __VA_ARGS__);                                                          \
     }                                                                                                                           \
   } while (0)
   auto demap = [&](hipStream_t q, int l0, int l1) {

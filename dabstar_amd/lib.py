@@ -215,6 +215,13 @@ class Demap:
         check(load().dabx_demap_get_snr_db(self._h, _p(out)))
         return out
 
+    def lcd_data(self):
+        """(snr_db, mer_db, mean_value) of the LCD record, batch floats each (dabx_demap_get_lcd_data)."""
+        out = [np.zeros(self.batch, np.float32) for _ in range(3)]
+        load().dabx_demap_get_lcd_data.argtypes = [C.c_void_p] * 4
+        check(load().dabx_demap_get_lcd_data(self._h, *[_p(o) for o in out]))
+        return tuple(out)
+
     def decode_symbols(self, fft, clock_err):
         fft = np.ascontiguousarray(fft, np.complex64).reshape(self.batch, -1, 2048)
         ce = np.ascontiguousarray(np.broadcast_to(np.asarray(clock_err, np.float32), (self.batch,)))
@@ -308,7 +315,7 @@ class Stats(C.Structure):
                 ("cifs_decoded", C.c_int64), ("signal_level", C.c_float), ("peak_level", C.c_float),
                 ("level_margin_events", C.c_int64), ("level_rewalk_events", C.c_int64), ("level_unanchored_events", C.c_int64),
                 ("level_healed_events", C.c_int64), ("fic_ber_bits", C.c_int64), ("fic_ber_errors", C.c_int64),
-                ("reserved", C.c_int64 * 2)]
+                ("mer_db_est", C.c_float), ("reserved_f", C.c_float), ("reserved", C.c_int64 * 1)]
 
 
 # ---- bulk delivery (include/dabx.h "Bulk delivery"): the slab's records as numpy dtypes -----------------------------
@@ -322,7 +329,7 @@ CHUNK_HEADER = np.dtype([("magic", "<u4"), ("abi", "<u4"), ("seq", "<u8"), ("n_s
 CHUNK_STREAM = np.dtype([("first_frame", "<i8"), ("n_frames", "<i4"), ("frames_lost", "<i4"), ("state", "<i4"),
                          ("fic_ratio_percent", "<i4"), ("cif_count", "<i4"), ("snr_db_est", "<f4"), ("freq_offs_bb_hz", "<f4"),
                          ("clock_err_hz", "<f4"), ("signal_level", "<f4"), ("fic_ber_bits", "<i4"), ("fic_ber_errors", "<i4"),
-                         ("reserved", "<i4"), ("fib_ok", "<i8"), ("fib_total", "<i8")])
+                         ("mer_db_est", "<f4"), ("fib_ok", "<i8"), ("fib_total", "<i8")])
 CHUNK_FRAME = np.dtype([("sym0_pos", "<i8"), ("start_index", "<i4"), ("reserved", "<i4")])
 CHUNK_SUBCH = np.dtype([("active", "<i4"), ("subch_id", "<i4"), ("kbps", "<i4"), ("dab_plus", "<i4"), ("start_cif", "<i8"),
                         ("first_cif", "<i8"), ("n_cifs", "<i4"), ("cifs_lost", "<i4"), ("first_sf", "<i8"), ("n_sf", "<i4"),
@@ -510,10 +517,13 @@ class Engine:
     def set_fig_reference_quirks(self, on):
         check(load().dabx_set_fig_reference_quirks(self._h, int(on)))
 
+    def set_lcd_statistics(self, on):
+        check(load().dabx_set_lcd_statistics(self._h, int(on)))
+
     def follow_fic(self, stream):
         out = Reconf()
         check(load().dabx_follow_fic(self._h, stream, C.byref(out)))
-        return {k: getattr(out, k) for k, _ in Reconf._fields_ if k != "reserved"}
+        return {k: getattr(out, k) for k, _ in Reconf._fields_ if not k.startswith("reserved")}
 
     def next_subchannels(self, stream, max_out=64):
         out = (SubchDesc * max_out)()
@@ -630,7 +640,7 @@ class Engine:
         out = DeliveryInfo()
         load().dabx_delivery_get_info.argtypes = [C.c_void_p, C.c_void_p]
         check(load().dabx_delivery_get_info(self._h, C.byref(out)))
-        return {k: getattr(out, k) for k, _ in DeliveryInfo._fields_ if k != "reserved"}
+        return {k: getattr(out, k) for k, _ in DeliveryInfo._fields_ if not k.startswith("reserved")}
 
     def delivery_wait_free(self, n=1, timeout_ms=-1):
         return check(load().dabx_delivery_wait_free(self._h, int(n), int(timeout_ms)))
@@ -645,7 +655,7 @@ class Engine:
     def stats(self, stream):
         st = Stats()
         check(load().dabx_get_stats_sized(self._h, stream, C.byref(st), C.c_size_t(C.sizeof(st))))
-        return {k: getattr(st, k) for k, _ in Stats._fields_ if k != "reserved"}
+        return {k: getattr(st, k) for k, _ in Stats._fields_ if not k.startswith("reserved")}
 
     def counters(self):
         out = (C.c_int64 * 16)()
@@ -774,7 +784,7 @@ class FibDecoder:
     def info(self):
         out = FibdecInfo()
         check(load().dabx_fibdec_get_info(self._h, C.byref(out)))
-        return {k: getattr(out, k) for k, _ in FibdecInfo._fields_ if k != "reserved"}
+        return {k: getattr(out, k) for k, _ in FibdecInfo._fields_ if not k.startswith("reserved")}
 
     def subchannels(self, next=False, max_out=64):
         out = (SubchDesc * max_out)()

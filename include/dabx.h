@@ -167,6 +167,11 @@ int dabx_demap_set_soft_bit_gen_type(dabx_demap *d, int type /*1..3*/);
 /* SLcdData::SNR as decode_symbol computes it for the LCD statistics (:326-343 with _compute_noise_Power :358-371) from the
  * state as it stands: 10 log10((mMeanPowerOvrAll - noise) / noise); snr_db = batch floats. */
 int dabx_demap_get_snr_db(dabx_demap *d, float *snr_db);
+/* The device-side numbers of the LCD record (OfdmDecoder::SLcdData, ofdm_decoder.h:53-61; filled at ofdm_decoder.cpp:326-345) from the state
+ * as it stands, batch floats each, any pointer may be NULL: SNR as above; MER = 10 log10((pi/4)^2 / mean over the carriers of
+ * mStdDevSqPhaseVector) (:204-208, :331-340: the per-carrier IIR of the squared phase distance from the diagonal); mean_value = mMeanValue
+ * (:294), which the record carries as TestData1. */
+int dabx_demap_get_lcd_data(dabx_demap *d, float *snr_db, float *mer_db, float *mean_value);
 
 /* PhaseReference::correlate_with_phase_ref_and_find_max_peak (base/ofdm/phasereference.cpp:87-213):
  * v = batch x 2048 cf32, returns start index per problem (or -1). */
@@ -303,7 +308,11 @@ typedef struct {
   int64_t fic_ber_bits;      /* FicDecoder::mFicBits / mFicErrors (fic_decoder.h:74-75): transmitted FIC bits compared with the re-encoded */
   int64_t fic_ber_errors;    /* decoder output and those that differed (ViterbiSpiral::calculate_BER, viterbi_spiral.cpp:128-164), both halved
                                 every 40 FIC blocks (fic_decoder.cpp:201-210); the channel BER the reference displays is errors / bits */
-  int64_t reserved[2];       /* zero; later fields go here without changing the record's size */
+  /* -- ABI 6 (in the place of the first reserved word: the record's size is unchanged) -- */
+  float   mer_db_est;        /* OfdmDecoder's LCD MER (ofdm_decoder.cpp:204-208, 331-340) after the newest frame's last symbol; 0 unless
+                                dabx_set_lcd_statistics switched its per-carrier IIR on */
+  float   reserved_f;
+  int64_t reserved[1];       /* zero; later fields go here without changing the record's size */
 } dabx_stats;
 
 void dabx_default_config(dabx_config *cfg);
@@ -389,6 +398,13 @@ int  dabx_follow_fic(dabx_engine *e, int stream, dabx_reconf *out);
  * (fib_decoder_fig0.cpp:103), dabx_fibdec_set_reference_quirks -- so that an engine-level reconfiguration can be compared with the reference's
  * own behaviour for flags 1 and 2 as well. */
 int  dabx_set_fig_reference_quirks(dabx_engine *e, int on);
+/* OfdmDecoder's LCD record (SLcdData, ofdm_decoder.h:53-61) carries, next to the SNR the engine always estimates (dabx_stats.snr_db_est), the MER:
+ * 10 log10((pi/4)^2 / mean_k mStdDevSqPhaseVector[k]), a per-carrier IIR of the squared phase distance from the constellation's diagonal
+ * (ofdm_decoder.cpp:204-208, 331-340) that feeds no soft bit.  on != 0 advances that IIR in the demapper too (a few instructions per carrier and
+ * symbol; off by default: a display statistic of one receiver, not of 512) and dabx_stats.mer_db_est / dabx_chunk_stream.mer_db_est report it
+ * after every frame; switched on in mid-stream the IIR starts from what it last held (zero after a reset / loss of lock, like the reference's).
+ * Drains the engine. */
+int  dabx_set_lcd_statistics(dabx_engine *e, int on);
 int  dabx_next_subchannels(dabx_engine *e, int stream, dabx_subch_desc *out, int max_out);
 /* ... and the CURRENT table of the same decoder (after a swap: the former next table plus whatever the new configuration's own FIGs,
  * C/N = 0, have added since -- first description wins). */
@@ -498,7 +514,11 @@ typedef struct {
   int32_t state, fic_ratio_percent, cif_count;      /* as in dabx_stats, after the chunk's last frame */
   float   snr_db_est, freq_offs_bb_hz, clock_err_hz, signal_level;
   int32_t fic_ber_bits, fic_ber_errors;             /* FicDecoder's channel-BER counters (dabx_stats) */
-  int32_t reserved;
+  float   mer_db_est;                               /* dabx_stats.mer_db_est (0 unless dabx_set_lcd_statistics).  The two LCD statistics
+                                                       (snr_db_est, mer_db_est) are what the demapper had last written when the record was
+                                                       gathered: with 48 streams and more the chunk's last frame's MSC symbols may still be
+                                                       in the demapper then (a HIP stream of its own), and they are that frame's or the
+                                                       previous one's; dabx_get_stats after dabx_synchronize shows the last frame's */
   int64_t fib_ok, fib_total;                        /* cumulative */
 } dabx_chunk_stream;        /* 72 bytes */
 typedef struct {

@@ -42,6 +42,9 @@ public:
   // conceals (:316 length check, :339 CRC).  No header is parsed and no CRC is run on the host.
   std::function<void(int subChId, const uint8_t *au, int len, bool crc_ok, int au_idx, const dabx_superframe_info &sf)> on_access_unit;
   std::function<void(int ficPercent, float freqOffsBbHz, float clockErrHz, float snrDb)> on_status;   // slot_show_fic_status, ..._freq_corr_bb_Hz, ..._clock_error
+  // OfdmDecoder::signal_show_lcd_data's device-side numbers (ofdm_decoder.cpp:326-345): setting it before the first run() switches the MER's
+  // per-carrier IIR on in the engine (dabx_set_lcd_statistics)
+  std::function<void(float snrDb, float merDb)> on_lcd_data;
 
   std::function<void(const std::vector<dabx_tii_result> &)> on_tii;                                 // signal_show_tii
   // IFibDecoder::signal_change_in_configuration (fib_decoder_fig0.cpp:109) -- which the reference answers with "not supported yet"
@@ -115,6 +118,7 @@ public:
       }
       if (verify_frame_ >= 0 && before.frames >= verify_frame_) stop_services_that_ended();
     }
+    if (on_lcd_data && !lcd_on_) { check(dabx_set_lcd_statistics(eng_, 1), "dabx_set_lcd_statistics"); lcd_on_ = true; }
     check(dabx_process(eng_, max_frames, 1), "dabx_process");
     check(dabx_get_stats(eng_, 0, &after), "dabx_get_stats");
     const int frames = (int)(after.frames - before.frames);
@@ -124,6 +128,7 @@ public:
       if (tii_on_ && on_tii) deliver_tii();
       if (eti_ && any_service()) write_eti();     // like EtiGenerator: nothing before the FIC has named the sub-channels
       if (on_status) on_status(after.fic_ratio_percent, after.freq_offs_bb_hz, after.clock_err_hz, after.snr_db_est);
+      if (on_lcd_data && lcd_on_) on_lcd_data(after.snr_db_est, after.mer_db_est);
     }
     return frames;
   }
@@ -221,7 +226,7 @@ private:
   std::vector<long long> delivered_, sf_delivered_;
   std::FILE *eti_ = nullptr;
   long long eti_frames_ = 0;
-  bool tii_on_ = false, tii_collisions_ = false;
+  bool tii_on_ = false, tii_collisions_ = false, lcd_on_ = false;
   int tii_threshold_ = 6, tii_sub_id_ = 0;
   long long applied_cif_ = -1;                  // first CIF of the newest configuration that has been switched to
   long long verify_frame_ = -1;                 // frame at which services kept through a switch without being listed are checked against the new table

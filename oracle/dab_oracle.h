@@ -195,6 +195,9 @@ void ora_demap_store_ref(ora_demap *d, const ora_cf32 *fft);         /* ofdm_dec
 void ora_demap_store_null(ora_demap *d, const ora_cf32 *fft);        /* ofdm_decoder.cpp:114-130 */
 void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_t out[ORA_2K]); /* :147-355 */
 float ora_demap_snr_db(const ora_demap *d);                       /* :326-343, :358-371 (SNR of the LCD statistics) */
+float ora_demap_mean_value(const ora_demap *d);
+const float *ora_demap_std_dev_sq(const ora_demap *d);
+float ora_demap_mer_db(const ora_demap *d);                       /* :331-340 (MER of the LCD statistics, from the :204-208 IIR) */
 
 /* PRS correlator / coarse CFO: ofdm/phasereference.cpp */
 typedef struct {
@@ -246,6 +249,7 @@ typedef struct {
   float   *peak_level;    /* n_frames : SampleReader::peakLevel likewise */
   int32_t *fic_ber_bits;   /* n_frames : FicDecoder::mFicBits / mFicErrors after the frame's four FIC blocks (fic_decoder.cpp:199-210) */
   int32_t *fic_ber_errors;
+  float   *mer_db;        /* n_frames : MER of the LCD statistics after symbol 75, ofdm_decoder.cpp:331-340 */
 } ora_rx_capture;
 void ora_rx_enable_soft_capture(ora_receiver *r, int on);
 const ora_rx_capture *ora_rx_get_capture(ora_receiver *r);

@@ -261,6 +261,15 @@ float ora_demap_snr_db(const ora_demap *d)
   return 10.0f * log10f(snr);
 }
 
+/* ofdm_decoder.cpp:331-340 (LCD statistics): MER from the per-carrier phase-deviation IIR of :204-208 */
+float ora_demap_mer_db(const ora_demap *d)
+{
+  float std_dev_sq_ovr_all = 0.0f;
+  for (int idx = 0; idx < ORA_K; idx++) std_dev_sq_ovr_all += d->std_dev_sq[idx];
+  std_dev_sq_ovr_all /= (float)ORA_K;
+  return 10.0f * log10f(F_PI_4 * F_PI_4 / std_dev_sq_ovr_all);
+}
+
 /* heap helpers for ctypes-based tests */
 ora_demap *ora_demap_new(void) { ora_demap *d = (ora_demap *)malloc(sizeof(ora_demap)); ora_demap_init(d); return d; }
 void ora_demap_free(ora_demap *d) { free(d); }
@@ -268,3 +277,5 @@ ora_phaseref *ora_phaseref_new(void) { ora_phaseref *p = (ora_phaseref *)malloc(
 void ora_phaseref_free(ora_phaseref *p) { free(p); }
 void ora_phaseref_set_strongest(ora_phaseref *p, int on) { p->strongest = on; }
 void ora_demap_set_type(ora_demap *d, int type) { d->soft_bit_type = type; }
+float ora_demap_mean_value(const ora_demap *d) { return d->mean_value; }                     /* mMeanValue: SLcdData::TestData1, :344 */
+const float *ora_demap_std_dev_sq(const ora_demap *d) { return d->std_dev_sq; }             /* mStdDevSqPhaseVector (tests) */

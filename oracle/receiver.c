@@ -189,6 +189,7 @@ void ora_rx_destroy(ora_receiver *r)
   free(r->cap.fibs); free(r->cap.fib_crc); free(r->cap.soft); free(r->cap.start_idx); free(r->cap.fbb); free(r->cap.sym0_pos);
   free(r->cap.fbb_end); free(r->cap.clock_err); free(r->cap.fic_ratio); free(r->cap.snr_db); free(r->cap.fic_overflow); free(r->cap.msc_overflow);
   free(r->cap.s_level); free(r->cap.peak_level); free(r->cap.fic_ber_bits); free(r->cap.fic_ber_errors);
+  free(r->cap.mer_db);
   free(r);
 }
 
@@ -211,6 +212,7 @@ static void cap_reserve(ora_receiver *r, int n)
   r->cap.clock_err = (float *)realloc(r->cap.clock_err, sizeof(float) * (size_t)na);
   r->cap.fic_ratio = (int32_t *)realloc(r->cap.fic_ratio, sizeof(int32_t) * (size_t)na);
   r->cap.snr_db = (float *)realloc(r->cap.snr_db, sizeof(float) * (size_t)na);
+  r->cap.mer_db = (float *)realloc(r->cap.mer_db, sizeof(float) * (size_t)na);
   r->cap.fic_overflow = (int32_t *)realloc(r->cap.fic_overflow, sizeof(int32_t) * (size_t)na);
   r->cap.msc_overflow = (int32_t *)realloc(r->cap.msc_overflow, sizeof(int32_t) * (size_t)na);
   r->cap.s_level = (float *)realloc(r->cap.s_level, sizeof(float) * (size_t)na);
@@ -290,6 +292,7 @@ static int process_rest_of_frame(ora_receiver *r, int *sample_count, int frame_n
     if (sym > 3) msc_process_block(r, r->bits, sym);              /* :357-360 */
   }
   r->cap.snr_db[frame_no] = ora_demap_snr_db(&r->dm);
+  r->cap.mer_db[frame_no] = ora_demap_mer_db(&r->dm);
   r->phase_offs_cp = atan2f(fc_im, fc_re);                        /* :366 */
 
   limit_sym(&r->phase_offs_cp, 20.0f * (float)(M_PI / 180.0));    /* :240-242 */
@@ -397,6 +400,7 @@ int ora_rx_run_spectra(ora_receiver *r, const ora_cf32 *spectra, const ora_cf32 
       if (sym <= 3) ora_fic_process_block(&r->fic, r->bits, sym);
       if (sym > 3) msc_process_block(r, r->bits, sym);
     }
+    r->cap.mer_db[f] = ora_demap_mer_db(&r->dm);
     r->cap.snr_db[f] = ora_demap_snr_db(&r->dm);                  /* after symbol 75, before the null symbol (as process_rest_of_frame) */
     if (!((r->fic.cif_count & 7) >= 4)) ora_demap_store_null(&r->dm, nulls + (size_t)f * ORA_TU);
     for (int i = 0; i < 12; i++) {

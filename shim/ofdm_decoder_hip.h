@@ -70,14 +70,14 @@ public:
     if (iCurOfdmSymbIdx == 1) mMeanSigmaSqFreqCorr += 0.2f * (freqCorr * freqCorr - mMeanSigmaSqFreqCorr);   // :296-300 mean_filter(.., 0.2f)
     if (showStatisticData)                                         // :326-352
     {
-      float snr = 0.0f;
-      dabx_shim_check(dabx_demap_get_snr_db(mpDemap, &snr), "dabx_demap_get_snr_db");
+      float snr = 0.0f, mer = 0.0f, meanValue = 0.0f;
+      dabx_shim_check(dabx_demap_get_lcd_data(mpDemap, &snr, &mer, &meanValue), "dabx_demap_get_lcd_data");
       mLcdData.CurOfdmSymbolNo = iCurOfdmSymbIdx + 1;
       mLcdData.SNR = snr;                                          // 10 log10((mMeanPowerOvrAll - noise) / noise), computed on the device
       mLcdData.MeanSigmaSqFreqCorr = std::sqrt(mMeanSigmaSqFreqCorr);
       mLcdData.TestData2 = freqCorr;
-      mLcdData.MER = 0.0f;                                         // the phase-deviation IIR behind it (mStdDevSqPhaseVector) feeds no soft bit and is not kept on the device
-      mLcdData.TestData1 = 0.0f;
+      mLcdData.MER = mer;                                          // 10 log10((pi/4)^2 / mean mStdDevSqPhaseVector), :204-208, 331-340: on the device too
+      mLcdData.TestData1 = meanValue;                              // mMeanValue, :344
 #ifndef DABX_SHIM_STANDALONE
       emit signal_show_lcd_data(mLcdData);
 #endif

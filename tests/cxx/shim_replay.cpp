@@ -24,6 +24,9 @@ int main(int argc, char **argv)
     rx.on_fib = [&](const uint8_t *, bool ok, int) { fibs++; fibs_ok += ok; };
     rx.on_logical_frame = [&](int id, const uint8_t *, int) { lf++; lf_per_service[id]++; lf_this_run[id]++; };
     rx.on_super_frame = [&](int, const uint8_t *, int) { sf++; };
+    long long lcd_records = 0;
+    float lcd_snr = 0.f, lcd_mer = 0.f;
+    rx.on_lcd_data = [&](float snr_db, float mer_db) { lcd_records++; lcd_snr = snr_db; lcd_mer = mer_db; };   // signal_show_lcd_data's device-side numbers
     // the AAC decoder's seat: access units arrive sliced and judged (dabx_superframe_info); this stub only counts -- and, being a TEST, checks
     // the verdicts it was handed with a CRC of its own (crc.cpp:75-86: CCITT, start 0xFFFF, complemented, over the frame without its last two bytes)
     long long aus = 0, aus_ok = 0, au_verdict_mismatch = 0, au_bytes = 0;
@@ -81,9 +84,10 @@ int main(int argc, char **argv)
     per += "}";
     std::printf("{\"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"services\": %zu, "
                 "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"config_changes\": %lld, \"change_cif\": %lld, "
-                "\"access_units\": %lld, \"access_units_ok\": %lld, \"au_verdict_mismatch\": %lld, \"au_bytes\": %lld, \"lf_per_service\": %s}\n",
+                "\"access_units\": %lld, \"access_units_ok\": %lld, \"au_verdict_mismatch\": %lld, \"au_bytes\": %lld, \"lcd_records\": %lld, \"lcd_snr\": %.3f, "
+                "\"lcd_mer\": %.3f, \"lf_per_service\": %s}\n",
                 frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, config_changes, change_cif,
-                aus, aus_ok, au_verdict_mismatch, au_bytes, per.c_str());
+                aus, aus_ok, au_verdict_mismatch, au_bytes, lcd_records, (double)lcd_snr, (double)lcd_mer, per.c_str());
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "shim_replay: %s\n", e.what());

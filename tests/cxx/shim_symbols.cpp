@@ -120,8 +120,10 @@ int main(int argc, char ** argv)
   i32 lcd_count = 0;
   const OfdmDecoder::SLcdData & lcd = ofdm.dabx_last_lcd_data(&lcd_count);
   std::printf("{\"frames\": %d, \"fibs_delivered\": %zu, \"drivers\": %zu, \"logical_frames\": %zu, \"mean_fic_ratio\": %.1f, "
-              "\"stopped_ok\": %s, \"ratio_reset\": %s, \"fic_status_ber\": %.9g, \"lcd_count\": %d, \"lcd_snr\": %.4f, \"lcd_symbol\": %d}\n",
+              "\"stopped_ok\": %s, \"ratio_reset\": %s, \"fic_status_ber\": %.9g, \"lcd_count\": %d, \"lcd_snr\": %.4f, \"lcd_symbol\": %d, "
+              "\"lcd_mer\": %.4f, \"lcd_mean_value\": %.6g}\n",
               n_frames, rec.fibs.size(), rec.frames.size(), total_frames, (double)ratio_sum / n_frames, stopped_ok ? "true" : "false",
-              ratio_reset ? "true" : "false", (double)fic.dabx_last_fic_ber(), (int)lcd_count, (double)lcd.SNR, (int)lcd.CurOfdmSymbolNo);
+              ratio_reset ? "true" : "false", (double)fic.dabx_last_fic_ber(), (int)lcd_count, (double)lcd.SNR, (int)lcd.CurOfdmSymbolNo,
+              (double)lcd.MER, (double)lcd.TestData1);
   return 0;
 }

@@ -31,7 +31,8 @@ class RxCapture(C.Structure):
                 ("fbb_end", C.POINTER(C.c_float)), ("clock_err", C.POINTER(C.c_float)), ("fic_ratio", C.POINTER(C.c_int32)),
                 ("snr_db", C.POINTER(C.c_float)), ("fic_overflow", C.POINTER(C.c_int32)), ("msc_overflow", C.POINTER(C.c_int32)),
                 ("s_level", C.POINTER(C.c_float)), ("peak_level", C.POINTER(C.c_float)),
-                ("fic_ber_bits", C.POINTER(C.c_int32)), ("fic_ber_errors", C.POINTER(C.c_int32))]
+                ("fic_ber_bits", C.POINTER(C.c_int32)), ("fic_ber_errors", C.POINTER(C.c_int32)),
+                ("mer_db", C.POINTER(C.c_float))]
 
 
 def build_oracle():
@@ -116,6 +117,12 @@ def oracle():
     L.ora_demap_free.argtypes = [C.c_void_p]
     L.ora_demap_snr_db.argtypes = [C.c_void_p]
     L.ora_demap_snr_db.restype = C.c_float
+    L.ora_demap_mer_db.argtypes = [C.c_void_p]
+    L.ora_demap_mer_db.restype = C.c_float
+    L.ora_demap_mean_value.argtypes = [C.c_void_p]
+    L.ora_demap_mean_value.restype = C.c_float
+    L.ora_demap_std_dev_sq.argtypes = [C.c_void_p]
+    L.ora_demap_std_dev_sq.restype = C.POINTER(C.c_float)
     L.ora_demap_set_type.argtypes = [C.c_void_p, C.c_int]
     L.ora_demap_reset.argtypes = [C.c_void_p]
     L.ora_demap_store_ref.argtypes = [C.c_void_p, _c64p]

@@ -59,6 +59,8 @@ def test_adapter_replays_a_recording_to_eti(tmp_path, select):
     # the AAC decoder's seat (on_access_unit): three access units per super frame of this multiplex, sliced and judged on the device; the stub's own
     # CRC (a test's check, not a host's duty) agrees with every verdict it was handed
     assert res["access_units"] == 3 * res["super_frames"] == res["access_units_ok"] and res["au_verdict_mismatch"] == 0 and res["au_bytes"] > 0
+    # signal_show_lcd_data's numbers through the adapter (on_lcd_data switches the MER's IIR on in the engine): a 22-dB channel
+    assert res["lcd_records"] >= 5 and 18.0 < res["lcd_snr"] < 32.0 and 15.0 < res["lcd_mer"] < 26.0, res
     eti = np.fromfile(out, np.uint8).reshape(-1, 6144)
     assert len(eti) == res["eti_frames"] >= 40
     want_ids = select or list(range(18))

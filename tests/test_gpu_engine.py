@@ -32,6 +32,7 @@ def _oracle_run(x, subch, want_soft=False, config=None):
                fbb=np.ctypeslib.as_array(cap.fbb, (n,)).copy(),
                fbb_end=np.ctypeslib.as_array(cap.fbb_end, (n,)).copy(), clock_err=np.ctypeslib.as_array(cap.clock_err, (n,)).copy(),
                fic_ratio=np.ctypeslib.as_array(cap.fic_ratio, (n,)).copy(), snr_db=np.ctypeslib.as_array(cap.snr_db, (n,)).copy(),
+               mer_db=np.ctypeslib.as_array(cap.mer_db, (n,)).copy(),
                s_level=np.ctypeslib.as_array(cap.s_level, (n,)).copy(), peak_level=np.ctypeslib.as_array(cap.peak_level, (n,)).copy(),
                sym0=np.ctypeslib.as_array(cap.sym0_pos, (n,)).copy(),
                ber_bits=np.ctypeslib.as_array(cap.fic_ber_bits, (n,)).copy(), ber_errors=np.ctypeslib.as_array(cap.fic_ber_errors, (n,)).copy(),
@@ -45,13 +46,15 @@ def _oracle_run(x, subch, want_soft=False, config=None):
     return res
 
 
-def _engine_run(x, subch, n_frames, **kw):
+def _engine_run(x, subch, n_frames, lcd=False, **kw):
     eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=max(1, len(subch)), out_frames=4, **kw)
     if subch:
         eng.set_subchannels(subch)
+    if lcd:
+        eng.set_lcd_statistics(1)        # the demapper instances that advance the LCD record's MER too (dabx_set_lcd_statistics)
     eng.push_iq(0, x)
     fibs, crc, msc, sfs, starts, fbbs = [], [], [[] for _ in subch], [[] for _ in subch], [], []
-    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[])       # per frame, as they stand when the frame is complete
+    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[], mer_db=[])       # per frame, as they stand when the frame is complete
     last_sf = [0] * len(subch)
     for step in range(n_frames + 3):
         before = eng.stats(0)["frames"]
@@ -62,7 +65,7 @@ def _engine_run(x, subch, n_frames, **kw):
         f, c = eng.read_fibs(0, 1)
         fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
         eng.scalars["clock_err"].append(st["clock_err_hz"]); eng.scalars["fic_ratio"].append(st["fic_ratio_percent"])
-        eng.scalars["snr_db"].append(st["snr_db_est"])
+        eng.scalars["snr_db"].append(st["snr_db_est"]); eng.scalars["mer_db"].append(st["mer_db_est"])
         for j in range(len(subch)):
             m = eng.read_msc(0, j, 4)
             msc[j].append((st["frames"], m))
@@ -81,6 +84,10 @@ def _check_frame_scalars(eng, fbbs, ora, n):
     a, b = np.asarray(eng.scalars["snr_db"][:n], np.float64), ora["snr_db"][:n].astype(np.float64)
     ok = np.isfinite(a) & np.isfinite(b)                       # an all-zero stretch (drop-out) makes 0/0 on both sides alike
     assert np.array_equal(np.isnan(a), np.isnan(b)) and ok.sum() >= n - 3 and np.abs(a[ok] - b[ok]).max() <= 0.02
+    # MER of the same record (ofdm_decoder.cpp:204-208, 331-340): 0.02 dB where the engine tracks it (dabx_set_lcd_statistics), 0 where not
+    m = np.asarray(eng.scalars["mer_db"][:n], np.float64)
+    if m.any():
+        assert np.abs(m - ora["mer_db"][:n].astype(np.float64)).max() <= 0.02, (m, ora["mer_db"][:n])
 
 
 @pytest.mark.parametrize("seed,snr,cfo,toff", [(1, 20.0, 1234.5, 50000), (2, 12.0, -1987.0, 170001), (3, 30.0, 0.0, 3),
@@ -91,9 +98,12 @@ def test_fic_and_msc_bit_exact_vs_oracle(seed, snr, cfo, toff):
     n_total = 28 * ds.TF
     x = ds.channel(ens.iq, snr_db=snr, cfo_hz=cfo, timing_offset=toff, seed=seed, n_out=n_total)
     ora = _oracle_run(x, subch)
-    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"])
+    eng, fibs, crc, msc, starts, fbbs = _engine_run(x, subch, ora["n"], lcd=seed in (2, 4))
     n = min(len(fibs), ora["n"])
     assert n >= ora["n"] - 1 and n >= 20
+    assert bool(np.any(eng.scalars["mer_db"])) == (seed in (2, 4))        # off by default: the record then says 0
+    if seed in (2, 4):
+        assert snr - 3.0 < eng.scalars["mer_db"][n - 1] < snr + 3.0
     assert np.array_equal(starts[:n], ora["start"][:n])
     assert np.array_equal(crc[:n], ora["crc"][:n])
     assert np.array_equal(fibs[:n], ora["fibs"][:n])
@@ -356,6 +366,47 @@ def test_many_streams_fast_msc_path_matches_single_stream_path(snr):
             assert np.array_equal(eng.read_msc(s, j, 32), ref.read_msc(0, j, 32)), (s, j)
             assert np.array_equal(eng.read_superframes(s, j, 4), ref.read_superframes(0, j, 4)), (s, j)
         ref.close()
+    eng.close()
+
+
+def test_lcd_mer_in_the_many_stream_schedule_and_in_the_delivered_record():
+    """dabx_set_lcd_statistics on an engine of 48 streams (two demapper launches per frame, the per-carrier IIR handed from one to the other
+    through HBM like the rest of the state): the MER after every frame against the oracle's (0.02 dB), the FIBs untouched by the switch, the
+    delivered stream record carrying the float dabx_get_stats shows for this frame or (the MSC symbols' demapper runs on a HIP stream of its
+    own, the record is gathered behind the frame chain) for the one before; a fresh engine says 0."""
+    ens = ds.build_ensemble(10, [], seed=9)
+    n_streams, n_frames = 48, 12
+    xs = {s: ds.channel(ens.iq, snr_db=14.0 + 0.25 * s, cfo_hz=-800.0 + 30.0 * s, timing_offset=1000 + 4099 * s, seed=500 + s,
+                        n_out=(n_frames + 2) * ds.TF) for s in (0, 17, 47)}
+    ora = {s: _oracle_run(xs[s], []) for s in xs}
+    eng = dx.Engine(n_streams=n_streams, ring_frames=n_frames + 3, max_subch=1, out_frames=8, fic_only=True)
+    assert eng.stats(0)["mer_db_est"] == 0.0
+    eng.set_lcd_statistics(1)
+    for s in range(n_streams):
+        eng.push_iq(s, xs[s if s in xs else 0])
+    eng.delivery_open(slots=4, what=1)
+    got = {s: [] for s in xs}
+    prev = {s: 0.0 for s in xs}
+    done = 0
+    while done < n_frames:
+        eng.process(1)
+        eng.synchronize()
+        st = {s: eng.stats(s) for s in xs}
+        ch = eng.delivery_next(wait=True)
+        for s in xs:
+            if int(ch.streams[s]["n_frames"]):
+                got[s].append(st[s]["mer_db_est"])
+                assert np.float32(ch.streams[s]["mer_db_est"]) in (np.float32(st[s]["mer_db_est"]), np.float32(prev[s])), s
+                prev[s] = st[s]["mer_db_est"]
+        ch.release()
+        done += 1
+    eng.delivery_close()
+    for s in xs:
+        n = min(len(got[s]), ora[s]["n"])
+        assert n >= n_frames - 3, (s, n)
+        assert np.abs(np.asarray(got[s][:n], np.float64) - ora[s]["mer_db"][:n]).max() <= 0.02, (s, got[s][:n], ora[s]["mer_db"][:n])
+        f, c = eng.read_fibs(s, 8)
+        assert c.all() and np.array_equal(f[-1], ora[s]["fibs"][min(len(got[s]), ora[s]["n"]) - 1])
     eng.close()
 
 

@@ -210,6 +210,11 @@ def test_demapper_matches_oracle(soft_type):
         assert np.array_equal(got > 0, exp > 0) or (d[(got > 0) != (exp > 0)] <= 2).all()
         # SLcdData::SNR (ofdm_decoder.cpp:326-343) from mMeanPowerOvrAll and the null-symbol noise power: 0.02 dB
         assert abs(float(dm.snr_db()[0]) - float(L.ora_demap_snr_db(od))) <= 0.02, f
+        # ... and the record's other device-side numbers: MER (:204-208, 331-340; 0.02 dB) and mMeanValue = TestData1 (:344)
+        snr, mer, mean_value = dm.lcd_data()
+        assert snr[0] == dm.snr_db()[0]
+        assert abs(float(mer[0]) - float(L.ora_demap_mer_db(od))) <= 0.02, (f, float(mer[0]), float(L.ora_demap_mer_db(od)))
+        assert abs(float(mean_value[0]) / float(L.ora_demap_mean_value(od)) - 1.0) <= 1e-5, f
         L.ora_demap_store_null(od, spec[f, 76])
         dm.store_null_symbol_without_tii(spec[f, 76])
     L.ora_demap_free(od)

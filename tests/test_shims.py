@@ -92,6 +92,8 @@ def test_one_ensemble_symbol_by_symbol_through_the_three_shims(tmp_path):
     # the status signals: one signal_fic_status (48 FIC blocks: the 40th reports) with the channel BER of a 19-dB channel, one LCD record
     # (after 5 frames of symbols, on symbol 1 of the frame that follows: ofdm_decoder.cpp:155-157; the next would fall into a 13th frame)
     assert 0.0 <= res["fic_status_ber"] < 5e-3 and res["lcd_count"] == 1 and 15.0 < res["lcd_snr"] < 30.0 and res["lcd_symbol"] == 2
+    # ... whose MER (:204-208, 331-340: the phase-deviation IIR has seen 5 frames and a symbol, not settled yet) and TestData1 = mMeanValue come from the device too
+    assert 10.0 < res["lcd_mer"] < 30.0 and res["lcd_mean_value"] > 0.0
 
     # ---- oracle: the same per-symbol class calls on the same FFT outputs (all four services from frame 0)
     L = ol.oracle()
