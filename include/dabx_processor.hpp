@@ -45,6 +45,15 @@ public:
   // OfdmDecoder::signal_show_lcd_data's device-side numbers (ofdm_decoder.cpp:326-345): setting it before the first run() switches the MER's
   // per-carrier IIR on in the engine (dabx_set_lcd_statistics)
   std::function<void(float snrDb, float merDb)> on_lcd_data;
+  // signal_show_clock_err and signal_linear_peak_and_rms_level, "about each second" (dab_processor.cpp:252-263): the sample clock's error from
+  // the samples the last more-than-ten frames took (INPUT_RATE * (samples / (frames * T_F) - 1): an average, not on_status's IIR), and
+  // SampleReader's levels (get_linear_peak_level_and_clear; the engine tracks the peak in lock with cfg.exact_level_tracker = 1 only).
+  // A loss of lock starts the count over.
+  std::function<void(float clockErrHz)> on_clock_error;
+  std::function<void(float peakLevel, float meanLevel)> on_signal_level;
+  // signal_dip_sync_found (a null symbol's end was found: the stream went from the search into a frame) / signal_no_dip_sync_found (eight
+  // frame lengths searched without one, dab_processor.cpp:418-433)
+  std::function<void(bool found)> on_time_sync;
 
   std::function<void(const std::vector<dabx_tii_result> &)> on_tii;                                 // signal_show_tii
   // IFibDecoder::signal_change_in_configuration (fib_decoder_fig0.cpp:109) -- which the reference answers with "not supported yet"
@@ -130,8 +139,30 @@ public:
       if (on_status) on_status(after.fic_ratio_percent, after.freq_offs_bb_hz, after.clock_err_hz, after.snr_db_est);
       if (on_lcd_data && lcd_on_) on_lcd_data(after.snr_db_est, after.mer_db_est);
     }
+    status_signals(before, after, frames);
     return frames;
   }
+
+private:
+  void status_signals(const dabx_stats &before, const dabx_stats &after, int frames)
+  {
+    const bool was_in = before.state == 2, is_in = after.state == 2;
+    if (!was_in && is_in && on_time_sync) on_time_sync(true);
+    if (!is_in) {
+      // TimeSyncer reports NO_DIP_FOUND after a frame length without a dip (timesyncer.cpp:63-67); eight in a row raise the signal
+      searched_ += after.samples_consumed - before.samples_consumed;
+      if (searched_ >= 8LL * 196608) { searched_ = 0; if (on_time_sync) on_time_sync(false); }
+    } else searched_ = 0;
+    if (!(was_in && is_in) || frames <= 0) { clk_frames_ = 0; clk_samples_ = 0; return; }
+    clk_frames_ += frames; clk_samples_ += after.samples_consumed - before.samples_consumed;
+    if (clk_frames_ > 10) {
+      if (on_clock_error) on_clock_error(2048000.0f * ((float)clk_samples_ / ((float)clk_frames_ * 196608.0f) - 1.0f));
+      if (on_signal_level) on_signal_level(after.peak_level, after.signal_level);
+      clk_frames_ = 0; clk_samples_ = 0;
+    }
+  }
+  long long clk_frames_ = 0, clk_samples_ = 0, searched_ = 0;
+public:
 
   // ---- FIB decoder getters (IFibDecoder subset: fib_decoder.cpp:547-570, 673-691) ------------------------------------
   std::vector<dabx_subch_desc> get_sub_channels()

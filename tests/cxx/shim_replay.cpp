@@ -27,6 +27,11 @@ int main(int argc, char **argv)
     long long lcd_records = 0;
     float lcd_snr = 0.f, lcd_mer = 0.f;
     rx.on_lcd_data = [&](float snr_db, float mer_db) { lcd_records++; lcd_snr = snr_db; lcd_mer = mer_db; };   // signal_show_lcd_data's device-side numbers
+    long long clock_reports = 0, sync_found = 0, sync_not_found = 0;
+    float clock_err = 0.f, level_mean = 0.f;
+    rx.on_clock_error = [&](float hz) { clock_reports++; clock_err = hz; };
+    rx.on_signal_level = [&](float, float mean) { level_mean = mean; };
+    rx.on_time_sync = [&](bool found) { (found ? sync_found : sync_not_found)++; };
     // the AAC decoder's seat: access units arrive sliced and judged (dabx_superframe_info); this stub only counts -- and, being a TEST, checks
     // the verdicts it was handed with a CRC of its own (crc.cpp:75-86: CCITT, start 0xFFFF, complemented, over the frame without its last two bytes)
     long long aus = 0, aus_ok = 0, au_verdict_mismatch = 0, au_bytes = 0;
@@ -85,9 +90,11 @@ int main(int argc, char **argv)
     std::printf("{\"frames\": %lld, \"fibs\": %lld, \"fibs_ok\": %lld, \"logical_frames\": %lld, \"super_frames\": %lld, \"services\": %zu, "
                 "\"eti_frames\": %lld, \"stalls\": %lld, \"late_added_at\": %lld, \"config_changes\": %lld, \"change_cif\": %lld, "
                 "\"access_units\": %lld, \"access_units_ok\": %lld, \"au_verdict_mismatch\": %lld, \"au_bytes\": %lld, \"lcd_records\": %lld, \"lcd_snr\": %.3f, "
-                "\"lcd_mer\": %.3f, \"lf_per_service\": %s}\n",
+                "\"lcd_mer\": %.3f, \"clock_reports\": %lld, \"clock_err_hz\": %.3f, \"level_mean\": %.5f, \"sync_found\": %lld, \"sync_not_found\": %lld, "
+                "\"lf_per_service\": %s}\n",
                 frames, fibs, fibs_ok, lf, sf, lf_per_service.size(), rx.eti_frames_written(), n_stalls, late_added_at, config_changes, change_cif,
-                aus, aus_ok, au_verdict_mismatch, au_bytes, lcd_records, (double)lcd_snr, (double)lcd_mer, per.c_str());
+                aus, aus_ok, au_verdict_mismatch, au_bytes, lcd_records, (double)lcd_snr, (double)lcd_mer, clock_reports,
+                (double)clock_err, (double)level_mean, sync_found, sync_not_found, per.c_str());
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "shim_replay: %s\n", e.what());

@@ -61,6 +61,10 @@ def test_adapter_replays_a_recording_to_eti(tmp_path, select):
     assert res["access_units"] == 3 * res["super_frames"] == res["access_units_ok"] and res["au_verdict_mismatch"] == 0 and res["au_bytes"] > 0
     # signal_show_lcd_data's numbers through the adapter (on_lcd_data switches the MER's IIR on in the engine): a 22-dB channel
     assert res["lcd_records"] >= 5 and 18.0 < res["lcd_snr"] < 32.0 and 15.0 < res["lcd_mer"] < 26.0, res
+    # signal_dip_sync_found once, never signal_no_dip_sync_found; signal_show_clock_err after the first more-than-ten frames in lock: this
+    # channel has no clock offset (the frames took 196 608 samples each: within a sample per eleven frames); signal_linear_peak_and_rms_level's mean
+    assert res["sync_found"] == 1 and res["sync_not_found"] == 0 and res["clock_reports"] >= 1 and abs(res["clock_err_hz"]) < 2.0, res
+    assert 0.01 < res["level_mean"] < 1.0, res
     eti = np.fromfile(out, np.uint8).reshape(-1, 6144)
     assert len(eti) == res["eti_frames"] >= 40
     want_ids = select or list(range(18))
