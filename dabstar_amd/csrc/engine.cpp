@@ -1614,7 +1614,7 @@ static int ingest_open_impl(dabx_engine *e, const dabx_ingest_config *cfg, const
     I.pitch = align_up(need, 256);
     I.capacity = I.pitch * (size_t)S_;
   }
-  if (I.copy_engine == 0 && (rc = sdma_open(e->device, &I.sdma))) return rc;
+  if (I.copy_engine == 0 && (rc = sdma_open(e->device, &I.sdma))) { ingest_free(e); return rc; }      // (the per-stream tables above go with it)
 #define H(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { set_error("HIP error %d (%s) at %s:%d", (int)err__, hipGetErrorString(err__), __FILE__, __LINE__); ingest_free(e); return DABX_E_HIP; } } while (0)
   if (I.copy_engine == 1) H(hipStreamCreateWithFlags(&I.cs, hipStreamNonBlocking));
   H(hipEventCreateWithFlags(&I.committed, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -1733,6 +1733,9 @@ static int ingest_commit_general(dabx_engine *e, int k)
   const std::vector<size_t> &nb = I.n_bytes[(size_t)k];
   std::vector<IngestJob> jobs((size_t)S);
   unsigned max_n = 0, max_out = 0;
+  // the page-locked staging records (jobs_host, counts_host) are written below: the previous commit's asynchronous copies of them -- two
+  // commits may follow each other without a submit in between -- have to be through first
+  DABX_HIP(hipStreamSynchronize(e->ingest));
   for (int s = 0; s < S; s++) {
     IngestJob &j = jobs[(size_t)s];
     j = IngestJob{};
@@ -1760,7 +1763,6 @@ static int ingest_commit_general(dabx_engine *e, int k)
     jobs[(size_t)s].dst0 = e->wr_host[s];               // the host's own count of committed samples: no device-side index is read
     announce_write(e, s, e->wr_host[s] + I.counts_host[s]);
   }
-  DABX_HIP(hipStreamSynchronize(e->ingest));            // the staging records of the previous commit have been read
   memcpy(I.jobs_host, jobs.data(), sizeof(IngestJob) * (size_t)S);
   DABX_HIP(hipMemcpyAsync(I.jobs_dev, I.jobs_host, sizeof(IngestJob) * (size_t)S, hipMemcpyHostToDevice, e->ingest));
   DABX_HIP(hipMemcpyAsync(I.counts_dev, I.counts_host, sizeof(unsigned) * (size_t)S, hipMemcpyHostToDevice, e->ingest));
@@ -1949,6 +1951,7 @@ int dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms)
   if (!e || n < 0) return DABX_E_ARG;
   Delivery &D = e->dl;
   if (!D.open) { set_error("dabx_delivery_wait_free: no delivery open"); return DABX_E_STATE; }
+  if ((size_t)n > D.slots.size()) { set_error("dabx_delivery_wait_free: %d slabs asked for, the delivery has %zu", n, D.slots.size()); return DABX_E_ARG; }
   std::unique_lock<std::mutex> lk(D.mu);
   auto free_now = [&D]() { int k = 0; for (const auto &sl : D.slots) k += sl.state == Delivery::FREE; return k; };
   if (timeout_ms < 0) D.cv.wait(lk, [&]() { return free_now() >= n; });

@@ -551,7 +551,8 @@ int  dabx_delivery_close(dabx_engine *e);      /* drains the engine; chunks not 
 int  dabx_delivery_next(dabx_engine *e, int wait, dabx_chunk *out);
 int  dabx_delivery_release(dabx_engine *e, uint64_t seq);
 /* Back-pressure for the engine's thread: waits (at most timeout_ms, < 0 = for ever) until n host slabs are free and returns the
- * number that are (>= n: a dabx_process call that closes n chunks will be accepted; < n: timed out). */
+ * number that are (>= n: a dabx_process call that closes n chunks will be accepted; < n: timed out).  n above the number of host slabs
+ * the delivery was opened with is an error (it would wait for ever). */
 int  dabx_delivery_wait_free(dabx_engine *e, int n, int timeout_ms);
 /* What the copies themselves took (the copier's own clock around each transfer): link rate = bytes_copied / copy_seconds. */
 typedef struct {
