@@ -195,6 +195,7 @@ void ora_demap_store_ref(ora_demap *d, const ora_cf32 *fft);         /* ofdm_dec
 void ora_demap_store_null(ora_demap *d, const ora_cf32 *fft);        /* ofdm_decoder.cpp:114-130 */
 void ora_demap_symbol(ora_demap *d, const ora_cf32 *fft, float clock_err, int16_t out[ORA_2K]); /* :147-355 */
 float ora_demap_snr_db(const ora_demap *d);                       /* :326-343, :358-371 (SNR of the LCD statistics) */
+const int16_t *ora_interleave_map(void);                          /* the 16-entry time-de-interleaver map, backend.cpp:129 / eti_generator.cpp:22 */
 float ora_demap_mean_value(const ora_demap *d);
 const float *ora_demap_std_dev_sq(const ora_demap *d);
 float ora_demap_mer_db(const ora_demap *d);                       /* :331-340 (MER of the LCD statistics, from the :204-208 IIR) */

@@ -6,6 +6,7 @@
 #include <string.h>
 
 static const int16_t kInterleaveMap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15}; /* backend.cpp:129 */
+const int16_t *ora_interleave_map(void) { return kInterleaveMap; }      /* (tests: compared with the reference object's own table, eti_generator.cpp:22) */
 
 static void sink_append(uint8_t **buf, size_t *len, size_t *cap, const uint8_t *src, size_t n)
 {

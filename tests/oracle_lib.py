@@ -119,6 +119,8 @@ def oracle():
     L.ora_demap_snr_db.restype = C.c_float
     L.ora_demap_mer_db.argtypes = [C.c_void_p]
     L.ora_demap_mer_db.restype = C.c_float
+    L.ora_interleave_map.argtypes = []
+    L.ora_interleave_map.restype = C.POINTER(C.c_int16)
     L.ora_demap_mean_value.argtypes = [C.c_void_p]
     L.ora_demap_mean_value.restype = C.c_float
     L.ora_demap_std_dev_sq.argtypes = [C.c_void_p]

@@ -266,3 +266,28 @@ def test_simd_viterbi_restatement_equals_the_avx2_object_code(variant):
                 R.ref_viterbi(np.ascontiguousarray(soft[i]), n, live)
                 assert np.array_equal(live, want[i]), (n, i)
     assert differs >= (10 if variant == "avx2" else 4)        # the bodies really decode differently on these inputs
+
+
+def test_time_deinterleaver_map_is_the_reference_objects_own_table(tmp_path):
+    """Backend::_process_segment / EtiGenerator::_process_cif read `interleaveMap` (backend.cpp:129, eti_generator.cpp:22): out_n[i] =
+    in_(n - 16 + map[i % 16])[i].  Neither class can be linked here, but eti_generator.cpp compiles UNMODIFIED into an object
+    (oracle/ref/Makefile), and the table is a read-only symbol of it: its 16 int16 words, read out of the object file, are the oracle's
+    map, the synthesiser's, and the 4-bit reversal the device kernels compute (vit_t.hip: bitrev4)."""
+    import subprocess
+    obj = os.path.join(os.path.dirname(ol.REF_SO), "eti_generator.o")
+    if not os.path.exists(obj):
+        pytest.skip("oracle/_ref/eti_generator.o not built")
+    sym = [l.split() for l in subprocess.run(["nm", "-S", obj], capture_output=True, text=True, check=True).stdout.splitlines() if l.endswith("interleaveMap")]
+    assert len(sym) == 1 and sym[0][2] in "rR" and int(sym[0][1], 16) == 32, sym
+    sec = str(tmp_path / "rodata.bin")
+    # the section the symbol lives in: the first read-only data section that holds 32 bytes at its offset (objdump names it)
+    hdr = subprocess.run(["objdump", "-t", obj], capture_output=True, text=True, check=True).stdout
+    section = [l.split()[-3] for l in hdr.splitlines() if l.endswith("interleaveMap")][0]
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=" + section, obj, sec], check=True)
+    off = int(sym[0][0], 16)
+    ref_map = np.frombuffer(open(sec, "rb").read()[off:off + 32], "<i2")
+    ora_map = np.ctypeslib.as_array(ol.oracle().ora_interleave_map(), (16,))
+    assert np.array_equal(ref_map, ora_map), (ref_map, ora_map)
+    from tools import dab_synth as ds
+    assert np.array_equal(ref_map, ds.INTERLEAVE_MAP)
+    assert [int(v) for v in ref_map] == [((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3) for v in range(16)]
