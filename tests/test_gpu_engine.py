@@ -85,9 +85,11 @@ def _check_frame_scalars(eng, fbbs, ora, n):
     ok = np.isfinite(a) & np.isfinite(b)                       # an all-zero stretch (drop-out) makes 0/0 on both sides alike
     assert np.array_equal(np.isnan(a), np.isnan(b)) and ok.sum() >= n - 3 and np.abs(a[ok] - b[ok]).max() <= 0.02
     # MER of the same record (ofdm_decoder.cpp:204-208, 331-340): 0.02 dB where the engine tracks it (dabx_set_lcd_statistics), 0 where not
-    m = np.asarray(eng.scalars["mer_db"][:n], np.float64)
-    if m.any():
-        assert np.abs(m - ora["mer_db"][:n].astype(np.float64)).max() <= 0.02, (m, ora["mer_db"][:n])
+    m = np.asarray(eng.scalars.get("mer_db", [])[:n], np.float64)
+    if m.size and np.nan_to_num(m, nan=1.0, posinf=1.0, neginf=1.0).any():
+        w = ora["mer_db"][:n].astype(np.float64)
+        ok = np.isfinite(m) & np.isfinite(w)                   # (a frame of zeros: 0 / 0 on both sides alike)
+        assert ok.sum() >= n - 3 and np.array_equal(np.isfinite(m), np.isfinite(w)) and np.abs(m[ok] - w[ok]).max() <= 0.02, (m, w)
 
 
 @pytest.mark.parametrize("seed,snr,cfo,toff", [(1, 20.0, 1234.5, 50000), (2, 12.0, -1987.0, 170001), (3, 30.0, 0.0, 3),
@@ -154,9 +156,11 @@ def test_mobile_channels_follow_the_oracle(profile, doppler, snr, ppm, drift):
     ora = _oracle_run(x, subch)
     eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=18, out_frames=4)
     eng.set_subchannels(subch)
+    if profile == "TU6":
+        eng.set_lcd_statistics(1)          # the MER's IIR through fades and (where a fade costs the lock) demapper resets
     eng.push_iq(0, x)
     fibs, crc, starts, fbbs, idle, steps = [], [], [], [], 0, 0
-    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[])
+    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[], mer_db=[])
     while idle < 4 and steps < 400:                                # a fade may cost the lock: acquisition passes are steps without a frame
         before = eng.stats(0)
         eng.process(1)
@@ -167,7 +171,7 @@ def test_mobile_channels_follow_the_oracle(profile, doppler, snr, ppm, drift):
             f, c = eng.read_fibs(0, 1)
             fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
             eng.scalars["clock_err"].append(st["clock_err_hz"]); eng.scalars["fic_ratio"].append(st["fic_ratio_percent"])
-            eng.scalars["snr_db"].append(st["snr_db_est"])
+            eng.scalars["snr_db"].append(st["snr_db_est"]); eng.scalars["mer_db"].append(st["mer_db_est"])
     fibs, crc, starts, fbbs = np.array(fibs), np.array(crc), np.array(starts), np.array(fbbs)
     n = min(len(fibs), ora["n"])
     assert n >= ora["n"] - 1 and n >= 24, (len(fibs), ora["n"], steps)
@@ -794,9 +798,11 @@ def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind, acquire_mode
     ora = _oracle_run(x, subch)
     eng = dx.Engine(n_streams=1, ring_frames=len(x) // ds.TF + 1, max_subch=18, out_frames=4, acquire_mode=acquire_mode)
     eng.set_subchannels(subch)
+    if acquire_mode == 1:
+        eng.set_lcd_statistics(1)          # OfdmDecoder::reset zeroes the MER's IIR with the rest (ofdm_decoder.cpp:92)
     eng.push_iq(0, x)
     fibs, crc, starts, fbbs, idle, steps = [], [], [], [], 0, 0
-    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[])
+    eng.scalars = dict(clock_err=[], fic_ratio=[], snr_db=[], mer_db=[])
     while idle < 4 and steps < 400:                         # a step without a frame is an acquisition pass: keep going
         before = eng.stats(0)
         eng.process(1)
@@ -807,7 +813,7 @@ def test_loss_of_lock_and_reacquisition_follow_the_oracle(gap_kind, acquire_mode
             f, c = eng.read_fibs(0, 1)
             fibs.append(f[0]); crc.append(c[0]); starts.append(st["last_start_index"]); fbbs.append(st["freq_offs_bb_hz"])
             eng.scalars["clock_err"].append(st["clock_err_hz"]); eng.scalars["fic_ratio"].append(st["fic_ratio_percent"])
-            eng.scalars["snr_db"].append(st["snr_db_est"])
+            eng.scalars["snr_db"].append(st["snr_db_est"]); eng.scalars["mer_db"].append(st["mer_db_est"])
     fibs, crc, starts, fbbs = np.array(fibs), np.array(crc), np.array(starts), np.array(fbbs)
     n = min(len(fibs), ora["n"])
     assert n >= ora["n"] - 1 and n >= 24, (len(fibs), ora["n"], steps)
