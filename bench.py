@@ -82,6 +82,7 @@ def parse():
                          "measured in a leg either way (delivered_to_host.consumers).  Same-box pairs at 20 steps: python 463 k, C++ 440 k in the timed regions "
                          "(profiles/r06_ab/ab10_consumers.txt; as a leg both reach 455-468 k): the python thread stays the default")
     ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each; value = the median region")
+    ap.add_argument("--short-chunk-last", action="store_true", help="experiment: a region's short chunk last instead of first (profiles/r06_ab/ab14)")
     ap.add_argument("--taper", action="store_true",
                     help="experiments: with the delivery open, issue the last 7 frames of a region as chunks of 4, 2, 1 (the final slab copy, which nothing "
                          "can overlap, is then a seventh as long).  Measured SLOWER (0.82 against 0.94 of the undelivered rate at 20 steps, "
@@ -392,6 +393,8 @@ def region_chunks(n, chunk=7, taper=False):
     last chunk's slab has crossed the link, and that copy (101 MB = 1.8 ms for 7 frames of 512 x 18, a tenth of a 20-step region) overlaps
     nothing; the slab of a 1-frame chunk takes 0.26 ms, and the copies of the 4- and 2-frame chunks run next to the frames that follow them.
     (For results left on the device the taper costs more than it saves: step_chunks' note.)"""
+    if taper == "short-last":          # experiment: the region's short chunk LAST (its slab, the un-overlapped transfer, is the smaller one)
+        return [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
     if not taper or chunk != 7 or n < chunk:
         return step_chunks(n, chunk)
     return step_chunks(n - chunk, chunk) + [4, 2, 1]
@@ -1046,7 +1049,7 @@ def main():
     # ---- the timed regions: args.regions (3) x EXACTLY args.steps steps, each bracketed by barrier + device synchronisation on both sides;
     # `value` is the MEDIAN region (one 19-ms region is a lottery ticket: 517-560 k across the pool for one library), value_min / value_max the
     # spread.  With the delivery open (default) a region ends when the consumer has taken and given back the last chunk: IQ -> bytes in host memory.
-    taper = deliver_on and args.taper
+    taper = deliver_on and ("short-last" if args.short_chunk_last else args.taper)
     regions = []
     for _ in range(max(1, args.regions)):
         c1 = eng.counters()
