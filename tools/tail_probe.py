@@ -29,6 +29,28 @@ e.set_subchannels(subch)
 bench.fill_rings(e, torch, dev, args, 0, subch)
 e.commit(9 * TF)
 LIGHT = os.environ.get("DABX_PROBE_LIGHT_CONSUMER", "0") == "1"      # the consumer only takes and releases (no sums)
+CXX = os.environ.get("DABX_PROBE_CXX", "0") == "1"                    # the C++ consumer thread of tests/cxx/consumer_thread.cpp instead of the python one
+
+
+class CxxProbeSink:
+    """bench.CxxSink behind the probe's Sink interface (no per-chunk time stamps: the thread is not ours)."""
+    def __init__(self):
+        self.s = bench.CxxSink(e, [])
+        self.base = self.s.chunks
+        self.land, self.rel, self.stop = [], [], False
+        self.th = self
+
+    @property
+    def n(self):
+        return self.s.chunks - self.base
+
+    @n.setter
+    def n(self, v):
+        self.base = self.s.chunks - v
+
+    def join(self, timeout=None):
+        self.s.finish()
+
 
 
 class Sink:
@@ -76,7 +98,7 @@ for rep in range(3):
         sink = None
         if what >= 0:
             e.delivery_open(slots=4, what=what)
-            sink = Sink()
+            sink = CxxProbeSink() if CXX else Sink()
         run(21, sink)
         e.synchronize()
         while sink is not None and sink.n < 3:
